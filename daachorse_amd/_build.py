@@ -1,0 +1,45 @@
+"""Builds daachorse_amd/lib/libdaachorse_amd.so for gfx950 with hipcc (in-tree, so the .so
+travels with the repository snapshot to the GPU box)."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libdaachorse_amd.so")
+
+SOURCES = ["pma.cpp", "repack.cpp", "builder.cpp", "api.hip", "scan_kernels.hip", "synth.hip"]
+HEADERS = ["pma.hpp", "repack.hpp", "device_tables.hpp", os.path.join("..", "..", "include", "daachorse_amd.h"),
+           os.path.join("..", "..", "include", "daac_synth.h")]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in files)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

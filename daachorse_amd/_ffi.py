@@ -1,0 +1,83 @@
+"""ctypes loader for the C ABI (include/daachorse_amd.h).  Fails loudly: there is no fallback."""
+import ctypes as C
+import os
+
+from . import _build
+
+_lib = None
+
+
+class DaachorseError(RuntimeError):
+    """Mirror of daachorse::errors::DaachorseError (reference src/errors.rs:10-22) plus the
+    boundary's extra statuses; `.code` is the daac_status."""
+
+    NAMES = {1: "InvalidArgument", 2: "AutomatonScale", 3: "InvalidConversion", 4: "InvalidAutomaton",
+             5: "MatchKindMismatch", 6: "Unsupported", 7: "Device"}
+
+    def __init__(self, code, msg):
+        super().__init__(f"{self.NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Match(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("value", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class Info(C.Structure):
+    _fields_ = [("match_kind", C.c_uint8), ("num_states", C.c_uint32), ("states_len", C.c_uint64),
+                ("outputs_len", C.c_uint64), ("heap_bytes", C.c_uint64), ("max_pattern_len", C.c_uint32),
+                ("num_classes", C.c_uint32), ("tier_dense_states", C.c_uint32), ("tier_lds_states", C.c_uint32),
+                ("tier_lds_bytes", C.c_uint32), ("tiered_available", C.c_uint8)]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: the HIP extension has not been built (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'`).  daachorse_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    P, vp, sz, u8p = C.POINTER, C.c_void_p, C.c_size_t, C.c_void_p
+    L.daac_last_error.restype = C.c_char_p
+    L.daac_free.argtypes = [vp]
+    L.daac_bytewise_from_serialized.argtypes = [C.c_char_p, sz, P(vp), P(sz)]
+    L.daac_bytewise_from_parts.argtypes = [vp, sz, vp, vp, sz, vp, sz, C.c_uint8, C.c_uint32, P(vp)]
+    L.daac_bytewise_build.argtypes = [vp, vp, vp, sz, C.c_uint8, C.c_uint32, P(vp)]
+    L.daac_pma_serialize.argtypes = [vp, P(vp), P(sz)]
+    L.daac_pma_info.argtypes = [vp, P(Info)]
+    L.daac_pma_free.argtypes = [vp]
+    L.daac_pma_upload.argtypes = [vp, C.c_int]
+    L.daac_scan.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp)]
+    L.daac_matches_count.argtypes = [vp]
+    L.daac_matches_count.restype = sz
+    L.daac_matches_data.argtypes = [vp]
+    L.daac_matches_data.restype = vp
+    L.daac_matches_free.argtypes = [vp]
+    L.daac_scan_count.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(C.c_uint64), P(C.c_uint64), vp]
+    L.daac_iter_open.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp)]
+    L.daac_iter_next.argtypes = [vp, P(Match)]
+    L.daac_iter_next.restype = C.c_int
+    L.daac_iter_close.argtypes = [vp]
+    L.daac_set_option.argtypes = [C.c_char_p, C.c_int64]
+    L.daac_synth_uniform.argtypes = [vp, sz, C.c_uint64, vp, C.c_uint32, C.c_uint64, vp]
+    L.daac_synth_wordsoup.argtypes = [vp, sz, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32,
+                                      vp, C.c_uint32, C.c_uint64, vp]
+    for name in ("daac_bytewise_from_serialized", "daac_bytewise_from_parts", "daac_bytewise_build", "daac_pma_serialize",
+                 "daac_pma_info", "daac_pma_upload", "daac_scan", "daac_scan_count", "daac_iter_open", "daac_set_option",
+                 "daac_synth_uniform", "daac_synth_wordsoup"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        msg = lib().daac_last_error()
+        raise DaachorseError(status, msg.decode("utf-8", "replace") if msg else "")
+
+
+def set_option(name, value):
+    check(lib().daac_set_option(name.encode(), int(value)))

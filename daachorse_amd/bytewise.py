@@ -1,0 +1,278 @@
+"""Host-side mirror of the crate's bytewise API over the C ABI.
+
+Same names, argument meaning and error behaviour as reference src/bytewise.rs /
+src/bytewise/builder.rs, so the parity tests read like the reference's own tests:
+
+    pma = DoubleArrayAhoCorasick.new(["bcd", "ab", "a"])
+    [(m.start(), m.end(), m.value()) for m in pma.find_overlapping_iter("abcd")]
+
+Every scan runs on the MI355X through libdaachorse_amd.so; nothing here computes matches.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import DaachorseError
+
+MATCH_DTYPE = np.dtype([("start", "<u8"), ("end", "<u8"), ("value", "<u4"), ("_pad", "<u4")])
+
+
+class MatchKind(enum.IntEnum):
+    """src/lib.rs:324-346"""
+    Standard = 0
+    LeftmostLongest = 1
+    LeftmostFirst = 2
+
+
+class ScanMode(enum.IntEnum):
+    FindOverlapping = 0
+    Find = 1
+    LeftmostFind = 2
+    FindOverlappingNoSuffix = 3
+
+
+class Engine(enum.IntEnum):
+    Auto = 0
+    Tiered = 1
+    DArray = 2
+
+
+class Match:
+    """src/lib.rs:286-320"""
+    __slots__ = ("_s", "_e", "_v")
+
+    def __init__(self, start, end, value):
+        self._s, self._e, self._v = int(start), int(end), int(value)
+
+    def start(self):
+        return self._s
+
+    def end(self):
+        return self._e
+
+    def value(self):
+        return self._v
+
+    def __eq__(self, o):
+        return isinstance(o, Match) and (self._s, self._e, self._v) == (o._s, o._e, o._v)
+
+    def __repr__(self):
+        return f"Match(start={self._s}, end={self._e}, value={self._v})"
+
+
+def _as_bytes(x):
+    if isinstance(x, str):
+        return x.encode("utf-8")
+    return bytes(x)
+
+
+class _Haystack:
+    """A haystack argument: str/bytes/numpy (host) or a torch CUDA uint8 tensor (device)."""
+
+    def __init__(self, h):
+        self.keep = h
+        self.is_device = 0
+        if hasattr(h, "data_ptr") and hasattr(h, "is_cuda"):  # torch tensor
+            if h.dtype.itemsize != 1 or not h.is_contiguous():
+                raise DaachorseError(1, "haystack tensor must be contiguous uint8")
+            self.ptr, self.len, self.is_device = h.data_ptr(), h.numel(), int(h.is_cuda)
+            if self.len == 0:
+                self.ptr = None
+            return
+        if isinstance(h, np.ndarray):
+            a = np.ascontiguousarray(h, dtype=np.uint8)
+        else:
+            a = np.frombuffer(_as_bytes(h), dtype=np.uint8)
+        self.keep = a
+        self.ptr = a.ctypes.data if a.size else None
+        self.len = a.size
+
+
+class _LazyIter:
+    """Iterator<Item = Match<u32>> over daac_iter_* (bytewise/iter.rs next())."""
+
+    def __init__(self, pma, mode, haystack, engine, stream):
+        self._pma = pma
+        self._h = _Haystack(haystack)
+        self._it = C.c_void_p()
+        _ffi.check(_ffi.lib().daac_iter_open(pma._h, int(mode), int(engine), self._h.ptr, self._h.len, self._h.is_device,
+                                             stream, C.byref(self._it)))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        m = _ffi.Match()
+        r = _ffi.lib().daac_iter_next(self._it, C.byref(m))
+        if r == 1:
+            return Match(m.start, m.end, m.value)
+        if r == 0:
+            raise StopIteration
+        _ffi.check(-r)
+
+    def __del__(self):
+        try:
+            if self._it:
+                _ffi.lib().daac_iter_close(self._it)
+                self._it = None
+        except Exception:
+            pass
+
+
+class DoubleArrayAhoCorasick:
+    """DoubleArrayAhoCorasick<u32> (reference src/bytewise.rs:54-68)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().daac_pma_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- construction (bytewise.rs:103-110, 154-161) ------------------------------------------------
+    @classmethod
+    def new(cls, patterns):
+        return DoubleArrayAhoCorasickBuilder().build(patterns)
+
+    @classmethod
+    def with_values(cls, patvals):
+        return DoubleArrayAhoCorasickBuilder().build_with_values(patvals)
+
+    # ---- (de)serialisation (bytewise.rs:801-820, 868-964) --------------------------------------------
+    def serialize(self):
+        buf, n = C.c_void_p(), C.c_size_t()
+        _ffi.check(_ffi.lib().daac_pma_serialize(self._h, C.byref(buf), C.byref(n)))
+        data = C.string_at(buf, n.value)
+        _ffi.lib().daac_free(buf)
+        return data
+
+    @classmethod
+    def deserialize(cls, source):
+        """-> (pma, remaining bytes), as the reference returns (Self, &[u8])"""
+        source = bytes(source)
+        h, consumed = C.c_void_p(), C.c_size_t()
+        _ffi.check(_ffi.lib().daac_bytewise_from_serialized(source, len(source), C.byref(h), C.byref(consumed)))
+        return cls(h), source[consumed.value:]
+
+    @classmethod
+    def from_parts(cls, kind, num_states, outputs, states=None, leftmost_states=None, fails=None):
+        def arr(x, cols):
+            if x is None:
+                return None, 0
+            a = np.ascontiguousarray(x, dtype=np.uint32).reshape(-1, cols) if cols > 1 else np.ascontiguousarray(x, dtype=np.uint32)
+            return a, len(a)
+        st, n_st = arr(states, 3)
+        ls, n_ls = arr(leftmost_states, 2)
+        fl, _ = arr(fails, 1)
+        ou, n_ou = arr(outputs, 3)
+        h = C.c_void_p()
+        p = lambda a: a.ctypes.data if a is not None and a.size else None
+        _ffi.check(_ffi.lib().daac_bytewise_from_parts(p(st), n_st, p(ls), p(fl), n_ls, p(ou), n_ou, int(kind), int(num_states),
+                                                       C.byref(h)))
+        return cls(h)
+
+    # ---- introspection -----------------------------------------------------------------------------------
+    def info(self):
+        i = _ffi.Info()
+        _ffi.check(_ffi.lib().daac_pma_info(self._h, C.byref(i)))
+        return i
+
+    def match_kind(self):
+        return MatchKind(self.info().match_kind)
+
+    def num_states(self):
+        return self.info().num_states
+
+    def heap_bytes(self):
+        return self.info().heap_bytes
+
+    def upload(self, device=0):
+        _ffi.check(_ffi.lib().daac_pma_upload(self._h, device))
+        return self
+
+    # ---- lazy iterators, crate names (bytewise.rs:190-203, 292-314, 410-428, 547-566) --------------------
+    def find_iter(self, haystack, engine=Engine.Auto, stream=None):
+        return _LazyIter(self, ScanMode.Find, haystack, engine, stream)
+
+    def find_overlapping_iter(self, haystack, engine=Engine.Auto, stream=None):
+        return _LazyIter(self, ScanMode.FindOverlapping, haystack, engine, stream)
+
+    def find_overlapping_no_suffix_iter(self, haystack, engine=Engine.Auto, stream=None):
+        return _LazyIter(self, ScanMode.FindOverlappingNoSuffix, haystack, engine, stream)
+
+    def leftmost_find_iter(self, haystack, engine=Engine.Auto, stream=None):
+        return _LazyIter(self, ScanMode.LeftmostFind, haystack, engine, stream)
+
+    # ---- eager forms (`.collect()` / `.count()` on the iterators) ---------------------------------------------
+    def scan(self, mode, haystack, engine=Engine.Auto, stream=None):
+        """-> numpy structured array (start, end, value) in the reference's order"""
+        h = _Haystack(haystack)
+        out = C.c_void_p()
+        _ffi.check(_ffi.lib().daac_scan(self._h, int(mode), int(engine), h.ptr, h.len, h.is_device, stream, C.byref(out)))
+        n = _ffi.lib().daac_matches_count(out)
+        if n:
+            buf = (C.c_char * (n * MATCH_DTYPE.itemsize)).from_address(_ffi.lib().daac_matches_data(out))
+            res = np.frombuffer(buf, dtype=MATCH_DTYPE).copy()
+        else:
+            res = np.zeros(0, dtype=MATCH_DTYPE)
+        _ffi.lib().daac_matches_free(out)
+        return res
+
+    def scan_count(self, mode, haystack, engine=Engine.Auto, stream=None, result_dev=None):
+        """-> (count, checksum); with `result_dev` (device pointer to 3 x u64) the call is asynchronous."""
+        h = _Haystack(haystack)
+        if result_dev is not None:
+            _ffi.check(_ffi.lib().daac_scan_count(self._h, int(mode), int(engine), h.ptr, h.len, h.is_device, stream, None, None,
+                                                  result_dev))
+            return None
+        cnt, cs = C.c_uint64(), C.c_uint64()
+        _ffi.check(_ffi.lib().daac_scan_count(self._h, int(mode), int(engine), h.ptr, h.len, h.is_device, stream, C.byref(cnt),
+                                              C.byref(cs), None))
+        return cnt.value, cs.value
+
+
+class DoubleArrayAhoCorasickBuilder:
+    """reference src/bytewise/builder.rs:21-244"""
+
+    def __init__(self):
+        self._kind = MatchKind.Standard
+        self._num_free_blocks = 16
+
+    def match_kind(self, kind):
+        self._kind = MatchKind(kind)
+        return self
+
+    def num_free_blocks(self, n):
+        assert n >= 1  # builder.rs:113
+        self._num_free_blocks = int(n)
+        return self
+
+    def build(self, patterns):
+        return self._build(list(patterns), None)
+
+    def build_with_values(self, patvals):
+        patvals = list(patvals)
+        return self._build([p for p, _ in patvals], [v for _, v in patvals])
+
+    def _build(self, patterns, values):
+        pats = [_as_bytes(p) for p in patterns]
+        offs = np.zeros(len(pats) + 1, dtype=np.uint64)
+        if pats:
+            offs[1:] = np.cumsum([len(p) for p in pats], dtype=np.uint64)
+        blob = np.frombuffer(b"".join(pats) or b"\0", dtype=np.uint8)
+        vals = None
+        if values is not None:
+            if any(not (0 <= int(v) <= 0xFFFFFFFF) for v in values):
+                raise DaachorseError(3, "value does not fit u32")
+            vals = np.ascontiguousarray(values, dtype=np.uint32)
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().daac_bytewise_build(blob.ctypes.data, offs.ctypes.data,
+                                                  vals.ctypes.data if vals is not None and vals.size else None,
+                                                  len(pats), int(self._kind), self._num_free_blocks, C.byref(h)))
+        return DoubleArrayAhoCorasick(h)

@@ -1,0 +1,536 @@
+// C ABI of the MI355X-native daachorse scan path (include/daachorse_amd.h): handle management,
+// device upload of the re-packed automaton, scan drivers.  No CPU scan fallback lives here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "device_tables.hpp"
+#include "pma.hpp"
+#include "repack.hpp"
+
+namespace daac {
+const char *last_error_cstr();
+
+// ------------------------------------------------------------------------------------ options
+struct Options {
+    std::atomic<int64_t> seg_bytes{0};       // 0 = auto
+    std::atomic<int64_t> lds_budget{96 * 1024};
+    std::atomic<int64_t> dense_depth{-1};
+    std::atomic<int64_t> rows_share_pct{45};
+    std::atomic<int64_t> blocks_per_cu{0};   // 0 = auto
+    std::atomic<int64_t> threads{1024};
+    std::atomic<int64_t> iter_window{64ll << 20};
+    std::atomic<int64_t> max_result_bytes{8ll << 30};
+};
+static Options g_opt;
+
+static daac_status hip_fail(hipError_t e, const char *what) {
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return DAAC_ERR_DEVICE;
+}
+#define HIP_TRY(expr)                                                      \
+    do {                                                                   \
+        hipError_t _e = (expr);                                            \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);                  \
+    } while (0)
+
+// ----------------------------------------------------------------------------- device tables
+struct DeviceTables {
+    int device = -1;
+    int num_cu = 0;
+    std::vector<void *> allocs;
+    bool tier_ok = false;
+    TierDev tier{};
+    DArrayDev da{};
+    TierTables tier_host_meta;  // sizes only (vectors cleared after upload)
+
+    ~DeviceTables() {
+        for (void *p : allocs) (void)hipFree(p);
+    }
+    template <class T>
+    daac_status put(const std::vector<T> &v, const T *&out) {
+        // padded so that 16-byte granule copies into LDS never run past the allocation
+        const size_t bytes = v.size() * sizeof(T);
+        const size_t padded = ((bytes + 15) & ~size_t(15)) + 16;
+        void *d = nullptr;
+        HIP_TRY(hipMalloc(&d, padded));
+        allocs.push_back(d);
+        HIP_TRY(hipMemset(d, 0, padded));
+        if (bytes) HIP_TRY(hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice));
+        out = static_cast<const T *>(d);
+        return DAAC_OK;
+    }
+};
+
+}  // namespace daac
+
+using namespace daac;
+
+struct daac_pma {
+    HostPma host;
+    std::mutex mu;
+    std::map<int, std::unique_ptr<DeviceTables>> dev;
+};
+
+struct daac_matches {
+    std::vector<daac_match> v;
+};
+
+// --------------------------------------------------------------------------------------- upload
+static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) {
+    auto it = pma->dev.find(device);
+    if (it != pma->dev.end()) { *out = it->second.get(); return DAAC_OK; }
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<DeviceTables> t(new DeviceTables);
+    t->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    t->num_cu = prop.multiProcessorCount;
+
+    const HostPma &h = pma->host;
+    daac_status st;
+    // outputs, shared by both engines
+    const uint32_t *d_outputs = nullptr;
+    {
+        std::vector<uint32_t> flat(h.outputs.size() * 3);
+        for (size_t i = 0; i < h.outputs.size(); ++i) {
+            flat[3 * i] = h.outputs[i].value; flat[3 * i + 1] = h.outputs[i].length; flat[3 * i + 2] = h.outputs[i].parent;
+        }
+        if ((st = t->put(flat, d_outputs)) != DAAC_OK) return st;
+    }
+    // DARRAY engine: always available
+    {
+        DArrayTables da;
+        build_darray_tables(h, da);
+        const U32x2 *hot; const uint32_t *fail; const U32x4 *root; const OutSum *osum;
+        if ((st = t->put(da.hot, hot)) != DAAC_OK) return st;
+        if ((st = t->put(da.fail, fail)) != DAAC_OK) return st;
+        if ((st = t->put(da.root, root)) != DAAC_OK) return st;
+        if ((st = t->put(da.osum, osum)) != DAAC_OK) return st;
+        t->da.hot = reinterpret_cast<const uint2 *>(hot);
+        t->da.fail = fail;
+        t->da.root = reinterpret_cast<const uint4 *>(root);
+        t->da.osum = reinterpret_cast<const uint2 *>(osum);
+        t->da.outputs = d_outputs;
+        t->da.n = static_cast<uint32_t>(h.states_len());
+        t->da.root_flag = output_pos_of(h.opos_ch(kRoot)) != 0;
+    }
+    // TIERED engine
+    {
+        RepackOptions ro;
+        ro.lds_budget = static_cast<uint32_t>(g_opt.lds_budget.load());
+        ro.dense_depth = static_cast<int>(g_opt.dense_depth.load());
+        ro.rows_share_pct = static_cast<uint32_t>(g_opt.rows_share_pct.load());
+        TierTables tt;
+        if (build_tier_tables(h, ro, tt)) {
+            TierDev &d = t->tier;
+            const uint16_t *r16 = nullptr; const uint32_t *r32 = nullptr;
+            if (tt.row32) { if ((st = t->put(tt.rows32, r32)) != DAAC_OK) return st; d.rows = r32; }
+            else { if ((st = t->put(tt.rows16, r16)) != DAAC_OK) return st; d.rows = r16; }
+            const U32x4 *grec; const OutSum *ssum;
+            if ((st = t->put(tt.bcmap, d.bcmap)) != DAAC_OK) return st;
+            if ((st = t->put(tt.bfail, d.bfail)) != DAAC_OK) return st;
+            if ((st = t->put(tt.ssum, ssum)) != DAAC_OK) return st;
+            if ((st = t->put(tt.cls, d.cls)) != DAAC_OK) return st;
+            if ((st = t->put(tt.grec, grec)) != DAAC_OK) return st;
+            if ((st = t->put(tt.sopos, d.sopos)) != DAAC_OK) return st;
+            d.ssum = reinterpret_cast<const uint2 *>(ssum);
+            d.grec = reinterpret_cast<const uint4 *>(grec);
+            d.outputs = d_outputs;
+            d.C = tt.C; d.NA = tt.NA; d.NB = tt.NB; d.N = tt.N;
+            auto pad16 = [](uint32_t x) { return (x + 15u) & ~15u; };
+            d.off_bcmap = pad16(tt.NA * tt.C * (tt.row32 ? 4u : 2u));
+            d.off_bfail = d.off_bcmap + pad16((tt.NB - tt.NA) * 4u);
+            d.off_ssum = d.off_bfail + pad16((tt.NB - tt.NA) * 4u);
+            d.off_cls = d.off_ssum + pad16(tt.NA * 8u);
+            d.lds_bytes = std::max<uint32_t>(d.off_cls + 256u, 1024u);
+            d.row32 = tt.row32;
+            d.root_flag = tt.root_flag;
+            t->tier_ok = true;
+            // keep the sizes for daac_pma_info
+            tt.rows16.clear(); tt.rows32.clear(); tt.bcmap.clear(); tt.bfail.clear(); tt.grec.clear(); tt.ssum.clear(); tt.sopos.clear(); tt.old_of_new.clear();
+            t->tier_host_meta = tt;
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipSetDevice(prev));
+    *out = t.get();
+    pma->dev[device] = std::move(t);
+    return DAAC_OK;
+}
+
+static daac_status get_tables(daac_pma *pma, DeviceTables **out) {
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    std::lock_guard<std::mutex> g(pma->mu);
+    return upload_locked(pma, device, out);
+}
+
+// ---------------------------------------------------------------------------------- scan driver
+namespace {
+
+struct Plan {
+    bool tier;
+    uint32_t blocks, threads;
+    ScanArgs a;
+};
+
+daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int engine, uint64_t begin, uint64_t end, Plan &pl,
+                      bool &heads) {
+    const HostPma &h = pma->host;
+    if (mode == DAAC_FIND_OVERLAPPING || mode == DAAC_FIND_OVERLAPPING_NO_SUFFIX || mode == DAAC_FIND) {
+        if (!h.is_standard()) { set_error("Error: match_kind must be standard."); return DAAC_ERR_MATCH_KIND; }
+    } else if (mode == DAAC_LEFTMOST_FIND) {
+        if (h.is_standard()) { set_error("Error: match_kind must be leftmost."); return DAAC_ERR_MATCH_KIND; }
+    } else {
+        set_error("unknown scan mode");
+        return DAAC_ERR_INVALID_ARGUMENT;
+    }
+    if (mode == DAAC_FIND || mode == DAAC_LEFTMOST_FIND) {
+        set_error("find_iter / leftmost_find_iter are not on the device yet");
+        return DAAC_ERR_UNSUPPORTED;
+    }
+    heads = mode == DAAC_FIND_OVERLAPPING_NO_SUFFIX;
+    if (engine == DAAC_ENGINE_TIERED && !t->tier_ok) {
+        set_error("TIERED engine not available for this automaton (more than 31 distinct pattern bytes, or not standard)");
+        return DAAC_ERR_UNSUPPORTED;
+    }
+    pl.tier = engine == DAAC_ENGINE_TIERED || (engine == DAAC_ENGINE_AUTO && t->tier_ok);
+    const uint32_t lmax = h.max_pattern_len();
+    const uint32_t halo = lmax > 0 ? lmax - 1 : 0;
+    uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
+    threads = std::min(1024u, std::max(64u, threads & ~63u));
+    uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
+    const uint32_t lds = pl.tier ? t->tier.lds_bytes : 4096u;
+    if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / std::max(lds, 1u)));
+    const uint64_t lanes = static_cast<uint64_t>(t->num_cu) * bpc * threads;
+    const uint64_t len = end - begin;
+    uint64_t S = static_cast<uint64_t>(g_opt.seg_bytes.load());
+    if (S == 0) {
+        S = (len + lanes - 1) / lanes;
+        const uint64_t min_seg = std::max<uint64_t>(256, 16ull * halo);
+        S = std::max(S, min_seg);
+    }
+    S = (std::max<uint64_t>(S, 16) + 15) & ~15ull;
+    const uint64_t nseg = len ? (len + S - 1) / S : 0;
+    pl.threads = threads;
+    pl.blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (nseg + threads - 1) / threads)));
+    pl.a = ScanArgs{};
+    pl.a.begin = begin;
+    pl.a.len = end;
+    pl.a.seg_bytes = S;
+    pl.a.nseg = nseg;
+    pl.a.halo = halo;
+    return DAAC_OK;
+}
+
+hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, hipStream_t s) {
+    return pl.tier ? launch_tier_scan(t->tier, pl.a, kmode, heads, pl.blocks, pl.threads, s)
+                   : launch_darray_scan(t->da, pl.a, kmode, heads, pl.blocks, pl.threads, s);
+}
+
+// Scans [begin, end) of a haystack whose byte 0 is at `dev_hay` (device pointer; only bytes
+// >= begin - halo are dereferenced) and returns the matches with end in (begin, end] — plus
+// ROOT's list at end = 0 when begin == 0 — in reference order.
+daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int engine, const uint8_t *dev_hay, uint64_t begin,
+                                   uint64_t end, hipStream_t stream, std::vector<daac_match> &out) {
+    Plan pl;
+    bool heads = false;
+    daac_status st = make_plan(pma, t, mode, engine, begin, end, pl, heads);
+    if (st != DAAC_OK) return st;
+    out.clear();
+    // an empty range still has to report ROOT's list at end = 0: run one (empty) segment
+    if (pl.a.nseg == 0) { if (begin != 0) return DAAC_OK; pl.a.nseg = 1; }
+    pl.a.hay = dev_hay;
+    unsigned long long *d_counts = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), (pl.a.nseg + 1) * sizeof(unsigned long long)));
+    std::unique_ptr<void, void (*)(void *)> g1(d_counts, [](void *p) { (void)hipFree(p); });
+    pl.a.seg_counts = d_counts;
+    pl.a.result = d_counts + pl.a.nseg;
+    HIP_TRY(launch(t, pl, 1, heads, stream));
+    HIP_TRY(launch_exclusive_scan(d_counts, pl.a.nseg, d_counts + pl.a.nseg, stream));
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_counts + pl.a.nseg, sizeof(total), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (total == 0) return DAAC_OK;
+    if (total * sizeof(daac_match) > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+        set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
+        return DAAC_ERR_AUTOMATON_SCALE;
+    }
+    daac_match *d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), total * sizeof(daac_match)));
+    std::unique_ptr<void, void (*)(void *)> g2(d_out, [](void *p) { (void)hipFree(p); });
+    pl.a.out = d_out;
+    HIP_TRY(launch(t, pl, 2, heads, stream));
+    out.resize(total);
+    HIP_TRY(hipMemcpyAsync(out.data(), d_out, total * sizeof(daac_match), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return DAAC_OK;
+}
+
+// Host haystack window -> device buffer holding bytes [copy_from, end); returns the pointer that
+// byte 0 of the haystack would have.
+daac_status stage_window(const uint8_t *host_hay, uint64_t copy_from, uint64_t end, hipStream_t stream, void **dbuf,
+                         const uint8_t **virt_base) {
+    const uint64_t n = end - copy_from;
+    const uint64_t skew = copy_from & 15;  // keep the haystack's 16-byte phase for the vector loop
+    HIP_TRY(hipMalloc(dbuf, n + skew + 32));
+    if (n) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(*dbuf) + skew, host_hay + copy_from, n, hipMemcpyHostToDevice, stream));
+    *virt_base = static_cast<const uint8_t *>(*dbuf) + skew - copy_from;
+    return DAAC_OK;
+}
+
+}  // namespace
+
+// ============================================================================== exported C ABI
+extern "C" {
+
+const char *daac_last_error(void) { return last_error_cstr(); }
+void daac_free(void *p) { std::free(p); }
+
+daac_status daac_bytewise_from_serialized(const uint8_t *blob, size_t len, daac_pma **out, size_t *consumed) {
+    if (!blob || !out) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    std::unique_ptr<daac_pma> p(new daac_pma);
+    const daac_status st = HostPma::deserialize(blob, len, p->host, consumed);
+    if (st != DAAC_OK) return st;
+    *out = p.release();
+    return DAAC_OK;
+}
+
+daac_status daac_bytewise_from_parts(const uint32_t *states, size_t n_states, const uint32_t *lstates, const uint32_t *fails,
+                                     size_t n_lstates, const uint32_t *outputs, size_t n_outputs, uint8_t match_kind,
+                                     uint32_t num_states, daac_pma **out) {
+    if (!out || match_kind > 2) { set_error("bad argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    std::unique_ptr<daac_pma> p(new daac_pma);
+    HostPma &h = p->host;
+    h.match_kind = match_kind;
+    h.num_states = num_states;
+    h.states.resize(n_states);
+    if (n_states) std::memcpy(h.states.data(), states, n_states * sizeof(StateRec));
+    h.lstates.resize(n_lstates);
+    h.fails.resize(n_lstates);
+    if (n_lstates) {
+        std::memcpy(h.lstates.data(), lstates, n_lstates * sizeof(LStateRec));
+        std::memcpy(h.fails.data(), fails, n_lstates * sizeof(uint32_t));
+    }
+    h.outputs.resize(n_outputs);
+    if (n_outputs) std::memcpy(h.outputs.data(), outputs, n_outputs * sizeof(OutputRec));
+    if (h.is_standard()) h.build_root_table();
+    const daac_status st = h.validate();
+    if (st != DAAC_OK) return st;
+    *out = p.release();
+    return DAAC_OK;
+}
+
+daac_status daac_bytewise_build(const uint8_t *blob, const uint64_t *offsets, const uint32_t *values, size_t n, uint8_t match_kind,
+                                uint32_t num_free_blocks, daac_pma **out) {
+    if (!out || (n && (!blob || !offsets))) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    try {
+        std::unique_ptr<daac_pma> p(new daac_pma);
+        const daac_status st = build_bytewise(blob, offsets, values, n, match_kind, num_free_blocks, p->host);
+        if (st != DAAC_OK) return st;
+        *out = p.release();
+        return DAAC_OK;
+    } catch (const std::bad_alloc &) {
+        set_error("out of memory while building the automaton");
+        return DAAC_ERR_AUTOMATON_SCALE;
+    }
+}
+
+daac_status daac_pma_serialize(const daac_pma *pma, uint8_t **buf, size_t *len) {
+    if (!pma || !buf || !len) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    std::vector<uint8_t> v;
+    pma->host.serialize(v);
+    uint8_t *b = static_cast<uint8_t *>(std::malloc(v.size() ? v.size() : 1));
+    if (!b) { set_error("out of memory"); return DAAC_ERR_AUTOMATON_SCALE; }
+    std::memcpy(b, v.data(), v.size());
+    *buf = b;
+    *len = v.size();
+    return DAAC_OK;
+}
+
+daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
+    if (!pma || !info) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    std::memset(info, 0, sizeof(*info));
+    const HostPma &h = pma->host;
+    info->match_kind = h.match_kind;
+    info->num_states = h.num_states;
+    info->states_len = h.states_len();
+    info->outputs_len = h.outputs.size();
+    info->heap_bytes = h.heap_bytes();
+    info->max_pattern_len = h.max_pattern_len();
+    std::lock_guard<std::mutex> g(const_cast<daac_pma *>(pma)->mu);
+    if (!pma->dev.empty()) {
+        const DeviceTables *t = pma->dev.begin()->second.get();
+        info->tiered_available = t->tier_ok;
+        if (t->tier_ok) {
+            info->num_classes = t->tier.C;
+            info->tier_dense_states = t->tier.NA;
+            info->tier_lds_states = t->tier.NB;
+            info->tier_lds_bytes = t->tier.lds_bytes;
+        }
+    }
+    return DAAC_OK;
+}
+
+void daac_pma_free(daac_pma *pma) { delete pma; }
+
+daac_status daac_pma_upload(daac_pma *pma, int device) {
+    if (!pma) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    std::lock_guard<std::mutex> g(pma->mu);
+    DeviceTables *t = nullptr;
+    return upload_locked(pma, device, &t);
+}
+
+daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
+                            uint64_t *count, uint64_t *checksum, uint64_t *result_dev) {
+    if (!pma || (len && !hay) || (!result_dev && (!count || !checksum))) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceTables *t = nullptr;
+    daac_status st = get_tables(pma, &t);
+    if (st != DAAC_OK) return st;
+    Plan pl;
+    bool heads = false;
+    if ((st = make_plan(pma, t, mode, engine, 0, len, pl, heads)) != DAAC_OK) return st;
+    if (pl.a.nseg == 0) pl.a.nseg = 1;  // ROOT's list at end = 0
+    void *staged = nullptr;
+    const uint8_t *dev_hay = hay;
+    if (!hay_is_device && len) {
+        if ((st = stage_window(hay, 0, len, stream, &staged, &dev_hay)) != DAAC_OK) return st;
+    }
+    std::unique_ptr<void, void (*)(void *)> g1(staged, [](void *p) { if (p) (void)hipFree(p); });
+    pl.a.hay = dev_hay;
+    unsigned long long *d_res = reinterpret_cast<unsigned long long *>(result_dev);
+    void *own = nullptr;
+    if (!d_res) { HIP_TRY(hipMalloc(&own, 3 * sizeof(unsigned long long))); d_res = static_cast<unsigned long long *>(own); }
+    std::unique_ptr<void, void (*)(void *)> g2(own, [](void *p) { if (p) (void)hipFree(p); });
+    pl.a.result = d_res;
+    HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
+    HIP_TRY(launch(t, pl, 0, heads, stream));
+    if (result_dev && !count) {
+        if (staged) HIP_TRY(hipStreamSynchronize(stream));
+        return DAAC_OK;
+    }
+    unsigned long long r[3];
+    HIP_TRY(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (count) *count = r[0];
+    if (checksum) *checksum = ((r[1] & 0xffffffffull) << 32) | (r[2] & 0xffffffffull);
+    return DAAC_OK;
+}
+
+daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
+                      daac_matches **out) {
+    if (!pma || !out || (len && !hay)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceTables *t = nullptr;
+    daac_status st = get_tables(pma, &t);
+    if (st != DAAC_OK) return st;
+    void *staged = nullptr;
+    const uint8_t *dev_hay = hay;
+    if (!hay_is_device && len) {
+        if ((st = stage_window(hay, 0, len, stream, &staged, &dev_hay)) != DAAC_OK) return st;
+    }
+    std::unique_ptr<void, void (*)(void *)> g1(staged, [](void *p) { if (p) (void)hipFree(p); });
+    std::unique_ptr<daac_matches> m(new daac_matches);
+    if ((st = scan_range_materialize(pma, t, mode, engine, dev_hay, 0, len, stream, m->v)) != DAAC_OK) return st;
+    *out = m.release();
+    return DAAC_OK;
+}
+
+size_t daac_matches_count(const daac_matches *m) { return m ? m->v.size() : 0; }
+const daac_match *daac_matches_data(const daac_matches *m) { return m && !m->v.empty() ? m->v.data() : nullptr; }
+void daac_matches_free(daac_matches *m) { delete m; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ lazy iterator
+struct daac_iter {
+    daac_pma *pma;
+    int mode, engine;
+    const uint8_t *hay;
+    uint64_t len;
+    bool hay_is_device;
+    hipStream_t stream;
+    uint64_t next_begin = 0;   // first byte of the next window
+    bool started = false, done = false;
+    std::vector<daac_match> buf;
+    size_t pos = 0;
+};
+
+extern "C" {
+
+daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream,
+                           daac_iter **out) {
+    if (!pma || !out || (len && !hay)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    DeviceTables *t = nullptr;
+    daac_status st = get_tables(pma, &t);
+    if (st != DAAC_OK) return st;
+    Plan pl;
+    bool heads;
+    if ((st = make_plan(pma, t, mode, engine, 0, len, pl, heads)) != DAAC_OK) return st;  // kind / mode checks up front
+    daac_iter *it = new daac_iter;
+    it->pma = pma; it->mode = mode; it->engine = engine; it->hay = hay; it->len = len;
+    it->hay_is_device = hay_is_device != 0;
+    it->stream = static_cast<hipStream_t>(stream);
+    *out = it;
+    return DAAC_OK;
+}
+
+int daac_iter_next(daac_iter *it, daac_match *m) {
+    if (!it || !m) return -DAAC_ERR_INVALID_ARGUMENT;
+    for (;;) {
+        if (it->pos < it->buf.size()) { *m = it->buf[it->pos++]; return 1; }
+        if (it->done) return 0;
+        DeviceTables *t = nullptr;
+        daac_status st = get_tables(it->pma, &t);
+        if (st != DAAC_OK) return -st;
+        const uint64_t window = std::max<uint64_t>(4096, static_cast<uint64_t>(g_opt.iter_window.load()));
+        const uint64_t begin = it->next_begin;
+        const uint64_t end = std::min<uint64_t>(it->len, begin + window);
+        const uint32_t lmax = it->pma->host.max_pattern_len();
+        const uint64_t halo = lmax ? lmax - 1 : 0;
+        void *staged = nullptr;
+        const uint8_t *dev_hay = it->hay;
+        if (!it->hay_is_device && end > 0) {
+            const uint64_t from = begin > halo ? begin - halo : 0;
+            if ((st = stage_window(it->hay, from, end, it->stream, &staged, &dev_hay)) != DAAC_OK) return -st;
+        }
+        it->buf.clear();
+        it->pos = 0;
+        st = scan_range_materialize(it->pma, t, it->mode, it->engine, dev_hay, begin, end, it->stream, it->buf);
+        if (staged) (void)hipFree(staged);
+        if (st != DAAC_OK) return -st;
+        it->next_begin = end;
+        if (end >= it->len) it->done = true;
+    }
+}
+
+void daac_iter_close(daac_iter *it) { delete it; }
+
+daac_status daac_set_option(const char *name, int64_t value) {
+    if (!name) { set_error("null option name"); return DAAC_ERR_INVALID_ARGUMENT; }
+    const std::string n(name);
+    if (n == "seg_bytes") g_opt.seg_bytes = value;
+    else if (n == "lds_budget") g_opt.lds_budget = value;
+    else if (n == "dense_depth") g_opt.dense_depth = value;
+    else if (n == "rows_share_pct") g_opt.rows_share_pct = value;
+    else if (n == "blocks_per_cu") g_opt.blocks_per_cu = value;
+    else if (n == "threads") g_opt.threads = value;
+    else if (n == "iter_window") g_opt.iter_window = value;
+    else if (n == "max_result_bytes") g_opt.max_result_bytes = value;
+    else { set_error("unknown option: " + n); return DAAC_ERR_INVALID_ARGUMENT; }
+    return DAAC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Kernel argument structs shared by the HIP kernels and the host driver.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/daachorse_amd.h"
+
+namespace daac {
+
+// TIERED engine tables (see repack.hpp).  All pointers are device pointers; the first five are
+// staged into LDS by every workgroup at kernel start, at the byte offsets given below.
+struct TierDev {
+    const void *rows;        // NA x C entries, u16 (id | flag << 15) or u32 (id | flag << 31)
+    const uint32_t *bcmap;   // NB - NA child bitmaps
+    const uint32_t *bfail;   // NB - NA failure links (new ids)
+    const uint2 *ssum;       // N x {output count, sum of h32}; [0, NA) also staged in LDS
+    const uint8_t *cls;      // 256 byte -> class
+    const uint4 *grec;       // N x {cmap, omap, first_child, fail}
+    const uint32_t *sopos;   // N output_pos per state (1-based, 0 = none)
+    const uint32_t *outputs; // n_outputs x {value, length, parent}
+    uint32_t C, NA, NB, N;
+    uint32_t off_bcmap, off_bfail, off_ssum, off_cls, lds_bytes;  // rows are at offset 0
+    uint32_t row32, root_flag;
+};
+
+// DARRAY engine tables: the reference's double array, hot/cold split.
+struct DArrayDev {
+    const uint2 *hot;        // {base, opos_ch} per slot
+    const uint32_t *fail;    // per slot
+    const uint4 *root;       // 256 x {child, child.base, child.opos_ch, 0}, staged into LDS
+    const uint2 *osum;       // per output record {chain count, chain sum of h32}
+    const uint32_t *outputs; // n_outputs x {value, length, parent}
+    uint32_t n, root_flag;
+};
+
+struct ScanArgs {
+    const uint8_t *hay;  // address of haystack byte 0 (only bytes >= begin - halo are read)
+    uint64_t begin;      // scan range is [begin, len): matches with end in (begin, len] are reported
+    uint64_t len;
+    uint64_t seg_bytes;  // bytes per lane-segment
+    uint64_t nseg;
+    uint32_t halo;       // max pattern length - 1
+    unsigned long long *result;      // MODE 0: {count, S1, S2}
+    unsigned long long *seg_counts;  // MODE 1 out / MODE 2 in (exclusive offsets)
+    daac_match *out;                 // MODE 2
+};
+
+hipError_t launch_tier_scan(const TierDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,
+                            hipStream_t stream);
+hipError_t launch_darray_scan(const DArrayDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,
+                              hipStream_t stream);
+hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned long long *total, hipStream_t stream);
+
+}  // namespace daac

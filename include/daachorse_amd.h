@@ -1,0 +1,155 @@
+/*
+ * daachorse_amd.h — C ABI of the MI355X-native daachorse scan path.
+ *
+ * This is the drop-in boundary for ONE path of the daachorse crate (v4.0.0): the bytewise
+ * double-array Aho-Corasick scan (find_overlapping_iter / find_iter / leftmost_find_iter and
+ * friends over DoubleArrayAhoCorasick<u32>).  The reference has no FFI of its own; every entry
+ * point below names the Rust item (file:line under the reference tree) whose work it takes
+ * over, and INTEGRATION.md shows the `extern "C"` block a crate maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary, no torch/HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = the default stream);
+ *   - every call returns a daac_status; daac_last_error() gives a thread-local message;
+ *   - automata are immutable after creation: any number of host threads may scan the same
+ *     handle concurrently (each call brings its own stream);
+ *   - V = u32 only (pattern values are 32-bit), positions are 64-bit.
+ *   - there is NO CPU scan backend in this library: a scan without a usable gfx950 device
+ *     returns DAAC_ERR_DEVICE.
+ */
+#ifndef DAACHORSE_AMD_H
+#define DAACHORSE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/errors.rs:10-22 (first four), plus the panics / extras of this boundary */
+typedef enum {
+    DAAC_OK = 0,
+    DAAC_ERR_INVALID_ARGUMENT = 1,  /* DaachorseError::InvalidArgument   */
+    DAAC_ERR_AUTOMATON_SCALE = 2,   /* DaachorseError::AutomatonScale    */
+    DAAC_ERR_INVALID_CONVERSION = 3,/* DaachorseError::InvalidConversion */
+    DAAC_ERR_INVALID_AUTOMATON = 4, /* DaachorseError::InvalidAutomaton  */
+    DAAC_ERR_MATCH_KIND = 5,        /* the reference PANICS here: bytewise.rs:194-197, 299-302, 551-554 */
+    DAAC_ERR_UNSUPPORTED = 6,       /* e.g. leftmost kinds with an empty pattern (SURVEY §8a note D) */
+    DAAC_ERR_DEVICE = 7             /* HIP error / no gfx950 device */
+} daac_status;
+
+/* src/lib.rs:324-346 (repr(u8)) */
+typedef enum { DAAC_STANDARD = 0, DAAC_LEFTMOST_LONGEST = 1, DAAC_LEFTMOST_FIRST = 2 } daac_match_kind;
+
+/* Which iterator of src/bytewise/iter.rs a scan reproduces */
+typedef enum {
+    DAAC_FIND_OVERLAPPING = 0,           /* FindOverlappingIterator          iter.rs:117-177 */
+    DAAC_FIND = 1,                       /* FindIterator                     iter.rs:44-114  */
+    DAAC_LEFTMOST_FIND = 2,              /* LeftmostFindIterator             iter.rs:247-341 */
+    DAAC_FIND_OVERLAPPING_NO_SUFFIX = 3  /* FindOverlappingNoSuffixIterator  iter.rs:180-244 */
+} daac_scan_mode;
+
+/* Which device engine to use.  AUTO picks TIERED when the automaton qualifies. */
+typedef enum {
+    DAAC_ENGINE_AUTO = 0,
+    DAAC_ENGINE_TIERED = 1, /* re-packed bitmap-rank trie, top levels dense in LDS */
+    DAAC_ENGINE_DARRAY = 2  /* the reference's own double array, hot/cold split   */
+} daac_engine;
+
+/* Match<u32> (src/lib.rs:286-320): start() = end - length, end(), value() */
+typedef struct {
+    uint64_t start;
+    uint64_t end;
+    uint32_t value;
+    uint32_t _pad;
+} daac_match;
+
+typedef struct {
+    uint8_t match_kind;       /* DoubleArrayAhoCorasick::match_kind()  bytewise.rs:735-737 */
+    uint32_t num_states;      /* ::num_states()                        bytewise.rs:785-787 */
+    uint64_t states_len;      /* double-array elements (multiple of 256) */
+    uint64_t outputs_len;
+    uint64_t heap_bytes;      /* ::heap_bytes()                        bytewise.rs:764-770 */
+    uint32_t max_pattern_len; /* max Output::length — the halo is this minus one */
+    /* device-side re-pack (valid after upload) */
+    uint32_t num_classes;     /* byte classes incl. class 0 = "byte occurs in no pattern" */
+    uint32_t tier_dense_states;  /* states with a dense, fail-resolved LDS row */
+    uint32_t tier_lds_states;    /* + states whose child bitmap lives in LDS */
+    uint32_t tier_lds_bytes;     /* LDS bytes of the automaton tables per workgroup */
+    uint8_t tiered_available;    /* 0 if only the DARRAY engine can run this automaton */
+} daac_info;
+
+typedef struct daac_pma daac_pma;         /* an automaton (host copy + per-device re-pack) */
+typedef struct daac_matches daac_matches; /* result of an eager scan */
+typedef struct daac_iter daac_iter;       /* lazy iterator façade */
+
+const char *daac_last_error(void);
+void daac_free(void *p);
+
+/* ---- construction / (de)serialisation ------------------------------------------------------ */
+
+/* DoubleArrayAhoCorasick::deserialize (bytewise.rs:868-964): parses the crate's serialize()
+ * blob for V = u32 with the same validation, rebuilds root_table (bytewise.rs:1040-1056).
+ * The caller keeps `blob`. */
+daac_status daac_bytewise_from_serialized(const uint8_t *blob, size_t len, daac_pma **out, size_t *consumed);
+
+/* Takes the automaton's arrays directly (what a Rust shim has in hand without serialising):
+ * `states` = n_states x {base, fail, opos_ch} (State<u32>, bytewise.rs:1131-1137) or, for leftmost
+ * kinds, `lstates` = n x {base, opos_ch} + `fails` (bytewise.rs:61-63); `outputs` = n_outputs x
+ * {value, length, parent} (lib.rs:213-218).  Same validation as deserialize. */
+daac_status daac_bytewise_from_parts(const uint32_t *states, size_t n_states,
+                                     const uint32_t *lstates, const uint32_t *fails, size_t n_lstates,
+                                     const uint32_t *outputs, size_t n_outputs,
+                                     uint8_t match_kind, uint32_t num_states, daac_pma **out);
+
+/* DoubleArrayAhoCorasickBuilder::build / build_with_values (bytewise/builder.rs:152-244) on the
+ * host CPU.  Patterns are one blob + n+1 offsets; values == NULL means value = index. */
+daac_status daac_bytewise_build(const uint8_t *blob, const uint64_t *offsets, const uint32_t *values,
+                                size_t n, uint8_t match_kind, uint32_t num_free_blocks, daac_pma **out);
+
+/* DoubleArrayAhoCorasick::serialize (bytewise.rs:801-820); free the buffer with daac_free. */
+daac_status daac_pma_serialize(const daac_pma *pma, uint8_t **buf, size_t *len);
+daac_status daac_pma_info(const daac_pma *pma, daac_info *info);
+void daac_pma_free(daac_pma *pma);
+
+/* Re-packs the automaton for the GPU and copies it to `device` (idempotent).  Scans upload
+ * lazily to the current device if this was not called. */
+daac_status daac_pma_upload(daac_pma *pma, int device);
+
+/* ---- scans ----------------------------------------------------------------------------------- */
+
+/* Eager scan of one haystack; replaces driving the iterator to exhaustion
+ * (`pma.find_overlapping_iter(h).collect()` etc.).  `hay` is a host pointer, or a device pointer
+ * if hay_is_device != 0.  Matches come back in the reference's order. */
+daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len,
+                      int hay_is_device, void *stream, daac_matches **out);
+size_t daac_matches_count(const daac_matches *m);
+const daac_match *daac_matches_data(const daac_matches *m); /* host memory, owned by `m` */
+void daac_matches_free(daac_matches *m);
+
+/* Count + order-independent checksum of the match stream without materialising it
+ * (`.count()` on the iterator).  checksum = (S1 << 32) | S2 with, over all matches,
+ *   h = low32(mix64(value << 32 | length)),  S1 = sum h,  S2 = sum h * low32(end)   (mod 2^32).
+ * Asynchronous on `stream` when `result_dev` != NULL: the 3 x u64 {count, S1, S2} are left in
+ * device memory there and count/checksum may be NULL; otherwise the call synchronises. */
+daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len,
+                            int hay_is_device, void *stream, uint64_t *count, uint64_t *checksum,
+                            uint64_t *result_dev);
+
+/* Lazy façade = Iterator::next() (iter.rs:58, 133, 195, 272): scans the haystack window by
+ * window on the device and hands tuples out one at a time.  The haystack must stay alive until
+ * close (the Rust iterator owns/borrows `P` the same way). */
+daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len,
+                           int hay_is_device, void *stream, daac_iter **out);
+int daac_iter_next(daac_iter *it, daac_match *m); /* 1 = Some(m), 0 = None, <0 = -daac_status */
+void daac_iter_close(daac_iter *it);
+
+/* ---- tuning knobs (optional) ----------------------------------------------------------------- */
+/* name/value pairs for experiments: "seg_bytes", "lds_budget", "dense_depth", "blocks_per_cu" ... */
+daac_status daac_set_option(const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

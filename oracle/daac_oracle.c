@@ -886,42 +886,47 @@ int orc_find_overlapping_stepper(const orc_pma *p, const uint8_t *hay, size_t le
 }
 
 /* ================================================================ count + checksum
- * checksum(M) = sum over matches of  H(value,length) * G(end)   (mod 2^64)
- *   mix64 = SplitMix64 finaliser,  H = mix64(value<<32 | length),  G = mix64(end + K) | 1.
- * Order independent; the per-match term factorises into a per-output-record constant and a
- * per-position factor, so a scanner can fold a whole output list with one multiply
- * (the HIP path does).  This file computes it the slow, obvious way: match by match. */
+ * Over all matches, with h = low32(mix64(value << 32 | length)) (mix64 = SplitMix64 finaliser):
+ *     S1 = sum h            (mod 2^32)
+ *     S2 = sum h * low32(end)   (mod 2^32)
+ *     checksum = (S1 << 32) | S2
+ * Order independent, and linear in per-output-list constants, so a scanner can fold a whole
+ * output list with one multiply-add (the HIP path does).  This file computes it the slow,
+ * obvious way: match by match. */
 static inline uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
     return z ^ (z >> 31);
 }
-static inline uint64_t term(uint32_t value, uint64_t length, uint64_t end) {
-    uint64_t h = mix64(((uint64_t)value << 32) | (uint64_t)(uint32_t)length);
-    uint64_t g = mix64(end + 0x9e3779b97f4a7c15ull) | 1ull;
-    return h * g;
+typedef struct { uint32_t s1, s2; } cksum;
+static inline void ck_add(cksum *k, uint32_t value, uint64_t length, uint64_t end) {
+    uint32_t h = (uint32_t)mix64(((uint64_t)value << 32) | (uint64_t)(uint32_t)length);
+    k->s1 += h;
+    k->s2 += h * (uint32_t)end;
 }
+static inline uint64_t ck_fin(cksum k) { return ((uint64_t)k.s1 << 32) | k.s2; }
 uint64_t orc_matches_checksum(const orc_match *m, size_t n) {
-    uint64_t s = 0;
-    for (size_t i = 0; i < n; i++) s += term(m[i].value, m[i].end - m[i].start, m[i].end);
-    return s;
+    cksum k = {0, 0};
+    for (size_t i = 0; i < n; i++) ck_add(&k, m[i].value, m[i].end - m[i].start, m[i].end);
+    return ck_fin(k);
 }
 
 /* Scans hay[from..to) with the literal iterator, counting only matches with end > lo.
  * `from` is at most Lmax-1 bytes before `lo` (SURVEY §8a note A). */
 static void count_range(const orc_pma *p, const uint8_t *hay, size_t from, size_t to, size_t lo,
-                        int emit_root, uint64_t *count, uint64_t *sum) {
+                        int emit_root, uint64_t *count, cksum *sum) {
     ovl_it it = {p, hay + from, to - from, 0, ROOT_STATE_IDX, 0,
                  emit_root ? opos_a(p->states[ROOT_STATE_IDX].opos_ch) : 0};
-    uint64_t l, e, c = 0, s = 0; uint32_t val;
+    uint64_t l, e, c = 0; uint32_t val;
+    cksum k = {0, 0};
     while (ovl_next(&it, &l, &e, &val)) {
         uint64_t ge = e + from;
-        if (ge > lo || (emit_root && ge == 0)) { c++; s += term(val, l, ge); }
+        if (ge > lo || (emit_root && ge == 0)) { c++; ck_add(&k, val, l, ge); }
     }
-    *count = c; *sum = s;
+    *count = c; *sum = k;
 }
 
-typedef struct { const orc_pma *p; const uint8_t *hay; size_t from, to, lo; int emit_root; uint64_t count, sum; } cr_job;
+typedef struct { const orc_pma *p; const uint8_t *hay; size_t from, to, lo; int emit_root; uint64_t count; cksum sum; } cr_job;
 static void *cr_thread(void *a) {
     cr_job *j = (cr_job *)a;
     count_range(j->p, j->hay, j->from, j->to, j->lo, j->emit_root, &j->count, &j->sum);
@@ -933,7 +938,9 @@ int orc_overlapping_count(const orc_pma *p, const uint8_t *hay, size_t len, int 
     if (p->match_kind != ORC_STANDARD) return ORC_ERR_MATCH_KIND;
     if (threads < 1) threads = 1;
     if (threads == 1 || len < (size_t)threads * 4096) {
-        count_range(p, hay, 0, len, 0, 1, count, checksum);
+        cksum k;
+        count_range(p, hay, 0, len, 0, 1, count, &k);
+        *checksum = ck_fin(k);
         return ORC_OK;
     }
     uint32_t lmax = orc_max_pattern_len(p);
@@ -948,9 +955,10 @@ int orc_overlapping_count(const orc_pma *p, const uint8_t *hay, size_t len, int 
         jobs[t].to = hi; jobs[t].lo = lo; jobs[t].emit_root = (t == 0);
         pthread_create(&th[t], NULL, cr_thread, &jobs[t]);
     }
-    uint64_t c = 0, s = 0;
-    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); c += jobs[t].count; s += jobs[t].sum; }
+    uint64_t c = 0;
+    cksum k = {0, 0};
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); c += jobs[t].count; k.s1 += jobs[t].sum.s1; k.s2 += jobs[t].sum.s2; }
     free(jobs); free(th);
-    *count = c; *checksum = s;
+    *count = c; *checksum = ck_fin(k);
     return ORC_OK;
 }

@@ -78,7 +78,8 @@ int orc_find_stepper(const orc_pma *p, const uint8_t *hay, size_t len, orc_match
 int orc_find_overlapping_stepper(const orc_pma *p, const uint8_t *hay, size_t len, orc_match **out, size_t *n);
 
 /* Count + order-independent checksum of the find_overlapping_iter stream
- * (the definition of the checksum is in the .c file; the HIP path implements the same one).
+ * (checksum = (S1 << 32) | S2, S1 = sum h, S2 = sum h * low32(end) mod 2^32, h = low32(mix64(value << 32 | length));
+ * the HIP path implements the same definition).
  * `threads` > 1 splits the haystack into contiguous shards with an (Lmax-1)-byte halo. */
 int orc_overlapping_count(const orc_pma *p, const uint8_t *hay, size_t len, int threads,
                           uint64_t *count, uint64_t *checksum);

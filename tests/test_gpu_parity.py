@@ -1,0 +1,213 @@
+"""Parity of the HIP scan path (through the C ABI) with the CPU oracle — runs on the MI355X.
+
+Bit-exact comparison of (start, end, value) tuples in the reference's order; count + checksum on
+larger inputs.  Both device engines (TIERED and DARRAY) are exercised.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import iter_vector_runs
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+import daachorse_amd as da
+from daachorse_amd import Engine, ScanMode, synth
+
+API_MODE = {"find_overlapping_iter": ScanMode.FindOverlapping,
+            "find_overlapping_no_suffix_iter": ScanMode.FindOverlappingNoSuffix}
+ENGINES = [Engine.Tiered, Engine.DArray]
+
+
+def _pma(patterns, values=None, kind="Standard"):
+    o = orc.OraclePma.build(patterns, values=values, kind=kind)
+    p, rest = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    assert rest == b""
+    return o, p
+
+
+def _sev(m):
+    return [(int(x["start"]), int(x["end"]), int(x["value"])) for x in m]
+
+
+def _same(a, b):
+    return len(a) == len(b) and np.array_equal(a["start"], b["start"]) and np.array_equal(a["end"], b["end"]) and \
+        np.array_equal(a["value"], b["value"])
+
+
+@pytest.fixture(autouse=True)
+def _reset_options():
+    yield
+    da.set_option("seg_bytes", 0)
+    da.set_option("iter_window", 64 << 20)
+
+
+def test_golden_vectors_overlapping(vectors):
+    """tests/aho_corasick_crate_test.rs search_standard_overlapping (BASICS + OVERLAPPING) on the GPU."""
+    n = 0
+    for runner, case in iter_vector_runs(vectors):
+        if runner["api"] != "find_overlapping_iter":
+            continue
+        _, p = _pma(case["patterns"])
+        want = [tuple(t) for t in case["matches"]]
+        for eng in ENGINES:
+            got = p.scan(ScanMode.FindOverlapping, case["haystack"], engine=eng)
+            assert [(int(m["value"]), int(m["start"]), int(m["end"])) for m in got] == want, (case["name"], eng)
+            cnt, cs = p.scan_count(ScanMode.FindOverlapping, case["haystack"], engine=eng)
+            assert cnt == len(want) and cs == orc.matches_checksum(got), (case["name"], eng)
+        lazy = [(m.value(), m.start(), m.end()) for m in p.find_overlapping_iter(case["haystack"])]
+        assert lazy == want, case["name"]
+        n += 1
+    assert n == 57
+
+
+def test_known_answers(pins):
+    for ka in pins["known_answers"]:
+        if ka["api"] not in API_MODE:
+            continue
+        if "patvals" in ka:
+            pats, vals = [p for p, _ in ka["patvals"]], [v for _, v in ka["patvals"]]
+        else:
+            pats, vals = ka["patterns"], None
+        _, p = _pma(pats, values=vals)
+        for eng in ENGINES:
+            got = _sev(p.scan(API_MODE[ka["api"]], ka["haystack"], engine=eng))
+            assert got == [tuple(t) for t in ka["matches_sev"]], (ka["cite"], eng)
+
+
+def test_matchkind_mismatch_is_an_error(pins):
+    """The reference panics (tests/matchkind_mismatch_test.rs); the C ABI returns status 5."""
+    for e in pins["matchkind_mismatch"]["must_fail"]:
+        mode = {"find_iter": ScanMode.Find, "find_overlapping_iter": ScanMode.FindOverlapping,
+                "find_overlapping_no_suffix_iter": ScanMode.FindOverlappingNoSuffix,
+                "leftmost_find_iter": ScanMode.LeftmostFind}[e["api"]]
+        _, p = _pma(["a"], kind=e["kind"])
+        with pytest.raises(da.DaachorseError) as ei:
+            p.scan(mode, "")
+        assert ei.value.code == 5
+
+
+def test_empty_pattern_set_never_matches():
+    _, p = _pma([])
+    hay = bytes(itertools.chain.from_iterable((a, b) for a in range(0, 256, 3) for b in range(0, 256, 7)))
+    for eng in ENGINES:
+        assert len(p.scan(ScanMode.FindOverlapping, hay, engine=eng)) == 0
+        assert p.scan_count(ScanMode.FindOverlapping, hay, engine=eng) == (0, 0)
+
+
+@pytest.mark.parametrize("seg_bytes", [16, 48, 0])
+def test_fuzz_small_alphabets(seg_bytes):
+    """Random tiny pattern sets (incl. "", duplicates) over {a,b,c}; 16-byte segments make nearly
+    every match straddle a segment boundary, which is what the halo has to get right."""
+    rng = np.random.default_rng(1234 + seg_bytes)
+    da.set_option("seg_bytes", seg_bytes)
+    for it in range(60):
+        npat = int(rng.integers(1, 7))
+        pats = [bytes(rng.integers(97, 100, size=int(rng.integers(0, 6))).astype(np.uint8)) for _ in range(npat)]
+        hay = rng.integers(97, 100 + (it % 2), size=int(rng.integers(0, 400)), dtype=np.uint8)
+        o, p = _pma(pats)
+        want = o.find_overlapping_iter(hay)
+        want_ns = o.find_overlapping_no_suffix_iter(hay)
+        for eng in ENGINES:
+            got = p.scan(ScanMode.FindOverlapping, hay, engine=eng)
+            assert _same(got, want), (pats, bytes(hay), eng, _sev(got)[:8], _sev(want)[:8])
+            assert p.scan_count(ScanMode.FindOverlapping, hay, engine=eng) == (len(want), orc.matches_checksum(want))
+            got_ns = p.scan(ScanMode.FindOverlappingNoSuffix, hay, engine=eng)
+            assert _same(got_ns, want_ns), (pats, bytes(hay), eng)
+            assert p.scan_count(ScanMode.FindOverlappingNoSuffix, hay, engine=eng) == (len(want_ns), orc.matches_checksum(want_ns))
+
+
+def test_unaligned_and_device_haystacks():
+    import torch
+    rng = np.random.default_rng(5)
+    pats = ["ab", "bca", "c", "abcab", "bb", "cabcabc"]
+    o, p = _pma(pats)
+    base = rng.integers(97, 100, size=70_000, dtype=np.uint8)
+    dev = torch.from_numpy(base).cuda()
+    for off in (0, 1, 7, 15, 16, 33):
+        for n in (0, 1, 15, 16, 17, 4099, 65_536):
+            want = o.find_overlapping_iter(base[off:off + n])
+            for eng in ENGINES:
+                got = p.scan(ScanMode.FindOverlapping, dev[off:off + n], engine=eng)
+                assert _same(got, want), (off, n, eng)
+                got_h = p.scan(ScanMode.FindOverlapping, base[off:off + n], engine=eng)
+                assert _same(got_h, want), (off, n, eng)
+
+
+def test_lazy_iterator_windows():
+    rng = np.random.default_rng(9)
+    pats = ["abra", "cad", "abracadabra", "a", "ra"]
+    o, p = _pma(pats)
+    hay = rng.choice(np.frombuffer(b"abrcd", dtype=np.uint8), size=50_000)
+    want = _sev(o.find_overlapping_iter(hay))
+    da.set_option("iter_window", 4096)
+    got = [(m.start(), m.end(), m.value()) for m in p.find_overlapping_iter(hay)]
+    assert got == want
+
+
+def test_byte_alphabet_falls_back_to_darray():
+    """> 31 distinct pattern bytes: TIERED is unavailable, AUTO must still be exact."""
+    rng = np.random.default_rng(11)
+    pats = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 9))).astype(np.uint8)) for _ in range(300)]
+    o, p = _pma(pats)
+    hay = rng.integers(0, 256, size=200_000, dtype=np.uint8)
+    hay[1000:1000 + len(pats[0])] = np.frombuffer(pats[0], dtype=np.uint8)
+    want = o.find_overlapping_iter(hay)
+    assert _same(p.scan(ScanMode.FindOverlapping, hay), want)
+    with pytest.raises(da.DaachorseError) as ei:
+        p.scan(ScanMode.FindOverlapping, hay, engine=Engine.Tiered)
+    assert ei.value.code == 6
+
+
+def test_device_generators_match_numpy():
+    import torch
+    t = torch.empty(100_003, dtype=torch.uint8, device="cuda")
+    synth.device_uniform(t, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE, offset=12345)
+    assert np.array_equal(t.cpu().numpy(), synth.uniform_haystack(100_003, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE, offset=12345))
+    words = synth.patterns_cfg3(500)
+    synth.device_wordsoup(t, synth.SEEDS["cfg3_dense"], words, 20, offset=777)
+    assert np.array_equal(t.cpu().numpy(), synth.wordsoup_haystack(100_003, synth.SEEDS["cfg3_dense"], words, 20, offset=777))
+
+
+def test_cfg2_1000_patterns():
+    """BASELINE configs[1] automaton on 8 MiB: sparse random-ASCII and dense pattern soup."""
+    import torch
+    pats = synth.patterns_cfg2()
+    o, p = _pma(pats)
+    n = 8 << 20
+    sparse = synth.uniform_haystack(n, synth.SEEDS["cfg2_hay"], synth.ALPHA_PRINTABLE)
+    dense = synth.wordsoup_haystack(n, synth.SEEDS["cfg2_dense"], pats, 13, noise_256=0)
+    for hay in (sparse, dense):
+        want = o.find_overlapping_iter(hay)
+        dev = torch.from_numpy(hay).cuda()
+        for eng in ENGINES:
+            got = p.scan(ScanMode.FindOverlapping, dev, engine=eng)
+            assert _same(got, want), eng
+            assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == (len(want), orc.matches_checksum(want))
+
+
+def test_cfg3_100k_patterns():
+    """BASELINE configs[2] automaton (100k words): full tuples on 4 MiB, count + checksum on 64 MiB."""
+    import torch
+    pats = synth.patterns_cfg3()
+    o, p = _pma(pats)
+    info = p.upload().info()
+    assert info.tiered_available
+    small = synth.uniform_haystack(4 << 20, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+    want = o.find_overlapping_iter(small)
+    for eng in ENGINES:
+        got = p.scan(ScanMode.FindOverlapping, small, engine=eng)
+        assert _same(got, want), eng
+    n = 64 << 20
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+    host = dev.cpu().numpy()
+    want_cc = o.overlapping_count(host, threads=8)
+    for eng in ENGINES:
+        assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want_cc, eng
+    synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20)
+    want_cc = o.overlapping_count(dev.cpu().numpy(), threads=8)
+    for eng in ENGINES:
+        assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want_cc, eng

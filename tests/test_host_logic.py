@@ -1,0 +1,141 @@
+"""CPU-side tests of the product's host logic (no GPU): C-ABI surface, blob handling, re-pack."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import oracle as orc
+
+import daachorse_amd as da
+from daachorse_amd import _ffi, synth
+
+
+def test_abi_exports_every_declared_symbol():
+    names = set()
+    for hdr in ("daachorse_amd.h", "daac_synth.h"):
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        names |= set(re.findall(r"\b(daac_[a-z_0-9]+)\s*\(", src))
+    assert len(names) >= 20
+    lib = C.CDLL(_ffi._build.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported"
+
+
+def test_no_oracle_in_product():
+    """The product path must never route through oracle/ (or any CPU scan fallback)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "daachorse_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower() or f == "__init__.py" and False, f"{f} mentions the oracle"
+
+
+def test_blob_roundtrip_and_validation(pins):
+    for e in pins["serialize_roundtrip"]:
+        blob = orc.OraclePma.build(e["patterns"], kind=e["kind"]).serialize()
+        pma, rest = da.DoubleArrayAhoCorasick.deserialize(blob + b"tail")
+        assert rest == b"tail"
+        assert pma.serialize() == blob
+    with pytest.raises(da.DaachorseError) as ei:
+        da.DoubleArrayAhoCorasick.deserialize(bytes(pins["invalid_blob"]["blob"]))
+    assert ei.value.code == 4
+    # truncated / corrupted blobs are rejected, never crash
+    blob = orc.OraclePma.build(["abba", "baaba", "ababa"]).serialize()
+    for cut in (0, 3, 4, 17, len(blob) - 1):
+        with pytest.raises(da.DaachorseError):
+            da.DoubleArrayAhoCorasick.deserialize(blob[:cut])
+    bad = bytearray(blob)
+    bad[4:8] = (0x7FFFFFFF).to_bytes(4, "little")  # base of state 0 out of range
+    with pytest.raises(da.DaachorseError):
+        da.DoubleArrayAhoCorasick.deserialize(bytes(bad))
+
+
+def test_info_matches_reference_pins(pins):
+    for e in pins["heap_bytes"]:
+        pma, _ = da.DoubleArrayAhoCorasick.deserialize(orc.OraclePma.build(e["patterns"]).serialize())
+        assert pma.heap_bytes() == e["heap_bytes"]
+    for e in pins["num_states"]:
+        pma, _ = da.DoubleArrayAhoCorasick.deserialize(orc.OraclePma.build(e["patterns"]).serialize())
+        assert pma.num_states() == e["num_states"]
+
+
+def test_from_parts_equals_blob():
+    o = orc.OraclePma.build(["he", "she", "his", "hers"])
+    a = da.DoubleArrayAhoCorasick.from_parts(0, o.num_states, o.outputs(), states=o.states())
+    assert a.serialize() == o.serialize()
+    o = orc.OraclePma.build(["he", "she", "his", "hers"], kind="LeftmostLongest")
+    a = da.DoubleArrayAhoCorasick.from_parts(1, o.num_states, o.outputs(), leftmost_states=o.leftmost_states(), fails=o.fails())
+    assert a.serialize() == o.serialize()
+
+
+@pytest.fixture(scope="module")
+def repack_check(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("native") / "repack_check")
+    csrc = os.path.join(ROOT, "daachorse_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "repack_check.cpp"),
+                           os.path.join(csrc, "pma.cpp"), os.path.join(csrc, "repack.cpp")])
+    return exe
+
+
+def _run_check(exe, tmp_path, patterns, hay, budget, depth=-1):
+    blob = tmp_path / "a.blob"
+    h = tmp_path / "h.bin"
+    blob.write_bytes(orc.OraclePma.build(patterns).serialize())
+    np.asarray(hay, dtype=np.uint8).tofile(h)
+    out = subprocess.check_output([exe, str(blob), str(budget), str(depth), str(h)]).decode()
+    return out
+
+
+def test_repack_tables_follow_reference_delta(repack_check, tmp_path):
+    """Tier tables walked with the kernel's step rule land on the reference's state, byte for byte."""
+    rng = np.random.default_rng(1)
+    # tiny alphabets, deep failure chains, the empty pattern, duplicates
+    cases = [(["a", "ab", "bab", "bc", "bca", "c", "caa"], b"abc"),
+             (["", "a", "aa", "aaa"], b"ab"),
+             (["abcabcabd", "bcabd", "cab", "ab", "ab"], b"abcd"),
+             (synth.patterns_cfg2(200), synth.ALPHA_LOWER)]
+    for pats, alpha in cases:
+        hay = rng.choice(np.frombuffer(alpha, dtype=np.uint8), size=20000)
+        for budget in (1024, 4096, 98304):
+            for depth in (-1, 0, 1):
+                out = _run_check(repack_check, tmp_path, pats, hay, budget, depth)
+                assert out.startswith("OK") or out.startswith("UNAVAILABLE"), out
+    out = _run_check(repack_check, tmp_path, pats, hay, 98304)
+    assert out.startswith("OK")
+    # more than 31 distinct pattern bytes: the tiered engine must decline (DARRAY takes over)
+    wide = [bytes([i, i + 1]) for i in range(40)]
+    assert _run_check(repack_check, tmp_path, wide, hay, 98304).startswith("UNAVAILABLE")
+
+
+def test_repack_cfg3_dictionary(repack_check, tmp_path):
+    pats = synth.patterns_cfg3(20000)
+    hay = synth.uniform_haystack(1 << 18, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+    out = _run_check(repack_check, tmp_path, pats, hay, 98304)
+    assert out.startswith("OK"), out
+
+
+def test_synth_definitions_are_stable():
+    """Seeds and generators are part of the benchmark definition: pin a few bytes/patterns."""
+    h = synth.uniform_haystack(64, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+    assert synth.uniform_haystack(40, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE, offset=13).tobytes() == h[13:53].tobytes()
+    p2 = synth.patterns_cfg2(50)
+    assert len(set(p2)) == 50 and all(4 <= len(p) <= 12 for p in p2)
+    p3 = synth.patterns_cfg3(3000)
+    assert len(set(p3)) == 3000 and all(2 <= len(p) <= 16 for p in p3)
+    ws = synth.wordsoup_haystack(400, synth.SEEDS["cfg3_dense"], p3, 20)
+    assert synth.wordsoup_haystack(100, synth.SEEDS["cfg3_dense"], p3, 20, offset=137).tobytes() == ws[137:237].tobytes()
+
+
+def test_scan_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    pma, _ = da.DoubleArrayAhoCorasick.deserialize(orc.OraclePma.build(["a"]).serialize())
+    with pytest.raises(da.DaachorseError) as ei:
+        pma.scan_count(da.ScanMode.FindOverlapping, "aaa")
+    assert ei.value.code == 7
