@@ -39,6 +39,10 @@ def lib():
         raise ImportError(
             f"{path} is missing: the HIP extension has not been built (run `python -c 'import __graft_entry__ as g; "
             "g.build()'`).  daachorse_amd has no CPU fallback.")
+    # PyTorch-ROCm ships its own libamdhip64; two HIP runtimes in one process cannot both own the
+    # GPU.  torch is this package's plumbing for device memory and streams, so its runtime is loaded
+    # first and libdaachorse_amd.so binds to the same one.
+    import torch  # noqa: F401
     L = C.CDLL(path)
     P, vp, sz, u8p = C.POINTER, C.c_void_p, C.c_size_t, C.c_void_p
     L.daac_last_error.restype = C.c_char_p

@@ -60,7 +60,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.reps
-            cc = tuple(int(x) & 0xFFFFFFFFFFFFFFFF for x in res.tolist())
+            r = res.tolist()
+            cc = (int(r[0]), int(r[1]) & 0xFFFFFFFF, int(r[2]) & 0xFFFFFFFF)
             ok = ref is None or cc == ref
             ref = ref or cc
             print(f"{cfg}  NA={info.tier_dense_states} NB={info.tier_lds_states} lds={info.tier_lds_bytes}  "
