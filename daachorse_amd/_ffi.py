@@ -27,7 +27,8 @@ class Info(C.Structure):
     _fields_ = [("match_kind", C.c_uint8), ("num_states", C.c_uint32), ("states_len", C.c_uint64),
                 ("outputs_len", C.c_uint64), ("heap_bytes", C.c_uint64), ("max_pattern_len", C.c_uint32),
                 ("num_classes", C.c_uint32), ("tier_dense_states", C.c_uint32), ("tier_lds_states", C.c_uint32),
-                ("tier_lds_bytes", C.c_uint32), ("tiered_available", C.c_uint8)]
+                ("tier_lds_bytes", C.c_uint32), ("tiered_available", C.c_uint8), ("gram_available", C.c_uint8),
+                ("gram_k", C.c_uint32), ("gram_lds_bytes", C.c_uint32)]
 
 
 def lib():

@@ -37,6 +37,7 @@ class Engine(enum.IntEnum):
     Auto = 0
     Tiered = 1
     DArray = 2
+    Gram = 3
 
 
 class Match:

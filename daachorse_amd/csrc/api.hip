@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "device_tables.hpp"
+#include "gram.hpp"
 #include "pma.hpp"
 #include "repack.hpp"
 
@@ -29,6 +30,9 @@ struct Options {
     std::atomic<int64_t> threads{1024};
     std::atomic<int64_t> iter_window{64ll << 20};
     std::atomic<int64_t> max_result_bytes{8ll << 30};
+    std::atomic<int64_t> gram_lds_budget{150 * 1024};
+    std::atomic<int64_t> gram_region{16 * 1024};
+    std::atomic<int64_t> gram_slab{2048};
 };
 static Options g_opt;
 
@@ -51,6 +55,8 @@ struct DeviceTables {
     TierDev tier{};
     DArrayDev da{};
     TierTables tier_host_meta;  // sizes only (vectors cleared after upload)
+    bool gram_ok = false;
+    GramDev gram{};
 
     ~DeviceTables() {
         for (void *p : allocs) (void)hipFree(p);
@@ -157,6 +163,40 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             d.row32 = tt.row32;
             d.root_flag = tt.root_flag;
             t->tier_ok = true;
+            // GRAM count engine, derived from the tier tables
+            GramTables gt;
+            if (tt.N < (1u << 28) && build_gram_tables(h, tt, static_cast<uint32_t>(g_opt.gram_lds_budget.load()), gt)) {
+                GramDev &g = t->gram;
+                const U32x2 *tshort; const U32x2 *wown; const U32x4 *drec;
+                if ((st = t->put(gt.cls, g.cls)) != DAAC_OK) return st;
+                if ((st = t->put(gt.tshort, tshort)) != DAAC_OK) return st;
+                if ((st = t->put(gt.wbits, g.wbits)) != DAAC_OK) return st;
+                if ((st = t->put(gt.wrank, g.wrank)) != DAAC_OK) return st;
+                if ((st = t->put(gt.wown, wown)) != DAAC_OK) return st;
+                if ((st = t->put(gt.bbits, g.bbits)) != DAAC_OK) return st;
+                if ((st = t->put(gt.brank, g.brank)) != DAAC_OK) return st;
+                if ((st = t->put(gt.bsuper, g.bsuper)) != DAAC_OK) return st;
+                if ((st = t->put(gt.drec, drec)) != DAAC_OK) return st;
+                g.tshort = reinterpret_cast<const uint2 *>(tshort);
+                g.wown = reinterpret_cast<const uint2 *>(wown);
+                g.drec = reinterpret_cast<const uint4 *>(drec);
+                auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
+                g.off_tshort = 256;
+                g.off_wbits = g.off_tshort + p16(gt.tshort.size() * 8);
+                g.off_wrank = g.off_wbits + p16(gt.wbits.size() * 4);
+                g.off_wown = g.off_wrank + p16(gt.wrank.size() * 2);
+                g.off_bbits = g.off_wown + p16(gt.wown.size() * 8);
+                g.off_brank = g.off_bbits + p16(gt.bbits.size() * 4);
+                g.off_bsuper = g.off_brank + p16(gt.brank.size() * 2);
+                g.off_scratch = g.off_bsuper + p16(gt.bsuper.size() * 4);
+                g.lds_bytes = std::max<uint32_t>(g.off_scratch + 16u, 1024u);
+                g.K = gt.K; g.C = gt.C; g.CC = gt.C * gt.C; g.CCC = gt.C * gt.C * gt.C;
+                g.level_start = gt.level_start;
+                g.unused_byte = gt.unused_byte;
+                g.has_short = gt.has_short;
+                g.has_word = gt.has_word;
+                t->gram_ok = true;
+            }
             // keep the sizes for daac_pma_info
             tt.rows16.clear(); tt.rows32.clear(); tt.bcmap.clear(); tt.bfail.clear(); tt.grec.clear(); tt.ssum.clear(); tt.sopos.clear(); tt.old_of_new.clear();
             t->tier_host_meta = tt;
@@ -203,6 +243,10 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
     heads = mode == DAAC_FIND_OVERLAPPING_NO_SUFFIX;
     if (engine == DAAC_ENGINE_TIERED && !t->tier_ok) {
         set_error("TIERED engine not available for this automaton (more than 31 distinct pattern bytes, or not standard)");
+        return DAAC_ERR_UNSUPPORTED;
+    }
+    if (engine == DAAC_ENGINE_GRAM) {
+        set_error("the GRAM engine only serves daac_scan_count(DAAC_FIND_OVERLAPPING)");
         return DAAC_ERR_UNSUPPORTED;
     }
     pl.tier = engine == DAAC_ENGINE_TIERED || (engine == DAAC_ENGINE_AUTO && t->tier_ok);
@@ -379,6 +423,11 @@ daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
             info->tier_lds_states = t->tier.NB;
             info->tier_lds_bytes = t->tier.lds_bytes;
         }
+        info->gram_available = t->gram_ok;
+        if (t->gram_ok) {
+            info->gram_k = t->gram.K;
+            info->gram_lds_bytes = t->gram.lds_bytes;
+        }
     }
     return DAAC_OK;
 }
@@ -399,9 +448,15 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
     DeviceTables *t = nullptr;
     daac_status st = get_tables(pma, &t);
     if (st != DAAC_OK) return st;
+    const bool use_gram = mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len < (1ull << 35) &&
+                          (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && t->gram_ok));
+    if (engine == DAAC_ENGINE_GRAM && (!use_gram || !t->gram_ok)) {
+        set_error("GRAM engine not available for this automaton / mode");
+        return DAAC_ERR_UNSUPPORTED;
+    }
     Plan pl;
     bool heads = false;
-    if ((st = make_plan(pma, t, mode, engine, 0, len, pl, heads)) != DAAC_OK) return st;
+    if ((st = make_plan(pma, t, mode, use_gram ? DAAC_ENGINE_AUTO : engine, 0, len, pl, heads)) != DAAC_OK) return st;
     if (pl.a.nseg == 0) pl.a.nseg = 1;  // ROOT's list at end = 0
     void *staged = nullptr;
     const uint8_t *dev_hay = hay;
@@ -416,7 +471,31 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
     std::unique_ptr<void, void (*)(void *)> g2(own, [](void *p) { if (p) (void)hipFree(p); });
     pl.a.result = d_res;
     HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
-    HIP_TRY(launch(t, pl, 0, heads, stream));
+    if (use_gram && len != 0) {
+        GramArgs ga{};
+        ga.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dev_hay) & 15u);
+        ga.hay_al = dev_hay - ga.lead;
+        ga.vlen = ga.lead + static_cast<uint64_t>(len);
+        uint64_t region = static_cast<uint64_t>(g_opt.gram_region.load());
+        region = std::max<uint64_t>(1024, region & ~1023ull);
+        ga.region_bytes = region;
+        ga.nregions = (ga.vlen + region - 1) / region;
+        ga.result = d_res;
+        const uint32_t threads = 1024;
+        uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
+        if (bpc == 0) bpc = std::max(1u, std::min(2u, (160u * 1024u) / t->gram.lds_bytes));
+        const uint32_t blocks = static_cast<uint32_t>(
+            std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (ga.nregions + 15) / 16)));
+        ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(2048, g_opt.gram_slab.load()));
+        void *wq = nullptr;
+        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * 16 * ga.wq_slab * sizeof(unsigned long long), stream));
+        ga.wq = static_cast<unsigned long long *>(wq);
+        const hipError_t le = launch_gram_scan(t->gram, ga, blocks, threads, stream);
+        HIP_TRY(hipFreeAsync(wq, stream));
+        HIP_TRY(le);
+    } else {
+        HIP_TRY(launch(t, pl, 0, heads, stream));
+    }
     if (result_dev && !count) {
         if (staged) HIP_TRY(hipStreamSynchronize(stream));
         return DAAC_OK;
@@ -529,6 +608,9 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "threads") g_opt.threads = value;
     else if (n == "iter_window") g_opt.iter_window = value;
     else if (n == "max_result_bytes") g_opt.max_result_bytes = value;
+    else if (n == "gram_lds_budget") g_opt.gram_lds_budget = value;
+    else if (n == "gram_region") g_opt.gram_region = value;
+    else if (n == "gram_slab") g_opt.gram_slab = value;
     else { set_error("unknown option: " + n); return DAAC_ERR_INVALID_ARGUMENT; }
     return DAAC_OK;
 }

@@ -47,6 +47,35 @@ struct ScanArgs {
     daac_match *out;                 // MODE 2
 };
 
+// GRAM engine tables (see gram.hpp).  Everything up to `drec` is staged into LDS.
+struct GramDev {
+    const uint8_t *cls;       // 256
+    const uint2 *tshort;      // C^(K-1) x {count, hsum}
+    const uint32_t *wbits;    // K-gram pattern bitmap
+    const uint16_t *wrank;
+    const uint2 *wown;        // per set bit {count, hsum}
+    const uint32_t *bbits;    // (K+1)-gram trie-prefix bitmap
+    const uint16_t *brank;
+    const uint32_t *bsuper;
+    const uint4 *drec;        // N x {cmap, first_child, own_cnt, own_hsum}  (HBM / L2)
+    uint32_t off_tshort, off_wbits, off_wrank, off_wown, off_bbits, off_brank, off_bsuper, off_scratch, lds_bytes;
+    uint32_t K, C, CC, CCC;
+    uint32_t level_start, unused_byte, has_short, has_word;
+};
+
+struct GramArgs {
+    const uint8_t *hay_al;   // haystack address rounded down to 16 bytes
+    uint32_t lead;           // bytes between hay_al and haystack byte 0 (0..15)
+    uint64_t vlen;           // lead + haystack length ("virtual" positions count from hay_al)
+    uint64_t region_bytes;   // contiguous bytes a wave takes at a time (multiple of 1024)
+    uint64_t nregions;
+    unsigned long long *result;  // {count, S1, S2}
+    unsigned long long *wq;      // per-wave walker slabs
+    uint32_t wq_slab;            // entries per wave
+};
+
+hipError_t launch_gram_scan(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream);
+
 hipError_t launch_tier_scan(const TierDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,
                             hipStream_t stream);
 hipError_t launch_darray_scan(const DArrayDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,

@@ -50,11 +50,13 @@ typedef enum {
     DAAC_FIND_OVERLAPPING_NO_SUFFIX = 3  /* FindOverlappingNoSuffixIterator  iter.rs:180-244 */
 } daac_scan_mode;
 
-/* Which device engine to use.  AUTO picks TIERED when the automaton qualifies. */
+/* Which device engine to use.  AUTO picks GRAM for daac_scan_count(FIND_OVERLAPPING) and TIERED
+ * for everything else when the automaton qualifies, DARRAY otherwise. */
 typedef enum {
     DAAC_ENGINE_AUTO = 0,
     DAAC_ENGINE_TIERED = 1, /* re-packed bitmap-rank trie, top levels dense in LDS */
-    DAAC_ENGINE_DARRAY = 2  /* the reference's own double array, hot/cold split   */
+    DAAC_ENGINE_DARRAY = 2, /* the reference's own double array, hot/cold split   */
+    DAAC_ENGINE_GRAM = 3    /* count/checksum only: k-gram context tables in LDS, no state chain */
 } daac_engine;
 
 /* Match<u32> (src/lib.rs:286-320): start() = end - length, end(), value() */
@@ -78,6 +80,9 @@ typedef struct {
     uint32_t tier_lds_states;    /* + states whose child bitmap lives in LDS */
     uint32_t tier_lds_bytes;     /* LDS bytes of the automaton tables per workgroup */
     uint8_t tiered_available;    /* 0 if only the DARRAY engine can run this automaton */
+    uint8_t gram_available;      /* the GRAM count engine can run this automaton */
+    uint32_t gram_k;             /* context length K of the GRAM tables */
+    uint32_t gram_lds_bytes;
 } daac_info;
 
 typedef struct daac_pma daac_pma;         /* an automaton (host copy + per-device re-pack) */

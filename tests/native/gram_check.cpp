@@ -1,0 +1,88 @@
+// Host-logic test for the GRAM tables (no GPU needed): evaluates count + checksum of the
+// find_overlapping stream from the GRAM tables, position by position exactly as the HIP kernel
+// does, and compares with the literal automaton walk on the original double array.
+//   usage: gram_check <blob> <lds_budget> <haystack-file>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
+#include <vector>
+
+#include "../../daachorse_amd/csrc/gram.hpp"
+#include "../../daachorse_amd/csrc/pma.hpp"
+#include "../../daachorse_amd/csrc/repack.hpp"
+
+using namespace daac;
+
+static std::vector<uint8_t> slurp(const char *path) {
+    std::ifstream f(path, std::ios::binary);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char **argv) {
+    if (argc < 4) return 2;
+    const std::vector<uint8_t> blob = slurp(argv[1]);
+    HostPma p;
+    if (HostPma::deserialize(blob.data(), blob.size(), p, nullptr) != DAAC_OK) { std::printf("BADBLOB\n"); return 1; }
+    RepackOptions ro;
+    TierTables t;
+    if (!build_tier_tables(p, ro, t)) { std::printf("UNAVAILABLE tier\n"); return 0; }
+    GramTables g;
+    if (!build_gram_tables(p, t, static_cast<uint32_t>(std::atoi(argv[2])), g)) { std::printf("UNAVAILABLE gram\n"); return 0; }
+    const std::vector<uint8_t> hay = slurp(argv[3]);
+    const size_t n = hay.size();
+    const uint32_t K = g.K, C = g.C;
+
+    // reference: literal automaton walk, outputs by list walk
+    uint64_t rc = 0;
+    uint32_t r1 = 0, r2 = 0;
+    uint32_t st = 0;
+    for (size_t i = 0; i < n; ++i) {
+        st = p.next_state(st, hay[i]);
+        for (uint32_t op = output_pos_of(p.states[st].opos_ch); op != 0; op = p.outputs[op - 1].parent) {
+            const uint32_t h = match_hash32(p.outputs[op - 1].value, p.outputs[op - 1].length);
+            rc++; r1 += h; r2 += h * static_cast<uint32_t>(i + 1);
+        }
+    }
+
+    // GRAM evaluation
+    auto cls = [&](long long pos) -> uint32_t { return (pos >= 0 && static_cast<size_t>(pos) < n) ? g.cls[hay[pos]] : 0u; };
+    uint32_t pk1 = 1;
+    for (uint32_t i = 0; i + 1 < K; ++i) pk1 *= C;
+    uint64_t gc = 0;
+    uint32_t g1 = 0, g2 = 0;
+    for (size_t pz = 0; pz < n; ++pz) {
+        const long long p0 = static_cast<long long>(pz);
+        const uint32_t end = static_cast<uint32_t>(pz + 1);
+        uint32_t iS = 0;
+        for (uint32_t tt = 0; tt + 1 < K; ++tt) iS = iS * C + cls(p0 - (K - 2) + tt);
+        const uint32_t iW = cls(p0 - (K - 1)) * pk1 + iS;
+        const uint32_t iB = cls(p0 - K) * pk1 * C + iW;
+        const U32x2 s = g.tshort[iS];
+        gc += s.x; g1 += s.y; g2 += s.y * end;
+        const uint32_t ww = g.wbits[iW >> 5];
+        if ((ww >> (iW & 31)) & 1u) {
+            const U32x2 o = g.wown[g.wrank[iW >> 5] + __builtin_popcount(ww & ((1u << (iW & 31)) - 1u))];
+            gc += o.x; g1 += o.y; g2 += o.y * end;
+        }
+        const uint32_t bw = g.bbits[iB >> 5];
+        if ((bw >> (iB & 31)) & 1u) {
+            uint32_t id = g.level_start + g.bsuper[iB >> 11] + g.brank[iB >> 5] + __builtin_popcount(bw & ((1u << (iB & 31)) - 1u));
+            long long nx = p0 + 1;
+            for (;;) {
+                const U32x4 r = g.drec[id];
+                gc += r.z; g1 += r.w; g2 += r.w * static_cast<uint32_t>(nx);
+                const uint32_t kn = cls(nx);
+                if (((r.x >> kn) & 1u) == 0) break;
+                id = r.y + __builtin_popcount(r.x & ((1u << kn) - 1u));
+                ++nx;
+            }
+        }
+    }
+    if (gc != rc || g1 != r1 || g2 != r2) {
+        std::printf("MISMATCH count %llu vs %llu, s1 %08x vs %08x, s2 %08x vs %08x\n", (unsigned long long)gc, (unsigned long long)rc, g1, r1, g2, r2);
+        return 1;
+    }
+    std::printf("OK %zu K=%u C=%u count=%llu lds=%u short=%d word=%d\n", n, K, C, (unsigned long long)gc, g.lds_bytes, int(g.has_short), int(g.has_word));
+    return 0;
+}

@@ -32,6 +32,22 @@ def _sev(m):
     return [(int(x["start"]), int(x["end"]), int(x["value"])) for x in m]
 
 
+def _check_counts(p, mode, hay, want):
+    """count + checksum on every engine that can serve the request (GRAM declines some automata)"""
+    expect = (len(want), orc.matches_checksum(want))
+    for eng in ENGINES + [Engine.Auto]:
+        assert p.scan_count(mode, hay, engine=eng) == expect, eng
+    if mode == ScanMode.FindOverlapping:
+        try:
+            got = p.scan_count(mode, hay, engine=Engine.Gram)
+        except da.DaachorseError as e:
+            assert e.code == 6
+            return False
+        assert got == expect, "gram"
+        return True
+    return False
+
+
 def _same(a, b):
     return len(a) == len(b) and np.array_equal(a["start"], b["start"]) and np.array_equal(a["end"], b["end"]) and \
         np.array_equal(a["value"], b["value"])
@@ -50,13 +66,12 @@ def test_golden_vectors_overlapping(vectors):
     for runner, case in iter_vector_runs(vectors):
         if runner["api"] != "find_overlapping_iter":
             continue
-        _, p = _pma(case["patterns"])
+        o, p = _pma(case["patterns"])
         want = [tuple(t) for t in case["matches"]]
         for eng in ENGINES:
             got = p.scan(ScanMode.FindOverlapping, case["haystack"], engine=eng)
             assert [(int(m["value"]), int(m["start"]), int(m["end"])) for m in got] == want, (case["name"], eng)
-            cnt, cs = p.scan_count(ScanMode.FindOverlapping, case["haystack"], engine=eng)
-            assert cnt == len(want) and cs == orc.matches_checksum(got), (case["name"], eng)
+        _check_counts(p, ScanMode.FindOverlapping, case["haystack"], o.find_overlapping_iter(case["haystack"]))
         lazy = [(m.value(), m.start(), m.end()) for m in p.find_overlapping_iter(case["haystack"])]
         assert lazy == want, case["name"]
         n += 1
@@ -103,6 +118,7 @@ def test_fuzz_small_alphabets(seg_bytes):
     every match straddle a segment boundary, which is what the halo has to get right."""
     rng = np.random.default_rng(1234 + seg_bytes)
     da.set_option("seg_bytes", seg_bytes)
+    gram_runs = 0
     for it in range(60):
         npat = int(rng.integers(1, 7))
         pats = [bytes(rng.integers(97, 100, size=int(rng.integers(0, 6))).astype(np.uint8)) for _ in range(npat)]
@@ -113,10 +129,11 @@ def test_fuzz_small_alphabets(seg_bytes):
         for eng in ENGINES:
             got = p.scan(ScanMode.FindOverlapping, hay, engine=eng)
             assert _same(got, want), (pats, bytes(hay), eng, _sev(got)[:8], _sev(want)[:8])
-            assert p.scan_count(ScanMode.FindOverlapping, hay, engine=eng) == (len(want), orc.matches_checksum(want))
             got_ns = p.scan(ScanMode.FindOverlappingNoSuffix, hay, engine=eng)
             assert _same(got_ns, want_ns), (pats, bytes(hay), eng)
-            assert p.scan_count(ScanMode.FindOverlappingNoSuffix, hay, engine=eng) == (len(want_ns), orc.matches_checksum(want_ns))
+        gram_runs += _check_counts(p, ScanMode.FindOverlapping, hay, want)
+        _check_counts(p, ScanMode.FindOverlappingNoSuffix, hay, want_ns)
+    assert gram_runs > 20  # only pattern sets containing "" are declined
 
 
 def test_unaligned_and_device_haystacks():
@@ -134,6 +151,8 @@ def test_unaligned_and_device_haystacks():
                 assert _same(got, want), (off, n, eng)
                 got_h = p.scan(ScanMode.FindOverlapping, base[off:off + n], engine=eng)
                 assert _same(got_h, want), (off, n, eng)
+            assert _check_counts(p, ScanMode.FindOverlapping, dev[off:off + n], want), (off, n)
+            assert _check_counts(p, ScanMode.FindOverlapping, base[off:off + n], want), (off, n)
 
 
 def test_lazy_iterator_windows():
@@ -185,7 +204,7 @@ def test_cfg2_1000_patterns():
         for eng in ENGINES:
             got = p.scan(ScanMode.FindOverlapping, dev, engine=eng)
             assert _same(got, want), eng
-            assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == (len(want), orc.matches_checksum(want))
+        assert _check_counts(p, ScanMode.FindOverlapping, dev, want)
 
 
 def test_cfg3_100k_patterns():
@@ -194,7 +213,7 @@ def test_cfg3_100k_patterns():
     pats = synth.patterns_cfg3()
     o, p = _pma(pats)
     info = p.upload().info()
-    assert info.tiered_available
+    assert info.tiered_available and info.gram_available and info.gram_k == 3
     small = synth.uniform_haystack(4 << 20, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
     want = o.find_overlapping_iter(small)
     for eng in ENGINES:
@@ -205,9 +224,15 @@ def test_cfg3_100k_patterns():
     synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
     host = dev.cpu().numpy()
     want_cc = o.overlapping_count(host, threads=8)
-    for eng in ENGINES:
+    for eng in ENGINES + [Engine.Gram, Engine.Auto]:
         assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want_cc, eng
     synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20)
     want_cc = o.overlapping_count(dev.cpu().numpy(), threads=8)
-    for eng in ENGINES:
+    for eng in ENGINES + [Engine.Gram, Engine.Auto]:
         assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want_cc, eng
+    # a small K (tables squeezed into a few KB of LDS) must give the same answer
+    da.set_option("gram_lds_budget", 8192)
+    p2, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    assert p2.upload().info().gram_k == 2
+    assert p2.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want_cc
+    da.set_option("gram_lds_budget", 150 * 1024)

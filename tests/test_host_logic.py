@@ -119,6 +119,35 @@ def test_repack_cfg3_dictionary(repack_check, tmp_path):
     assert out.startswith("OK"), out
 
 
+@pytest.fixture(scope="module")
+def gram_check(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("native") / "gram_check")
+    csrc = os.path.join(ROOT, "daachorse_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "gram_check.cpp"),
+                           os.path.join(csrc, "pma.cpp"), os.path.join(csrc, "repack.cpp"), os.path.join(csrc, "gram.cpp")])
+    return exe
+
+
+def test_gram_tables_reproduce_the_match_stream(gram_check, tmp_path):
+    """count + checksum evaluated from the k-gram tables (the kernel's rule) == literal automaton walk"""
+    rng = np.random.default_rng(2)
+    cases = [(["a", "ab", "bab", "bc", "bca", "c", "caa", "abcabcab", "bb", "bb"], b"abc"),
+             (["abcabcabd", "bcabd", "cab", "ab", "ab", "dddddddd"], b"abcd"),
+             (synth.patterns_cfg2(300), synth.ALPHA_LOWER),
+             (synth.patterns_cfg3(20000), synth.ALPHA_LOWER_SPACE)]
+    for pats, alpha in cases:
+        blob = tmp_path / "a.blob"
+        blob.write_bytes(orc.OraclePma.build(pats).serialize())
+        h = tmp_path / "h.bin"
+        rng.choice(np.frombuffer(alpha, dtype=np.uint8), size=60000).tofile(h)
+        for budget in (150000, 6000):
+            out = subprocess.check_output([gram_check, str(blob), str(budget), str(h)]).decode()
+            assert out.startswith("OK"), out
+    # "" as a pattern: declined
+    blob.write_bytes(orc.OraclePma.build(["", "a"]).serialize())
+    assert subprocess.check_output([gram_check, str(blob), "150000", str(h)]).decode().startswith("UNAVAILABLE")
+
+
 def test_synth_definitions_are_stable():
     """Seeds and generators are part of the benchmark definition: pin a few bytes/patterns."""
     h = synth.uniform_haystack(64, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
