@@ -33,6 +33,8 @@ struct Options {
     std::atomic<int64_t> gram_lds_budget{150 * 1024};
     std::atomic<int64_t> gram_region{16 * 1024};
     std::atomic<int64_t> gram_slab{2048};
+    std::atomic<int64_t> gram_pipeline{1};
+    std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
 };
 static Options g_opt;
 
@@ -167,7 +169,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             GramTables gt;
             if (tt.N < (1u << 28) && build_gram_tables(h, tt, static_cast<uint32_t>(g_opt.gram_lds_budget.load()), gt)) {
                 GramDev &g = t->gram;
-                const U32x2 *tshort; const U32x2 *wown; const U32x4 *drec;
+                const U32x2 *tshort; const U32x2 *wown; const U32x4 *drec; const U32x2 *dhit;
                 if ((st = t->put(gt.cls, g.cls)) != DAAC_OK) return st;
                 if ((st = t->put(gt.tshort, tshort)) != DAAC_OK) return st;
                 if ((st = t->put(gt.wbits, g.wbits)) != DAAC_OK) return st;
@@ -177,6 +179,8 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 if ((st = t->put(gt.brank, g.brank)) != DAAC_OK) return st;
                 if ((st = t->put(gt.bsuper, g.bsuper)) != DAAC_OK) return st;
                 if ((st = t->put(gt.drec, drec)) != DAAC_OK) return st;
+                if ((st = t->put(gt.dhit, dhit)) != DAAC_OK) return st;
+                g.dhit = reinterpret_cast<const uint2 *>(dhit);
                 g.tshort = reinterpret_cast<const uint2 *>(tshort);
                 g.wown = reinterpret_cast<const uint2 *>(wown);
                 g.drec = reinterpret_cast<const uint4 *>(drec);
@@ -187,8 +191,18 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 g.off_wown = g.off_wrank + p16(gt.wrank.size() * 2);
                 g.off_bbits = g.off_wown + p16(gt.wown.size() * 8);
                 g.off_brank = g.off_bbits + p16(gt.bbits.size() * 4);
-                g.off_bsuper = g.off_brank + p16(gt.brank.size() * 2);
-                g.off_scratch = g.off_bsuper + p16(gt.bsuper.size() * 4);
+                // Without the rank directory two workgroups may fit one CU (<= 80 KB each); worth it when
+                // the level is small, i.e. B hits are rare whatever the text.
+                const uint32_t without_rank = g.off_brank + 16u;
+                g.rank_in_lds = !(without_rank <= 80u * 1024u && gt.dhit.size() <= 8192);
+                if (g_opt.gram_rank_in_lds.load() >= 0) g.rank_in_lds = g_opt.gram_rank_in_lds.load() != 0;
+                if (g.rank_in_lds) {
+                    g.off_bsuper = g.off_brank + p16(gt.brank.size() * 2);
+                    g.off_scratch = g.off_bsuper + p16(gt.bsuper.size() * 4);
+                } else {
+                    g.off_bsuper = g.off_brank;
+                    g.off_scratch = g.off_brank;
+                }
                 g.lds_bytes = std::max<uint32_t>(g.off_scratch + 16u, 1024u);
                 g.K = gt.K; g.C = gt.C; g.CC = gt.C * gt.C; g.CCC = gt.C * gt.C * gt.C;
                 g.level_start = gt.level_start;
@@ -481,14 +495,17 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;
         ga.result = d_res;
-        const uint32_t threads = 1024;
+        uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
+        threads = std::min(1024u, std::max(64u, threads & ~63u));
+        const uint32_t wpb = threads / 64;
         uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
-        if (bpc == 0) bpc = std::max(1u, std::min(2u, (160u * 1024u) / t->gram.lds_bytes));
+        if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / t->gram.lds_bytes));
         const uint32_t blocks = static_cast<uint32_t>(
-            std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (ga.nregions + 15) / 16)));
+            std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (ga.nregions + wpb - 1) / wpb)));
         ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(2048, g_opt.gram_slab.load()));
+        ga.pipeline = g_opt.gram_pipeline.load() != 0;
         void *wq = nullptr;
-        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * 16 * ga.wq_slab * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * sizeof(unsigned long long), stream));
         ga.wq = static_cast<unsigned long long *>(wq);
         const hipError_t le = launch_gram_scan(t->gram, ga, blocks, threads, stream);
         HIP_TRY(hipFreeAsync(wq, stream));
@@ -611,6 +628,8 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_lds_budget") g_opt.gram_lds_budget = value;
     else if (n == "gram_region") g_opt.gram_region = value;
     else if (n == "gram_slab") g_opt.gram_slab = value;
+    else if (n == "gram_pipeline") g_opt.gram_pipeline = value;
+    else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else { set_error("unknown option: " + n); return DAAC_ERR_INVALID_ARGUMENT; }
     return DAAC_OK;
 }

@@ -58,9 +58,11 @@ struct GramDev {
     const uint16_t *brank;
     const uint32_t *bsuper;
     const uint4 *drec;        // N x {cmap, first_child, own_cnt, own_hsum}  (HBM / L2)
+    const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}          (HBM / L2)
     uint32_t off_tshort, off_wbits, off_wrank, off_wown, off_bbits, off_brank, off_bsuper, off_scratch, lds_bytes;
     uint32_t K, C, CC, CCC;
     uint32_t level_start, unused_byte, has_short, has_word;
+    uint32_t rank_in_lds;     // brank/bsuper staged in LDS (else read from L2 on hits)
 };
 
 struct GramArgs {
@@ -72,6 +74,7 @@ struct GramArgs {
     unsigned long long *result;  // {count, S1, S2}
     unsigned long long *wq;      // per-wave walker slabs
     uint32_t wq_slab;            // entries per wave
+    uint32_t pipeline;           // consume the deep reads half a chunk late (software pipeline)
 };
 
 hipError_t launch_gram_scan(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream);

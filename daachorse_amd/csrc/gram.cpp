@@ -62,6 +62,11 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
         const uint64_t bytes = 256 + pad16(ipow(C, cand - 1) * 8) + pad16(wwords * 4) + pad16(wwords * 2) + pad16(nword * 8) +
                                pad16(bwords * 4) + pad16(bwords * 2) + pad16(((bwords + 63) / 64) * 4);
         if (bytes > lds_budget) continue;
+        // the 8-byte hit record of a depth-(K+1) state carries no count: it must be 0/1 and visible in the sum
+        bool regular = true;
+        for (uint32_t s = 0; s < N && regular; ++s)
+            if (depth[s] == cand + 1 && own_cnt[s] != (own_hs[s] != 0 ? 1u : 0u)) regular = false;
+        if (!regular) continue;
         K = cand;
         lds = static_cast<uint32_t>(bytes);
         break;
@@ -116,6 +121,7 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
             else if (gram[s] <= prev_gram) return false;  // numbering is not lexicographic: do not trust ranks
             prev_gram = gram[s];
             out.bbits[g >> 5] |= 1u << (g & 31);
+            out.dhit.push_back(U32x2{r.x, own_hs[s]});
         }
     }
     out.wrank.resize(out.wbits.size());

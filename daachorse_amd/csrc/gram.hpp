@@ -42,6 +42,7 @@ struct GramTables {
     std::vector<uint16_t> brank;    // per word of bbits: set bits before it within its 64-word superblock
     std::vector<uint32_t> bsuper;   // per 64 words: set bits before the superblock
     std::vector<U32x4> drec;        // N: {cmap, first_child, own_cnt, own_hsum}
+    std::vector<U32x2> dhit;        // per depth-(K+1) state, in rank order: {cmap, own_hsum}; own_cnt == (own_hsum != 0)
     uint32_t lds_bytes = 0;
 };
 

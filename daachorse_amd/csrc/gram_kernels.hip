@@ -1,14 +1,16 @@
 // GRAM engine kernels (gfx950): count + checksum of the find_overlapping stream without a state
 // chain.  See gram.hpp for the method.  One wavefront streams 1 KiB per step with fully coalesced
-// 16-byte loads; every position is independent, so there is no halo and no warm-up:
+// 16-byte loads (kept PF steps ahead, so enough bytes are in flight to cover HBM latency); every
+// position is independent, so there is no halo and no warm-up:
 //
 //   per position p (all in LDS): class of the byte, T_{K-1}[last K-1 classes] -> short patterns,
 //   W_K bit (+rank -> record) -> patterns of length K, B_{K+1} bit -> "a longer pattern may start
-//   K bytes back".  For set B bits the rank directory gives the depth-(K+1) state id; its 16-byte
-//   record is the ONLY HBM/L2 access of the fast pass (issued for 8 positions at a time, then
-//   consumed).  Branches that continue past depth K+1 are rare; the wave appends them to its own
-//   slab (ballot-compacted, no atomics) and finishes them 64 at a time with a goto-only trie walk
-//   whenever the slab fills up and at the end of its work.
+//   K bytes back".  For set B bits the rank directory gives the depth-(K+1) state id; its 8-byte
+//   {child bitmap, own h32 sum} record is the ONLY HBM/L2 access of the fast pass; the reads of a
+//   group of positions are issued together and (optionally) consumed one group later, behind the
+//   next group's LDS work.  Branches that continue past depth K+1 are rare; the wave appends their
+//   positions to its own slab (ballot-compacted, no atomics) and finishes them 64 at a time with a
+//   goto-only trie walk whenever the slab fills up and at the end of its work.
 //
 // Roofline: HBM bytes of haystack (1 B read per byte); integer/bit work only, no MFMA.
 #include <hip/hip_runtime.h>
@@ -20,6 +22,8 @@
 namespace daac {
 
 typedef uint32_t g_u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kGroup = 4;     // positions whose LDS reads are issued together (lgkmcnt tracks at most 15 reads)
+constexpr int kPrefetch = 1;  // haystack chunks in flight per lane beyond the current one
 
 __device__ __forceinline__ unsigned long long gram_wave_sum(unsigned long long v) {
 #pragma unroll
@@ -48,8 +52,8 @@ __device__ __forceinline__ void gram_reduce(unsigned long long cnt, uint32_t s1,
     }
 }
 
-template <int K>
-__global__ __launch_bounds__(1024) void gram_count_kernel(const GramDev g, const GramArgs a) {
+template <int K, bool HAS_SHORT, bool HAS_WORD, int TPB, bool PIPE>
+__global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const GramArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gram_copy(smem, g.cls, 256);
     gram_copy(smem + g.off_tshort, g.tshort, g.off_wbits - g.off_tshort);
@@ -57,8 +61,10 @@ __global__ __launch_bounds__(1024) void gram_count_kernel(const GramDev g, const
     gram_copy(smem + g.off_wrank, g.wrank, g.off_wown - g.off_wrank);
     gram_copy(smem + g.off_wown, g.wown, g.off_bbits - g.off_wown);
     gram_copy(smem + g.off_bbits, g.bbits, g.off_brank - g.off_bbits);
-    gram_copy(smem + g.off_brank, g.brank, g.off_bsuper - g.off_brank);
-    gram_copy(smem + g.off_bsuper, g.bsuper, g.off_scratch - g.off_bsuper);
+    if (g.rank_in_lds) {
+        gram_copy(smem + g.off_brank, g.brank, g.off_bsuper - g.off_brank);
+        gram_copy(smem + g.off_bsuper, g.bsuper, g.off_scratch - g.off_bsuper);
+    }
     __syncthreads();
     const uint8_t *l_cls = reinterpret_cast<const uint8_t *>(smem);
     const uint2 *l_short = reinterpret_cast<const uint2 *>(smem + g.off_tshort);
@@ -66,8 +72,10 @@ __global__ __launch_bounds__(1024) void gram_count_kernel(const GramDev g, const
     const uint16_t *l_wrank = reinterpret_cast<const uint16_t *>(smem + g.off_wrank);
     const uint2 *l_wown = reinterpret_cast<const uint2 *>(smem + g.off_wown);
     const uint32_t *l_bbits = reinterpret_cast<const uint32_t *>(smem + g.off_bbits);
-    const uint16_t *l_brank = reinterpret_cast<const uint16_t *>(smem + g.off_brank);
-    const uint32_t *l_bsuper = reinterpret_cast<const uint32_t *>(smem + g.off_bsuper);
+    // the rank directory of B is only touched on hits: small automata keep it in L2 so that two
+    // workgroups fit one CU's LDS
+    const uint16_t *l_brank = g.rank_in_lds ? reinterpret_cast<const uint16_t *>(smem + g.off_brank) : g.brank;
+    const uint32_t *l_bsuper = g.rank_in_lds ? reinterpret_cast<const uint32_t *>(smem + g.off_bsuper) : g.bsuper;
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t C = g.C;
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(1024) void gram_count_kernel(const GramDev g, const
     const uint32_t ub4 = g.unused_byte * 0x01010101u;
     const uint8_t *__restrict__ hay = a.hay_al;
     const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
-    // this wave's slab of pending walkers: entry = state id | (virtual position of the next byte) << 28
+    // this wave's slab of pending walkers: entry = virtual position of the last byte of a (K+1)-gram
     unsigned long long *__restrict__ slab =
         a.wq + (static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * a.wq_slab;
     uint32_t wq_n = 0;  // wave-uniform
@@ -102,25 +110,59 @@ __global__ __launch_bounds__(1024) void gram_count_kernel(const GramDev g, const
     auto class_at = [&](uint64_t p) -> uint32_t {  // class of the byte at virtual position p
         return (p >= a.lead && p < a.vlen) ? l_cls[hay[p]] : 0u;
     };
-    // Finishes the queued branches, 64 per round.  A walker's state was reached by consuming the byte
-    // before `vnext`, so its own patterns end at (vnext - lead); it then follows the goto function.
+    // offset within its level of the depth-(K+1) state whose gram index is `ib` (its B bit is set)
+    auto deep_rank = [&](uint32_t ib, uint32_t word) -> uint32_t {
+        const uint32_t w = ib >> 5;
+        return l_bsuper[w >> 6] + l_brank[w] + __popc(word & ((1u << (ib & 31u)) - 1u));
+    };
+    // Finishes the queued branches, 64 per round.  An entry is the position p of the last byte of a
+    // (K+1)-gram whose depth-(K+1) state (already counted) has a child on the byte at p + 1.
     auto drain = [&]() {
         for (uint32_t i = lane; i < wq_n; i += 64) {
-            const unsigned long long w = slab[i];
-            uint32_t id = static_cast<uint32_t>(w) & 0x0fffffffu;
-            uint64_t vnext = w >> 28;
+            const uint64_t p = slab[i];
+            uint32_t ib = 0;
+#pragma unroll
+            for (int t = K; t >= 0; --t) ib = ib * C + (p >= static_cast<uint64_t>(t) ? class_at(p - t) : 0u);
+            uint4 r = g.drec[g.level_start + deep_rank(ib, l_bbits[ib >> 5])];  // {cmap, first_child, own_cnt, own_hsum}
+            uint64_t vnext = p + 1;
             for (;;) {
-                const uint4 r = g.drec[id];  // {cmap, first_child, own_cnt, own_hsum}
+                const uint32_t kn = class_at(vnext);
+                if (((r.x >> kn) & 1u) == 0) break;
+                r = g.drec[r.y + __popc(r.x & ((1u << kn) - 1u))];
+                ++vnext;  // the child consumed the byte before vnext: its own patterns end at vnext - lead
                 tot_cnt += r.z;
                 tot_s1 += r.w;
                 tot_s2 += r.w * static_cast<uint32_t>(vnext - a.lead);
-                const uint32_t kn = class_at(vnext);
-                if (((r.x >> kn) & 1u) == 0) break;
-                id = r.y + __popc(r.x & ((1u << kn) - 1u));
-                ++vnext;
             }
         }
         wq_n = 0;
+    };
+
+    // HBM/L2 reads issued one group ago and not yet consumed (software pipeline)
+    uint2 pend[kGroup];
+    uint32_t pend_hits = 0, pend_kn0 = 0, pend_e0 = 0;
+    uint64_t pend_v = 0;
+    auto consume_pending = [&]() {
+        if (__any(pend_hits != 0)) {
+#pragma unroll
+            for (int jj = 0; jj < kGroup; ++jj) {
+                const uint32_t kn = (pend_kn0 >> (8 * jj)) & 0xffu;
+                const bool hit = (pend_hits >> jj) & 1u;
+                const uint2 r = pend[jj];  // {cmap, own h32 sum}; zero when not a hit
+                tot_cnt += r.y != 0;
+                tot_s1 += r.y;
+                tot_s2 += r.y * (pend_e0 + jj);
+                const bool go = hit && ((r.x >> kn) & 1u);
+                const unsigned long long m = __ballot(go);
+                if (m != 0) {  // rare: the branch goes on past depth K+1 -> queue a walker
+                    if (go)
+                        slab[wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
+                            pend_v + jj;
+                    wq_n += __popcll(m);
+                }
+            }
+        }
+        pend_hits = 0;
     };
 
     for (uint64_t region = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); region < a.nregions;
@@ -132,11 +174,19 @@ __global__ __launch_bounds__(1024) void gram_count_kernel(const GramDev g, const
 #pragma unroll
         for (int i = 0; i < K; ++i) carry |= (rbase >= static_cast<uint64_t>(K - i) ? class_at(rbase - (K - i)) : 0u) << (8 * i);
 
-        uint4 cur = load_chunk(rbase + lane * 16);
+        uint4 pf[kPrefetch + 1];
+#pragma unroll
+        for (int i = 0; i <= kPrefetch; ++i)
+            pf[i] = (rbase + 1024ull * i < rend) ? load_chunk(rbase + 1024ull * i + lane * 16) : uint4{ub4, ub4, ub4, ub4};
+
         for (uint64_t sb = rbase; sb < rend; sb += 1024) {
-            if (wq_n + 1024u > a.wq_slab) drain();  // a step can add at most 16 x 64 walkers
+            if (wq_n + 1536u > a.wq_slab) drain();  // a step retires at most 16 (+ pending) x 64 walkers
             const uint64_t v = sb + lane * 16;
-            const uint4 nxt = (sb + 1024 < rend) ? load_chunk(v + 1024) : uint4{ub4, ub4, ub4, ub4};
+            const uint4 cur = pf[0];
+#pragma unroll
+            for (int i = 0; i < kPrefetch; ++i) pf[i] = pf[i + 1];
+            pf[kPrefetch] = (sb + 1024ull * (kPrefetch + 1) < rend) ? load_chunk(v + 1024ull * (kPrefetch + 1)) : uint4{ub4, ub4, ub4, ub4};
+
             // ---- byte classes of this lane's 16 positions plus K to the left and 1 to the right ----
             uint32_t kx[K + 17];
             {
@@ -156,111 +206,117 @@ __global__ __launch_bounds__(1024) void gram_count_kernel(const GramDev g, const
             if (lane == 63) right = class_at(sb + 1024);
             kx[K + 16] = right;
 
-            // ---- fast path: every position independently ------------------------------------------------
+            // ---- per group of kGroup positions: LDS work of every position independently (all reads of the
+            // group in flight before the first is consumed), then retire the HBM/L2 reads issued one group
+            // ago, then issue this group's (one 8-byte record per B hit) ------------------------------------
             uint32_t ccnt = 0, A = 0, T = 0;       // T = sum over positions of running A (prefix trick for h * end)
-            uint32_t hitmask = 0;                  // B_{K+1} hits of this lane
-            uint32_t iB[16];
+            const uint32_t e0 = static_cast<uint32_t>(v - a.lead) + 1u;  // end of this lane's position 0
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                uint32_t iS = 0;
+            for (int grp = 0; grp < 16 / kGroup; ++grp) {
+                uint32_t iS[kGroup], iW[kGroup], iB[kGroup], bw[kGroup], ww[kGroup], wr[kGroup];
+                uint2 ts[kGroup], wo[kGroup];
 #pragma unroll
-                for (int t = 0; t < K - 1; ++t) iS = iS * C + kx[j + 2 + t];     // K-1 classes ending at j
-                const uint32_t iW = kx[j + 1] * PK1 + iS;                          // K classes
-                iB[j] = kx[j] * PK + iW;                                           // K+1 classes
-                uint32_t hs = 0;
-                if (g.has_short) {
-                    const uint2 t = l_short[iS];
-                    ccnt += t.x;
-                    hs = t.y;
+                for (int jj = 0; jj < kGroup; ++jj) {
+                    const int j = grp * kGroup + jj;
+                    uint32_t sidx = kx[j + 2];                                         // K-1 classes ending at j
+                    if (K == 3) sidx = __umul24(sidx, C) + kx[j + 3];
+                    iS[jj] = sidx;
+                    iW[jj] = __umul24(kx[j + 1], PK1) + sidx;                          // K classes
+                    iB[jj] = __umul24(kx[j], PK) + iW[jj];                             // K+1 classes
                 }
-                if (g.has_word) {
-                    const uint32_t ww = l_wbits[iW >> 5];
-                    if ((ww >> (iW & 31)) & 1u) {
-                        const uint2 o = l_wown[l_wrank[iW >> 5] + __popc(ww & ((1u << (iW & 31)) - 1u))];
-                        ccnt += o.x;
-                        hs += o.y;
+#pragma unroll
+                for (int jj = 0; jj < kGroup; ++jj) {
+                    if (HAS_SHORT) ts[jj] = l_short[iS[jj]];
+                    if (HAS_WORD) { ww[jj] = l_wbits[iW[jj] >> 5]; wr[jj] = l_wrank[iW[jj] >> 5]; }
+                    bw[jj] = l_bbits[iB[jj] >> 5];
+                }
+                if (HAS_WORD) {
+#pragma unroll
+                    for (int jj = 0; jj < kGroup; ++jj) {
+                        const uint32_t sh = iW[jj] & 31u;
+                        const bool hit = (ww[jj] >> sh) & 1u;
+                        const uint32_t rank = wr[jj] + __popc(ww[jj] & ((1u << sh) - 1u));
+                        const uint2 o = l_wown[hit ? rank : 0u];
+                        wo[jj] = hit ? o : uint2{0u, 0u};
                     }
                 }
-                A += hs;
-                T += A;
-                const uint32_t bw = l_bbits[iB[j] >> 5];
-                hitmask |= ((bw >> (iB[j] & 31)) & 1u) << j;
+                uint32_t hits = 0;
+#pragma unroll
+                for (int jj = 0; jj < kGroup; ++jj) {
+                    if (HAS_SHORT || HAS_WORD) {
+                        uint32_t hs = 0;
+                        if (HAS_SHORT) { ccnt += ts[jj].x; hs = ts[jj].y; }
+                        if (HAS_WORD) { ccnt += wo[jj].x; hs += wo[jj].y; }
+                        A += hs;
+                        T += A;
+                    }
+                    hits |= ((bw[jj] >> (iB[jj] & 31u)) & 1u) << jj;
+                }
+                if (PIPE) consume_pending();
+                if (__any(hits != 0)) {
+#pragma unroll
+                    for (int jj = 0; jj < kGroup; ++jj) {
+                        pend[jj] = uint2{0u, 0u};
+                        if ((hits >> jj) & 1u) pend[jj] = g.dhit[deep_rank(iB[jj], bw[jj])];
+                    }
+                    pend_hits = hits;
+                    pend_e0 = e0 + kGroup * grp;
+                    pend_v = v + kGroup * grp;
+                    uint32_t x0 = 0;
+#pragma unroll
+                    for (int t = 0; t < kGroup; ++t) x0 |= kx[K + grp * kGroup + t + 1] << (8 * t);  // class of the next byte
+                    pend_kn0 = x0;
+                }
+                if (!PIPE) consume_pending();
             }
-            // sum_j hs_j * (e0 + j) with e0 = end of position 0 = (v - lead) + 1:  A * (e0 + 16) - T
-            const uint32_t e0 = static_cast<uint32_t>(v - a.lead) + 1u;
-            uint32_t s1 = A, s2 = A * (e0 + 16u) - T;
-
-            // ---- deep path: one 16-byte record per B hit, 8 positions in flight ---------------------------
-            if (__any(hitmask != 0)) {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    uint4 rec[8];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int j = half * 8 + jj;
-                        rec[jj] = uint4{0, 0, 0, 0};
-                        if ((hitmask >> j) & 1u) {
-                            const uint32_t w = iB[j] >> 5;
-                            const uint32_t bw = l_bbits[w];
-                            const uint32_t id = g.level_start + l_bsuper[w >> 6] + l_brank[w] + __popc(bw & ((1u << (iB[j] & 31)) - 1u));
-                            rec[jj] = g.drec[id];
-                        }
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int j = half * 8 + jj;
-                        if ((hitmask >> j) & 1u) {
-                            const uint4 r = rec[jj];  // {cmap, first_child, own_cnt, own_hsum}
-                            ccnt += r.z;
-                            s1 += r.w;
-                            s2 += r.w * (e0 + j);
-                        }
-                    }
-                    // rare: the branch goes on past depth K+1 -> queue a walker (wave-ballot compaction)
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int j = half * 8 + jj;
-                        const uint32_t kn = kx[K + j + 1];
-                        const bool go = ((hitmask >> j) & 1u) && ((rec[jj].x >> kn) & 1u);
-                        const unsigned long long m = __ballot(go);
-                        if (m != 0) {
-                            if (go) {
-                                const uint32_t child = rec[jj].y + __popc(rec[jj].x & ((1u << kn) - 1u));
-                                const uint32_t slot = wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
-                                                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
-                                slab[slot] = static_cast<unsigned long long>(child) | ((v + j + 2) << 28);
-                            }
-                            wq_n += __popcll(m);
-                        }
-                    }
-                }
-            }
+            // sum_j hs_j * (e0 + j):  A * (e0 + 16) - T
             tot_cnt += ccnt;
-            tot_s1 += s1;
-            tot_s2 += s2;
-            cur = nxt;
+            tot_s1 += A;
+            tot_s2 += A * (e0 + 16u) - T;
         }
     }
+    consume_pending();
     drain();
     gram_reduce(tot_cnt, tot_s1, tot_s2, reinterpret_cast<unsigned long long *>(smem), a.result);
 }
 
-hipError_t launch_gram_scan(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
-    hipError_t e;
-    if (dev.K == 3) {
-        if (dev.lds_bytes > 64 * 1024 &&
-            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram_count_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(dev.lds_bytes))) != hipSuccess)
-            return e;
-        hipLaunchKernelGGL(gram_count_kernel<3>, dim3(blocks), dim3(threads), dev.lds_bytes, stream, dev, a);
-    } else {
-        if (dev.lds_bytes > 64 * 1024 &&
-            (e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram_count_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(dev.lds_bytes))) != hipSuccess)
-            return e;
-        hipLaunchKernelGGL(gram_count_kernel<2>, dim3(blocks), dim3(threads), dev.lds_bytes, stream, dev, a);
+template <int K, bool S, bool W, int TPB, bool PIPE>
+static hipError_t launch_pipe(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
+    if (dev.lds_bytes > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram_count_kernel<K, S, W, TPB, PIPE>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dev.lds_bytes));
+        if (e != hipSuccess) return e;
     }
+    hipLaunchKernelGGL((gram_count_kernel<K, S, W, TPB, PIPE>), dim3(blocks), dim3(threads), dev.lds_bytes, stream, dev, a);
     return hipGetLastError();
+}
+template <int K, bool S, bool W, int TPB>
+static hipError_t launch_tpb(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
+    return a.pipeline ? launch_pipe<K, S, W, TPB, true>(dev, a, blocks, threads, stream)
+                      : launch_pipe<K, S, W, TPB, false>(dev, a, blocks, threads, stream);
+}
+
+// Three register budgets: 1024-thread workgroups (128 VGPRs, 4 waves/SIMD), 768 (168 VGPRs,
+// 3 waves/SIMD) and <= 512 (256 VGPRs, 2 waves/SIMD) with one workgroup per CU.
+template <int K, bool S, bool W>
+static hipError_t launch_one(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
+    if (threads > 768) return launch_tpb<K, S, W, 1024>(dev, a, blocks, threads, stream);
+    if (threads > 512) return launch_tpb<K, S, W, 768>(dev, a, blocks, threads, stream);
+    return launch_tpb<K, S, W, 512>(dev, a, blocks, threads, stream);
+}
+
+hipError_t launch_gram_scan(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
+    const int sel = (dev.K == 3 ? 4 : 0) | (dev.has_short ? 2 : 0) | (dev.has_word ? 1 : 0);
+    switch (sel) {
+        case 0: return launch_one<2, false, false>(dev, a, blocks, threads, stream);
+        case 1: return launch_one<2, false, true>(dev, a, blocks, threads, stream);
+        case 2: return launch_one<2, true, false>(dev, a, blocks, threads, stream);
+        case 3: return launch_one<2, true, true>(dev, a, blocks, threads, stream);
+        case 4: return launch_one<3, false, false>(dev, a, blocks, threads, stream);
+        case 5: return launch_one<3, false, true>(dev, a, blocks, threads, stream);
+        case 6: return launch_one<3, true, false>(dev, a, blocks, threads, stream);
+        default: return launch_one<3, true, true>(dev, a, blocks, threads, stream);
+    }
 }
 
 }  // namespace daac

@@ -67,7 +67,10 @@ int main(int argc, char **argv) {
         }
         const uint32_t bw = g.bbits[iB >> 5];
         if ((bw >> (iB & 31)) & 1u) {
-            uint32_t id = g.level_start + g.bsuper[iB >> 11] + g.brank[iB >> 5] + __builtin_popcount(bw & ((1u << (iB & 31)) - 1u));
+            const uint32_t rank = g.bsuper[iB >> 11] + g.brank[iB >> 5] + __builtin_popcount(bw & ((1u << (iB & 31)) - 1u));
+            uint32_t id = g.level_start + rank;
+            const U32x2 hrec = g.dhit[rank];  // what the fast pass reads: must agree with the full record
+            if (hrec.x != g.drec[id].x || hrec.y != g.drec[id].w || g.drec[id].z != (hrec.y != 0 ? 1u : 0u)) { std::printf("MISMATCH dhit\n"); return 1; }
             long long nx = p0 + 1;
             for (;;) {
                 const U32x4 r = g.drec[id];
