@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3"])
     ap.add_argument("--haystack", default="sparse", choices=["sparse", "dense"])
     ap.add_argument("--bytes", type=int, default=0, help="haystack bytes per GPU (default: the config's size)")
-    ap.add_argument("--engine", default="auto", choices=["auto", "tiered", "darray"])
+    ap.add_argument("--engine", default="auto", choices=["auto", "gram", "tiered", "darray"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--opt", action="append", default=[], help="name=value tuning option (daac_set_option)")
@@ -61,7 +61,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         da.set_option(k, int(v))
-    engine = {"auto": Engine.Auto, "tiered": Engine.Tiered, "darray": Engine.DArray}[args.engine]
+    engine = {"auto": Engine.Auto, "gram": Engine.Gram, "tiered": Engine.Tiered, "darray": Engine.DArray}[args.engine]
+    mat_engine = Engine.Auto if engine == Engine.Gram else engine  # GRAM only counts
 
     # ---- automaton (host CPU, not timed) --------------------------------------------------------
     if args.workload == "cfg3":
@@ -114,10 +115,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]  # memset + scan kernel on the launch stream
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    from daachorse_amd import dist as ddist
+    elapsed = ddist.max_over_ranks(elapsed, device="cuda")
     total_count = int(result[0].item())
     checksum = ((int(result[1].item()) & 0xFFFFFFFF) << 32) | (int(result[2].item()) & 0xFFFFFFFF)
 
@@ -141,11 +140,13 @@ def main():
                    "patterns": len(patterns), "engine": args.engine, "num_states": info.num_states,
                    "automaton_bytes": info.heap_bytes, "byte_classes": info.num_classes,
                    "lds_dense_states": info.tier_dense_states, "lds_states": info.tier_lds_states,
-                   "lds_table_bytes": info.tier_lds_bytes, "parallelism": f"haystack-shard x{world}",
+                   "lds_table_bytes": info.tier_lds_bytes, "gram_k": info.gram_k, "gram_lds_bytes": info.gram_lds_bytes,
+                   "parallelism": f"haystack-shard x{world}",
                    "matches_per_byte": round(total_count / total_bytes, 4), "host_build_seconds": round(build_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "daac::scan_kernel<TierEngine, count>", "kernel_ms": round(avg_kernel_s * 1e3, 4),
+                     "kernel": "daac::gram_count_kernel" if info.gram_available and args.engine in ("auto", "gram") else "daac::scan_kernel",
+                     "kernel_ms": round(avg_kernel_s * 1e3, 4),
                      "algorithmic_bytes_per_launch": nbytes},
         "match_count": total_count, "match_checksum": f"{checksum:016x}" if world == 1 else None,
     }
@@ -159,10 +160,10 @@ def main():
     # ---- materialising scan of a prefix (reported, not the metric) -----------------------------------
     if args.materialize_mib > 0:
         n = min(nbytes, args.materialize_mib << 20)
-        pma.scan(ScanMode.FindOverlapping, hay[:n], engine=engine)
+        pma.scan(ScanMode.FindOverlapping, hay[:n], engine=mat_engine)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        m = pma.scan(ScanMode.FindOverlapping, hay[:n], engine=engine)
+        m = pma.scan(ScanMode.FindOverlapping, hay[:n], engine=mat_engine)
         dt = time.perf_counter() - t0
         out["materialize"] = {"bytes": n, "matches": int(len(m)), "seconds": round(dt, 4), "GB/s": round(n / dt / 1e9, 3),
                               "note": "count pass + scan + write pass + D2H of 24-byte tuples"}

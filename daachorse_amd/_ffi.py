@@ -62,6 +62,7 @@ def lib():
     L.daac_matches_data.restype = vp
     L.daac_matches_free.argtypes = [vp]
     L.daac_scan_count.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(C.c_uint64), P(C.c_uint64), vp]
+    L.daac_scan_count_range.argtypes = [vp, C.c_int, C.c_int, u8p, sz, sz, C.c_int, vp, P(C.c_uint64), P(C.c_uint64), vp]
     L.daac_iter_open.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp)]
     L.daac_iter_next.argtypes = [vp, P(Match)]
     L.daac_iter_next.restype = C.c_int
@@ -71,7 +72,7 @@ def lib():
     L.daac_synth_wordsoup.argtypes = [vp, sz, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32,
                                       vp, C.c_uint32, C.c_uint64, vp]
     for name in ("daac_bytewise_from_serialized", "daac_bytewise_from_parts", "daac_bytewise_build", "daac_pma_serialize",
-                 "daac_pma_info", "daac_pma_upload", "daac_scan", "daac_scan_count", "daac_iter_open", "daac_set_option",
+                 "daac_pma_info", "daac_pma_upload", "daac_scan", "daac_scan_count", "daac_scan_count_range", "daac_iter_open", "daac_set_option",
                  "daac_synth_uniform", "daac_synth_wordsoup"):
         getattr(L, name).restype = C.c_int
     _lib = L

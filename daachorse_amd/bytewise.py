@@ -225,16 +225,17 @@ class DoubleArrayAhoCorasick:
         _ffi.lib().daac_matches_free(out)
         return res
 
-    def scan_count(self, mode, haystack, engine=Engine.Auto, stream=None, result_dev=None):
-        """-> (count, checksum); with `result_dev` (device pointer to 3 x u64) the call is asynchronous."""
+    def scan_count(self, mode, haystack, engine=Engine.Auto, stream=None, result_dev=None, begin=0):
+        """-> (count, checksum) of the matches with end in (begin, len]; with `result_dev` (device
+        pointer to 3 x u64 = count, S1, S2) the call is asynchronous and returns None."""
         h = _Haystack(haystack)
         if result_dev is not None:
-            _ffi.check(_ffi.lib().daac_scan_count(self._h, int(mode), int(engine), h.ptr, h.len, h.is_device, stream, None, None,
-                                                  result_dev))
+            _ffi.check(_ffi.lib().daac_scan_count_range(self._h, int(mode), int(engine), h.ptr, h.len, begin, h.is_device, stream,
+                                                        None, None, result_dev))
             return None
         cnt, cs = C.c_uint64(), C.c_uint64()
-        _ffi.check(_ffi.lib().daac_scan_count(self._h, int(mode), int(engine), h.ptr, h.len, h.is_device, stream, C.byref(cnt),
-                                              C.byref(cs), None))
+        _ffi.check(_ffi.lib().daac_scan_count_range(self._h, int(mode), int(engine), h.ptr, h.len, begin, h.is_device, stream,
+                                                    C.byref(cnt), C.byref(cs), None))
         return cnt.value, cs.value
 
 

@@ -455,14 +455,17 @@ daac_status daac_pma_upload(daac_pma *pma, int device) {
     return upload_locked(pma, device, &t);
 }
 
-daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
-                            uint64_t *count, uint64_t *checksum, uint64_t *result_dev) {
-    if (!pma || (len && !hay) || (!result_dev && (!count || !checksum))) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin, int hay_is_device,
+                                  void *stream_, uint64_t *count, uint64_t *checksum, uint64_t *result_dev) {
+    if (!pma || (len && !hay) || (!result_dev && (!count || !checksum)) || begin > len) {
+        set_error("bad argument");
+        return DAAC_ERR_INVALID_ARGUMENT;
+    }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceTables *t = nullptr;
     daac_status st = get_tables(pma, &t);
     if (st != DAAC_OK) return st;
-    const bool use_gram = mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len < (1ull << 35) &&
+    const bool use_gram = mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len < (1ull << 35) && begin == 0 &&
                           (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && t->gram_ok));
     if (engine == DAAC_ENGINE_GRAM && (!use_gram || !t->gram_ok)) {
         set_error("GRAM engine not available for this automaton / mode");
@@ -470,12 +473,13 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
     }
     Plan pl;
     bool heads = false;
-    if ((st = make_plan(pma, t, mode, use_gram ? DAAC_ENGINE_AUTO : engine, 0, len, pl, heads)) != DAAC_OK) return st;
-    if (pl.a.nseg == 0) pl.a.nseg = 1;  // ROOT's list at end = 0
+    if ((st = make_plan(pma, t, mode, use_gram ? DAAC_ENGINE_AUTO : engine, begin, len, pl, heads)) != DAAC_OK) return st;
+    if (pl.a.nseg == 0 && begin == 0) pl.a.nseg = 1;  // ROOT's list at end = 0
     void *staged = nullptr;
     const uint8_t *dev_hay = hay;
     if (!hay_is_device && len) {
-        if ((st = stage_window(hay, 0, len, stream, &staged, &dev_hay)) != DAAC_OK) return st;
+        const uint64_t from = begin > pl.a.halo ? begin - pl.a.halo : 0;
+        if ((st = stage_window(hay, from, len, stream, &staged, &dev_hay)) != DAAC_OK) return st;
     }
     std::unique_ptr<void, void (*)(void *)> g1(staged, [](void *p) { if (p) (void)hipFree(p); });
     pl.a.hay = dev_hay;
@@ -510,7 +514,7 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
         const hipError_t le = launch_gram_scan(t->gram, ga, blocks, threads, stream);
         HIP_TRY(hipFreeAsync(wq, stream));
         HIP_TRY(le);
-    } else {
+    } else if (pl.a.nseg != 0) {
         HIP_TRY(launch(t, pl, 0, heads, stream));
     }
     if (result_dev && !count) {
@@ -523,6 +527,11 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
     if (count) *count = r[0];
     if (checksum) *checksum = ((r[1] & 0xffffffffull) << 32) | (r[2] & 0xffffffffull);
     return DAAC_OK;
+}
+
+daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream,
+                            uint64_t *count, uint64_t *checksum, uint64_t *result_dev) {
+    return daac_scan_count_range(pma, mode, engine, hay, len, 0, hay_is_device, stream, count, checksum, result_dev);
 }
 
 daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,

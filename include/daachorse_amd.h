@@ -142,6 +142,13 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
                             int hay_is_device, void *stream, uint64_t *count, uint64_t *checksum,
                             uint64_t *result_dev);
 
+/* The same over the tail of a haystack: counts the matches with end in (begin, len] — what one
+ * shard of a haystack split across devices contributes.  Bytes before begin - (Lmax - 1) are never
+ * read (they need not be resident), byte 0 of the haystack is still `hay`. */
+daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin,
+                                  int hay_is_device, void *stream, uint64_t *count, uint64_t *checksum,
+                                  uint64_t *result_dev);
+
 /* Lazy façade = Iterator::next() (iter.rs:58, 133, 195, 272): scans the haystack window by
  * window on the device and hands tuples out one at a time.  The haystack must stay alive until
  * close (the Rust iterator owns/borrows `P` the same way). */

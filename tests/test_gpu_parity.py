@@ -236,3 +236,27 @@ def test_cfg3_100k_patterns():
     assert p2.upload().info().gram_k == 2
     assert p2.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want_cc
     da.set_option("gram_lds_budget", 150 * 1024)
+
+
+def test_shard_tail_counts_add_up():
+    """daac_scan_count_range: the matches with end in (begin, len] — what one device of a sharded
+    haystack contributes.  Shards of one haystack must add up to the whole, at any split point."""
+    import torch
+    from daachorse_amd import dist as ddist
+    pats = synth.patterns_cfg3(5000)
+    o, p = _pma(pats)
+    n = 1_000_003
+    hay = synth.wordsoup_haystack(n, synth.SEEDS["cfg3_dense"], pats, 20)
+    dev = torch.from_numpy(hay).cuda()
+    whole = o.overlapping_count(hay)
+    all_m = o.find_overlapping_iter(hay)
+    for cuts in ([0, n], [0, 1, n], [0, 333_333, 666_671, n], [0, 17, 4096, 500_000, n - 1, n]):
+        tot_c, tot_1, tot_2 = 0, 0, 0
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            want = all_m[(all_m["end"] > lo) & (all_m["end"] <= hi)]
+            for src in (dev[:hi], hay[:hi]):
+                got = p.scan_count(ScanMode.FindOverlapping, src, begin=lo)
+                assert got == (len(want), orc.matches_checksum(want)), (lo, hi)
+            s1, s2 = ddist.split_checksum(got[1])
+            tot_c, tot_1, tot_2 = tot_c + got[0], tot_1 + s1, tot_2 + s2
+        assert (tot_c, ddist.join_checksum(tot_1, tot_2)) == whole, cuts
