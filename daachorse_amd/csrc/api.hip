@@ -30,7 +30,7 @@ struct Options {
     std::atomic<int64_t> threads{1024};
     std::atomic<int64_t> iter_window{64ll << 20};
     std::atomic<int64_t> max_result_bytes{8ll << 30};
-    std::atomic<int64_t> gram_lds_budget{150 * 1024};
+    std::atomic<int64_t> gram_lds_budget{158 * 1024};
     std::atomic<int64_t> gram_region{16 * 1024};
     std::atomic<int64_t> gram_slab{2048};
     std::atomic<int64_t> gram_pipeline{1};
@@ -169,35 +169,30 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             GramTables gt;
             if (tt.N < (1u << 28) && build_gram_tables(h, tt, static_cast<uint32_t>(g_opt.gram_lds_budget.load()), gt)) {
                 GramDev &g = t->gram;
-                const U32x2 *tshort; const U32x2 *wown; const U32x4 *drec; const U32x2 *dhit;
+                const U32x2 *combo; const U32x4 *drec; const U32x2 *dhit;
                 if ((st = t->put(gt.cls, g.cls)) != DAAC_OK) return st;
-                if ((st = t->put(gt.tshort, tshort)) != DAAC_OK) return st;
-                if ((st = t->put(gt.wbits, g.wbits)) != DAAC_OK) return st;
-                if ((st = t->put(gt.wrank, g.wrank)) != DAAC_OK) return st;
-                if ((st = t->put(gt.wown, wown)) != DAAC_OK) return st;
+                if ((st = t->put(gt.cid, g.cid)) != DAAC_OK) return st;
+                if ((st = t->put(gt.combo, combo)) != DAAC_OK) return st;
                 if ((st = t->put(gt.bbits, g.bbits)) != DAAC_OK) return st;
                 if ((st = t->put(gt.brank, g.brank)) != DAAC_OK) return st;
                 if ((st = t->put(gt.bsuper, g.bsuper)) != DAAC_OK) return st;
                 if ((st = t->put(gt.drec, drec)) != DAAC_OK) return st;
                 if ((st = t->put(gt.dhit, dhit)) != DAAC_OK) return st;
-                g.dhit = reinterpret_cast<const uint2 *>(dhit);
-                g.tshort = reinterpret_cast<const uint2 *>(tshort);
-                g.wown = reinterpret_cast<const uint2 *>(wown);
+                g.combo = reinterpret_cast<const uint2 *>(combo);
                 g.drec = reinterpret_cast<const uint4 *>(drec);
+                g.dhit = reinterpret_cast<const uint2 *>(dhit);
                 auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
-                g.off_tshort = 256;
-                g.off_wbits = g.off_tshort + p16(gt.tshort.size() * 8);
-                g.off_wrank = g.off_wbits + p16(gt.wbits.size() * 4);
-                g.off_wown = g.off_wrank + p16(gt.wrank.size() * 2);
-                g.off_bbits = g.off_wown + p16(gt.wown.size() * 8);
+                g.has_short = gt.has_short;
+                g.off_cid = 256;
+                g.off_combo = g.off_cid + (gt.has_short ? p16(gt.cid.size() * 2) : 0u);   // not staged when unused
+                g.off_bbits = g.off_combo + (gt.has_short ? p16(gt.combo.size() * 8) : 0u);
                 g.off_brank = g.off_bbits + p16(gt.bbits.size() * 4);
                 // Without the rank directory two workgroups may fit one CU (<= 80 KB each); worth it when
                 // the level is small, i.e. B hits are rare whatever the text.
-                const uint32_t without_rank = g.off_brank + 16u;
-                g.rank_in_lds = !(without_rank <= 80u * 1024u && gt.dhit.size() <= 8192);
+                g.rank_in_lds = !(g.off_brank + 16u <= 80u * 1024u && gt.dhit.size() <= 8192);
                 if (g_opt.gram_rank_in_lds.load() >= 0) g.rank_in_lds = g_opt.gram_rank_in_lds.load() != 0;
                 if (g.rank_in_lds) {
-                    g.off_bsuper = g.off_brank + p16(gt.brank.size() * 2);
+                    g.off_bsuper = g.off_brank + p16(gt.brank.size());
                     g.off_scratch = g.off_bsuper + p16(gt.bsuper.size() * 4);
                 } else {
                     g.off_bsuper = g.off_brank;
@@ -207,8 +202,6 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 g.K = gt.K; g.C = gt.C; g.CC = gt.C * gt.C; g.CCC = gt.C * gt.C * gt.C;
                 g.level_start = gt.level_start;
                 g.unused_byte = gt.unused_byte;
-                g.has_short = gt.has_short;
-                g.has_word = gt.has_word;
                 t->gram_ok = true;
             }
             // keep the sizes for daac_pma_info

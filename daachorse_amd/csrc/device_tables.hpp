@@ -50,18 +50,16 @@ struct ScanArgs {
 // GRAM engine tables (see gram.hpp).  Everything up to `drec` is staged into LDS.
 struct GramDev {
     const uint8_t *cls;       // 256
-    const uint2 *tshort;      // C^(K-1) x {count, hsum}
-    const uint32_t *wbits;    // K-gram pattern bitmap
-    const uint16_t *wrank;
-    const uint2 *wown;        // per set bit {count, hsum}
+    const uint16_t *cid;      // C^K: K-gram -> combination id (0 = no pattern ends here)
+    const uint2 *combo;       // per id {count, hsum}
     const uint32_t *bbits;    // (K+1)-gram trie-prefix bitmap
-    const uint16_t *brank;
-    const uint32_t *bsuper;
+    const uint8_t *brank;     // per word: set bits before it inside its 8-word superblock
+    const uint32_t *bsuper;   // per 8 words: set bits before the superblock
     const uint4 *drec;        // N x {cmap, first_child, own_cnt, own_hsum}  (HBM / L2)
     const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}          (HBM / L2)
-    uint32_t off_tshort, off_wbits, off_wrank, off_wown, off_bbits, off_brank, off_bsuper, off_scratch, lds_bytes;
+    uint32_t off_cid, off_combo, off_bbits, off_brank, off_bsuper, off_scratch, lds_bytes;  // cls at 0
     uint32_t K, C, CC, CCC;
-    uint32_t level_start, unused_byte, has_short, has_word;
+    uint32_t level_start, unused_byte, has_short;
     uint32_t rank_in_lds;     // brank/bsuper staged in LDS (else read from L2 on hits)
 };
 

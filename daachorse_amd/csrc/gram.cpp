@@ -2,6 +2,7 @@
 #include "gram.hpp"
 
 #include <algorithm>
+#include <utility>
 
 namespace daac {
 
@@ -52,23 +53,46 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
 
     // ---- choose K -----------------------------------------------------------------------------
     auto pad16 = [](uint64_t x) { return static_cast<uint32_t>((x + 15) & ~15ull); };
+    std::vector<uint32_t> new_of_old(p.states.size(), 0xffffffffu);
+    for (uint32_t s = 0; s < N; ++s) new_of_old[tier.old_of_new[s]] = s;
+
     uint32_t K = 0, lds = 0;
     for (uint32_t cand : {3u, 2u}) {
-        const uint64_t wwords = (ipow(C, cand) + 31) / 32, bwords = (ipow(C, cand + 1) + 31) / 32;
-        if (bwords * 32 >= (1ull << 31)) continue;
-        uint64_t nword = 0;
-        for (uint32_t s = 0; s < N; ++s) nword += depth[s] == cand && own_cnt[s] != 0;
-        if (nword >= 65536) continue;  // wrank is u16
-        const uint64_t bytes = 256 + pad16(ipow(C, cand - 1) * 8) + pad16(wwords * 4) + pad16(wwords * 2) + pad16(nword * 8) +
-                               pad16(bwords * 4) + pad16(bwords * 2) + pad16(((bwords + 63) / 64) * 4);
-        if (bytes > lds_budget) continue;
+        const uint64_t ngram = ipow(C, cand), bwords = (ipow(C, cand + 1) + 31) / 32;
+        if (bwords * 32 >= (1ull << 31) || ngram >= (1ull << 24)) continue;
         // the 8-byte hit record of a depth-(K+1) state carries no count: it must be 0/1 and visible in the sum
         bool regular = true;
         for (uint32_t s = 0; s < N && regular; ++s)
             if (depth[s] == cand + 1 && own_cnt[s] != (own_hs[s] != 0 ? 1u : 0u)) regular = false;
         if (!regular) continue;
+        // CID / COMBO: everything of length <= K that ends after these K classes, found with the
+        // reference's own delta (a class-0 byte resets to ROOT); distinct {count, hsum} pairs share an id
+        std::vector<uint16_t> cid(static_cast<size_t>(ngram), 0);
+        std::vector<U32x2> combo{U32x2{0, 0}};
+        std::vector<std::pair<uint64_t, uint16_t>> seen;  // sorted (count << 32 | hsum) -> id
+        bool ok = true;
+        for (uint32_t g = 0; g < ngram && ok; ++g) {
+            uint32_t st = kRoot;
+            for (uint32_t i = 0; i < cand; ++i) st = p.next_state(st, rep[(g / static_cast<uint32_t>(ipow(C, cand - 1 - i))) % C]);
+            const OutSum o = tier.ssum[new_of_old[st]];
+            if (o.cnt == 0) continue;
+            const uint64_t key = (static_cast<uint64_t>(o.cnt) << 32) | o.hsum;
+            auto it = std::lower_bound(seen.begin(), seen.end(), std::make_pair(key, uint16_t(0)));
+            if (it == seen.end() || it->first != key) {
+                if (combo.size() >= 65535) { ok = false; break; }
+                it = seen.insert(it, std::make_pair(key, static_cast<uint16_t>(combo.size())));
+                combo.push_back(U32x2{o.cnt, o.hsum});
+            }
+            cid[g] = it->second;
+        }
+        if (!ok) continue;
+        const uint64_t bytes = 256 + pad16(ngram * 2) + pad16(combo.size() * 8) + pad16(bwords * 4) + pad16(bwords) +
+                               pad16(((bwords + 7) / 8) * 4) + 64;
+        if (bytes > lds_budget) continue;
         K = cand;
         lds = static_cast<uint32_t>(bytes);
+        out.cid = std::move(cid);
+        out.combo = std::move(combo);
         break;
     }
     if (K == 0) return false;
@@ -79,29 +103,12 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
     out.unused_byte = rep[0];
     out.cls = tier.cls;
     out.lds_bytes = lds;
+    out.has_short = out.combo.size() > 1;
 
-    std::vector<uint32_t> new_of_old(p.states.size(), 0xffffffffu);
-    for (uint32_t s = 0; s < N; ++s) new_of_old[tier.old_of_new[s]] = s;
-
-    // ---- T_{K-1}: everything of length <= K-1 that ends after these K-1 classes ------------------
-    const uint32_t nshort = static_cast<uint32_t>(ipow(C, K - 1));
-    out.tshort.assign(nshort, U32x2{0, 0});
-    for (uint32_t g = 0; g < nshort; ++g) {
-        uint32_t st = kRoot;
-        for (uint32_t i = 0; i < K - 1; ++i) {
-            const uint32_t k = (g / static_cast<uint32_t>(ipow(C, K - 2 - i))) % C;
-            st = p.next_state(st, rep[k]);  // the reference's own delta; a class-0 byte resets to ROOT
-        }
-        const OutSum s = tier.ssum[new_of_old[st]];
-        out.tshort[g] = U32x2{s.cnt, s.hsum};
-        if (s.cnt != 0) out.has_short = true;
-    }
-
-    // ---- W_K and B_{K+1} with their rank directories; per-state walk records ------------------------
+    // ---- B_{K+1} with its rank directory; per-state walk records ------------------------------------
     // Breadth-first ids order each level lexicographically by class string (children are numbered
     // parent by parent, class-ascending), i.e. by gram index: the rank of a set bit in B_{K+1} is
-    // the state's offset within its level, and W_K's compact records follow the same order.
-    out.wbits.assign(static_cast<size_t>((ipow(C, K) + 31) / 32), 0);
+    // the state's offset within its level.
     out.bbits.assign(static_cast<size_t>((ipow(C, K + 1) + 31) / 32), 0);
     out.drec.resize(N);
     out.level_start = N;
@@ -110,12 +117,7 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
     for (uint32_t s = 0; s < N; ++s) {
         const U32x4 r = tier.grec[s];
         out.drec[s] = U32x4{r.x, r.z, own_cnt[s], own_hs[s]};
-        if (depth[s] == K && own_cnt[s] != 0) {
-            const uint32_t g = static_cast<uint32_t>(gram[s]);
-            out.wbits[g >> 5] |= 1u << (g & 31);
-            out.wown.push_back(U32x2{own_cnt[s], own_hs[s]});
-            out.has_word = true;
-        } else if (depth[s] == K + 1) {
+        if (depth[s] == K + 1) {
             const uint32_t g = static_cast<uint32_t>(gram[s]);
             if (first_in_level) { out.level_start = s; first_in_level = false; }
             else if (gram[s] <= prev_gram) return false;  // numbering is not lexicographic: do not trust ranks
@@ -124,16 +126,12 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
             out.dhit.push_back(U32x2{r.x, own_hs[s]});
         }
     }
-    out.wrank.resize(out.wbits.size());
-    uint32_t run = 0;
-    for (size_t w = 0; w < out.wbits.size(); ++w) { out.wrank[w] = static_cast<uint16_t>(run); run += __builtin_popcount(out.wbits[w]); }
     out.brank.resize(out.bbits.size());
-    out.bsuper.assign((out.bbits.size() + 63) / 64, 0);
-    run = 0;
-    uint32_t in_super = 0;
+    out.bsuper.assign((out.bbits.size() + 7) / 8, 0);
+    uint32_t run = 0, in_super = 0;
     for (size_t w = 0; w < out.bbits.size(); ++w) {
-        if ((w & 63) == 0) { out.bsuper[w >> 6] = run; in_super = 0; }
-        out.brank[w] = static_cast<uint16_t>(in_super);
+        if ((w & 7) == 0) { out.bsuper[w >> 3] = run; in_super = 0; }
+        out.brank[w] = static_cast<uint8_t>(in_super);  // < 7 * 32
         const uint32_t c = __builtin_popcount(out.bbits[w]);
         in_super += c;
         run += c;

@@ -5,9 +5,9 @@
 // replaced by direct context lookups, which removes the serial dependency between bytes (every
 // position is independent, loads are coalesced, nothing to warm up):
 //
-//   * an occurrence of length <= K ending at position p is a function of the last K byte classes:
-//       T_{K-1}[last K-1 classes] = {count, sum of h32} of all patterns of length <= K-1 ending here
-//       W_K[last K classes]       = bitmap "these K classes are a pattern"; rank -> {count, h32 sum}
+//   * the occurrences of length <= K ending at position p are a function of the last K byte classes:
+//       CID[last K classes] -> id (u16) of the distinct {count, sum of h32} combination, 0 = nothing;
+//       COMBO[id]           -> {count, sum of h32} of all patterns of length <= K ending here
 //   * an occurrence of length > K is found from its START: the (K+1)-gram bitmap B_{K+1} says
 //     whether the K+1 bytes ending at p are a trie prefix; its rank (popcount directory, also in
 //     LDS) IS the offset of the depth-(K+1) state in the breadth-first numbering, so one 16-byte
@@ -30,17 +30,14 @@ struct GramTables {
     bool available = false;
     uint32_t K = 0, C = 0, N = 0;
     uint8_t unused_byte = 0;        // a byte of class 0 (occurs in no pattern)
-    bool has_short = false;         // any pattern of length <= K-1
-    bool has_word = false;          // any pattern of length == K
+    bool has_short = false;         // any pattern of length <= K
     uint32_t level_start = 0;       // id of the first depth-(K+1) state
     std::vector<uint8_t> cls;       // 256
-    std::vector<U32x2> tshort;      // C^(K-1): {count, hsum} of patterns of length <= K-1 ending here
-    std::vector<uint32_t> wbits;    // ceil(C^K / 32): K-gram is a pattern
-    std::vector<uint16_t> wrank;    // per word of wbits: number of set bits before it
-    std::vector<U32x2> wown;        // per set bit, in index order: {count, hsum} of the length-K pattern(s)
+    std::vector<uint16_t> cid;      // C^K: combination id of the K-gram, 0 = no pattern ends here
+    std::vector<U32x2> combo;       // per id: {count, hsum} of the patterns of length <= K ending here
     std::vector<uint32_t> bbits;    // ceil(C^(K+1) / 32): (K+1)-gram is a trie prefix
-    std::vector<uint16_t> brank;    // per word of bbits: set bits before it within its 64-word superblock
-    std::vector<uint32_t> bsuper;   // per 64 words: set bits before the superblock
+    std::vector<uint8_t> brank;     // per word of bbits: set bits before it within its 8-word superblock
+    std::vector<uint32_t> bsuper;   // per 8 words: set bits before the superblock
     std::vector<U32x4> drec;        // N: {cmap, first_child, own_cnt, own_hsum}
     std::vector<U32x2> dhit;        // per depth-(K+1) state, in rank order: {cmap, own_hsum}; own_cnt == (own_hsum != 0)
     uint32_t lds_bytes = 0;

@@ -3,8 +3,8 @@
 // 16-byte loads (kept PF steps ahead, so enough bytes are in flight to cover HBM latency); every
 // position is independent, so there is no halo and no warm-up:
 //
-//   per position p (all in LDS): class of the byte, T_{K-1}[last K-1 classes] -> short patterns,
-//   W_K bit (+rank -> record) -> patterns of length K, B_{K+1} bit -> "a longer pattern may start
+//   per position p (all in LDS): class of the byte, CID[last K classes] -> COMBO[id] = count and
+//   h32 sum of every pattern of length <= K ending here, B_{K+1} bit -> "a longer pattern may start
 //   K bytes back".  For set B bits the rank directory gives the depth-(K+1) state id; its 8-byte
 //   {child bitmap, own h32 sum} record is the ONLY HBM/L2 access of the fast pass; the reads of a
 //   group of positions are issued together and (optionally) consumed one group later, behind the
@@ -52,34 +52,32 @@ __device__ __forceinline__ void gram_reduce(unsigned long long cnt, uint32_t s1,
     }
 }
 
-template <int K, bool HAS_SHORT, bool HAS_WORD, int TPB, bool PIPE>
+template <int K, bool HAS_SHORT, int TPB, bool PIPE, bool RANK_LDS>
 __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const GramArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gram_copy(smem, g.cls, 256);
-    gram_copy(smem + g.off_tshort, g.tshort, g.off_wbits - g.off_tshort);
-    gram_copy(smem + g.off_wbits, g.wbits, g.off_wrank - g.off_wbits);
-    gram_copy(smem + g.off_wrank, g.wrank, g.off_wown - g.off_wrank);
-    gram_copy(smem + g.off_wown, g.wown, g.off_bbits - g.off_wown);
+    if (HAS_SHORT) {
+        gram_copy(smem + g.off_cid, g.cid, g.off_combo - g.off_cid);
+        gram_copy(smem + g.off_combo, g.combo, g.off_bbits - g.off_combo);
+    }
     gram_copy(smem + g.off_bbits, g.bbits, g.off_brank - g.off_bbits);
-    if (g.rank_in_lds) {
+    if (RANK_LDS) {
         gram_copy(smem + g.off_brank, g.brank, g.off_bsuper - g.off_brank);
         gram_copy(smem + g.off_bsuper, g.bsuper, g.off_scratch - g.off_bsuper);
     }
     __syncthreads();
     const uint8_t *l_cls = reinterpret_cast<const uint8_t *>(smem);
-    const uint2 *l_short = reinterpret_cast<const uint2 *>(smem + g.off_tshort);
-    const uint32_t *l_wbits = reinterpret_cast<const uint32_t *>(smem + g.off_wbits);
-    const uint16_t *l_wrank = reinterpret_cast<const uint16_t *>(smem + g.off_wrank);
-    const uint2 *l_wown = reinterpret_cast<const uint2 *>(smem + g.off_wown);
+    const uint16_t *l_cid = reinterpret_cast<const uint16_t *>(smem + g.off_cid);
+    const uint2 *l_combo = reinterpret_cast<const uint2 *>(smem + g.off_combo);
     const uint32_t *l_bbits = reinterpret_cast<const uint32_t *>(smem + g.off_bbits);
     // the rank directory of B is only touched on hits: small automata keep it in L2 so that two
     // workgroups fit one CU's LDS
-    const uint16_t *l_brank = g.rank_in_lds ? reinterpret_cast<const uint16_t *>(smem + g.off_brank) : g.brank;
-    const uint32_t *l_bsuper = g.rank_in_lds ? reinterpret_cast<const uint32_t *>(smem + g.off_bsuper) : g.bsuper;
+    // (compile-time choice: a run-time select would turn these into generic pointers and flat loads)
+    const uint8_t *l_brank = reinterpret_cast<const uint8_t *>(smem + g.off_brank);
+    const uint32_t *l_bsuper = reinterpret_cast<const uint32_t *>(smem + g.off_bsuper);
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t C = g.C;
-    const uint32_t PK1 = K == 3 ? g.CC : g.C;    // C^(K-1)
     const uint32_t PK = K == 3 ? g.CCC : g.CC;   // C^K
     const uint32_t ub4 = g.unused_byte * 0x01010101u;
     const uint8_t *__restrict__ hay = a.hay_al;
@@ -113,7 +111,8 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     // offset within its level of the depth-(K+1) state whose gram index is `ib` (its B bit is set)
     auto deep_rank = [&](uint32_t ib, uint32_t word) -> uint32_t {
         const uint32_t w = ib >> 5;
-        return l_bsuper[w >> 6] + l_brank[w] + __popc(word & ((1u << (ib & 31u)) - 1u));
+        const uint32_t below = __popc(word & ((1u << (ib & 31u)) - 1u));
+        return RANK_LDS ? l_bsuper[w >> 3] + l_brank[w] + below : g.bsuper[w >> 3] + g.brank[w] + below;
     };
     // Finishes the queued branches, 64 per round.  An entry is the position p of the last byte of a
     // (K+1)-gram whose depth-(K+1) state (already counted) has a child on the byte at p + 1.
@@ -144,15 +143,15 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     uint64_t pend_v = 0;
     auto consume_pending = [&]() {
         if (__any(pend_hits != 0)) {
+            uint32_t dcnt = 0;
 #pragma unroll
             for (int jj = 0; jj < kGroup; ++jj) {
                 const uint32_t kn = (pend_kn0 >> (8 * jj)) & 0xffu;
-                const bool hit = (pend_hits >> jj) & 1u;
                 const uint2 r = pend[jj];  // {cmap, own h32 sum}; zero when not a hit
-                tot_cnt += r.y != 0;
+                dcnt += r.y != 0;
                 tot_s1 += r.y;
                 tot_s2 += r.y * (pend_e0 + jj);
-                const bool go = hit && ((r.x >> kn) & 1u);
+                const bool go = (r.x >> kn) & 1u;
                 const unsigned long long m = __ballot(go);
                 if (m != 0) {  // rare: the branch goes on past depth K+1 -> queue a walker
                     if (go)
@@ -161,6 +160,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                     wq_n += __popcll(m);
                 }
             }
+            tot_cnt += dcnt;
         }
         pend_hits = 0;
     };
@@ -213,41 +213,31 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             const uint32_t e0 = static_cast<uint32_t>(v - a.lead) + 1u;  // end of this lane's position 0
 #pragma unroll
             for (int grp = 0; grp < 16 / kGroup; ++grp) {
-                uint32_t iS[kGroup], iW[kGroup], iB[kGroup], bw[kGroup], ww[kGroup], wr[kGroup];
-                uint2 ts[kGroup], wo[kGroup];
+                uint32_t iW[kGroup], iB[kGroup], bw[kGroup], id[kGroup];
+                uint2 co[kGroup];
 #pragma unroll
                 for (int jj = 0; jj < kGroup; ++jj) {
                     const int j = grp * kGroup + jj;
-                    uint32_t sidx = kx[j + 2];                                         // K-1 classes ending at j
-                    if (K == 3) sidx = __umul24(sidx, C) + kx[j + 3];
-                    iS[jj] = sidx;
-                    iW[jj] = __umul24(kx[j + 1], PK1) + sidx;                          // K classes
-                    iB[jj] = __umul24(kx[j], PK) + iW[jj];                             // K+1 classes
+                    uint32_t widx = __umul24(kx[j + 1], C) + kx[j + 2];                // K classes ending at j
+                    if (K == 3) widx = __umul24(widx, C) + kx[j + 3];
+                    iW[jj] = widx;
+                    iB[jj] = __umul24(kx[j], PK) + widx;                               // K+1 classes
                 }
 #pragma unroll
                 for (int jj = 0; jj < kGroup; ++jj) {
-                    if (HAS_SHORT) ts[jj] = l_short[iS[jj]];
-                    if (HAS_WORD) { ww[jj] = l_wbits[iW[jj] >> 5]; wr[jj] = l_wrank[iW[jj] >> 5]; }
+                    if (HAS_SHORT) id[jj] = l_cid[iW[jj]];
                     bw[jj] = l_bbits[iB[jj] >> 5];
                 }
-                if (HAS_WORD) {
+                if (HAS_SHORT) {
 #pragma unroll
-                    for (int jj = 0; jj < kGroup; ++jj) {
-                        const uint32_t sh = iW[jj] & 31u;
-                        const bool hit = (ww[jj] >> sh) & 1u;
-                        const uint32_t rank = wr[jj] + __popc(ww[jj] & ((1u << sh) - 1u));
-                        const uint2 o = l_wown[hit ? rank : 0u];
-                        wo[jj] = hit ? o : uint2{0u, 0u};
-                    }
+                    for (int jj = 0; jj < kGroup; ++jj) co[jj] = l_combo[id[jj]];
                 }
                 uint32_t hits = 0;
 #pragma unroll
                 for (int jj = 0; jj < kGroup; ++jj) {
-                    if (HAS_SHORT || HAS_WORD) {
-                        uint32_t hs = 0;
-                        if (HAS_SHORT) { ccnt += ts[jj].x; hs = ts[jj].y; }
-                        if (HAS_WORD) { ccnt += wo[jj].x; hs += wo[jj].y; }
-                        A += hs;
+                    if (HAS_SHORT) {
+                        ccnt += co[jj].x;
+                        A += co[jj].y;
                         T += A;
                     }
                     hits |= ((bw[jj] >> (iB[jj] & 31u)) & 1u) << jj;
@@ -280,43 +270,39 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     gram_reduce(tot_cnt, tot_s1, tot_s2, reinterpret_cast<unsigned long long *>(smem), a.result);
 }
 
-template <int K, bool S, bool W, int TPB, bool PIPE>
-static hipError_t launch_pipe(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
+template <int K, bool S, int TPB, bool PIPE, bool RL>
+static hipError_t launch_rl(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
     if (dev.lds_bytes > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram_count_kernel<K, S, W, TPB, PIPE>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram_count_kernel<K, S, TPB, PIPE, RL>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dev.lds_bytes));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((gram_count_kernel<K, S, W, TPB, PIPE>), dim3(blocks), dim3(threads), dev.lds_bytes, stream, dev, a);
+    hipLaunchKernelGGL((gram_count_kernel<K, S, TPB, PIPE, RL>), dim3(blocks), dim3(threads), dev.lds_bytes, stream, dev, a);
     return hipGetLastError();
 }
-template <int K, bool S, bool W, int TPB>
+template <int K, bool S, int TPB, bool PIPE>
+static hipError_t launch_pipe(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
+    return dev.rank_in_lds ? launch_rl<K, S, TPB, PIPE, true>(dev, a, blocks, threads, stream)
+                           : launch_rl<K, S, TPB, PIPE, false>(dev, a, blocks, threads, stream);
+}
+template <int K, bool S, int TPB>
 static hipError_t launch_tpb(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
-    return a.pipeline ? launch_pipe<K, S, W, TPB, true>(dev, a, blocks, threads, stream)
-                      : launch_pipe<K, S, W, TPB, false>(dev, a, blocks, threads, stream);
+    return a.pipeline ? launch_pipe<K, S, TPB, true>(dev, a, blocks, threads, stream)
+                      : launch_pipe<K, S, TPB, false>(dev, a, blocks, threads, stream);
 }
 
 // Three register budgets: 1024-thread workgroups (128 VGPRs, 4 waves/SIMD), 768 (168 VGPRs,
 // 3 waves/SIMD) and <= 512 (256 VGPRs, 2 waves/SIMD) with one workgroup per CU.
-template <int K, bool S, bool W>
+template <int K, bool S>
 static hipError_t launch_one(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
-    if (threads > 768) return launch_tpb<K, S, W, 1024>(dev, a, blocks, threads, stream);
-    if (threads > 512) return launch_tpb<K, S, W, 768>(dev, a, blocks, threads, stream);
-    return launch_tpb<K, S, W, 512>(dev, a, blocks, threads, stream);
+    if (threads > 768) return launch_tpb<K, S, 1024>(dev, a, blocks, threads, stream);
+    if (threads > 512) return launch_tpb<K, S, 768>(dev, a, blocks, threads, stream);
+    return launch_tpb<K, S, 512>(dev, a, blocks, threads, stream);
 }
 
 hipError_t launch_gram_scan(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
-    const int sel = (dev.K == 3 ? 4 : 0) | (dev.has_short ? 2 : 0) | (dev.has_word ? 1 : 0);
-    switch (sel) {
-        case 0: return launch_one<2, false, false>(dev, a, blocks, threads, stream);
-        case 1: return launch_one<2, false, true>(dev, a, blocks, threads, stream);
-        case 2: return launch_one<2, true, false>(dev, a, blocks, threads, stream);
-        case 3: return launch_one<2, true, true>(dev, a, blocks, threads, stream);
-        case 4: return launch_one<3, false, false>(dev, a, blocks, threads, stream);
-        case 5: return launch_one<3, false, true>(dev, a, blocks, threads, stream);
-        case 6: return launch_one<3, true, false>(dev, a, blocks, threads, stream);
-        default: return launch_one<3, true, true>(dev, a, blocks, threads, stream);
-    }
+    if (dev.K == 3) return dev.has_short ? launch_one<3, true>(dev, a, blocks, threads, stream) : launch_one<3, false>(dev, a, blocks, threads, stream);
+    return dev.has_short ? launch_one<2, true>(dev, a, blocks, threads, stream) : launch_one<2, false>(dev, a, blocks, threads, stream);
 }
 
 }  // namespace daac

@@ -54,20 +54,14 @@ int main(int argc, char **argv) {
     for (size_t pz = 0; pz < n; ++pz) {
         const long long p0 = static_cast<long long>(pz);
         const uint32_t end = static_cast<uint32_t>(pz + 1);
-        uint32_t iS = 0;
-        for (uint32_t tt = 0; tt + 1 < K; ++tt) iS = iS * C + cls(p0 - (K - 2) + tt);
-        const uint32_t iW = cls(p0 - (K - 1)) * pk1 + iS;
+        uint32_t iW = 0;
+        for (uint32_t tt = 0; tt < K; ++tt) iW = iW * C + cls(p0 - (K - 1) + tt);
         const uint32_t iB = cls(p0 - K) * pk1 * C + iW;
-        const U32x2 s = g.tshort[iS];
+        const U32x2 s = g.combo[g.cid[iW]];
         gc += s.x; g1 += s.y; g2 += s.y * end;
-        const uint32_t ww = g.wbits[iW >> 5];
-        if ((ww >> (iW & 31)) & 1u) {
-            const U32x2 o = g.wown[g.wrank[iW >> 5] + __builtin_popcount(ww & ((1u << (iW & 31)) - 1u))];
-            gc += o.x; g1 += o.y; g2 += o.y * end;
-        }
         const uint32_t bw = g.bbits[iB >> 5];
         if ((bw >> (iB & 31)) & 1u) {
-            const uint32_t rank = g.bsuper[iB >> 11] + g.brank[iB >> 5] + __builtin_popcount(bw & ((1u << (iB & 31)) - 1u));
+            const uint32_t rank = g.bsuper[iB >> 8] + g.brank[iB >> 5] + __builtin_popcount(bw & ((1u << (iB & 31)) - 1u));
             uint32_t id = g.level_start + rank;
             const U32x2 hrec = g.dhit[rank];  // what the fast pass reads: must agree with the full record
             if (hrec.x != g.drec[id].x || hrec.y != g.drec[id].w || g.drec[id].z != (hrec.y != 0 ? 1u : 0u)) { std::printf("MISMATCH dhit\n"); return 1; }
@@ -86,6 +80,6 @@ int main(int argc, char **argv) {
         std::printf("MISMATCH count %llu vs %llu, s1 %08x vs %08x, s2 %08x vs %08x\n", (unsigned long long)gc, (unsigned long long)rc, g1, r1, g2, r2);
         return 1;
     }
-    std::printf("OK %zu K=%u C=%u count=%llu lds=%u short=%d word=%d\n", n, K, C, (unsigned long long)gc, g.lds_bytes, int(g.has_short), int(g.has_word));
+    std::printf("OK %zu K=%u C=%u count=%llu lds=%u short=%d combos=%zu\n", n, K, C, (unsigned long long)gc, g.lds_bytes, int(g.has_short), g.combo.size());
     return 0;
 }

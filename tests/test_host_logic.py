@@ -140,12 +140,12 @@ def test_gram_tables_reproduce_the_match_stream(gram_check, tmp_path):
         blob.write_bytes(orc.OraclePma.build(pats).serialize())
         h = tmp_path / "h.bin"
         rng.choice(np.frombuffer(alpha, dtype=np.uint8), size=60000).tofile(h)
-        for budget in (150000, 6000):
+        for budget in (160000, 9000):
             out = subprocess.check_output([gram_check, str(blob), str(budget), str(h)]).decode()
             assert out.startswith("OK"), out
     # "" as a pattern: declined
     blob.write_bytes(orc.OraclePma.build(["", "a"]).serialize())
-    assert subprocess.check_output([gram_check, str(blob), "150000", str(h)]).decode().startswith("UNAVAILABLE")
+    assert subprocess.check_output([gram_check, str(blob), "160000", str(h)]).decode().startswith("UNAVAILABLE")
 
 
 def test_synth_definitions_are_stable():
