@@ -123,6 +123,9 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         const U32x2 *hot; const uint32_t *fail; const U32x4 *root; const OutSum *osum;
         if ((st = t->put(da.hot, hot)) != DAAC_OK) return st;
         if ((st = t->put(da.fail, fail)) != DAAC_OK) return st;
+        t->da.fail_plain = fail;
+        if (!da.fail_plain.empty() && (st = t->put(da.fail_plain, t->da.fail_plain)) != DAAC_OK) return st;
+        t->da.leftmost = !h.is_standard();
         if ((st = t->put(da.root, root)) != DAAC_OK) return st;
         if ((st = t->put(da.osum, osum)) != DAAC_OK) return st;
         t->da.hot = reinterpret_cast<const uint2 *>(hot);
@@ -228,6 +231,8 @@ namespace {
 
 struct Plan {
     bool tier;
+    bool restart = false;   // find_iter / leftmost_find_iter: the restart scanners (DARRAY tables)
+    bool leftmost = false;
     uint32_t blocks, threads;
     ScanArgs a;
 };
@@ -243,9 +248,18 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
         set_error("unknown scan mode");
         return DAAC_ERR_INVALID_ARGUMENT;
     }
-    if (mode == DAAC_FIND || mode == DAAC_LEFTMOST_FIND) {
-        set_error("find_iter / leftmost_find_iter are not on the device yet");
-        return DAAC_ERR_UNSUPPORTED;
+    pl.restart = mode == DAAC_FIND || mode == DAAC_LEFTMOST_FIND;
+    pl.leftmost = mode == DAAC_LEFTMOST_FIND;
+    if (pl.restart) {
+        if (engine != DAAC_ENGINE_AUTO && engine != DAAC_ENGINE_DARRAY) {
+            set_error("find_iter / leftmost_find_iter run on the DARRAY tables only");
+            return DAAC_ERR_UNSUPPORTED;
+        }
+        if (pl.leftmost && output_pos_of(h.opos_ch(kRoot)) != 0) {
+            // SURVEY.md 8a note D: the reference's own behaviour is not pinned (and not terminating) here
+            set_error("leftmost_find_iter with an empty pattern in the set is not supported on the device");
+            return DAAC_ERR_UNSUPPORTED;
+        }
     }
     heads = mode == DAAC_FIND_OVERLAPPING_NO_SUFFIX;
     if (engine == DAAC_ENGINE_TIERED && !t->tier_ok) {
@@ -256,7 +270,7 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
         set_error("the GRAM engine only serves daac_scan_count(DAAC_FIND_OVERLAPPING)");
         return DAAC_ERR_UNSUPPORTED;
     }
-    pl.tier = engine == DAAC_ENGINE_TIERED || (engine == DAAC_ENGINE_AUTO && t->tier_ok);
+    pl.tier = !pl.restart && (engine == DAAC_ENGINE_TIERED || (engine == DAAC_ENGINE_AUTO && t->tier_ok));
     const uint32_t lmax = h.max_pattern_len();
     const uint32_t halo = lmax > 0 ? lmax - 1 : 0;
     uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
@@ -282,10 +296,16 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
     pl.a.seg_bytes = S;
     pl.a.nseg = nseg;
     pl.a.halo = halo;
+    pl.a.total_len = end;
+    if (pl.restart) {
+        pl.threads = 256;
+        pl.blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 8, (nseg + 255) / 256)));
+    }
     return DAAC_OK;
 }
 
-hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, hipStream_t s) {
+hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, hipStream_t s, unsigned long long *next_begin = nullptr) {
+    if (pl.restart) return launch_restart_scan(t->da, pl.a, kmode, pl.leftmost, next_begin, pl.blocks, pl.threads, s);
     return pl.tier ? launch_tier_scan(t->tier, pl.a, kmode, heads, pl.blocks, pl.threads, s)
                    : launch_darray_scan(t->da, pl.a, kmode, heads, pl.blocks, pl.threads, s);
 }
@@ -293,26 +313,38 @@ hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, 
 // Scans [begin, end) of a haystack whose byte 0 is at `dev_hay` (device pointer; only bytes
 // >= begin - halo are dereferenced) and returns the matches with end in (begin, end] — plus
 // ROOT's list at end = 0 when begin == 0 — in reference order.
+// For the restart scanners (find_iter / leftmost_find_iter) `begin` must be a sync point (0, or the
+// `next_begin` of the previous window), `total_len` is the real end of the haystack, and the scan runs
+// on to the first sync point >= end, which is returned in *next_begin.
 daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int engine, const uint8_t *dev_hay, uint64_t begin,
-                                   uint64_t end, hipStream_t stream, std::vector<daac_match> &out) {
+                                   uint64_t end, uint64_t total_len, hipStream_t stream, std::vector<daac_match> &out,
+                                   uint64_t *next_begin) {
     Plan pl;
     bool heads = false;
     daac_status st = make_plan(pma, t, mode, engine, begin, end, pl, heads);
     if (st != DAAC_OK) return st;
     out.clear();
+    if (next_begin) *next_begin = end;
     // an empty range still has to report ROOT's list at end = 0: run one (empty) segment
     if (pl.a.nseg == 0) { if (begin != 0) return DAAC_OK; pl.a.nseg = 1; }
     pl.a.hay = dev_hay;
+    pl.a.total_len = total_len;
     unsigned long long *d_counts = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), (pl.a.nseg + 1) * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), (pl.a.nseg + 2) * sizeof(unsigned long long)));
     std::unique_ptr<void, void (*)(void *)> g1(d_counts, [](void *p) { (void)hipFree(p); });
     pl.a.seg_counts = d_counts;
     pl.a.result = d_counts + pl.a.nseg;
-    HIP_TRY(launch(t, pl, 1, heads, stream));
+    unsigned long long *d_next = d_counts + pl.a.nseg + 1;
+    HIP_TRY(hipMemsetAsync(d_next, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(launch(t, pl, 1, heads, stream, d_next));
     HIP_TRY(launch_exclusive_scan(d_counts, pl.a.nseg, d_counts + pl.a.nseg, stream));
-    unsigned long long total = 0;
+    unsigned long long total = 0, nb = 0;
     HIP_TRY(hipMemcpyAsync(&total, d_counts + pl.a.nseg, sizeof(total), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&nb, d_next, sizeof(nb), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    // FindIterator with "" in the set reports every position whatever the text: windows need no sync point
+    const bool positional = pl.restart && !pl.leftmost && output_pos_of(pma->host.opos_ch(kRoot)) != 0;
+    if (pl.restart && !positional && next_begin) *next_begin = std::max<uint64_t>(nb, end);
     if (total == 0) return DAAC_OK;
     if (total * sizeof(daac_match) > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
         set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
@@ -322,7 +354,7 @@ daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), total * sizeof(daac_match)));
     std::unique_ptr<void, void (*)(void *)> g2(d_out, [](void *p) { (void)hipFree(p); });
     pl.a.out = d_out;
-    HIP_TRY(launch(t, pl, 2, heads, stream));
+    HIP_TRY(launch(t, pl, 2, heads, stream, nullptr));
     out.resize(total);
     HIP_TRY(hipMemcpyAsync(out.data(), d_out, total * sizeof(daac_match), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -541,7 +573,7 @@ daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, s
     }
     std::unique_ptr<void, void (*)(void *)> g1(staged, [](void *p) { if (p) (void)hipFree(p); });
     std::unique_ptr<daac_matches> m(new daac_matches);
-    if ((st = scan_range_materialize(pma, t, mode, engine, dev_hay, 0, len, stream, m->v)) != DAAC_OK) return st;
+    if ((st = scan_range_materialize(pma, t, mode, engine, dev_hay, 0, len, len, stream, m->v, nullptr)) != DAAC_OK) return st;
     *out = m.release();
     return DAAC_OK;
 }
@@ -562,6 +594,8 @@ struct daac_iter {
     hipStream_t stream;
     uint64_t next_begin = 0;   // first byte of the next window
     bool started = false, done = false;
+    bool restart = false;          // find_iter / leftmost_find_iter: windows end at sync points
+    void *owned_dev = nullptr;     // host haystack staged once (restart modes read past a window's nominal end)
     std::vector<daac_match> buf;
     size_t pos = 0;
 };
@@ -581,6 +615,13 @@ daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *h
     it->pma = pma; it->mode = mode; it->engine = engine; it->hay = hay; it->len = len;
     it->hay_is_device = hay_is_device != 0;
     it->stream = static_cast<hipStream_t>(stream);
+    it->restart = pl.restart;
+    if (it->restart && !it->hay_is_device && len) {
+        const uint8_t *virt = nullptr;
+        if ((st = stage_window(hay, 0, len, it->stream, &it->owned_dev, &virt)) != DAAC_OK) { delete it; return st; }
+        it->hay = virt;
+        it->hay_is_device = true;
+    }
     *out = it;
     return DAAC_OK;
 }
@@ -606,15 +647,19 @@ int daac_iter_next(daac_iter *it, daac_match *m) {
         }
         it->buf.clear();
         it->pos = 0;
-        st = scan_range_materialize(it->pma, t, it->mode, it->engine, dev_hay, begin, end, it->stream, it->buf);
+        uint64_t next_begin = end;
+        st = scan_range_materialize(it->pma, t, it->mode, it->engine, dev_hay, begin, end, it->len, it->stream, it->buf, &next_begin);
         if (staged) (void)hipFree(staged);
         if (st != DAAC_OK) return -st;
-        it->next_begin = end;
-        if (end >= it->len) it->done = true;
+        it->next_begin = next_begin;
+        if (next_begin >= it->len) it->done = true;
     }
 }
 
-void daac_iter_close(daac_iter *it) { delete it; }
+void daac_iter_close(daac_iter *it) {
+    if (it && it->owned_dev) (void)hipFree(it->owned_dev);
+    delete it;
+}
 
 daac_status daac_set_option(const char *name, int64_t value) {
     if (!name) { set_error("null option name"); return DAAC_ERR_INVALID_ARGUMENT; }

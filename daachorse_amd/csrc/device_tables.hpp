@@ -28,11 +28,12 @@ struct TierDev {
 // DARRAY engine tables: the reference's double array, hot/cold split.
 struct DArrayDev {
     const uint2 *hot;        // {base, opos_ch} per slot
-    const uint32_t *fail;    // per slot
+    const uint32_t *fail;    // per slot (the automaton's own links; leftmost kinds: 1 = DEAD)
+    const uint32_t *fail_plain;  // classic links of the same trie (== fail for Standard automata)
     const uint4 *root;       // 256 x {child, child.base, child.opos_ch, 0}, staged into LDS
     const uint2 *osum;       // per output record {chain count, chain sum of h32}
     const uint32_t *outputs; // n_outputs x {value, length, parent}
-    uint32_t n, root_flag;
+    uint32_t n, root_flag, leftmost;
 };
 
 struct ScanArgs {
@@ -45,6 +46,7 @@ struct ScanArgs {
     unsigned long long *result;      // MODE 0: {count, S1, S2}
     unsigned long long *seg_counts;  // MODE 1 out / MODE 2 in (exclusive offsets)
     daac_match *out;                 // MODE 2
+    uint64_t total_len;              // restart scanners: real end of the haystack (a.len is the nominal end of this window)
 };
 
 // GRAM engine tables (see gram.hpp).  Everything up to `drec` is staged into LDS.
@@ -81,6 +83,10 @@ hipError_t launch_tier_scan(const TierDev &dev, const ScanArgs &a, int mode, boo
                             hipStream_t stream);
 hipError_t launch_darray_scan(const DArrayDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,
                               hipStream_t stream);
+// Restart scanners (find_iter / leftmost_find_iter): kmode 0 = totals, 1 = per-segment counts, 2 = write.
+// `next_begin` (device, 1 x u64) receives the first sync point >= a.len's nominal end.
+hipError_t launch_restart_scan(const DArrayDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,
+                               uint32_t blocks, uint32_t threads, hipStream_t stream);
 hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned long long *total, hipStream_t stream);
 
 }  // namespace daac

@@ -51,6 +51,44 @@ void build_darray_tables(const HostPma &p, DArrayTables &out) {
         out.root[c] = U32x4{child, n ? p.base(child) : 0, n ? p.opos_ch(child) : 0, 0};
     }
     build_chain_sums(p, out.osum);
+
+    // Leftmost automata cut their failure links at output states (reference src/nfa_builder.rs:146-201).
+    // The restart scanners additionally need to know where NO occurrence can span a position; that is
+    // "the classic automaton is at ROOT", so the classic links are recomputed here over the same trie
+    // (breadth-first; fail(child of s on c) = delta(fail(s), c)).
+    out.fail_plain.clear();
+    if (!p.is_standard() && n != 0) {
+        out.fail_plain.assign(n, kRoot);
+        auto child_of = [&](uint32_t s, uint32_t c) -> uint32_t {
+            const uint32_t b = p.base(s);
+            if (b == 0) return 0xffffffffu;
+            const uint32_t t = b ^ c;
+            return (t < n && check_of(p.opos_ch(t)) == c && t != kRoot) ? t : 0xffffffffu;
+        };
+        std::vector<uint32_t> queue{kRoot};
+        std::vector<uint8_t> seen(n, 0);
+        seen[kRoot] = 1;
+        for (size_t qi = 0; qi < queue.size(); ++qi) {
+            const uint32_t s = queue[qi];
+            for (uint32_t c = 0; c < 256; ++c) {
+                const uint32_t t = child_of(s, c);
+                if (t == 0xffffffffu || seen[t]) continue;
+                seen[t] = 1;
+                uint32_t f = kRoot;
+                if (s != kRoot) {
+                    uint32_t x = out.fail_plain[s];
+                    for (;;) {
+                        const uint32_t y = child_of(x, c);
+                        if (y != 0xffffffffu) { f = y; break; }
+                        if (x == kRoot) break;
+                        x = out.fail_plain[x];
+                    }
+                }
+                out.fail_plain[t] = f;
+                queue.push_back(t);
+            }
+        }
+    }
 }
 
 uint32_t TierTables::lds_bytes() const {

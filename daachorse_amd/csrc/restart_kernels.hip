@@ -1,0 +1,214 @@
+// Restart scanners for gfx950: FindIterator (reference src/bytewise/iter.rs:58-113) and
+// LeftmostFindIterator (iter.rs:272-340) on the device.
+//
+// Both iterators restart from ROOT after every match, so the scan is a chain through the match
+// positions and cannot be cut at arbitrary offsets.  It CAN be cut at a *sync point*: a position p
+// where the classic Aho-Corasick state of the text before p is ROOT, i.e. no pattern occurrence
+// starts before p and ends after it.  Whatever the iterator did before p, at p it is at ROOT with
+// nothing pending, and nothing it reports later starts before p — so the text from one sync point
+// to the next can be scanned as if it were a haystack of its own.
+//
+// One lane per segment [lo, hi):
+//   p = first sync point >= lo   (classic automaton warmed up over the (Lmax-1)-byte halo, then
+//                                 advanced until it sits at ROOT); the lane owns nothing if p >= hi
+//   q = first sync point >= hi   (same procedure) — the next owner starts exactly there
+//   then the reference's loop, literally, over [p, q), positions offset by p.
+// Regions [p, q) partition the haystack in order, so matches are placed by the same
+// count -> exclusive scan -> write passes as the overlapping scan.  Text without sync points
+// degrades gracefully: fewer, longer regions (in the limit one lane scans everything; still exact).
+//
+// Tables: the reference's double array, hot {base, opos_ch} / cold fail (DArrayDev); for leftmost
+// automata the classic failure links are recomputed on the host (repack.cpp) next to the
+// automaton's own (DEAD-terminated) ones.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_tables.hpp"
+
+namespace daac {
+
+__device__ __forceinline__ uint64_t rs_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+struct RsState { uint32_t idx, base, opos_ch; };
+
+struct RestartTables {
+    const DArrayDev &d;
+    const uint4 *l_root;  // 256 x {child, child.base, child.opos_ch, 0} in LDS
+
+    // classic delta (failure links never stop): reference src/bytewise.rs:1063-1088 over fail_plain
+    __device__ __forceinline__ void step_plain(RsState &st, uint32_t c) const {
+        for (;;) {
+            if (st.idx == 0) {
+                const uint4 r = l_root[c];
+                st = RsState{r.x, r.y, r.z};
+                return;
+            }
+            if (st.base != 0) {
+                const uint32_t child = st.base ^ c;
+                const uint2 h = d.hot[child];
+                if ((h.y & 0xffu) == c) { st = RsState{child, h.x, h.y}; return; }
+            }
+            const uint32_t f = d.fail_plain[st.idx];
+            if (f == 0) { st.idx = 0; continue; }
+            const uint2 h = d.hot[f];
+            st = RsState{f, h.x, h.y};
+        }
+    }
+
+    // next_state_id_leftmost_unchecked, reference src/bytewise.rs:1094-1128 (returns ROOT on DEAD)
+    __device__ __forceinline__ void step_leftmost(RsState &st, uint32_t c) const {
+        for (;;) {
+            if (st.idx == 0) {  // at ROOT: the child if there is one, else stay (":1113-1116")
+                const uint4 r = l_root[c];
+                st = RsState{r.x, r.y, r.z};
+                return;
+            }
+            if (st.base != 0) {
+                const uint32_t child = st.base ^ c;
+                const uint2 h = d.hot[child];
+                if ((h.y & 0xffu) == c) { st = RsState{child, h.x, h.y}; return; }
+            }
+            const uint32_t f = d.fail[st.idx];
+            if (f <= 1u) {  // DEAD (1): stop; ROOT (0): retry from the root row
+                if (f == 1u) { st = RsState{0, 0, 0}; return; }
+                st.idx = 0;
+                continue;
+            }
+            const uint2 h = d.hot[f];
+            st = RsState{f, h.x, h.y};
+        }
+    }
+
+    // first sync point >= x: warm the classic automaton up over the halo, then run it to ROOT
+    __device__ __forceinline__ uint64_t sync_from(const uint8_t *hay, uint64_t x, uint32_t halo, uint64_t floor, uint64_t len) const {
+        if (x <= floor) return floor;  // the window start is a sync point by contract
+        if (x >= len) return len;
+        uint64_t pos = x > halo ? x - halo : 0;
+        if (pos < floor) pos = floor;
+        RsState st{0, 0, 0};
+        while (pos < x) step_plain(st, hay[pos++]);
+        while (st.idx != 0 && pos < len) step_plain(st, hay[pos++]);
+        return st.idx == 0 ? pos : len;
+    }
+};
+
+// KMODE 0: totals {count, S1, S2}; 1: per-segment counts; 2: write matches at out + seg_counts[seg]
+template <bool LEFTMOST, int KMODE>
+__global__ __launch_bounds__(256) void restart_scan_kernel(const DArrayDev dev, const ScanArgs a, unsigned long long *next_begin) {
+    __shared__ uint4 l_root[256];
+    __shared__ unsigned long long scratch[3 * 4];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root[i];
+    __syncthreads();
+    const RestartTables T{dev, l_root};
+    const uint8_t *__restrict__ hay = a.hay;
+    const uint64_t len = a.total_len;  // real end of the haystack; a.len is the nominal end of this window
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long tot_cnt = 0;
+    uint32_t tot_s1 = 0, tot_s2 = 0;
+
+    for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
+        const uint64_t lo = a.begin + seg * a.seg_bytes;
+        const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
+        const uint64_t p = T.sync_from(hay, lo, a.halo, a.begin, len);
+        const bool last = hi == a.len;
+        uint64_t q = 0;
+        if (p < hi || last) q = T.sync_from(hay, hi, a.halo, a.begin, len);
+        if (last && next_begin) *next_begin = q;  // where the next window (if any) has to start
+
+        unsigned long long cnt = 0;
+        uint32_t s1 = 0, s2 = 0;
+        daac_match *o = nullptr;
+        if (KMODE == 2) o = a.out + a.seg_counts[seg];
+        auto emit = [&](uint32_t opos, uint64_t end) {
+            const uint32_t *r = dev.outputs + 3u * (opos - 1u);
+            const uint32_t value = r[0], length = r[1];
+            if (KMODE == 2) {
+                daac_match m;
+                m.start = end - length; m.end = end; m.value = value; m._pad = 0;
+                *o++ = m;
+            } else {
+                const uint32_t h = static_cast<uint32_t>(rs_mix64((static_cast<uint64_t>(value) << 32) | length));
+                cnt += 1; s1 += h; s2 += h * static_cast<uint32_t>(end);
+            }
+        };
+
+        if (!LEFTMOST && dev.root_flag) {
+            // "" is a pattern: FindIterator degenerates to (p, p, first "" value) for every p
+            // (iter.rs:60-85), whatever the text; positions (lo, hi] belong to this segment, 0 to the first
+            const uint32_t op = dev.hot[0].y >> 8;
+            if (lo == 0) emit(op, 0);
+            for (uint64_t e = lo + 1; e <= hi; ++e) emit(op, e);
+        } else if (p < hi) {
+            if (!LEFTMOST) {
+                // FindIterator::next (iter.rs:87-112): restart at ROOT after every match, report the list head
+                RsState st{0, 0, 0};
+                for (uint64_t pos = p; pos < q; ++pos) {
+                    T.step_plain(st, hay[pos]);
+                    if ((st.opos_ch >> 8) != 0) {
+                        emit(st.opos_ch >> 8, pos + 1);
+                        st = RsState{0, 0, 0};
+                    }
+                }
+            } else {
+                // LeftmostFindIterator::next (iter.rs:272-340) over the virtual haystack [p, q); no "" pattern
+                RsState st{0, 0, 0};
+                uint64_t pos = p, self_pos = p;
+                uint32_t last_out = 0;
+                for (;;) {
+                    if (pos >= q) {  // end of the (virtual) haystack: iter.rs:320-339
+                        if (last_out == 0) break;
+                        emit(last_out, self_pos);
+                        pos = self_pos; st = RsState{0, 0, 0}; last_out = 0;  // the next call rescans from the match end
+                        continue;
+                    }
+                    T.step_leftmost(st, hay[pos]);
+                    if (st.idx == 0) {
+                        if (last_out != 0) {  // iter.rs:282-306: report, restart at the end of the match
+                            emit(last_out, self_pos);
+                            pos = self_pos; last_out = 0;
+                            continue;
+                        }
+                        ++pos;
+                    } else {
+                        if ((st.opos_ch >> 8) != 0) { last_out = st.opos_ch >> 8; self_pos = pos + 1; }  // iter.rs:307-315
+                        ++pos;
+                    }
+                }
+            }
+        }
+
+        if (KMODE == 0) { tot_cnt += cnt; tot_s1 += s1; tot_s2 += s2; }
+        else if (KMODE == 1) a.seg_counts[seg] = cnt;
+    }
+
+    if (KMODE == 0) {
+        unsigned long long c = tot_cnt, x1 = tot_s1, x2 = tot_s2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off, 64); x1 += __shfl_down(x1, off, 64); x2 += __shfl_down(x2, off, 64); }
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) { scratch[wave * 3] = c; scratch[wave * 3 + 1] = x1; scratch[wave * 3 + 2] = x2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long r0 = 0, r1 = 0, r2 = 0;
+            for (int w = 0; w < static_cast<int>((blockDim.x + 63) >> 6); ++w) { r0 += scratch[w * 3]; r1 += scratch[w * 3 + 1]; r2 += scratch[w * 3 + 2]; }
+            if (r0 | r1 | r2) { atomicAdd(a.result, r0); atomicAdd(a.result + 1, r1); atomicAdd(a.result + 2, r2); }
+        }
+    }
+}
+
+hipError_t launch_restart_scan(const DArrayDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,
+                               uint32_t blocks, uint32_t threads, hipStream_t stream) {
+    const dim3 g(blocks), b(threads > 256 ? 256 : threads);
+#define DAAC_RS(L, M) hipLaunchKernelGGL((restart_scan_kernel<L, M>), g, b, 0, stream, dev, a, next_begin)
+    if (leftmost) { if (kmode == 0) DAAC_RS(true, 0); else if (kmode == 1) DAAC_RS(true, 1); else DAAC_RS(true, 2); }
+    else { if (kmode == 0) DAAC_RS(false, 0); else if (kmode == 1) DAAC_RS(false, 1); else DAAC_RS(false, 2); }
+#undef DAAC_RS
+    return hipGetLastError();
+}
+
+}  // namespace daac

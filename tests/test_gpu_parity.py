@@ -17,7 +17,9 @@ import daachorse_amd as da
 from daachorse_amd import Engine, ScanMode, synth
 
 API_MODE = {"find_overlapping_iter": ScanMode.FindOverlapping,
-            "find_overlapping_no_suffix_iter": ScanMode.FindOverlappingNoSuffix}
+            "find_overlapping_no_suffix_iter": ScanMode.FindOverlappingNoSuffix,
+            "find_iter": ScanMode.Find, "leftmost_find_iter": ScanMode.LeftmostFind}
+KIND_CODE = {"Standard": 0, "LeftmostLongest": 1, "LeftmostFirst": 2}
 ENGINES = [Engine.Tiered, Engine.DArray]
 
 
@@ -78,16 +80,45 @@ def test_golden_vectors_overlapping(vectors):
     assert n == 57
 
 
+def _empty_pattern_leftmost(runner, case):
+    return runner["api"] == "leftmost_find_iter" and "" in case["patterns"]
+
+
+def test_golden_vectors_find_and_leftmost(vectors):
+    """search_standard_non_overlapping, search_leftmost_longest, search_leftmost_first
+    (tests/aho_corasick_crate_test.rs:537-589) on the GPU: eager scan, count + checksum, lazy iterator."""
+    n = skipped = 0
+    for runner, case in iter_vector_runs(vectors):
+        if runner["api"] not in ("find_iter", "leftmost_find_iter"):
+            continue
+        o, p = _pma(case["patterns"], kind=runner["kind"])
+        mode = API_MODE[runner["api"]]
+        if _empty_pattern_leftmost(runner, case):
+            # SURVEY 8a note D: the reference's behaviour with "" under leftmost kinds is not pinned
+            with pytest.raises(da.DaachorseError) as ei:
+                p.scan(mode, case["haystack"])
+            assert ei.value.code == 6
+            skipped += 1
+            continue
+        want = [tuple(t) for t in case["matches"]]
+        got = p.scan(mode, case["haystack"])
+        assert [(int(m["value"]), int(m["start"]), int(m["end"])) for m in got] == want, (runner, case["name"])
+        assert p.scan_count(mode, case["haystack"]) == (len(want), orc.matches_checksum(got)), case["name"]
+        it = p.find_iter(case["haystack"]) if mode == ScanMode.Find else p.leftmost_find_iter(case["haystack"])
+        assert [(m.value(), m.start(), m.end()) for m in it] == want, case["name"]
+        n += 1
+    assert n + skipped == 61 + 93 + 91 and skipped < 40
+
+
 def test_known_answers(pins):
     for ka in pins["known_answers"]:
-        if ka["api"] not in API_MODE:
-            continue
         if "patvals" in ka:
             pats, vals = [p for p, _ in ka["patvals"]], [v for _, v in ka["patvals"]]
         else:
             pats, vals = ka["patterns"], None
-        _, p = _pma(pats, values=vals)
-        for eng in ENGINES:
+        _, p = _pma(pats, values=vals, kind=ka["kind"])
+        engines = ENGINES if ka["api"].startswith("find_overlapping") else [Engine.Auto, Engine.DArray]
+        for eng in engines:
             got = _sev(p.scan(API_MODE[ka["api"]], ka["haystack"], engine=eng))
             assert got == [tuple(t) for t in ka["matches_sev"]], (ka["cite"], eng)
 
@@ -260,3 +291,60 @@ def test_shard_tail_counts_add_up():
             s1, s2 = ddist.split_checksum(got[1])
             tot_c, tot_1, tot_2 = tot_c + got[0], tot_1 + s1, tot_2 + s2
         assert (tot_c, ddist.join_checksum(tot_1, tot_2)) == whole, cuts
+
+
+@pytest.mark.parametrize("seg_bytes", [16, 64, 0])
+def test_fuzz_find_and_leftmost(seg_bytes):
+    """find_iter / leftmost_find_iter against the literal iterators of the oracle: tiny alphabets (few
+    sync points, long chains across segments), periodic texts that never synchronise, separators."""
+    rng = np.random.default_rng(4321 + seg_bytes)
+    da.set_option("seg_bytes", seg_bytes)
+    for it in range(50):
+        npat = int(rng.integers(1, 7))
+        pats = [bytes(rng.integers(97, 100, size=int(rng.integers(1, 6))).astype(np.uint8)) for _ in range(npat)]
+        if it % 7 == 0:
+            pats.append(b"")
+        if it % 5 == 0:
+            hay = np.frombuffer((b"ab" * 150)[:int(rng.integers(1, 300))], dtype=np.uint8)  # periodic: no sync point
+        else:
+            hay = rng.integers(97, 100 + (it % 3), size=int(rng.integers(0, 500)), dtype=np.uint8)
+        for kind in ("Standard", "LeftmostLongest", "LeftmostFirst"):
+            o, p = _pma(pats, kind=kind)
+            if kind == "Standard":
+                want, mode = o.find_iter(hay), ScanMode.Find
+            else:
+                mode = ScanMode.LeftmostFind
+                if b"" in pats:
+                    with pytest.raises(da.DaachorseError):
+                        p.scan(mode, hay)
+                    continue
+                want = o.leftmost_find_iter(hay)
+            got = p.scan(mode, hay)
+            assert _same(got, want), (kind, pats, bytes(hay), _sev(got)[:6], _sev(want)[:6])
+            assert p.scan_count(mode, hay) == (len(want), orc.matches_checksum(want)), (kind, pats)
+
+
+def test_find_and_leftmost_dictionaries():
+    """cfg2 / cfg3-style automata, all three kinds, MiB-sized sparse and dense haystacks, lazy windows."""
+    import torch
+    for pats, dense_slot in ((synth.patterns_cfg2(), 13), (synth.patterns_cfg3(20000), 20)):
+        n = 2 << 20
+        sparse = synth.uniform_haystack(n, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+        dense = synth.wordsoup_haystack(n, synth.SEEDS["cfg3_dense"], pats, dense_slot)
+        for kind in ("Standard", "LeftmostLongest", "LeftmostFirst"):
+            o, p = _pma(pats, kind=kind)
+            for hay in (sparse, dense):
+                want = o.find_iter(hay) if kind == "Standard" else o.leftmost_find_iter(hay)
+                mode = ScanMode.Find if kind == "Standard" else ScanMode.LeftmostFind
+                dev = torch.from_numpy(hay).cuda()
+                assert _same(p.scan(mode, dev), want), kind
+                assert p.scan_count(mode, dev) == (len(want), orc.matches_checksum(want)), kind
+    # lazy iterator across windows that end at sync points
+    da.set_option("iter_window", 8192)
+    o, p = _pma(pats, kind="LeftmostLongest")
+    small = dense[:200_000]
+    want = _sev(o.leftmost_find_iter(small))
+    assert [(m.start(), m.end(), m.value()) for m in p.leftmost_find_iter(small)] == want
+    o, p = _pma(pats)
+    want = _sev(o.find_iter(small))
+    assert [(m.start(), m.end(), m.value()) for m in p.find_iter(small)] == want
