@@ -229,6 +229,21 @@ static daac_status get_tables(daac_pma *pma, DeviceTables **out) {
 // ---------------------------------------------------------------------------------- scan driver
 namespace {
 
+// The reference panics when a query does not fit the automaton's MatchKind (bytewise.rs:194-197,
+// 299-302, 551-554); checked before anything touches the device.
+daac_status check_mode_kind(const daac_pma *pma, int mode) {
+    const bool standard = pma->host.is_standard();
+    if (mode == DAAC_FIND_OVERLAPPING || mode == DAAC_FIND_OVERLAPPING_NO_SUFFIX || mode == DAAC_FIND) {
+        if (!standard) { set_error("Error: match_kind must be standard."); return DAAC_ERR_MATCH_KIND; }
+    } else if (mode == DAAC_LEFTMOST_FIND) {
+        if (standard) { set_error("Error: match_kind must be leftmost."); return DAAC_ERR_MATCH_KIND; }
+    } else {
+        set_error("unknown scan mode");
+        return DAAC_ERR_INVALID_ARGUMENT;
+    }
+    return DAAC_OK;
+}
+
 struct Plan {
     bool tier;
     bool restart = false;   // find_iter / leftmost_find_iter: the restart scanners (DARRAY tables)
@@ -488,8 +503,9 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
     }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceTables *t = nullptr;
-    daac_status st = get_tables(pma, &t);
+    daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
+    if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
     const bool use_gram = mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len < (1ull << 35) && begin == 0 &&
                           (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && t->gram_ok));
     if (engine == DAAC_ENGINE_GRAM && (!use_gram || !t->gram_ok)) {
@@ -564,8 +580,9 @@ daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, s
     if (!pma || !out || (len && !hay)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceTables *t = nullptr;
-    daac_status st = get_tables(pma, &t);
+    daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
+    if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
     void *staged = nullptr;
     const uint8_t *dev_hay = hay;
     if (!hay_is_device && len) {
@@ -606,8 +623,9 @@ daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *h
                            daac_iter **out) {
     if (!pma || !out || (len && !hay)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     DeviceTables *t = nullptr;
-    daac_status st = get_tables(pma, &t);
+    daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
+    if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
     Plan pl;
     bool heads;
     if ((st = make_plan(pma, t, mode, engine, 0, len, pl, heads)) != DAAC_OK) return st;  // kind / mode checks up front

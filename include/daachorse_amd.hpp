@@ -1,0 +1,207 @@
+// daachorse_amd.hpp — header-only C++17 façade over the C ABI (include/daachorse_amd.h).
+//
+// The reference is a Rust crate; no Rust toolchain exists in this image, so the host side that a
+// crate user would touch is mirrored here in C++ with the crate's names, argument meaning and
+// error behaviour (reference src/bytewise.rs, src/bytewise/builder.rs, src/bytewise/iter.rs):
+//
+//     auto pma = daachorse::DoubleArrayAhoCorasick::new_({"bcd", "ab", "a"}).value();
+//     for (auto it = pma.find_overlapping_iter("abcd"); auto m = it.next();)
+//         use(m->start(), m->end(), m->value());
+//
+//   * construction / deserialisation return Result<T> (a value or a DaachorseError), like the
+//     crate's `Result<_, DaachorseError>` (src/errors.rs:10-22, 140);
+//   * calling a query of the wrong MatchKind PANICS in the crate (bytewise.rs:194-197, 299-302,
+//     551-554): here it throws daachorse::PanicError carrying the crate's message;
+//   * iterators are lazy (`next()`), borrow the automaton, and keep the haystack alive.
+// Every scan runs on the MI355X; there is no CPU scan path behind this header.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "daachorse_amd.h"
+
+namespace daachorse {
+
+enum class MatchKind : uint8_t { Standard = 0, LeftmostLongest = 1, LeftmostFirst = 2 };  // src/lib.rs:324-346
+
+struct DaachorseError {  // src/errors.rs:10-22
+    enum Kind { InvalidArgument = 1, AutomatonScale = 2, InvalidConversion = 3, InvalidAutomaton = 4, Unsupported = 6, Device = 7 } kind;
+    std::string message;
+};
+
+struct PanicError : std::runtime_error {  // the crate's assert!/panic! paths
+    using std::runtime_error::runtime_error;
+};
+
+template <class T>
+class Result {
+public:
+    Result(T v) : v_(std::move(v)) {}
+    Result(DaachorseError e) : v_(std::move(e)) {}
+    bool is_ok() const { return v_.index() == 0; }
+    bool is_err() const { return !is_ok(); }
+    T &value() {
+        if (is_err()) throw PanicError("called `Result::unwrap()` on an `Err` value: " + std::get<1>(v_).message);
+        return std::get<0>(v_);
+    }
+    T unwrap() { return std::move(value()); }
+    const DaachorseError &error() const { return std::get<1>(v_); }
+
+private:
+    std::variant<T, DaachorseError> v_;
+};
+
+class Match {  // src/lib.rs:286-320
+public:
+    Match(uint64_t s, uint64_t e, uint32_t v) : s_(s), e_(e), v_(v) {}
+    uint64_t start() const { return s_; }
+    uint64_t end() const { return e_; }
+    uint32_t value() const { return v_; }
+    bool operator==(const Match &o) const { return s_ == o.s_ && e_ == o.e_ && v_ == o.v_; }
+
+private:
+    uint64_t s_, e_;
+    uint32_t v_;
+};
+
+namespace detail {
+inline DaachorseError make_error(daac_status st) {
+    const char *m = daac_last_error();
+    return DaachorseError{static_cast<DaachorseError::Kind>(st), m ? m : ""};
+}
+struct PmaDeleter { void operator()(daac_pma *p) const { daac_pma_free(p); } };
+struct IterDeleter { void operator()(daac_iter *p) const { daac_iter_close(p); } };
+}  // namespace detail
+
+// Iterator<Item = Match<u32>>: FindIterator / FindOverlappingIterator / FindOverlappingNoSuffixIterator /
+// LeftmostFindIterator of src/bytewise/iter.rs, one type here because the device engine sits behind them.
+class MatchIterator {
+public:
+    std::optional<Match> next() {
+        daac_match m;
+        const int r = daac_iter_next(it_.get(), &m);
+        if (r == 1) return Match(m.start, m.end, m.value);
+        if (r == 0) return std::nullopt;
+        throw PanicError(std::string("device scan failed: ") + daac_last_error());
+    }
+    std::vector<Match> collect() {
+        std::vector<Match> out;
+        while (auto m = next()) out.push_back(*m);
+        return out;
+    }
+
+private:
+    friend class DoubleArrayAhoCorasick;
+    MatchIterator(daac_iter *it, std::unique_ptr<std::string> hay) : hay_(std::move(hay)), it_(it) {}
+    std::unique_ptr<std::string> hay_;  // the haystack lives (at a stable address) as long as the iterator (the crate's `P`)
+    std::unique_ptr<daac_iter, detail::IterDeleter> it_;
+};
+
+class DoubleArrayAhoCorasickBuilder;
+
+class DoubleArrayAhoCorasick {  // src/bytewise.rs:54-68
+public:
+    // bytewise.rs:103-110 / 154-161 (`new` is a keyword in C++)
+    static Result<DoubleArrayAhoCorasick> new_(const std::vector<std::string> &patterns);
+    static Result<DoubleArrayAhoCorasick> with_values(const std::vector<std::pair<std::string, uint32_t>> &patvals);
+
+    // bytewise.rs:868-964: (automaton, bytes consumed)
+    static Result<std::pair<DoubleArrayAhoCorasick, size_t>> deserialize(std::string_view source) {
+        daac_pma *h = nullptr;
+        size_t consumed = 0;
+        const daac_status st = daac_bytewise_from_serialized(reinterpret_cast<const uint8_t *>(source.data()), source.size(), &h, &consumed);
+        if (st != DAAC_OK) return detail::make_error(st);
+        return std::make_pair(DoubleArrayAhoCorasick(h), consumed);
+    }
+    std::string serialize() const {  // bytewise.rs:801-820
+        uint8_t *buf = nullptr;
+        size_t len = 0;
+        if (daac_pma_serialize(h_.get(), &buf, &len) != DAAC_OK) throw PanicError(daac_last_error());
+        std::string out(reinterpret_cast<char *>(buf), len);
+        daac_free(buf);
+        return out;
+    }
+
+    MatchIterator find_iter(std::string haystack) const { return open(DAAC_FIND, std::move(haystack), "Error: match_kind must be standard."); }
+    MatchIterator find_overlapping_iter(std::string haystack) const {
+        return open(DAAC_FIND_OVERLAPPING, std::move(haystack), "Error: match_kind must be standard.");
+    }
+    MatchIterator find_overlapping_no_suffix_iter(std::string haystack) const {
+        return open(DAAC_FIND_OVERLAPPING_NO_SUFFIX, std::move(haystack), "Error: match_kind must be standard.");
+    }
+    MatchIterator leftmost_find_iter(std::string haystack) const {
+        return open(DAAC_LEFTMOST_FIND, std::move(haystack), "Error: match_kind must be leftmost.");
+    }
+
+    MatchKind match_kind() const { return static_cast<MatchKind>(info().match_kind); }
+    size_t num_states() const { return info().num_states; }
+    size_t heap_bytes() const { return info().heap_bytes; }
+    daac_pma *raw() const { return h_.get(); }
+
+private:
+    friend class DoubleArrayAhoCorasickBuilder;
+    explicit DoubleArrayAhoCorasick(daac_pma *h) : h_(h) {}
+    daac_info info() const {
+        daac_info i;
+        daac_pma_info(h_.get(), &i);
+        return i;
+    }
+    MatchIterator open(int mode, std::string hay, const char *panic_msg) const {
+        auto keep = std::make_unique<std::string>(std::move(hay));
+        daac_iter *it = nullptr;
+        const daac_status st = daac_iter_open(h_.get(), mode, DAAC_ENGINE_AUTO, reinterpret_cast<const uint8_t *>(keep->data()), keep->size(),
+                                              0, nullptr, &it);
+        if (st == DAAC_ERR_MATCH_KIND) throw PanicError(panic_msg);
+        if (st != DAAC_OK) throw PanicError(std::string("device scan failed: ") + daac_last_error());
+        return MatchIterator(it, std::move(keep));
+    }
+    std::unique_ptr<daac_pma, detail::PmaDeleter> h_;
+};
+
+class DoubleArrayAhoCorasickBuilder {  // src/bytewise/builder.rs:21-244
+public:
+    DoubleArrayAhoCorasickBuilder &match_kind(MatchKind k) { kind_ = k; return *this; }
+    DoubleArrayAhoCorasickBuilder &num_free_blocks(uint32_t n) {
+        if (n < 1) throw PanicError("assertion failed: n >= 1");  // builder.rs:113
+        nfb_ = n;
+        return *this;
+    }
+    Result<DoubleArrayAhoCorasick> build(const std::vector<std::string> &patterns) const { return run(patterns, nullptr); }
+    Result<DoubleArrayAhoCorasick> build_with_values(const std::vector<std::pair<std::string, uint32_t>> &patvals) const {
+        std::vector<std::string> pats;
+        std::vector<uint32_t> vals;
+        for (const auto &pv : patvals) { pats.push_back(pv.first); vals.push_back(pv.second); }
+        return run(pats, &vals);
+    }
+
+private:
+    Result<DoubleArrayAhoCorasick> run(const std::vector<std::string> &pats, const std::vector<uint32_t> *vals) const {
+        std::string blob;
+        std::vector<uint64_t> offs{0};
+        for (const auto &p : pats) { blob += p; offs.push_back(blob.size()); }
+        daac_pma *h = nullptr;
+        const daac_status st = daac_bytewise_build(reinterpret_cast<const uint8_t *>(blob.data()), offs.data(), vals ? vals->data() : nullptr,
+                                                   pats.size(), static_cast<uint8_t>(kind_), nfb_, &h);
+        if (st != DAAC_OK) return detail::make_error(st);
+        return DoubleArrayAhoCorasick(h);
+    }
+    MatchKind kind_ = MatchKind::Standard;
+    uint32_t nfb_ = 16;
+};
+
+inline Result<DoubleArrayAhoCorasick> DoubleArrayAhoCorasick::new_(const std::vector<std::string> &patterns) {
+    return DoubleArrayAhoCorasickBuilder().build(patterns);
+}
+inline Result<DoubleArrayAhoCorasick> DoubleArrayAhoCorasick::with_values(const std::vector<std::pair<std::string, uint32_t>> &patvals) {
+    return DoubleArrayAhoCorasickBuilder().build_with_values(patvals);
+}
+
+}  // namespace daachorse

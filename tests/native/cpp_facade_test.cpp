@@ -1,0 +1,56 @@
+// The C++ façade (include/daachorse_amd.hpp) driven the way the reference's own doc tests drive the
+// crate (README.md:57-192, src/bytewise/builder.rs:38-55, tests/matchkind_mismatch_test.rs).
+//   usage: cpp_facade_test host   (no GPU: construction, serialisation, errors)
+//          cpp_facade_test gpu    (+ the scans)
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/daachorse_amd.hpp"
+
+using namespace daachorse;
+
+#define CHECK(cond)                                                        \
+    do {                                                                   \
+        if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); return 1; } \
+    } while (0)
+
+static bool same(const std::vector<Match> &got, const std::vector<Match> &want) { return got == want; }
+
+int main(int argc, char **argv) {
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    auto pma = DoubleArrayAhoCorasick::new_({"bcd", "ab", "a"}).unwrap();
+    CHECK(pma.num_states() == 6);       // src/bytewise.rs:777-783
+    CHECK(pma.heap_bytes() == 4132);    // src/bytewise.rs:756-762
+    CHECK(pma.match_kind() == MatchKind::Standard);
+    const std::string blob = pma.serialize();
+    auto again = DoubleArrayAhoCorasick::deserialize(blob + "xyz").unwrap();
+    CHECK(again.second == blob.size() && again.first.serialize() == blob);
+    CHECK(DoubleArrayAhoCorasick::deserialize(std::string(21, '\0')).is_err());  // src/bytewise.rs:1496-1507
+    CHECK(DoubleArrayAhoCorasickBuilder().num_free_blocks(0xffffffffu).build({"pattern"}).is_err());  // tests/invalid_option_test.rs
+    if (!gpu) { std::printf("OK host\n"); return 0; }
+
+    CHECK(same(pma.find_overlapping_iter("abcd").collect(), {Match(0, 1, 2), Match(0, 2, 1), Match(1, 4, 0)}));  // README.md:57-71
+    CHECK(same(pma.find_iter("abcd").collect(), {Match(0, 1, 2), Match(1, 4, 0)}));                               // README.md:82-93
+    auto it = pma.find_iter("abcd");  // lazy, one next() at a time like the doc test
+    auto m = it.next();
+    CHECK(m && m->start() == 0 && m->end() == 1 && m->value() == 2);
+    m = it.next();
+    CHECK(m && m->start() == 1 && m->end() == 4 && m->value() == 0);
+    CHECK(!it.next());
+    auto ll = DoubleArrayAhoCorasickBuilder().match_kind(MatchKind::LeftmostLongest).build({"ab", "a", "abcd"}).unwrap();
+    CHECK(same(ll.leftmost_find_iter("abcd").collect(), {Match(0, 4, 2)}));  // README.md:104-115
+    auto lf = DoubleArrayAhoCorasickBuilder().match_kind(MatchKind::LeftmostFirst).build({"ab", "a", "abcd"}).unwrap();
+    CHECK(same(lf.leftmost_find_iter("abcd").collect(), {Match(0, 2, 0)}));  // README.md:130-141
+    auto wv = DoubleArrayAhoCorasick::with_values({{"bcd", 0}, {"ab", 10}, {"a", 20}}).unwrap();
+    CHECK(same(wv.find_overlapping_iter("abcd").collect(), {Match(0, 1, 20), Match(0, 2, 10), Match(1, 4, 0)}));  // README.md:152-166
+    bool panicked = false;
+    try { ll.find_iter(""); } catch (const PanicError &e) { panicked = std::string(e.what()) == "Error: match_kind must be standard."; }
+    CHECK(panicked);  // tests/matchkind_mismatch_test.rs:5-11
+    panicked = false;
+    try { pma.leftmost_find_iter(""); } catch (const PanicError &e) { panicked = std::string(e.what()) == "Error: match_kind must be leftmost."; }
+    CHECK(panicked);  // tests/matchkind_mismatch_test.rs:65-71
+    std::printf("OK gpu\n");
+    return 0;
+}

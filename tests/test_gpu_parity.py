@@ -348,3 +348,15 @@ def test_find_and_leftmost_dictionaries():
     o, p = _pma(pats)
     want = _sev(o.find_iter(small))
     assert [(m.start(), m.end(), m.value()) for m in p.find_iter(small)] == want
+
+
+def test_cpp_facade_on_gpu(tmp_path):
+    """The C++ host façade (include/daachorse_amd.hpp) end to end: the README examples of the reference."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "cpp_facade_test")
+    libdir = os.path.join(ROOT, "daachorse_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "cpp_facade_test.cpp"),
+                           "-L" + libdir, "-ldaachorse_amd", "-Wl,-rpath," + libdir])
+    assert subprocess.check_output([exe, "gpu"]).decode().strip() == "OK gpu"

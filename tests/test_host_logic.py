@@ -160,6 +160,29 @@ def test_synth_definitions_are_stable():
     assert synth.wordsoup_haystack(100, synth.SEEDS["cfg3_dense"], p3, 20, offset=137).tobytes() == ws[137:237].tobytes()
 
 
+@pytest.fixture(scope="module")
+def cpp_facade(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("native") / "cpp_facade_test")
+    libdir = os.path.join(ROOT, "daachorse_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "cpp_facade_test.cpp"),
+                           "-L" + libdir, "-ldaachorse_amd", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_cpp_facade_host(cpp_facade):
+    """include/daachorse_amd.hpp compiles against the C ABI and behaves like the crate on the host side."""
+    assert subprocess.check_output([cpp_facade, "host"]).decode().strip() == "OK host"
+
+
+def test_matchkind_mismatch_needs_no_device(pins):
+    """The crate panics on a MatchKind mismatch before looking at the haystack; so does the boundary."""
+    for e in pins["matchkind_mismatch"]["must_fail"]:
+        pma = da.DoubleArrayAhoCorasickBuilder().match_kind(da.MatchKind[e["kind"]]).build(["a"])
+        with pytest.raises(da.DaachorseError) as ei:
+            list(getattr(pma, e["api"])(""))
+        assert ei.value.code == 5, e
+
+
 def test_scan_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
