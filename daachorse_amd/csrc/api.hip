@@ -192,7 +192,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 g.off_brank = g.off_bbits + p16(gt.bbits.size() * 4);
                 // Without the rank directory two workgroups may fit one CU (<= 80 KB each); worth it when
                 // the level is small, i.e. B hits are rare whatever the text.
-                g.rank_in_lds = !(g.off_brank + 16u <= 80u * 1024u && gt.dhit.size() <= 8192);
+                g.rank_in_lds = !(g.off_brank + 16u * 1024u <= 80u * 1024u && gt.dhit.size() <= 8192);
                 if (g_opt.gram_rank_in_lds.load() >= 0) g.rank_in_lds = g_opt.gram_rank_in_lds.load() != 0;
                 if (g.rank_in_lds) {
                     g.off_bsuper = g.off_brank + p16(gt.brank.size());
@@ -201,7 +201,8 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                     g.off_bsuper = g.off_brank;
                     g.off_scratch = g.off_brank;
                 }
-                g.lds_bytes = std::max<uint32_t>(g.off_scratch + 16u, 1024u);
+                // + one 128-entry x 8-byte hit ring per wave of a 1024-thread workgroup
+                g.lds_bytes = std::max<uint32_t>(g.off_scratch + 16u * 128u * 8u, 1024u);
                 g.K = gt.K; g.C = gt.C; g.CC = gt.C * gt.C; g.CCC = gt.C * gt.C * gt.C;
                 g.level_start = gt.level_start;
                 g.unused_byte = gt.unused_byte;

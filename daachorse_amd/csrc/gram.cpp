@@ -86,7 +86,7 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
             cid[g] = it->second;
         }
         if (!ok) continue;
-        const uint64_t bytes = 256 + pad16(ngram * 2) + pad16(combo.size() * 8) + pad16(bwords * 4) + pad16(bwords) +
+        const uint64_t bytes = 256 + pad16(ngram * 2) + pad16(combo.size() * 8) + pad16(bwords * 4 + 8) + pad16((bwords + 1) / 2) +
                                pad16(((bwords + 7) / 8) * 4) + 64;
         if (bytes > lds_budget) continue;
         K = cand;
@@ -126,12 +126,13 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
             out.dhit.push_back(U32x2{r.x, own_hs[s]});
         }
     }
-    out.brank.resize(out.bbits.size());
+    if (out.bbits.size() & 1) out.bbits.push_back(0);  // whole 64-bit pairs
+    out.brank.resize(out.bbits.size() / 2);
     out.bsuper.assign((out.bbits.size() + 7) / 8, 0);
     uint32_t run = 0, in_super = 0;
     for (size_t w = 0; w < out.bbits.size(); ++w) {
         if ((w & 7) == 0) { out.bsuper[w >> 3] = run; in_super = 0; }
-        out.brank[w] = static_cast<uint8_t>(in_super);  // < 7 * 32
+        if ((w & 1) == 0) out.brank[w >> 1] = static_cast<uint8_t>(in_super);  // <= 6 * 32
         const uint32_t c = __builtin_popcount(out.bbits[w]);
         in_super += c;
         run += c;

@@ -36,8 +36,8 @@ struct GramTables {
     std::vector<uint16_t> cid;      // C^K: combination id of the K-gram, 0 = no pattern ends here
     std::vector<U32x2> combo;       // per id: {count, hsum} of the patterns of length <= K ending here
     std::vector<uint32_t> bbits;    // ceil(C^(K+1) / 32): (K+1)-gram is a trie prefix
-    std::vector<uint8_t> brank;     // per word of bbits: set bits before it within its 8-word superblock
-    std::vector<uint32_t> bsuper;   // per 8 words: set bits before the superblock
+    std::vector<uint8_t> brank;     // per PAIR of bbits words (64 bits): set bits before the pair within its 8-word superblock
+    std::vector<uint32_t> bsuper;   // per 8 words (256 bits): set bits before the superblock
     std::vector<U32x4> drec;        // N: {cmap, first_child, own_cnt, own_hsum}
     std::vector<U32x2> dhit;        // per depth-(K+1) state, in rank order: {cmap, own_hsum}; own_cnt == (own_hsum != 0)
     uint32_t lds_bytes = 0;

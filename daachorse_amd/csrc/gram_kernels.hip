@@ -5,12 +5,14 @@
 //
 //   per position p (all in LDS): class of the byte, CID[last K classes] -> COMBO[id] = count and
 //   h32 sum of every pattern of length <= K ending here, B_{K+1} bit -> "a longer pattern may start
-//   K bytes back".  For set B bits the rank directory gives the depth-(K+1) state id; its 8-byte
-//   {child bitmap, own h32 sum} record is the ONLY HBM/L2 access of the fast pass; the reads of a
-//   group of positions are issued together and (optionally) consumed one group later, behind the
-//   next group's LDS work.  Branches that continue past depth K+1 are rare; the wave appends their
-//   positions to its own slab (ballot-compacted, no atomics) and finishes them 64 at a time with a
-//   goto-only trie walk whenever the slab fills up and at the end of its work.
+//   K bytes back".  Positions whose B bit is set are rare enough (16 % on the 100k-word automaton)
+//   that handling them in place would waste most lanes, so the wave COMPACTS them: a wave ballot
+//   gives every hit a slot in a 128-entry ring in LDS, and whenever 64 are queued all 64 lanes take
+//   one each: rank directory -> depth-(K+1) state -> its 8-byte {child bitmap, own h32 sum} record,
+//   the ONLY HBM/L2 access of the fast pass, consumed one batch later so its latency hides behind
+//   LDS work.  Branches that go on past depth K+1 are rarer still; their positions go to the wave's
+//   slab in HBM (ballot-compacted, no atomics) and are finished 64 at a time by a goto-only trie
+//   walk whenever the slab fills up and at the end of the wave's work.
 //
 // Roofline: HBM bytes of haystack (1 B read per byte); integer/bit work only, no MFMA.
 #include <hip/hip_runtime.h>
@@ -23,6 +25,7 @@ namespace daac {
 
 typedef uint32_t g_u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kGroup = 4;     // positions whose LDS reads are issued together (lgkmcnt tracks at most 15 reads)
+constexpr uint32_t kRing = 128;  // entries of a wave's hit stack in LDS (at most 63 left over + 64 new)
 constexpr int kPrefetch = 1;  // haystack chunks in flight per lane beyond the current one
 
 __device__ __forceinline__ unsigned long long gram_wave_sum(unsigned long long v) {
@@ -108,11 +111,15 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     auto class_at = [&](uint64_t p) -> uint32_t {  // class of the byte at virtual position p
         return (p >= a.lead && p < a.vlen) ? l_cls[hay[p]] : 0u;
     };
-    // offset within its level of the depth-(K+1) state whose gram index is `ib` (its B bit is set)
-    auto deep_rank = [&](uint32_t ib, uint32_t word) -> uint32_t {
+    // offset within its level of the depth-(K+1) state whose gram index is `ib` (its B bit is set):
+    // popcount directory = u32 per 256 bits + u8 per 64 bits + the bits below inside the 64-bit pair
+    auto deep_rank = [&](uint32_t ib) -> uint32_t {
         const uint32_t w = ib >> 5;
-        const uint32_t below = __popc(word & ((1u << (ib & 31u)) - 1u));
-        return RANK_LDS ? l_bsuper[w >> 3] + l_brank[w] + below : g.bsuper[w >> 3] + g.brank[w] + below;
+        const uint2 pair = *reinterpret_cast<const uint2 *>(l_bbits + (w & ~1u));
+        const bool odd = w & 1u;
+        const uint32_t word = odd ? pair.y : pair.x;
+        const uint32_t below = (odd ? __popc(pair.x) : 0u) + __popc(word & ((1u << (ib & 31u)) - 1u));
+        return RANK_LDS ? l_bsuper[w >> 3] + l_brank[w >> 1] + below : g.bsuper[w >> 3] + g.brank[w >> 1] + below;
     };
     // Finishes the queued branches, 64 per round.  An entry is the position p of the last byte of a
     // (K+1)-gram whose depth-(K+1) state (already counted) has a child on the byte at p + 1.
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             uint32_t ib = 0;
 #pragma unroll
             for (int t = K; t >= 0; --t) ib = ib * C + (p >= static_cast<uint64_t>(t) ? class_at(p - t) : 0u);
-            uint4 r = g.drec[g.level_start + deep_rank(ib, l_bbits[ib >> 5])];  // {cmap, first_child, own_cnt, own_hsum}
+            uint4 r = g.drec[g.level_start + deep_rank(ib)];  // {cmap, first_child, own_cnt, own_hsum}
             uint64_t vnext = p + 1;
             for (;;) {
                 const uint32_t kn = class_at(vnext);
@@ -137,32 +144,47 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         wq_n = 0;
     };
 
-    // HBM/L2 reads issued one group ago and not yet consumed (software pipeline)
-    uint2 pend[kGroup];
-    uint32_t pend_hits = 0, pend_kn0 = 0, pend_e0 = 0;
-    uint64_t pend_v = 0;
+    // ---- the hit ring: entry = {gram index | class of the next byte << 20, low 32 bits of the position}
+    // (a stack: batches are taken from the top, so no wrap-around arithmetic; order does not matter)
+    uint2 *ring = reinterpret_cast<uint2 *>(smem + g.off_scratch) + (threadIdx.x >> 6) * kRing;
+    uint32_t q_n = 0;                           // wave-uniform
+    uint2 pend = uint2{0u, 0u};                 // record read for the previous batch, not yet consumed
+    uint32_t pend_item = 0, pend_pos = 0;
+    bool pend_valid = false;                    // wave-uniform
+    uint64_t v_now = 0;                         // a recent 64-bit position of this wave (to widen pend_pos)
     auto consume_pending = [&]() {
-        if (__any(pend_hits != 0)) {
-            uint32_t dcnt = 0;
-#pragma unroll
-            for (int jj = 0; jj < kGroup; ++jj) {
-                const uint32_t kn = (pend_kn0 >> (8 * jj)) & 0xffu;
-                const uint2 r = pend[jj];  // {cmap, own h32 sum}; zero when not a hit
-                dcnt += r.y != 0;
-                tot_s1 += r.y;
-                tot_s2 += r.y * (pend_e0 + jj);
-                const bool go = (r.x >> kn) & 1u;
-                const unsigned long long m = __ballot(go);
-                if (m != 0) {  // rare: the branch goes on past depth K+1 -> queue a walker
-                    if (go)
-                        slab[wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
-                            pend_v + jj;
-                    wq_n += __popcll(m);
-                }
+        if (!pend_valid) return;
+        pend_valid = false;
+        const uint2 r = pend;                   // {cmap, own h32 sum}; zero for idle lanes
+        tot_cnt += r.y != 0;
+        tot_s1 += r.y;
+        tot_s2 += r.y * (pend_pos - a.lead + 1u);  // end = position - lead + 1 (mod 2^32)
+        const bool go = (r.x >> (pend_item >> 20)) & 1u;
+        const unsigned long long m = __ballot(go);
+        if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker (needs the full position)
+            if (go) {
+                uint64_t vp = (v_now & ~0xffffffffull) | pend_pos;
+                if (vp > v_now + (1ull << 31)) vp -= 1ull << 32;
+                else if (vp + (1ull << 31) < v_now) vp += 1ull << 32;
+                slab[wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] = vp;
             }
-            tot_cnt += dcnt;
+            wq_n += __popcll(m);
         }
-        pend_hits = 0;
+    };
+    // takes up to 64 queued hits, one per lane: issue their record reads, retire the previous batch
+    auto process_batch = [&]() {
+        consume_pending();
+        const uint32_t n = q_n < 64u ? q_n : 64u;
+        q_n -= n;
+        pend = uint2{0u, 0u};
+        pend_item = 0;
+        if (lane < n) {
+            const uint2 it = ring[q_n + lane];
+            pend_item = it.x;
+            pend_pos = it.y;
+            pend = g.dhit[deep_rank(it.x & 0xfffffu)];
+        }
+        pend_valid = true;
     };
 
     for (uint64_t region = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); region < a.nregions;
@@ -180,8 +202,10 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             pf[i] = (rbase + 1024ull * i < rend) ? load_chunk(rbase + 1024ull * i + lane * 16) : uint4{ub4, ub4, ub4, ub4};
 
         for (uint64_t sb = rbase; sb < rend; sb += 1024) {
-            if (wq_n + 1536u > a.wq_slab) drain();  // a step retires at most 16 (+ pending) x 64 walkers
+            if (wq_n + 256u > a.wq_slab) drain();  // a step retires at most a few batches of 64 walkers
             const uint64_t v = sb + lane * 16;
+            v_now = sb;
+            const uint32_t v32 = static_cast<uint32_t>(v);
             const uint4 cur = pf[0];
 #pragma unroll
             for (int i = 0; i < kPrefetch; ++i) pf[i] = pf[i + 1];
@@ -206,9 +230,8 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             if (lane == 63) right = class_at(sb + 1024);
             kx[K + 16] = right;
 
-            // ---- per group of kGroup positions: LDS work of every position independently (all reads of the
-            // group in flight before the first is consumed), then retire the HBM/L2 reads issued one group
-            // ago, then issue this group's (one 8-byte record per B hit) ------------------------------------
+            // ---- per group of kGroup positions: LDS work of every position independently (all reads of
+            // the group in flight before the first is consumed), then the B hits are queued ---------------
             uint32_t ccnt = 0, A = 0, T = 0;       // T = sum over positions of running A (prefix trick for h * end)
             const uint32_t e0 = static_cast<uint32_t>(v - a.lead) + 1u;  // end of this lane's position 0
 #pragma unroll
@@ -231,33 +254,31 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                 if (HAS_SHORT) {
 #pragma unroll
                     for (int jj = 0; jj < kGroup; ++jj) co[jj] = l_combo[id[jj]];
-                }
-                uint32_t hits = 0;
 #pragma unroll
-                for (int jj = 0; jj < kGroup; ++jj) {
-                    if (HAS_SHORT) {
+                    for (int jj = 0; jj < kGroup; ++jj) {
                         ccnt += co[jj].x;
                         A += co[jj].y;
                         T += A;
                     }
-                    hits |= ((bw[jj] >> (iB[jj] & 31u)) & 1u) << jj;
                 }
-                if (PIPE) consume_pending();
-                if (__any(hits != 0)) {
+                uint32_t hits = 0;
+#pragma unroll
+                for (int jj = 0; jj < kGroup; ++jj) hits |= __builtin_amdgcn_ubfe(bw[jj], iB[jj], 1) << jj;  // bit (iB & 31) of the word
+                if (__any(hits != 0)) {  // one branch per group when nothing hits (sparse automata)
 #pragma unroll
                     for (int jj = 0; jj < kGroup; ++jj) {
-                        pend[jj] = uint2{0u, 0u};
-                        if ((hits >> jj) & 1u) pend[jj] = g.dhit[deep_rank(iB[jj], bw[jj])];
+                        const int j = grp * kGroup + jj;
+                        const bool hit = (hits >> jj) & 1u;
+                        const unsigned long long m = __ballot(hit);
+                        if (m != 0) {  // wave-uniform
+                            if (hit)
+                                ring[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), q_n))] =
+                                    uint2{iB[jj] | (kx[K + j + 1] << 20), v32 + j};
+                            q_n += __popcll(m);
+                            if (q_n >= 64u) process_batch();
+                        }
                     }
-                    pend_hits = hits;
-                    pend_e0 = e0 + kGroup * grp;
-                    pend_v = v + kGroup * grp;
-                    uint32_t x0 = 0;
-#pragma unroll
-                    for (int t = 0; t < kGroup; ++t) x0 |= kx[K + grp * kGroup + t + 1] << (8 * t);  // class of the next byte
-                    pend_kn0 = x0;
                 }
-                if (!PIPE) consume_pending();
             }
             // sum_j hs_j * (e0 + j):  A * (e0 + 16) - T
             tot_cnt += ccnt;
@@ -265,6 +286,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             tot_s2 += A * (e0 + 16u) - T;
         }
     }
+    while (q_n != 0) process_batch();
     consume_pending();
     drain();
     gram_reduce(tot_cnt, tot_s1, tot_s2, reinterpret_cast<unsigned long long *>(smem), a.result);

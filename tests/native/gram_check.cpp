@@ -61,7 +61,9 @@ int main(int argc, char **argv) {
         gc += s.x; g1 += s.y; g2 += s.y * end;
         const uint32_t bw = g.bbits[iB >> 5];
         if ((bw >> (iB & 31)) & 1u) {
-            const uint32_t rank = g.bsuper[iB >> 8] + g.brank[iB >> 5] + __builtin_popcount(bw & ((1u << (iB & 31)) - 1u));
+            const uint32_t wi = iB >> 5;
+            const uint32_t rank = g.bsuper[wi >> 3] + g.brank[wi >> 1] + ((wi & 1) ? __builtin_popcount(g.bbits[wi - 1]) : 0) +
+                                  __builtin_popcount(bw & ((1u << (iB & 31)) - 1u));
             uint32_t id = g.level_start + rank;
             const U32x2 hrec = g.dhit[rank];  // what the fast pass reads: must agree with the full record
             if (hrec.x != g.drec[id].x || hrec.y != g.drec[id].w || g.drec[id].z != (hrec.y != 0 ? 1u : 0u)) { std::printf("MISMATCH dhit\n"); return 1; }
