@@ -87,6 +87,34 @@ int orc_overlapping_count(const orc_pma *p, const uint8_t *hay, size_t len, int 
 uint64_t orc_matches_checksum(const orc_match *m, size_t n);
 uint32_t orc_max_pattern_len(const orc_pma *p);
 
+/* ---------------------------------------------------------------- charwise engine (daac_oracle_charwise.c)
+ * State: src/charwise.rs:1096-1101, serialised base,check,fail,output_pos (1162-1167); check = PARENT index */
+typedef struct { uint32_t base, check, fail, output_pos; } orc_cstate;
+/* CharwiseDoubleArrayAhoCorasick<u32>: src/charwise.rs:59-65 (mapper: src/charwise/mapper.rs:10-13) */
+typedef struct {
+    orc_cstate *states;   size_t n_states;
+    uint32_t *table;      size_t n_table;   /* code point -> code, 0xffffffff = unmapped */
+    uint32_t alphabet_size;
+    orc_output *outputs;  size_t n_outputs;
+    uint8_t match_kind;
+    uint32_t num_states;
+} orc_cpma;
+
+/* patterns are UTF-8 (valid), one blob + n+1 offsets; values == NULL => value = index */
+int orc_cbuild(const uint8_t *blob, const uint64_t *offsets, const uint32_t *values, size_t n,
+               uint8_t match_kind, uint32_t num_free_blocks, orc_cpma **out);
+void orc_cfree_pma(orc_cpma *p);
+size_t orc_cheap_bytes(const orc_cpma *p);
+int orc_cserialize(const orc_cpma *p, uint8_t **buf, size_t *len);
+int orc_cdeserialize(const uint8_t *src, size_t len, orc_cpma **out, size_t *consumed);
+/* haystacks are valid UTF-8; positions are BYTE offsets (charwise/iter.rs) */
+int orc_cfind_iter(const orc_cpma *p, const uint8_t *hay, size_t len, orc_match **out, size_t *n);
+int orc_cfind_overlapping_iter(const orc_cpma *p, const uint8_t *hay, size_t len, orc_match **out, size_t *n);
+int orc_cfind_overlapping_no_suffix_iter(const orc_cpma *p, const uint8_t *hay, size_t len, orc_match **out, size_t *n);
+int orc_cleftmost_find_iter(const orc_cpma *p, const uint8_t *hay, size_t len, orc_match **out, size_t *n);
+int orc_cfind_stepper(const orc_cpma *p, const uint8_t *hay, size_t len, orc_match **out, size_t *n);
+int orc_cfind_overlapping_stepper(const orc_cpma *p, const uint8_t *hay, size_t len, orc_match **out, size_t *n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,8 +25,8 @@ class OracleError(RuntimeError):
 
 
 def build_lib(force=False):
-    src = os.path.join(_HERE, "daac_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("daac_oracle.c", "daac_oracle_charwise.c", "daac_oracle.h", "oracle_internal.h")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -37,6 +37,16 @@ class _Pma(C.Structure):
         ("root_table", C.c_void_p), ("n_root", C.c_size_t),
         ("lstates", C.c_void_p), ("n_lstates", C.c_size_t),
         ("fails", C.c_void_p), ("n_fails", C.c_size_t),
+        ("outputs", C.c_void_p), ("n_outputs", C.c_size_t),
+        ("match_kind", C.c_uint8), ("num_states", C.c_uint32),
+    ]
+
+
+class _CPma(C.Structure):
+    _fields_ = [
+        ("states", C.c_void_p), ("n_states", C.c_size_t),
+        ("table", C.c_void_p), ("n_table", C.c_size_t),
+        ("alphabet_size", C.c_uint32),
         ("outputs", C.c_void_p), ("n_outputs", C.c_size_t),
         ("match_kind", C.c_uint8), ("num_states", C.c_uint32),
     ]
@@ -70,6 +80,20 @@ def lib():
             f.restype = C.c_int
         L.orc_overlapping_count.argtypes = [P(_Pma), C.c_void_p, C.c_size_t, C.c_int, P(C.c_uint64), P(C.c_uint64)]
         L.orc_overlapping_count.restype = C.c_int
+        L.orc_cbuild.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint32, P(P(_CPma))]
+        L.orc_cbuild.restype = C.c_int
+        L.orc_cfree_pma.argtypes = [P(_CPma)]
+        L.orc_cheap_bytes.argtypes = [P(_CPma)]
+        L.orc_cheap_bytes.restype = C.c_size_t
+        L.orc_cserialize.argtypes = [P(_CPma), P(C.c_void_p), P(C.c_size_t)]
+        L.orc_cserialize.restype = C.c_int
+        L.orc_cdeserialize.argtypes = [C.c_char_p, C.c_size_t, P(P(_CPma)), P(C.c_size_t)]
+        L.orc_cdeserialize.restype = C.c_int
+        for name in ("orc_cfind_iter", "orc_cfind_overlapping_iter", "orc_cfind_overlapping_no_suffix_iter",
+                     "orc_cleftmost_find_iter", "orc_cfind_stepper", "orc_cfind_overlapping_stepper"):
+            f = getattr(L, name)
+            f.argtypes = [P(_CPma), C.c_void_p, C.c_size_t, P(C.c_void_p), P(C.c_size_t)]
+            f.restype = C.c_int
         L.orc_matches_checksum.argtypes = [C.c_void_p, C.c_size_t]
         L.orc_matches_checksum.restype = C.c_uint64
         _lib = L
@@ -230,6 +254,123 @@ class OraclePma:
         if rc:
             raise OracleError(rc, "overlapping_count")
         return cnt.value, cs.value
+
+
+class OracleCharwisePma:
+    """Mirror of CharwiseDoubleArrayAhoCorasick<u32> (src/charwise.rs:59-65) backed by the C oracle."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_cfree_pma(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @classmethod
+    def build(cls, patterns, values=None, kind=STANDARD, num_free_blocks=16):
+        kind = KIND.get(kind, kind)
+        blob, offs = pack_patterns(patterns)
+        vals = np.ascontiguousarray(values, dtype=np.uint32) if values is not None else None
+        out = C.POINTER(_CPma)()
+        rc = lib().orc_cbuild(blob.ctypes.data, offs.ctypes.data, vals.ctypes.data if vals is not None else None,
+                              len(patterns), kind, num_free_blocks, C.byref(out))
+        if rc:
+            raise OracleError(rc, "cbuild")
+        return cls(out)
+
+    @classmethod
+    def deserialize(cls, data):
+        out = C.POINTER(_CPma)()
+        consumed = C.c_size_t()
+        rc = lib().orc_cdeserialize(bytes(data), len(data), C.byref(out), C.byref(consumed))
+        if rc:
+            raise OracleError(rc, "cdeserialize")
+        p = cls(out)
+        p.consumed = consumed.value
+        return p
+
+    def serialize(self):
+        buf, n = C.c_void_p(), C.c_size_t()
+        rc = lib().orc_cserialize(self._h, C.byref(buf), C.byref(n))
+        if rc:
+            raise OracleError(rc, "cserialize")
+        data = C.string_at(buf, n.value)
+        lib().orc_free(buf)
+        return data
+
+    @property
+    def match_kind(self):
+        return self._h.contents.match_kind
+
+    @property
+    def num_states(self):
+        return self._h.contents.num_states
+
+    @property
+    def alphabet_size(self):
+        return self._h.contents.alphabet_size
+
+    def num_elements(self):
+        return self._h.contents.n_states
+
+    def heap_bytes(self):
+        return lib().orc_cheap_bytes(self._h)
+
+    def states(self):
+        """(n,4) u32 [base, check, fail, output_pos]"""
+        n = self._h.contents.n_states
+        buf = (C.c_uint32 * (n * 4)).from_address(self._h.contents.states)
+        return np.frombuffer(buf, dtype=np.uint32).reshape(n, 4).copy()
+
+    def table(self):
+        n = self._h.contents.n_table
+        if n == 0:
+            return np.zeros(0, dtype=np.uint32)
+        buf = (C.c_uint32 * n).from_address(self._h.contents.table)
+        return np.frombuffer(buf, dtype=np.uint32).copy()
+
+    def outputs(self):
+        n = self._h.contents.n_outputs
+        if n == 0:
+            return np.zeros((0, 3), dtype=np.uint32)
+        buf = (C.c_uint32 * (n * 3)).from_address(self._h.contents.outputs)
+        return np.frombuffer(buf, dtype=np.uint32).reshape(n, 3).copy()
+
+    def _scan(self, fname, haystack):
+        a = _hay(haystack)
+        out, n = C.c_void_p(), C.c_size_t()
+        rc = getattr(lib(), fname)(self._h, a.ctypes.data if a.size else None, a.size, C.byref(out), C.byref(n))
+        if rc:
+            raise OracleError(rc, fname)
+        if n.value:
+            buf = (C.c_char * (n.value * MATCH_DTYPE.itemsize)).from_address(out.value)
+            res = np.frombuffer(buf, dtype=MATCH_DTYPE).copy()
+        else:
+            res = np.zeros(0, dtype=MATCH_DTYPE)
+        lib().orc_free(out)
+        return res
+
+    def find_iter(self, h):
+        return self._scan("orc_cfind_iter", h)
+
+    def find_overlapping_iter(self, h):
+        return self._scan("orc_cfind_overlapping_iter", h)
+
+    def find_overlapping_no_suffix_iter(self, h):
+        return self._scan("orc_cfind_overlapping_no_suffix_iter", h)
+
+    def leftmost_find_iter(self, h):
+        return self._scan("orc_cleftmost_find_iter", h)
+
+    def find_stepper(self, h):
+        return self._scan("orc_cfind_stepper", h)
+
+    def find_overlapping_stepper(self, h):
+        return self._scan("orc_cfind_overlapping_stepper", h)
 
 
 def matches_checksum(m):

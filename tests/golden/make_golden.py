@@ -179,6 +179,66 @@ def main():
     with open(os.path.join(HERE, "bytewise_pins.json"), "w") as f:
         json.dump(pins, f, indent=1, sort_keys=True)
         f.write("\n")
+    # ---- charwise pins (values only), each with its citation ------------------------------------------
+    FW = {"A": "\uff21", "B": "\uff22", "C": "\uff23"}  # fullwidth letters used by the reference's layout test
+    cpins = {
+        "_source": "daachorse 4.0.0 src/charwise.rs / src/charwise/*.rs in-module tests and docs; see `cite`",
+        "runners": "the six charwise runners of tests/aho_corasick_crate_test.rs:592-645 use the same vector tables",
+        "double_array": {  # src/charwise.rs:1200-1267
+            "cite": "src/charwise.rs:1200-1267",
+            "patterns": [FW["A"] * 2, FW["A"] + FW["C"], FW["B"] + FW["C"], FW["C"]],
+            "base": [4, X, X, X, 8, X, 3, X, X, X, X],
+            "check": [1, 1, 6, 1, 0, 0, 0, 1, 4, 4, 1],
+            "fail": [0, 1, 5, 1, 0, 0, 0, 1, 4, 5, 1],
+        },
+        "num_states": [{"cite": "src/charwise.rs:1269-1281", "patterns": ["\uff41\uff42\uff42\uff41", "\uff42\uff41\uff41\uff42\uff41", "\uff41\uff42\uff41\uff42\uff41"], "num_states": 13},
+                       {"cite": "src/charwise.rs:769-781", "patterns": ["bcd", "ab", "a"], "num_states": 6}],
+        "num_elements": [{"cite": "src/charwise.rs:785-796", "patterns": ["bcd", "ab", "a"], "num_elements": 8}],
+        "heap_bytes": [{"cite": "src/charwise.rs:800-811", "patterns": ["bcd", "ab", "a"], "heap_bytes": 568}],
+        "input_order": {"cite": "src/charwise.rs:1283-1294",
+                        "sorted": [["\uff41\uff42\uff41\uff42\uff41", 0], ["\uff41\uff42\uff42\uff41", 1], ["\uff42\uff41\uff41\uff42\uff41", 2]],
+                        "unsorted": [["\uff41\uff42\uff42\uff41", 1], ["\uff42\uff41\uff41\uff42\uff41", 2], ["\uff41\uff42\uff41\uff42\uff41", 0]]},
+        "n_blocks": [  # src/charwise.rs:1297-1370: single-char patterns U+0000.., described not listed
+            {"cite": "src/charwise.rs:1297-1311", "name": "1_1", "gen": [{"prefix": [], "range": [0, 0x7d]}],
+             "num_states": 127, "states_len": 128, "base_of": {"0": 0x7e}},
+            {"cite": "src/charwise.rs:1313-1327", "name": "1_2", "gen": [{"prefix": [], "range": [0, 0x7e]}],
+             "num_states": 128, "states_len": 256, "base_of": {"0": 0x80}},
+            {"cite": "src/charwise.rs:1329-1349", "name": "2_1", "gen": [{"prefix": [], "range": [0, 0x7f]}, {"prefix": [0], "range": [0, 0x7d]}],
+             "num_states": 255, "states_len": 256, "base_of": {"0": 0x80, "128": 0x7e}},
+            {"cite": "src/charwise.rs:1351-1370", "name": "2_2", "gen": [{"prefix": [], "range": [0, 0x7f]}, {"prefix": [0], "range": [0, 0x7e]}],
+             "num_states": 256, "states_len": 384, "base_of": {"0": 0x80, "128": 0x100}},
+        ],
+        "multibyte_zero_length": [  # src/charwise.rs:1373-1456
+            {"cite": "src/charwise.rs:1373-1408", "api": "find_overlapping_iter", "kind": "Standard",
+             "patterns": ["a", "\u00e6", "\u3042", ""], "haystack": "\u3044\u3042abc\u00c6\u00e6\u3046",
+             "matches_sev": [[0, 0, 3], [3, 3, 3], [3, 6, 2], [6, 6, 3], [6, 7, 0], [7, 7, 3], [8, 8, 3], [9, 9, 3], [11, 11, 3],
+                             [11, 13, 1], [13, 13, 3], [16, 16, 3]]},
+            {"cite": "src/charwise.rs:1410-1433", "api": "find_iter", "kind": "Standard",
+             "patterns": ["a", "\u00e6", "\u3042", ""], "haystack": "\u3044\u3042abc\u00c6\u00e6\u3046",
+             "matches_sev": [[0, 0, 3], [3, 3, 3], [6, 6, 3], [7, 7, 3], [8, 8, 3], [9, 9, 3], [11, 11, 3], [13, 13, 3], [16, 16, 3]]},
+            {"cite": "src/charwise.rs:1435-1456", "api": "leftmost_find_iter", "kind": "LeftmostLongest",
+             "patterns": ["a", "\u00e6", "\u3042", ""], "haystack": "\u3044\u3042abc\u00c6\u00e6\u3046",
+             "matches_sev": [[0, 0, 3], [3, 6, 2], [6, 7, 0], [8, 8, 3], [9, 9, 3], [11, 13, 1], [16, 16, 3]]},
+        ],
+        "known_answers": [
+            {"cite": "README.md:181-192", "api": "find_iter", "kind": "Standard",
+             "patterns": ["\u5168\u4e16\u754c", "\u4e16\u754c", "\u306b"], "haystack": "\u5168\u4e16\u754c\u4e2d\u306b",
+             "matches_sev": [[0, 9, 0], [12, 15, 2]]},
+            {"cite": "src/charwise/iter.rs:595-620", "api": "find_overlapping_no_suffix_iter", "kind": "Standard",
+             "patterns": ["a", "ab", ""], "haystack": "ab", "matches_sev": [[0, 0, 2], [0, 1, 0], [0, 2, 1]]},
+        ],
+        "decoder": {  # src/charwise/iter.rs:543-593: code points and their END offsets in the concatenated string
+            "cite": "src/charwise/iter.rs:543-593",
+            "code_points": [0x0, 0x1, 0x2, 0x4, 0x8, 0x10, 0x1f, 0x20, 0x40, 0x7f, 0x80, 0x100, 0x1ff, 0x200, 0x400, 0x7ff, 0x800, 0x1000,
+                            0x1fff, 0x2000, 0x4000, 0x8000, 0xffff, 0x10000, 0x1ffff, 0x20000, 0x40000, 0x80000, 0x100000, 0x10ffff],
+            "end_offsets": [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 22, 25, 28, 31, 34, 37, 40, 43, 47, 51, 55, 59, 63, 67, 71],
+        },
+        "mapper": {"cite": "src/charwise/mapper.rs:87-99", "freqs": [3, 6, 0, 2, 3, 0, 3], "codes": [1, 0, X, 4, 2, X, 3]},
+    }
+    cpins = json.loads(json.dumps(cpins).replace("\\\\u", "\\u"))
+    with open(os.path.join(HERE, "charwise_pins.json"), "w") as f:
+        json.dump(cpins, f, indent=1, sort_keys=True)
+        f.write("\n")
     n = sum(len(v) for v in tables.values())
     print(f"wrote {n} vector cases in {len(tables)} tables + pins")
 
