@@ -28,7 +28,8 @@ class Info(C.Structure):
                 ("outputs_len", C.c_uint64), ("heap_bytes", C.c_uint64), ("max_pattern_len", C.c_uint32),
                 ("num_classes", C.c_uint32), ("tier_dense_states", C.c_uint32), ("tier_lds_states", C.c_uint32),
                 ("tier_lds_bytes", C.c_uint32), ("tiered_available", C.c_uint8), ("gram_available", C.c_uint8),
-                ("gram_k", C.c_uint32), ("gram_lds_bytes", C.c_uint32)]
+                ("gram_k", C.c_uint32), ("gram_lds_bytes", C.c_uint32),
+                ("charwise", C.c_uint8), ("alphabet_size", C.c_uint32)]
 
 
 def lib():
@@ -51,6 +52,8 @@ def lib():
     L.daac_bytewise_from_serialized.argtypes = [C.c_char_p, sz, P(vp), P(sz)]
     L.daac_bytewise_from_parts.argtypes = [vp, sz, vp, vp, sz, vp, sz, C.c_uint8, C.c_uint32, P(vp)]
     L.daac_bytewise_build.argtypes = [vp, vp, vp, sz, C.c_uint8, C.c_uint32, P(vp)]
+    L.daac_charwise_from_serialized.argtypes = [C.c_char_p, sz, P(vp), P(sz)]
+    L.daac_charwise_build.argtypes = [vp, vp, vp, sz, C.c_uint8, C.c_uint32, P(vp)]
     L.daac_pma_serialize.argtypes = [vp, P(vp), P(sz)]
     L.daac_pma_info.argtypes = [vp, P(Info)]
     L.daac_pma_free.argtypes = [vp]
@@ -71,7 +74,8 @@ def lib():
     L.daac_synth_uniform.argtypes = [vp, sz, C.c_uint64, vp, C.c_uint32, C.c_uint64, vp]
     L.daac_synth_wordsoup.argtypes = [vp, sz, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32,
                                       vp, C.c_uint32, C.c_uint64, vp]
-    for name in ("daac_bytewise_from_serialized", "daac_bytewise_from_parts", "daac_bytewise_build", "daac_pma_serialize",
+    for name in ("daac_bytewise_from_serialized", "daac_bytewise_from_parts", "daac_bytewise_build", "daac_charwise_from_serialized",
+                 "daac_charwise_build", "daac_pma_serialize",
                  "daac_pma_info", "daac_pma_upload", "daac_scan", "daac_scan_count", "daac_scan_count_range", "daac_iter_open", "daac_set_option",
                  "daac_synth_uniform", "daac_synth_wordsoup"):
         getattr(L, name).restype = C.c_int

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "charwise.hpp"
 #include "device_tables.hpp"
 #include "gram.hpp"
 #include "pma.hpp"
@@ -59,6 +60,7 @@ struct DeviceTables {
     TierTables tier_host_meta;  // sizes only (vectors cleared after upload)
     bool gram_ok = false;
     GramDev gram{};
+    CharDev chr{};  // charwise automata only
 
     ~DeviceTables() {
         for (void *p : allocs) (void)hipFree(p);
@@ -83,9 +85,15 @@ struct DeviceTables {
 using namespace daac;
 
 struct daac_pma {
-    HostPma host;
+    bool charwise = false;  // which of the two containers is populated
+    HostPma host;           // DoubleArrayAhoCorasick<u32>
+    HostCharPma chost;      // CharwiseDoubleArrayAhoCorasick<u32>
     std::mutex mu;
     std::map<int, std::unique_ptr<DeviceTables>> dev;
+
+    bool is_standard() const { return charwise ? chost.is_standard() : host.is_standard(); }
+    bool root_has_output() const { return charwise ? chost.states[kRoot].output_pos != 0 : output_pos_of(host.opos_ch(kRoot)) != 0; }
+    uint32_t max_pattern_len() const { return charwise ? chost.max_pattern_len() : host.max_pattern_len(); }
 };
 
 struct daac_matches {
@@ -107,14 +115,38 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
 
     const HostPma &h = pma->host;
     daac_status st;
-    // outputs, shared by both engines
+    // outputs, shared by all engines
     const uint32_t *d_outputs = nullptr;
     {
-        std::vector<uint32_t> flat(h.outputs.size() * 3);
-        for (size_t i = 0; i < h.outputs.size(); ++i) {
-            flat[3 * i] = h.outputs[i].value; flat[3 * i + 1] = h.outputs[i].length; flat[3 * i + 2] = h.outputs[i].parent;
+        const std::vector<OutputRec> &outs = pma->charwise ? pma->chost.outputs : h.outputs;
+        std::vector<uint32_t> flat(outs.size() * 3);
+        for (size_t i = 0; i < outs.size(); ++i) {
+            flat[3 * i] = outs[i].value; flat[3 * i + 1] = outs[i].length; flat[3 * i + 2] = outs[i].parent;
         }
         if ((st = t->put(flat, d_outputs)) != DAAC_OK) return st;
+    }
+    if (pma->charwise) {
+        CharTables ct;
+        build_char_tables(pma->chost, ct);
+        CharDev &c = t->chr;
+        const CStateRec *states; const OutSum *osum;
+        if ((st = t->put(ct.states, states)) != DAAC_OK) return st;
+        if ((st = t->put(ct.table, c.table)) != DAAC_OK) return st;
+        if ((st = t->put(ct.osum, osum)) != DAAC_OK) return st;
+        c.fail_plain = nullptr;
+        if (!ct.fail_plain.empty() && (st = t->put(ct.fail_plain, c.fail_plain)) != DAAC_OK) return st;
+        c.states = reinterpret_cast<const uint4 *>(states);
+        c.osum = reinterpret_cast<const uint2 *>(osum);
+        c.outputs = d_outputs;
+        c.table_len = static_cast<uint32_t>(ct.table.size());
+        c.n = static_cast<uint32_t>(ct.states.size());
+        c.root_flag = ct.root_flag;
+        c.leftmost = !pma->chost.is_standard();
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipSetDevice(prev));
+        *out = t.get();
+        pma->dev[device] = std::move(t);
+        return DAAC_OK;
     }
     // DARRAY engine: always available
     {
@@ -233,7 +265,7 @@ namespace {
 // The reference panics when a query does not fit the automaton's MatchKind (bytewise.rs:194-197,
 // 299-302, 551-554); checked before anything touches the device.
 daac_status check_mode_kind(const daac_pma *pma, int mode) {
-    const bool standard = pma->host.is_standard();
+    const bool standard = pma->is_standard();
     if (mode == DAAC_FIND_OVERLAPPING || mode == DAAC_FIND_OVERLAPPING_NO_SUFFIX || mode == DAAC_FIND) {
         if (!standard) { set_error("Error: match_kind must be standard."); return DAAC_ERR_MATCH_KIND; }
     } else if (mode == DAAC_LEFTMOST_FIND) {
@@ -245,8 +277,16 @@ daac_status check_mode_kind(const daac_pma *pma, int mode) {
     return DAAC_OK;
 }
 
+// SURVEY.md 8a note D: with "" in the set, a leftmost iterator whose haystack ends inside a longer pattern
+// yields the same empty match forever in the reference (charwise/iter.rs:385-398)
+daac_status diverged() {
+    set_error("the reference iterator does not terminate on this input (leftmost kind, empty pattern, haystack ends inside a pattern)");
+    return DAAC_ERR_UNSUPPORTED;
+}
+
 struct Plan {
     bool tier;
+    bool charwise = false;  // the charwise engine (scan_kernel<CharEngine> / char_restart_kernel)
     bool restart = false;   // find_iter / leftmost_find_iter: the restart scanners (DARRAY tables)
     bool leftmost = false;
     uint32_t blocks, threads;
@@ -255,14 +295,12 @@ struct Plan {
 
 daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int engine, uint64_t begin, uint64_t end, Plan &pl,
                       bool &heads) {
-    const HostPma &h = pma->host;
-    if (mode == DAAC_FIND_OVERLAPPING || mode == DAAC_FIND_OVERLAPPING_NO_SUFFIX || mode == DAAC_FIND) {
-        if (!h.is_standard()) { set_error("Error: match_kind must be standard."); return DAAC_ERR_MATCH_KIND; }
-    } else if (mode == DAAC_LEFTMOST_FIND) {
-        if (h.is_standard()) { set_error("Error: match_kind must be leftmost."); return DAAC_ERR_MATCH_KIND; }
-    } else {
-        set_error("unknown scan mode");
-        return DAAC_ERR_INVALID_ARGUMENT;
+    daac_status kst = check_mode_kind(pma, mode);
+    if (kst != DAAC_OK) return kst;
+    pl.charwise = pma->charwise;
+    if (pl.charwise && engine != DAAC_ENGINE_AUTO && engine != DAAC_ENGINE_DARRAY) {
+        set_error("charwise automata run on their double array only (engine AUTO or DARRAY)");
+        return DAAC_ERR_UNSUPPORTED;
     }
     pl.restart = mode == DAAC_FIND || mode == DAAC_LEFTMOST_FIND;
     pl.leftmost = mode == DAAC_LEFTMOST_FIND;
@@ -271,7 +309,7 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
             set_error("find_iter / leftmost_find_iter run on the DARRAY tables only");
             return DAAC_ERR_UNSUPPORTED;
         }
-        if (pl.leftmost && output_pos_of(h.opos_ch(kRoot)) != 0) {
+        if (pl.leftmost && !pl.charwise && pma->root_has_output()) {
             // SURVEY.md 8a note D: the reference's own behaviour is not pinned (and not terminating) here
             set_error("leftmost_find_iter with an empty pattern in the set is not supported on the device");
             return DAAC_ERR_UNSUPPORTED;
@@ -286,8 +324,8 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
         set_error("the GRAM engine only serves daac_scan_count(DAAC_FIND_OVERLAPPING)");
         return DAAC_ERR_UNSUPPORTED;
     }
-    pl.tier = !pl.restart && (engine == DAAC_ENGINE_TIERED || (engine == DAAC_ENGINE_AUTO && t->tier_ok));
-    const uint32_t lmax = h.max_pattern_len();
+    pl.tier = !pl.charwise && !pl.restart && (engine == DAAC_ENGINE_TIERED || (engine == DAAC_ENGINE_AUTO && t->tier_ok));
+    const uint32_t lmax = pma->max_pattern_len();
     const uint32_t halo = lmax > 0 ? lmax - 1 : 0;
     uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
     threads = std::min(1024u, std::max(64u, threads & ~63u));
@@ -321,6 +359,10 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
 }
 
 hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, hipStream_t s, unsigned long long *next_begin = nullptr) {
+    if (pl.charwise) {
+        return pl.restart ? launch_char_restart_scan(t->chr, pl.a, kmode, pl.leftmost, next_begin, pl.blocks, pl.threads, s)
+                          : launch_char_scan(t->chr, pl.a, kmode, heads, pl.blocks, pl.threads, s);
+    }
     if (pl.restart) return launch_restart_scan(t->da, pl.a, kmode, pl.leftmost, next_begin, pl.blocks, pl.threads, s);
     return pl.tier ? launch_tier_scan(t->tier, pl.a, kmode, heads, pl.blocks, pl.threads, s)
                    : launch_darray_scan(t->da, pl.a, kmode, heads, pl.blocks, pl.threads, s);
@@ -346,20 +388,23 @@ daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int
     pl.a.hay = dev_hay;
     pl.a.total_len = total_len;
     unsigned long long *d_counts = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), (pl.a.nseg + 2) * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), (pl.a.nseg + 3) * sizeof(unsigned long long)));
     std::unique_ptr<void, void (*)(void *)> g1(d_counts, [](void *p) { (void)hipFree(p); });
     pl.a.seg_counts = d_counts;
     pl.a.result = d_counts + pl.a.nseg;
     unsigned long long *d_next = d_counts + pl.a.nseg + 1;
-    HIP_TRY(hipMemsetAsync(d_next, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(d_next, 0, 2 * sizeof(unsigned long long), stream));
+    pl.a.flags = d_next + 1;
     HIP_TRY(launch(t, pl, 1, heads, stream, d_next));
     HIP_TRY(launch_exclusive_scan(d_counts, pl.a.nseg, d_counts + pl.a.nseg, stream));
-    unsigned long long total = 0, nb = 0;
+    unsigned long long total = 0, nbf[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(&total, d_counts + pl.a.nseg, sizeof(total), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&nb, d_next, sizeof(nb), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(nbf, d_next, sizeof(nbf), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    const unsigned long long nb = nbf[0];
+    if (nbf[1] & 1ull) return diverged();
     // FindIterator with "" in the set reports every position whatever the text: windows need no sync point
-    const bool positional = pl.restart && !pl.leftmost && output_pos_of(pma->host.opos_ch(kRoot)) != 0;
+    const bool positional = pl.restart && !pl.leftmost && pma->root_has_output();
     if (pl.restart && !positional && next_begin) *next_begin = std::max<uint64_t>(nb, end);
     if (total == 0) return DAAC_OK;
     if (total * sizeof(daac_match) > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
@@ -446,10 +491,36 @@ daac_status daac_bytewise_build(const uint8_t *blob, const uint64_t *offsets, co
     }
 }
 
+daac_status daac_charwise_from_serialized(const uint8_t *blob, size_t len, daac_pma **out, size_t *consumed) {
+    if (!blob || !out) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    std::unique_ptr<daac_pma> p(new daac_pma);
+    p->charwise = true;
+    const daac_status st = HostCharPma::deserialize(blob, len, p->chost, consumed);
+    if (st != DAAC_OK) return st;
+    *out = p.release();
+    return DAAC_OK;
+}
+
+daac_status daac_charwise_build(const uint8_t *blob, const uint64_t *offsets, const uint32_t *values, size_t n, uint8_t match_kind,
+                                uint32_t num_free_blocks, daac_pma **out) {
+    if (!out || (n && (!blob || !offsets))) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    try {
+        std::unique_ptr<daac_pma> p(new daac_pma);
+        p->charwise = true;
+        const daac_status st = build_charwise(blob, offsets, values, n, match_kind, num_free_blocks, p->chost);
+        if (st != DAAC_OK) return st;
+        *out = p.release();
+        return DAAC_OK;
+    } catch (const std::bad_alloc &) {
+        set_error("out of memory while building the automaton");
+        return DAAC_ERR_AUTOMATON_SCALE;
+    }
+}
+
 daac_status daac_pma_serialize(const daac_pma *pma, uint8_t **buf, size_t *len) {
     if (!pma || !buf || !len) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     std::vector<uint8_t> v;
-    pma->host.serialize(v);
+    if (pma->charwise) pma->chost.serialize(v); else pma->host.serialize(v);
     uint8_t *b = static_cast<uint8_t *>(std::malloc(v.size() ? v.size() : 1));
     if (!b) { set_error("out of memory"); return DAAC_ERR_AUTOMATON_SCALE; }
     std::memcpy(b, v.data(), v.size());
@@ -461,6 +532,18 @@ daac_status daac_pma_serialize(const daac_pma *pma, uint8_t **buf, size_t *len) 
 daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
     if (!pma || !info) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     std::memset(info, 0, sizeof(*info));
+    if (pma->charwise) {
+        const HostCharPma &c = pma->chost;
+        info->match_kind = c.match_kind;
+        info->num_states = c.num_states;
+        info->states_len = c.states.size();
+        info->outputs_len = c.outputs.size();
+        info->heap_bytes = c.heap_bytes();
+        info->max_pattern_len = c.max_pattern_len();
+        info->charwise = 1;
+        info->alphabet_size = c.alphabet_size;
+        return DAAC_OK;
+    }
     const HostPma &h = pma->host;
     info->match_kind = h.match_kind;
     info->num_states = h.num_states;
@@ -507,7 +590,7 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
     daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
     if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
-    const bool use_gram = mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len < (1ull << 35) && begin == 0 &&
+    const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len < (1ull << 35) && begin == 0 &&
                           (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && t->gram_ok));
     if (engine == DAAC_ENGINE_GRAM && (!use_gram || !t->gram_ok)) {
         set_error("GRAM engine not available for this automaton / mode");
@@ -531,6 +614,13 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
     std::unique_ptr<void, void (*)(void *)> g2(own, [](void *p) { if (p) (void)hipFree(p); });
     pl.a.result = d_res;
     HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
+    void *flagbuf = nullptr;
+    if (pl.charwise && pl.leftmost && pma->root_has_output()) {  // the one scan that can hit the non-terminating corner
+        HIP_TRY(hipMalloc(&flagbuf, sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(flagbuf, 0, sizeof(unsigned long long), stream));
+        pl.a.flags = static_cast<unsigned long long *>(flagbuf);
+    }
+    std::unique_ptr<void, void (*)(void *)> g3(flagbuf, [](void *p) { if (p) (void)hipFree(p); });
     if (use_gram && len != 0) {
         GramArgs ga{};
         ga.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dev_hay) & 15u);
@@ -559,13 +649,16 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
     } else if (pl.a.nseg != 0) {
         HIP_TRY(launch(t, pl, 0, heads, stream));
     }
+    unsigned long long flagv = 0;
+    if (flagbuf) HIP_TRY(hipMemcpyAsync(&flagv, flagbuf, sizeof(flagv), hipMemcpyDeviceToHost, stream));
     if (result_dev && !count) {
-        if (staged) HIP_TRY(hipStreamSynchronize(stream));
-        return DAAC_OK;
+        if (staged || flagbuf) HIP_TRY(hipStreamSynchronize(stream));
+        return (flagv & 1ull) ? diverged() : DAAC_OK;
     }
     unsigned long long r[3];
     HIP_TRY(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (flagv & 1ull) return diverged();
     if (count) *count = r[0];
     if (checksum) *checksum = ((r[1] & 0xffffffffull) << 32) | (r[2] & 0xffffffffull);
     return DAAC_OK;
@@ -656,7 +749,7 @@ int daac_iter_next(daac_iter *it, daac_match *m) {
         const uint64_t window = std::max<uint64_t>(4096, static_cast<uint64_t>(g_opt.iter_window.load()));
         const uint64_t begin = it->next_begin;
         const uint64_t end = std::min<uint64_t>(it->len, begin + window);
-        const uint32_t lmax = it->pma->host.max_pattern_len();
+        const uint32_t lmax = it->pma->max_pattern_len();
         const uint64_t halo = lmax ? lmax - 1 : 0;
         void *staged = nullptr;
         const uint8_t *dev_hay = it->hay;

@@ -1,0 +1,251 @@
+// Restart scanners of the charwise automaton for gfx950: FindIterator (reference
+// src/charwise/iter.rs:101-157) and LeftmostFindIterator (iter.rs:306-400) on the device.
+//
+// Same decomposition as restart_kernels.hip: the haystack is cut at *sync points* — character
+// boundaries where the classic Aho-Corasick state of the text so far is ROOT — and the text
+// between two sync points is scanned by one lane exactly as the reference scans a haystack of its
+// own.  What differs from the bytewise file: symbols are UTF-8 scalars mapped to dense codes
+// (charwise/mapper.rs), CHECK names the parent slot (charwise.rs:1022-1050), and positions move by
+// whole characters while staying byte offsets.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_tables.hpp"
+
+namespace daac {
+
+__device__ __forceinline__ uint64_t cw_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+struct CwState { uint32_t idx, base, fail, opos; };
+
+struct CharTables {
+    const CharDev &d;
+    uint4 root_rec;
+    const uint8_t *__restrict__ hay;
+    uint64_t len;  // real end of the haystack: nothing at or beyond it is read
+
+    __device__ __forceinline__ CwState root() const { return CwState{0, root_rec.x, root_rec.z, root_rec.w}; }
+
+    // One scalar at byte `pos` (a character boundary of well-formed UTF-8; charwise/iter.rs:64-98).
+    // A sequence cut by the end of the haystack is completed with zero payload bits, never read past.
+    __device__ __forceinline__ uint32_t scalar_at(uint64_t pos, uint32_t &clen) const {
+        const uint32_t b0 = hay[pos];
+        if (b0 < 0x80u) { clen = 1; return b0; }
+        const uint32_t n = b0 < 0xe0u ? 2u : b0 < 0xf0u ? 3u : 4u;
+        uint32_t cp = b0 < 0xe0u ? (b0 & 0x1fu) : b0 < 0xf0u ? (b0 & 0x0fu) : (b0 & 0x07u);
+        for (uint32_t k = 1; k < n; ++k) cp = (cp << 6) | (pos + k < len ? (hay[pos + k] & 0x3fu) : 0u);
+        clen = n;
+        return cp;
+    }
+    __device__ __forceinline__ uint32_t code_of(uint32_t cp) const { return cp < d.table_len ? d.table[cp] : 0xffffffffu; }
+    __device__ __forceinline__ void load(CwState &st, uint32_t slot, bool plain) const {
+        const uint4 r = d.states[slot];
+        st = CwState{slot, r.x, (plain && d.fail_plain) ? d.fail_plain[slot] : r.z, r.w};
+    }
+
+    // classic delta: next_state_id_unchecked (charwise.rs:1022-1050) over links that never stop at DEAD
+    __device__ __forceinline__ void step_plain(CwState &st, uint32_t cp) const {
+        const uint32_t code = code_of(cp);
+        if (code == 0xffffffffu) { st = root(); return; }
+        for (;;) {
+            if (st.base != 0) {
+                const uint32_t child = st.base ^ code;
+                const uint4 r = d.states[child];
+                if (r.y == st.idx) { st = CwState{child, r.x, d.fail_plain ? d.fail_plain[child] : r.z, r.w}; return; }
+            }
+            if (st.idx == 0) return;
+            load(st, st.fail, true);
+        }
+    }
+
+    // next_state_id_leftmost_unchecked (charwise.rs:1056-1092): DEAD links end the walk at ROOT
+    __device__ __forceinline__ void step_leftmost(CwState &st, uint32_t cp) const {
+        const uint32_t code = code_of(cp);
+        if (code == 0xffffffffu) { st = root(); return; }
+        for (;;) {
+            if (st.base != 0) {
+                const uint32_t child = st.base ^ code;
+                const uint4 r = d.states[child];
+                if (r.y == st.idx) { st = CwState{child, r.x, r.z, r.w}; return; }
+            }
+            if (st.idx == 0) return;
+            if (st.fail == 1u) { st = root(); return; }
+            load(st, st.fail, false);
+        }
+    }
+
+    // first sync point >= x
+    __device__ __forceinline__ uint64_t sync_from(uint64_t x, uint32_t halo, uint64_t floor) const {
+        if (x <= floor) return floor;  // the window start is a sync point by contract
+        if (x >= len) return len;
+        uint64_t pos = x > halo ? x - halo : 0;
+        if (pos <= floor) pos = floor;
+        else while (pos < len && (hay[pos] & 0xc0u) == 0x80u) ++pos;  // up to the next character boundary
+        CwState st = root();
+        uint32_t clen;
+        while (pos < x) { const uint32_t cp = scalar_at(pos, clen); pos += clen; step_plain(st, cp); }
+        while (st.idx != 0 && pos < len) { const uint32_t cp = scalar_at(pos, clen); pos += clen; step_plain(st, cp); }
+        if (pos > len) pos = len;
+        return st.idx == 0 ? pos : len;
+    }
+};
+
+// KMODE 0: totals {count, S1, S2}; 1: per-segment counts; 2: write matches at out + seg_counts[seg]
+template <bool LEFTMOST, int KMODE>
+__global__ __launch_bounds__(256) void char_restart_kernel(const CharDev dev, const ScanArgs a, unsigned long long *next_begin) {
+    __shared__ unsigned long long scratch[3 * 4];
+    const CharTables T{dev, dev.states[0], a.hay, a.total_len};
+    const uint8_t *__restrict__ hay = a.hay;
+    const uint64_t len = a.total_len;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long tot_cnt = 0;
+    uint32_t tot_s1 = 0, tot_s2 = 0;
+
+    for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
+        const uint64_t lo = a.begin + seg * a.seg_bytes;
+        const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
+        const bool positional = !LEFTMOST && dev.root_flag;
+        uint64_t p = 0, q = 0;
+        const bool last = hi == a.len;
+        if (!positional) {
+            p = T.sync_from(lo, a.halo, a.begin);
+            if (p < hi || last) q = T.sync_from(hi, a.halo, a.begin);
+        }
+        if (last && next_begin) *next_begin = positional ? hi : q;
+
+        unsigned long long cnt = 0;
+        uint32_t s1 = 0, s2 = 0;
+        daac_match *o = nullptr;
+        if (KMODE == 2) o = a.out + a.seg_counts[seg];
+        auto emit = [&](uint32_t opos, uint64_t end) {
+            const uint32_t *r = dev.outputs + 3u * (opos - 1u);
+            const uint32_t value = r[0], length = r[1];
+            if (KMODE == 2) {
+                daac_match m;
+                m.start = end - length; m.end = end; m.value = value; m._pad = 0;
+                *o++ = m;
+            } else {
+                const uint32_t h = static_cast<uint32_t>(cw_mix64((static_cast<uint64_t>(value) << 32) | length));
+                cnt += 1; s1 += h; s2 += h * static_cast<uint32_t>(end);
+            }
+        };
+
+        if (positional) {
+            // "" is a pattern: FindIterator reports (e, e, first "" value) at 0 and after every character
+            // (iter.rs:115-131); ends in (lo, hi] belong to this segment
+            const uint32_t op = T.root_rec.w;
+            if (lo == 0) emit(op, 0);
+            for (uint64_t e = lo + 1; e <= hi; ++e)
+                if (e >= len || (hay[e] & 0xc0u) != 0x80u) emit(op, e);
+        } else if (p < hi || (LEFTMOST && last && p >= len && p == a.begin)) {  // (an empty range still ends the haystack)
+            uint32_t clen;
+            if (!LEFTMOST) {
+                // FindIterator::next (iter.rs:133-156): back to ROOT after every match, report the list head
+                CwState st = T.root();
+                for (uint64_t pos = p; pos < q;) {
+                    const uint32_t cp = T.scalar_at(pos, clen);
+                    pos += clen;
+                    T.step_plain(st, cp);
+                    if (st.opos != 0) {
+                        emit(st.opos, pos);
+                        st = T.root();
+                    }
+                }
+            } else {
+                // LeftmostFindIterator::next (iter.rs:325-399), call by call, over the characters of [p, q).
+                // `init` is the ROOT state's output_pos: non-zero when "" is a pattern, which then matches at
+                // every position no longer match starts from (iter.rs:311-318); under that setting every walk
+                // is anchored at `pos` (all failure links are DEAD) and has died by the sync point q.
+                uint64_t pos = p;
+                uint32_t init = T.root_rec.w;
+                bool skip_empty = false;
+                const bool real_end = q >= len;
+                for (;;) {                       // one pass = one call of next()
+                    if (!real_end && pos >= q) break;  // the owner of the next region continues from q
+                    CwState st = T.root();
+                    uint32_t last = init;
+                    const uint32_t init_at_entry = init;
+                    bool returned = false, again;
+                    do {                         // the reference's loop 'a
+                        again = false;
+                        uint64_t i = pos, skips = 0;
+                        while (i < q) {
+                            const uint32_t cp = T.scalar_at(i, clen);
+                            i += clen;
+                            skips += clen;
+                            T.step_leftmost(st, cp);
+                            if (st.idx == 0) {
+                                if (last != 0) {
+                                    const uint32_t op = last;
+                                    const uint64_t end = pos;
+                                    if (last == init) {
+                                        pos += clen;
+                                        if (skip_empty) { skip_empty = false; again = true; break; }
+                                    } else {
+                                        skip_empty = true;
+                                    }
+                                    emit(op, end);
+                                    returned = true;
+                                    break;
+                                }
+                            } else if (st.opos != 0) {
+                                last = st.opos;
+                                pos += skips;
+                                skips = 0;
+                            }
+                        }
+                    } while (again);
+                    if (returned) continue;
+                    // the characters ran out (:385-398)
+                    if (!real_end) {             // at a sync point only a match already seen can be pending
+                        if (last != 0 && last != init_at_entry) { emit(last, pos); continue; }
+                        break;
+                    }
+                    if (pos >= len) init = 0;
+                    if (last == 0) break;        // None
+                    if (last == init_at_entry && pos < len) {
+                        // "" is a pattern and the haystack ends inside a longer one: the reference yields the
+                        // same empty match forever from here (SURVEY 8a note D).  Reported, not imitated.
+                        if (a.flags) atomicOr(a.flags, 1ull);
+                        break;
+                    }
+                    emit(last, pos);
+                }
+            }
+        }
+
+        if (KMODE == 0) { tot_cnt += cnt; tot_s1 += s1; tot_s2 += s2; }
+        else if (KMODE == 1) a.seg_counts[seg] = cnt;
+    }
+
+    if (KMODE == 0) {
+        unsigned long long c = tot_cnt, x1 = tot_s1, x2 = tot_s2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { c += __shfl_down(c, off, 64); x1 += __shfl_down(x1, off, 64); x2 += __shfl_down(x2, off, 64); }
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) { scratch[wave * 3] = c; scratch[wave * 3 + 1] = x1; scratch[wave * 3 + 2] = x2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long r0 = 0, r1 = 0, r2 = 0;
+            for (int w = 0; w < static_cast<int>((blockDim.x + 63) >> 6); ++w) { r0 += scratch[w * 3]; r1 += scratch[w * 3 + 1]; r2 += scratch[w * 3 + 2]; }
+            if (r0 | r1 | r2) { atomicAdd(a.result, r0); atomicAdd(a.result + 1, r1); atomicAdd(a.result + 2, r2); }
+        }
+    }
+}
+
+hipError_t launch_char_restart_scan(const CharDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,
+                                    uint32_t blocks, uint32_t threads, hipStream_t stream) {
+    const dim3 g(blocks), b(threads > 256 ? 256 : threads);
+#define DAAC_CW(L, M) hipLaunchKernelGGL((char_restart_kernel<L, M>), g, b, 0, stream, dev, a, next_begin)
+    if (leftmost) { if (kmode == 0) DAAC_CW(true, 0); else if (kmode == 1) DAAC_CW(true, 1); else DAAC_CW(true, 2); }
+    else { if (kmode == 0) DAAC_CW(false, 0); else if (kmode == 1) DAAC_CW(false, 1); else DAAC_CW(false, 2); }
+#undef DAAC_CW
+    return hipGetLastError();
+}
+
+}  // namespace daac

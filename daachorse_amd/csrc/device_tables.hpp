@@ -36,6 +36,16 @@ struct DArrayDev {
     uint32_t n, root_flag, leftmost;
 };
 
+// CHARWISE tables: the reference's charwise double array as is (charwise.rs:1096-1101) + the code mapper.
+struct CharDev {
+    const uint4 *states;         // {base, check = parent slot, fail, output_pos} per slot
+    const uint32_t *fail_plain;  // leftmost kinds: classic links of the same trie; Standard: null (states[].z is classic)
+    const uint32_t *table;       // code point -> code, 0xffffffff = not in any pattern (mapper.rs:36-42)
+    const uint2 *osum;           // per output record {chain count, chain sum of h32}
+    const uint32_t *outputs;     // n_outputs x {value, length, parent}
+    uint32_t table_len, n, root_flag, leftmost;
+};
+
 struct ScanArgs {
     const uint8_t *hay;  // address of haystack byte 0 (only bytes >= begin - halo are read)
     uint64_t begin;      // scan range is [begin, len): matches with end in (begin, len] are reported
@@ -47,6 +57,7 @@ struct ScanArgs {
     unsigned long long *seg_counts;  // MODE 1 out / MODE 2 in (exclusive offsets)
     daac_match *out;                 // MODE 2
     uint64_t total_len;              // restart scanners: real end of the haystack (a.len is the nominal end of this window)
+    unsigned long long *flags;       // optional, 1 x u64: bit 0 = the reference would not terminate on this input
 };
 
 // GRAM engine tables (see gram.hpp).  Everything up to `drec` is staged into LDS.
@@ -87,6 +98,11 @@ hipError_t launch_darray_scan(const DArrayDev &dev, const ScanArgs &a, int mode,
 // `next_begin` (device, 1 x u64) receives the first sync point >= a.len's nominal end.
 hipError_t launch_restart_scan(const DArrayDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,
                                uint32_t blocks, uint32_t threads, hipStream_t stream);
+// Charwise scans: lanes decode UTF-8 on the fly; positions and lengths stay byte offsets (charwise/iter.rs).
+hipError_t launch_char_scan(const CharDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,
+                            hipStream_t stream);
+hipError_t launch_char_restart_scan(const CharDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,
+                                    uint32_t blocks, uint32_t threads, hipStream_t stream);
 hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned long long *total, hipStream_t stream);
 
 }  // namespace daac

@@ -10,6 +10,26 @@ static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
 const char *last_error_cstr() { return g_last_error.c_str(); }
 
+bool fail_links_terminate(size_t n, const uint32_t *fail_at, size_t stride_words, bool dead_stops) {
+    std::vector<uint8_t> mark(n, 0);  // 0 unknown, 1 reaches a terminal, 2 on the current walk
+    std::vector<uint32_t> walk;
+    if (n > kRoot) mark[kRoot] = 1;
+    if (dead_stops && n > kDead) mark[kDead] = 1;
+    for (size_t s = 0; s < n; ++s) {
+        uint32_t cur = static_cast<uint32_t>(s);
+        walk.clear();
+        while (mark[cur] == 0) {
+            mark[cur] = 2;
+            walk.push_back(cur);
+            cur = fail_at[static_cast<size_t>(cur) * stride_words];
+            if (cur >= n) return false;
+        }
+        if (mark[cur] == 2) return false;  // came back to the walk: a cycle
+        for (uint32_t w : walk) mark[w] = 1;
+    }
+    return true;
+}
+
 size_t HostPma::heap_bytes() const {
     return states.size() * sizeof(StateRec) + root_table.size() * sizeof(uint32_t) +
            lstates.size() * sizeof(LStateRec) + fails.size() * sizeof(uint32_t) +
@@ -77,6 +97,7 @@ daac_status HostPma::validate() const {
         }
         for (uint32_t f : fails)
             if (f >= n) return bad("fail out of range");
+        if (!fail_links_terminate(n, fails.data(), 1, true)) return bad("failure links do not end at the root");
     } else {
         if (!lstates.empty() || !fails.empty()) return bad("standard kind with leftmost arrays");
         if (states.empty()) return bad("empty states");
@@ -89,6 +110,7 @@ daac_status HostPma::validate() const {
             const uint32_t op = output_pos_of(s.opos_ch);
             if (op != 0 && static_cast<size_t>(op - 1) >= nout) return bad("output_pos out of range");
         }
+        if (!fail_links_terminate(n, &states[0].fail, 3, false)) return bad("failure links do not end at the root");
     }
     for (size_t i = 0; i < nout; ++i) {
         const uint32_t par = outputs[i].parent;

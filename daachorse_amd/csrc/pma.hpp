@@ -33,6 +33,12 @@ inline uint32_t output_pos_of(uint32_t opos_ch) { return opos_ch >> 8; }        
 inline uint8_t check_of(uint32_t opos_ch) { return static_cast<uint8_t>(opos_ch); }  // intpack.rs:39-41
 
 void set_error(const std::string &msg);
+const char *last_error_cstr();
+
+// True when following `fail_at` from every slot ends at ROOT (or, with `dead_stops`, at DEAD): the
+// transition loops of the reference (and of the kernels) only terminate on such links.  The
+// reference's deserialize does not check this and would spin on a cyclic blob; a GPU must not.
+bool fail_links_terminate(size_t n, const uint32_t *fail_at, size_t stride_words, bool dead_stops);
 
 struct HostPma {
     std::vector<StateRec> states;        // Standard only

@@ -163,6 +163,63 @@ struct DArrayEngine {
     __device__ __forceinline__ const uint32_t *outputs() const { return d.outputs; }
 };
 
+// ------------------------------------------------------------------------------------ CharEngine
+// CharwiseDoubleArrayAhoCorasick (reference src/charwise.rs:1022-1050): the lane is fed bytes and
+// assembles UTF-8 scalars itself (charwise/iter.rs:64-98); a transition happens when a scalar is
+// complete, so `e` in the scan loop is the byte offset of the END of the character, which is what
+// the reference reports.  A segment may begin or end inside a character: continuation bytes seen
+// before the first lead byte are skipped, and a character cut by the segment end is finished by
+// the next lane (its halo starts earlier).  Unmapped scalars send the automaton to ROOT.
+struct CharEngine {
+    using Dev = CharDev;
+    struct State { uint32_t idx, base, fail, opos, cp, need; };
+
+    const CharDev &d;
+    uint4 root_rec;
+
+    __device__ CharEngine(const CharDev &dev, char *) : d(dev), root_rec(dev.states[0]) {}
+    __device__ void load_lds(char *) const {}
+
+    __device__ __forceinline__ State root() const { return State{0, root_rec.x, root_rec.z, root_rec.w, 0, 0}; }
+    __device__ __forceinline__ bool root_flag() const { return d.root_flag != 0; }
+
+    __device__ __forceinline__ bool step(State &st, uint32_t b) const {
+        if (b < 0x80u) { st.cp = b; st.need = 0; }
+        else if (b < 0xc0u) {
+            if (st.need == 0) return false;  // inside a character that began before the lane's first byte
+            st.cp = (st.cp << 6) | (b & 0x3fu);
+            if (--st.need != 0) return false;
+        } else {
+            st.cp = b < 0xe0u ? (b & 0x1fu) : b < 0xf0u ? (b & 0x0fu) : (b & 0x07u);
+            st.need = b < 0xe0u ? 1u : b < 0xf0u ? 2u : 3u;
+            return false;
+        }
+        const uint32_t code = st.cp < d.table_len ? d.table[st.cp] : 0xffffffffu;
+        if (code == 0xffffffffu) {  // charwise.rs:1031-1035
+            st.idx = 0; st.base = root_rec.x; st.fail = root_rec.z; st.opos = root_rec.w;
+            return root_rec.w != 0;
+        }
+        for (;;) {
+            if (st.base != 0) {
+                const uint32_t child = st.base ^ code;
+                const uint4 r = d.states[child];
+                if (r.y == st.idx) {
+                    st.idx = child; st.base = r.x; st.fail = r.z; st.opos = r.w;
+                    return r.w != 0;
+                }
+            }
+            if (st.idx == 0) return root_rec.w != 0;
+            const uint32_t f = st.fail;
+            const uint4 r = d.states[f];
+            st.idx = f; st.base = r.x; st.fail = r.z; st.opos = r.w;
+        }
+    }
+
+    __device__ __forceinline__ uint2 sum(const State &st) const { return d.osum[st.opos - 1]; }
+    __device__ __forceinline__ uint32_t opos(const State &st) const { return st.opos; }
+    __device__ __forceinline__ const uint32_t *outputs() const { return d.outputs; }
+};
+
 // --------------------------------------------------------------------------------- the scan kernel
 // MODE 0: count + checksum into a.result (atomics, one per workgroup)
 // MODE 1: per-segment match counts into a.seg_counts
@@ -343,6 +400,11 @@ hipError_t launch_tier_scan(const TierDev &dev, const ScanArgs &a, int mode, boo
 hipError_t launch_darray_scan(const DArrayDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,
                               hipStream_t stream) {
     return launch_mode<DArrayEngine>(dev, a, mode, heads, dim3(blocks), dim3(threads), 256 * 16, stream);
+}
+
+hipError_t launch_char_scan(const CharDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,
+                            hipStream_t stream) {
+    return launch_mode<CharEngine>(dev, a, mode, heads, dim3(blocks), dim3(threads), 1024, stream);
 }
 
 hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned long long *total, hipStream_t stream) {

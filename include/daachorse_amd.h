@@ -83,6 +83,8 @@ typedef struct {
     uint8_t gram_available;      /* the GRAM count engine can run this automaton */
     uint32_t gram_k;             /* context length K of the GRAM tables */
     uint32_t gram_lds_bytes;
+    uint8_t charwise;            /* 1: a CharwiseDoubleArrayAhoCorasick (src/charwise.rs), 0: bytewise */
+    uint32_t alphabet_size;      /* charwise: number of distinct code points in the patterns (mapper.rs:10-13) */
 } daac_info;
 
 typedef struct daac_pma daac_pma;         /* an automaton (host copy + per-device re-pack) */
@@ -113,7 +115,24 @@ daac_status daac_bytewise_from_parts(const uint32_t *states, size_t n_states,
 daac_status daac_bytewise_build(const uint8_t *blob, const uint64_t *offsets, const uint32_t *values,
                                 size_t n, uint8_t match_kind, uint32_t num_free_blocks, daac_pma **out);
 
-/* DoubleArrayAhoCorasick::serialize (bytewise.rs:801-820); free the buffer with daac_free. */
+/* ---- charwise automata (src/charwise.rs) --------------------------------------
+ * A charwise handle is a daac_pma like any other: daac_pma_*, daac_scan*, daac_iter_* serve it with
+ * the iterators of src/charwise/iter.rs (FindIterator :101-157, FindOverlappingIterator :160-221,
+ * FindOverlappingNoSuffixIterator :224-303, LeftmostFindIterator :306-400).  Haystacks are UTF-8
+ * (the reference takes AsRef<str>); start/end stay BYTE offsets, as in the reference.  Engines:
+ * AUTO or DARRAY (the charwise double array runs as is). */
+
+/* CharwiseDoubleArrayAhoCorasick::deserialize (charwise.rs:896-952), blob format of serialize()
+ * (charwise.rs:831-848: states x {base, check, fail, output_pos}, mapper table + alphabet_size,
+ * outputs, match_kind, num_states), same validation. */
+daac_status daac_charwise_from_serialized(const uint8_t *blob, size_t len, daac_pma **out, size_t *consumed);
+
+/* CharwiseDoubleArrayAhoCorasickBuilder::build / build_with_values (charwise/builder.rs:178-239) on the
+ * host CPU; patterns are UTF-8 (one blob + n+1 byte offsets).  Byte-identical arrays. */
+daac_status daac_charwise_build(const uint8_t *blob, const uint64_t *offsets, const uint32_t *values,
+                                size_t n, uint8_t match_kind, uint32_t num_free_blocks, daac_pma **out);
+
+/* ::serialize (bytewise.rs:801-820 / charwise.rs:831-848); free the buffer with daac_free. */
 daac_status daac_pma_serialize(const daac_pma *pma, uint8_t **buf, size_t *len);
 daac_status daac_pma_info(const daac_pma *pma, daac_info *info);
 void daac_pma_free(daac_pma *pma);
