@@ -94,6 +94,16 @@ struct daac_pma {
     bool is_standard() const { return charwise ? chost.is_standard() : host.is_standard(); }
     bool root_has_output() const { return charwise ? chost.states[kRoot].output_pos != 0 : output_pos_of(host.opos_ch(kRoot)) != 0; }
     uint32_t max_pattern_len() const { return charwise ? chost.max_pattern_len() : host.max_pattern_len(); }
+    // Bytes a lane reads ahead of its segment: a state is a suffix of the text of at most Lmax bytes, and a
+    // match that ends inside the segment starts at most Lmax - 1 bytes before it.  Charwise lanes take
+    // Lmax whole bytes — the leftmost iterator with "" in the set must also see a pattern that ends exactly
+    // at a cut (charwise/iter.rs:351-353, skip_empty) — and never less than 3, the distance to the lead byte
+    // of a character that straddles the cut.
+    uint32_t halo() const {
+        const uint32_t lmax = max_pattern_len();
+        if (charwise) return std::max(lmax, 3u);
+        return lmax > 0 ? lmax - 1 : 0;
+    }
 };
 
 struct daac_matches {
@@ -325,8 +335,7 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
         return DAAC_ERR_UNSUPPORTED;
     }
     pl.tier = !pl.charwise && !pl.restart && (engine == DAAC_ENGINE_TIERED || (engine == DAAC_ENGINE_AUTO && t->tier_ok));
-    const uint32_t lmax = pma->max_pattern_len();
-    const uint32_t halo = lmax > 0 ? lmax - 1 : 0;
+    const uint32_t halo = pma->halo();
     uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
     threads = std::min(1024u, std::max(64u, threads & ~63u));
     uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
@@ -749,8 +758,7 @@ int daac_iter_next(daac_iter *it, daac_match *m) {
         const uint64_t window = std::max<uint64_t>(4096, static_cast<uint64_t>(g_opt.iter_window.load()));
         const uint64_t begin = it->next_begin;
         const uint64_t end = std::min<uint64_t>(it->len, begin + window);
-        const uint32_t lmax = it->pma->max_pattern_len();
-        const uint64_t halo = lmax ? lmax - 1 : 0;
+        const uint64_t halo = it->pma->halo();
         void *staged = nullptr;
         const uint8_t *dev_hay = it->hay;
         if (!it->hay_is_device && end > 0) {

@@ -111,12 +111,12 @@ __global__ __launch_bounds__(256) void char_restart_kernel(const CharDev dev, co
         const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
         const bool positional = !LEFTMOST && dev.root_flag;
         uint64_t p = 0, q = 0;
-        const bool last = hi == a.len;
+        const bool final_seg = hi == a.len;
         if (!positional) {
             p = T.sync_from(lo, a.halo, a.begin);
-            if (p < hi || last) q = T.sync_from(hi, a.halo, a.begin);
+            if (p < hi || final_seg) q = T.sync_from(hi, a.halo, a.begin);
         }
-        if (last && next_begin) *next_begin = positional ? hi : q;
+        if (final_seg && next_begin) *next_begin = positional ? hi : q;
 
         unsigned long long cnt = 0;
         uint32_t s1 = 0, s2 = 0;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void char_restart_kernel(const CharDev dev, co
             if (lo == 0) emit(op, 0);
             for (uint64_t e = lo + 1; e <= hi; ++e)
                 if (e >= len || (hay[e] & 0xc0u) != 0x80u) emit(op, e);
-        } else if (p < hi || (LEFTMOST && last && p >= len && p == a.begin)) {  // (an empty range still ends the haystack)
+        } else if (p < hi || (LEFTMOST && final_seg && p >= len && p == a.begin)) {  // (an empty range still ends the haystack)
             uint32_t clen;
             if (!LEFTMOST) {
                 // FindIterator::next (iter.rs:133-156): back to ROOT after every match, report the list head
@@ -168,9 +168,13 @@ __global__ __launch_bounds__(256) void char_restart_kernel(const CharDev dev, co
                 for (;;) {                       // one pass = one call of next()
                     if (!real_end && pos >= q) break;  // the owner of the next region continues from q
                     CwState st = T.root();
-                    uint32_t last = init;
+                    uint32_t best = init;        // last_output_pos
                     const uint32_t init_at_entry = init;
-                    bool returned = false, again;
+                    // One emit site per path: hipcc 7.2 -O3 loses the advance of the output cursor when emit() is
+                    // inlined behind the nested break/continue of the literal transcription (seen in the ISA).
+                    uint32_t ret_op = 0;         // what this call returns, if the walk dies on a character
+                    uint64_t ret_end = 0;
+                    bool again;
                     do {                         // the reference's loop 'a
                         again = false;
                         uint64_t i = pos, skips = 0;
@@ -180,41 +184,40 @@ __global__ __launch_bounds__(256) void char_restart_kernel(const CharDev dev, co
                             skips += clen;
                             T.step_leftmost(st, cp);
                             if (st.idx == 0) {
-                                if (last != 0) {
-                                    const uint32_t op = last;
-                                    const uint64_t end = pos;
-                                    if (last == init) {
-                                        pos += clen;
-                                        if (skip_empty) { skip_empty = false; again = true; break; }
-                                    } else {
+                                if (best != 0) {
+                                    ret_end = pos;
+                                    if (best != init) {
                                         skip_empty = true;
+                                        ret_op = best;
+                                    } else {
+                                        pos += clen;
+                                        if (skip_empty) { skip_empty = false; again = true; }
+                                        else ret_op = best;
                                     }
-                                    emit(op, end);
-                                    returned = true;
                                     break;
                                 }
                             } else if (st.opos != 0) {
-                                last = st.opos;
+                                best = st.opos;
                                 pos += skips;
                                 skips = 0;
                             }
                         }
                     } while (again);
-                    if (returned) continue;
+                    if (ret_op != 0) { emit(ret_op, ret_end); continue; }
                     // the characters ran out (:385-398)
                     if (!real_end) {             // at a sync point only a match already seen can be pending
-                        if (last != 0 && last != init_at_entry) { emit(last, pos); continue; }
+                        if (best != 0 && best != init_at_entry) { emit(best, pos); continue; }
                         break;
                     }
                     if (pos >= len) init = 0;
-                    if (last == 0) break;        // None
-                    if (last == init_at_entry && pos < len) {
+                    if (best == 0) break;        // None
+                    if (best == init_at_entry && pos < len) {
                         // "" is a pattern and the haystack ends inside a longer one: the reference yields the
                         // same empty match forever from here (SURVEY 8a note D).  Reported, not imitated.
                         if (a.flags) atomicOr(a.flags, 1ull);
                         break;
                     }
-                    emit(last, pos);
+                    emit(best, pos);
                 }
             }
         }
