@@ -95,13 +95,14 @@ struct daac_pma {
     bool root_has_output() const { return charwise ? chost.states[kRoot].output_pos != 0 : output_pos_of(host.opos_ch(kRoot)) != 0; }
     uint32_t max_pattern_len() const { return charwise ? chost.max_pattern_len() : host.max_pattern_len(); }
     // Bytes a lane reads ahead of its segment: a state is a suffix of the text of at most Lmax bytes, and a
-    // match that ends inside the segment starts at most Lmax - 1 bytes before it.  Charwise lanes take
-    // Lmax whole bytes — the leftmost iterator with "" in the set must also see a pattern that ends exactly
+    // match that ends inside the segment starts at most Lmax - 1 bytes before it.  Charwise lanes (and bytewise
+    // leftmost automata with "" in the set) take Lmax whole bytes — the leftmost iterator with "" in the set must also see a pattern that ends exactly
     // at a cut (charwise/iter.rs:351-353, skip_empty) — and never less than 3, the distance to the lead byte
     // of a character that straddles the cut.
     uint32_t halo() const {
         const uint32_t lmax = max_pattern_len();
         if (charwise) return std::max(lmax, 3u);
+        if (!is_standard() && root_has_output()) return lmax;
         return lmax > 0 ? lmax - 1 : 0;
     }
 };
@@ -317,11 +318,6 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
     if (pl.restart) {
         if (engine != DAAC_ENGINE_AUTO && engine != DAAC_ENGINE_DARRAY) {
             set_error("find_iter / leftmost_find_iter run on the DARRAY tables only");
-            return DAAC_ERR_UNSUPPORTED;
-        }
-        if (pl.leftmost && !pl.charwise && pma->root_has_output()) {
-            // SURVEY.md 8a note D: the reference's own behaviour is not pinned (and not terminating) here
-            set_error("leftmost_find_iter with an empty pattern in the set is not supported on the device");
             return DAAC_ERR_UNSUPPORTED;
         }
     }
@@ -624,7 +620,7 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
     pl.a.result = d_res;
     HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
     void *flagbuf = nullptr;
-    if (pl.charwise && pl.leftmost && pma->root_has_output()) {  // the one scan that can hit the non-terminating corner
+    if (pl.leftmost && pma->root_has_output()) {  // the one scan that can hit the non-terminating corner
         HIP_TRY(hipMalloc(&flagbuf, sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(flagbuf, 0, sizeof(unsigned long long), stream));
         pl.a.flags = static_cast<unsigned long long *>(flagbuf);

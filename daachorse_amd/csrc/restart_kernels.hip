@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void restart_scan_kernel(const DArrayDev dev, 
             const uint32_t op = dev.hot[0].y >> 8;
             if (lo == 0) emit(op, 0);
             for (uint64_t e = lo + 1; e <= hi; ++e) emit(op, e);
-        } else if (p < hi) {
+        } else if (p < hi || (LEFTMOST && last && p >= len && p == a.begin)) {  // (an empty range still ends the haystack)
             if (!LEFTMOST) {
                 // FindIterator::next (iter.rs:87-112): restart at ROOT after every match, report the list head
                 RsState st{0, 0, 0};
@@ -155,29 +155,62 @@ __global__ __launch_bounds__(256) void restart_scan_kernel(const DArrayDev dev, 
                     }
                 }
             } else {
-                // LeftmostFindIterator::next (iter.rs:272-340) over the virtual haystack [p, q); no "" pattern
-                RsState st{0, 0, 0};
-                uint64_t pos = p, self_pos = p;
-                uint32_t last_out = 0;
-                for (;;) {
-                    if (pos >= q) {  // end of the (virtual) haystack: iter.rs:320-339
-                        if (last_out == 0) break;
-                        emit(last_out, self_pos);
-                        pos = self_pos; st = RsState{0, 0, 0}; last_out = 0;  // the next call rescans from the match end
-                        continue;
-                    }
-                    T.step_leftmost(st, hay[pos]);
-                    if (st.idx == 0) {
-                        if (last_out != 0) {  // iter.rs:282-306: report, restart at the end of the match
-                            emit(last_out, self_pos);
-                            pos = self_pos; last_out = 0;
-                            continue;
+                // LeftmostFindIterator::next (iter.rs:272-340), call by call, over the bytes of [p, q).
+                // `init` is ROOT's output_pos: non-zero when "" is a pattern, which then matches wherever no
+                // longer match starts (iter.rs:254-261); every walk is then anchored at `pos` (all failure links
+                // are DEAD) and has died by the sync point q.
+                uint64_t pos = p;
+                uint32_t init = dev.hot[0].y >> 8;
+                bool skip_empty = false;
+                const bool real_end = q >= len;
+                for (;;) {                           // one pass = one call of next()
+                    if (!real_end && pos >= q) break;  // the owner of the next region continues from q
+                    RsState st{0, 0, 0};
+                    uint32_t best = init;            // last_output_pos
+                    const uint32_t init_at_entry = init;
+                    // One emit site per path: hipcc 7.2 -O3 loses the advance of the output cursor when emit()
+                    // is inlined behind the nested break/continue of the literal transcription.
+                    uint32_t ret_op = 0;             // what this call returns, if the walk dies on a byte
+                    uint64_t ret_end = 0;
+                    bool again;
+                    do {                             // the reference's loop 'a
+                        again = false;
+                        for (uint64_t i = pos; i < q; ++i) {
+                            T.step_leftmost(st, hay[i]);
+                            if (st.idx == 0) {
+                                if (best != 0) {
+                                    ret_end = pos;
+                                    if (best != init) {
+                                        skip_empty = true;
+                                        ret_op = best;
+                                    } else {
+                                        pos += 1;
+                                        if (skip_empty) { skip_empty = false; again = true; }
+                                        else ret_op = best;
+                                    }
+                                    break;
+                                }
+                            } else if ((st.opos_ch >> 8) != 0) {
+                                best = st.opos_ch >> 8;
+                                pos = i + 1;
+                            }
                         }
-                        ++pos;
-                    } else {
-                        if ((st.opos_ch >> 8) != 0) { last_out = st.opos_ch >> 8; self_pos = pos + 1; }  // iter.rs:307-315
-                        ++pos;
+                    } while (again);
+                    if (ret_op != 0) { emit(ret_op, ret_end); continue; }
+                    // the bytes ran out (iter.rs:320-339)
+                    if (!real_end) {                 // at a sync point only a match already seen can be pending
+                        if (best != 0 && best != init_at_entry) { emit(best, pos); continue; }
+                        break;
                     }
+                    if (pos >= len) init = 0;
+                    if (best == 0) break;            // None
+                    if (best == init_at_entry && pos < len) {
+                        // "" is a pattern and the haystack ends inside a longer one: the reference yields the same
+                        // empty match forever from here (SURVEY 8a note D).  Reported, not imitated.
+                        if (a.flags) atomicOr(a.flags, 1ull);
+                        break;
+                    }
+                    emit(best, pos);
                 }
             }
         }

@@ -35,7 +35,7 @@ typedef enum {
     DAAC_ERR_INVALID_CONVERSION = 3,/* DaachorseError::InvalidConversion */
     DAAC_ERR_INVALID_AUTOMATON = 4, /* DaachorseError::InvalidAutomaton  */
     DAAC_ERR_MATCH_KIND = 5,        /* the reference PANICS here: bytewise.rs:194-197, 299-302, 551-554 */
-    DAAC_ERR_UNSUPPORTED = 6,       /* e.g. leftmost kinds with an empty pattern (SURVEY §8a note D) */
+    DAAC_ERR_UNSUPPORTED = 6,       /* an engine that cannot serve the request; or the one input on which the reference itself never terminates (leftmost kind, "" in the set, haystack ends inside a longer pattern: SURVEY §8a note D) */
     DAAC_ERR_DEVICE = 7             /* HIP error / no gfx950 device */
 } daac_status;
 
