@@ -224,6 +224,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 if ((st = t->put(gt.bsuper, g.bsuper)) != DAAC_OK) return st;
                 if ((st = t->put(gt.drec, drec)) != DAAC_OK) return st;
                 if ((st = t->put(gt.dhit, dhit)) != DAAC_OK) return st;
+                if ((st = t->put(gt.cfirst, g.cfirst)) != DAAC_OK) return st;
                 g.combo = reinterpret_cast<const uint2 *>(combo);
                 g.drec = reinterpret_cast<const uint4 *>(drec);
                 g.dhit = reinterpret_cast<const uint2 *>(dhit);
@@ -646,8 +647,8 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(2048, g_opt.gram_slab.load()));
         ga.pipeline = g_opt.gram_pipeline.load() != 0;
         void *wq = nullptr;
-        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * sizeof(unsigned long long), stream));
-        ga.wq = static_cast<unsigned long long *>(wq);
+        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * sizeof(uint4), stream));
+        ga.wq = static_cast<uint4 *>(wq);
         const hipError_t le = launch_gram_scan(t->gram, ga, blocks, threads, stream);
         HIP_TRY(hipFreeAsync(wq, stream));
         HIP_TRY(le);

@@ -70,6 +70,7 @@ struct GramDev {
     const uint32_t *bsuper;   // per 8 words: set bits before the superblock
     const uint4 *drec;        // N x {cmap, first_child, own_cnt, own_hsum}  (HBM / L2)
     const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}          (HBM / L2)
+    const uint32_t *cfirst;   // depth-(K+1) states by rank: id of the first child     (HBM / L2)
     uint32_t off_cid, off_combo, off_bbits, off_brank, off_bsuper, off_scratch, lds_bytes;  // cls at 0
     uint32_t K, C, CC, CCC;
     uint32_t level_start, unused_byte, has_short;
@@ -83,7 +84,7 @@ struct GramArgs {
     uint64_t region_bytes;   // contiguous bytes a wave takes at a time (multiple of 1024)
     uint64_t nregions;
     unsigned long long *result;  // {count, S1, S2}
-    unsigned long long *wq;      // per-wave walker slabs
+    uint4 *wq;                   // per-wave walker slabs: {position lo, position hi | class after next << 8, state, 0}
     uint32_t wq_slab;            // entries per wave
     uint32_t pipeline;           // consume the deep reads half a chunk late (software pipeline)
 };

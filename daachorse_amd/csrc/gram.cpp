@@ -124,6 +124,7 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
             prev_gram = gram[s];
             out.bbits[g >> 5] |= 1u << (g & 31);
             out.dhit.push_back(U32x2{r.x, own_hs[s]});
+            out.cfirst.push_back(r.z);
         }
     }
     if (out.bbits.size() & 1) out.bbits.push_back(0);  // whole 64-bit pairs

@@ -40,6 +40,7 @@ struct GramTables {
     std::vector<uint32_t> bsuper;   // per 8 words (256 bits): set bits before the superblock
     std::vector<U32x4> drec;        // N: {cmap, first_child, own_cnt, own_hsum}
     std::vector<U32x2> dhit;        // per depth-(K+1) state, in rank order: {cmap, own_hsum}; own_cnt == (own_hsum != 0)
+    std::vector<uint32_t> cfirst;   // same order: id of the state's first child (read only when a branch goes on)
     uint32_t lds_bytes = 0;
 };
 

@@ -85,8 +85,9 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     const uint32_t ub4 = g.unused_byte * 0x01010101u;
     const uint8_t *__restrict__ hay = a.hay_al;
     const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
-    // this wave's slab of pending walkers: entry = virtual position of the last byte of a (K+1)-gram
-    unsigned long long *__restrict__ slab =
+    // this wave's slab of pending walkers: {virtual position p of the last byte of a (K+1)-gram (lo, hi),
+    // class of the byte at p + 2 (<< 8 in .y), the depth-(K+2) state reached on the byte at p + 1}
+    uint4 *__restrict__ slab =
         a.wq + (static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * a.wq_slab;
     uint32_t wq_n = 0;  // wave-uniform
 
@@ -121,35 +122,34 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         const uint32_t below = (odd ? __popc(pair.x) : 0u) + __popc(word & ((1u << (ib & 31u)) - 1u));
         return RANK_LDS ? l_bsuper[w >> 3] + l_brank[w >> 1] + below : g.bsuper[w >> 3] + g.brank[w >> 1] + below;
     };
-    // Finishes the queued branches, 64 per round.  An entry is the position p of the last byte of a
-    // (K+1)-gram whose depth-(K+1) state (already counted) has a child on the byte at p + 1.
+    // Finishes the queued branches, 64 per round.  The entry names the depth-(K+2) state the branch has
+    // reached and the class of the next byte, so the haystack is only read again for the few branches
+    // that survive yet another level (2e-4 of the positions on the 100k-word automaton).
     auto drain = [&]() {
         for (uint32_t i = lane; i < wq_n; i += 64) {
-            const uint64_t p = slab[i];
-            uint32_t ib = 0;
-#pragma unroll
-            for (int t = K; t >= 0; --t) ib = ib * C + (p >= static_cast<uint64_t>(t) ? class_at(p - t) : 0u);
-            uint4 r = g.drec[g.level_start + deep_rank(ib)];  // {cmap, first_child, own_cnt, own_hsum}
-            uint64_t vnext = p + 1;
+            const uint4 e = slab[i];
+            uint64_t vnext = ((static_cast<uint64_t>(e.y & 0xffu) << 32) | e.x) + 2;  // the state consumed the byte before vnext
+            uint4 r = g.drec[e.z];                 // {cmap, first_child, own_cnt, own_hsum}
+            uint32_t kn = e.y >> 8;
             for (;;) {
-                const uint32_t kn = class_at(vnext);
-                if (((r.x >> kn) & 1u) == 0) break;
-                r = g.drec[r.y + __popc(r.x & ((1u << kn) - 1u))];
-                ++vnext;  // the child consumed the byte before vnext: its own patterns end at vnext - lead
-                tot_cnt += r.z;
+                tot_cnt += r.z;                   // its own patterns end at vnext - lead
                 tot_s1 += r.w;
                 tot_s2 += r.w * static_cast<uint32_t>(vnext - a.lead);
+                if (((r.x >> kn) & 1u) == 0) break;
+                r = g.drec[r.y + __popc(r.x & ((1u << kn) - 1u))];
+                ++vnext;
+                kn = class_at(vnext);
             }
         }
         wq_n = 0;
     };
 
-    // ---- the hit ring: entry = {gram index | class of the next byte << 20, low 32 bits of the position}
+    // ---- the hit ring: entry = {gram index | classes of the next two bytes << 20 / << 25, low 32 bits of the position}
     // (a stack: batches are taken from the top, so no wrap-around arithmetic; order does not matter)
     uint2 *ring = reinterpret_cast<uint2 *>(smem + g.off_scratch) + (threadIdx.x >> 6) * kRing;
     uint32_t q_n = 0;                           // wave-uniform
     uint2 pend = uint2{0u, 0u};                 // record read for the previous batch, not yet consumed
-    uint32_t pend_item = 0, pend_pos = 0;
+    uint32_t pend_item = 0, pend_pos = 0, pend_rank = 0;
     bool pend_valid = false;                    // wave-uniform
     uint64_t v_now = 0;                         // a recent 64-bit position of this wave (to widen pend_pos)
     auto consume_pending = [&]() {
@@ -159,14 +159,17 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         tot_cnt += r.y != 0;
         tot_s1 += r.y;
         tot_s2 += r.y * (pend_pos - a.lead + 1u);  // end = position - lead + 1 (mod 2^32)
-        const bool go = (r.x >> (pend_item >> 20)) & 1u;
+        const uint32_t k1 = (pend_item >> 20) & 31u;
+        const bool go = (r.x >> k1) & 1u;
         const unsigned long long m = __ballot(go);
         if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker (needs the full position)
             if (go) {
                 uint64_t vp = (v_now & ~0xffffffffull) | pend_pos;
                 if (vp > v_now + (1ull << 31)) vp -= 1ull << 32;
                 else if (vp + (1ull << 31) < v_now) vp += 1ull << 32;
-                slab[wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] = vp;
+                const uint32_t child = g.cfirst[pend_rank] + __popc(r.x & ((1u << k1) - 1u));
+                slab[wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
+                    uint4{static_cast<uint32_t>(vp), static_cast<uint32_t>(vp >> 32) | ((pend_item >> 25) << 8), child, 0u};
             }
             wq_n += __popcll(m);
         }
@@ -182,7 +185,8 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             const uint2 it = ring[q_n + lane];
             pend_item = it.x;
             pend_pos = it.y;
-            pend = g.dhit[deep_rank(it.x & 0xfffffu)];
+            pend_rank = deep_rank(it.x & 0xfffffu);
+            pend = g.dhit[pend_rank];
         }
         pend_valid = true;
     };
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             pf[kPrefetch] = (sb + 1024ull * (kPrefetch + 1) < rend) ? load_chunk(v + 1024ull * (kPrefetch + 1)) : uint4{ub4, ub4, ub4, ub4};
 
             // ---- byte classes of this lane's 16 positions plus K to the left and 1 to the right ----
-            uint32_t kx[K + 17];
+            uint32_t kx[K + 18];
             {
                 const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
@@ -226,9 +230,10 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             carry = __shfl(pk, 63, 64);
 #pragma unroll
             for (int i = 0; i < K; ++i) kx[i] = (left >> (8 * i)) & 0xffu;
-            uint32_t right = __shfl_down(kx[K], 1, 64);
-            if (lane == 63) right = class_at(sb + 1024);
-            kx[K + 16] = right;
+            uint32_t right = __shfl_down(kx[K] | (kx[K + 1] << 5), 1, 64);  // the two classes after this lane's 16
+            if (lane == 63) right = class_at(sb + 1024) | (class_at(sb + 1025) << 5);
+            kx[K + 16] = right & 31u;
+            kx[K + 17] = right >> 5;
 
             // ---- per group of kGroup positions: LDS work of every position independently (all reads of
             // the group in flight before the first is consumed), then the B hits are queued ---------------
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                         if (m != 0) {  // wave-uniform
                             if (hit)
                                 ring[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), q_n))] =
-                                    uint2{iB[jj] | (kx[K + j + 1] << 20), v32 + j};
+                                    uint2{iB[jj] | ((kx[K + j + 1] | (kx[K + j + 2] << 5)) << 20), v32 + j};
                             q_n += __popcll(m);
                             if (q_n >= 64u) process_batch();
                         }

@@ -67,14 +67,23 @@ int main(int argc, char **argv) {
             uint32_t id = g.level_start + rank;
             const U32x2 hrec = g.dhit[rank];  // what the fast pass reads: must agree with the full record
             if (hrec.x != g.drec[id].x || hrec.y != g.drec[id].w || g.drec[id].z != (hrec.y != 0 ? 1u : 0u)) { std::printf("MISMATCH dhit\n"); return 1; }
-            long long nx = p0 + 1;
-            for (;;) {
-                const U32x4 r = g.drec[id];
-                gc += r.z; g1 += r.w; g2 += r.w * static_cast<uint32_t>(nx);
-                const uint32_t kn = cls(nx);
-                if (((r.x >> kn) & 1u) == 0) break;
-                id = r.y + __builtin_popcount(r.x & ((1u << kn) - 1u));
-                ++nx;
+            // fast pass: the depth-(K+1) state's own pattern, then "does the branch go on with the next byte"
+            gc += hrec.y != 0; g1 += hrec.y; g2 += hrec.y * end;
+            const uint32_t k1 = cls(p0 + 1), k2 = cls(p0 + 2);
+            if ((hrec.x >> k1) & 1u) {
+                // walker, as queued by the kernel: the child state via cfirst, the class after next in the entry
+                if (g.cfirst[rank] != g.drec[id].y) { std::printf("MISMATCH cfirst\n"); return 1; }
+                id = g.cfirst[rank] + __builtin_popcount(hrec.x & ((1u << k1) - 1u));
+                long long nx = p0 + 2;  // the state consumed the byte before nx
+                uint32_t kn = k2;
+                for (;;) {
+                    const U32x4 r = g.drec[id];
+                    gc += r.z; g1 += r.w; g2 += r.w * static_cast<uint32_t>(nx);
+                    if (((r.x >> kn) & 1u) == 0) break;
+                    id = r.y + __builtin_popcount(r.x & ((1u << kn) - 1u));
+                    ++nx;
+                    kn = cls(nx);
+                }
             }
         }
     }
