@@ -34,7 +34,7 @@ struct Options {
     std::atomic<int64_t> gram_lds_budget{158 * 1024};
     std::atomic<int64_t> gram_region{16 * 1024};
     std::atomic<int64_t> gram_slab{2048};
-    std::atomic<int64_t> gram_pipeline{1};
+    std::atomic<int64_t> gram_dense{-1};        // -1 = decide per automaton
     std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
 };
 static Options g_opt;
@@ -250,6 +250,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 g.K = gt.K; g.C = gt.C; g.CC = gt.C * gt.C; g.CCC = gt.C * gt.C * gt.C;
                 g.level_start = gt.level_start;
                 g.unused_byte = gt.unused_byte;
+                g.n_deep = static_cast<uint32_t>(gt.dhit.size());
                 t->gram_ok = true;
             }
             // keep the sizes for daac_pma_info
@@ -645,7 +646,9 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         const uint32_t blocks = static_cast<uint32_t>(
             std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (ga.nregions + wpb - 1) / wpb)));
         ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(2048, g_opt.gram_slab.load()));
-        ga.pipeline = g_opt.gram_pipeline.load() != 0;
+        // more than ~1 % of the (K+1)-grams are trie prefixes: some lane of the wave hits on nearly every position
+        ga.dense = g_opt.gram_dense.load() >= 0 ? g_opt.gram_dense.load() != 0
+                                                : static_cast<uint64_t>(t->gram.n_deep) * 100 > static_cast<uint64_t>(t->gram.CCC) * (t->gram.K == 3 ? t->gram.C : 1);
         void *wq = nullptr;
         HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * sizeof(uint4), stream));
         ga.wq = static_cast<uint4 *>(wq);
@@ -792,7 +795,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_lds_budget") g_opt.gram_lds_budget = value;
     else if (n == "gram_region") g_opt.gram_region = value;
     else if (n == "gram_slab") g_opt.gram_slab = value;
-    else if (n == "gram_pipeline") g_opt.gram_pipeline = value;
+    else if (n == "gram_dense") g_opt.gram_dense = value;
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else { set_error("unknown option: " + n); return DAAC_ERR_INVALID_ARGUMENT; }
     return DAAC_OK;

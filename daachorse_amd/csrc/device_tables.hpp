@@ -75,6 +75,7 @@ struct GramDev {
     uint32_t K, C, CC, CCC;
     uint32_t level_start, unused_byte, has_short;
     uint32_t rank_in_lds;     // brank/bsuper staged in LDS (else read from L2 on hits)
+    uint32_t n_deep;          // number of depth-(K+1) states = set bits of B
 };
 
 struct GramArgs {
@@ -86,7 +87,7 @@ struct GramArgs {
     unsigned long long *result;  // {count, S1, S2}
     uint4 *wq;                   // per-wave walker slabs: {position lo, position hi | class after next << 8, state, 0}
     uint32_t wq_slab;            // entries per wave
-    uint32_t pipeline;           // consume the deep reads half a chunk late (software pipeline)
+    uint32_t dense;              // B hits are frequent: queue them position by position without testing the group first
 };
 
 hipError_t launch_gram_scan(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream);

@@ -28,6 +28,19 @@ constexpr int kGroup = 4;     // positions whose LDS reads are issued together (
 constexpr uint32_t kRing = 128;  // entries of a wave's hit stack in LDS (at most 63 left over + 64 new)
 constexpr int kPrefetch = 1;  // haystack chunks in flight per lane beyond the current one
 
+// 24-bit multiply-adds, spelled out: left to itself hipcc turns some `__umul24(a, b) + c` of the gram
+// indices into the quarter-rate v_mad_u64_u32.
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b_uniform, uint32_t c) {
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t mad_i24(uint32_t a, int32_t b_uniform, uint32_t c) {
+    uint32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
+}
+
 __device__ __forceinline__ unsigned long long gram_wave_sum(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -55,7 +68,7 @@ __device__ __forceinline__ void gram_reduce(unsigned long long cnt, uint32_t s1,
     }
 }
 
-template <int K, bool HAS_SHORT, int TPB, bool PIPE, bool RANK_LDS>
+template <int K, bool HAS_SHORT, int TPB, bool DENSE, bool RANK_LDS>
 __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const GramArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gram_copy(smem, g.cls, 256);
@@ -82,6 +95,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t C = g.C;
     const uint32_t PK = K == 3 ? g.CCC : g.CC;   // C^K
+    const int32_t negPK = -static_cast<int32_t>(PK);
     const uint32_t ub4 = g.unused_byte * 0x01010101u;
     const uint8_t *__restrict__ hay = a.hay_al;
     const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
@@ -239,6 +253,10 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             // the group in flight before the first is consumed), then the B hits are queued ---------------
             uint32_t ccnt = 0, A = 0, T = 0;       // T = sum over positions of running A (prefix trick for h * end)
             const uint32_t e0 = static_cast<uint32_t>(v - a.lead) + 1u;  // end of this lane's position 0
+            // gram indices as a chain: the (K+1)-gram ending at j is the K-gram ending at j - 1 shifted by one
+            // class, and dropping its oldest class leaves the K-gram ending at j (two 24-bit mads per position)
+            uint32_t wprev = mad_u24(kx[0], C, kx[1]);                               // K classes ending before position 0
+            if (K == 3) wprev = mad_u24(wprev, C, kx[2]);
 #pragma unroll
             for (int grp = 0; grp < 16 / kGroup; ++grp) {
                 uint32_t iW[kGroup], iB[kGroup], bw[kGroup], id[kGroup];
@@ -246,15 +264,14 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
 #pragma unroll
                 for (int jj = 0; jj < kGroup; ++jj) {
                     const int j = grp * kGroup + jj;
-                    uint32_t widx = __umul24(kx[j + 1], C) + kx[j + 2];                // K classes ending at j
-                    if (K == 3) widx = __umul24(widx, C) + kx[j + 3];
-                    iW[jj] = widx;
-                    iB[jj] = __umul24(kx[j], PK) + widx;                               // K+1 classes
+                    iB[jj] = mad_u24(wprev, C, kx[j + K]);                           // K+1 classes ending at j
+                    wprev = mad_i24(kx[j], negPK, iB[jj]);
+                    iW[jj] = wprev;                                                   // K classes ending at j
                 }
 #pragma unroll
                 for (int jj = 0; jj < kGroup; ++jj) {
                     if (HAS_SHORT) id[jj] = l_cid[iW[jj]];
-                    bw[jj] = l_bbits[iB[jj] >> 5];
+                    bw[jj] = l_bbits[__builtin_amdgcn_ubfe(iB[jj], 5, 27)];
                 }
                 if (HAS_SHORT) {
 #pragma unroll
@@ -266,22 +283,30 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                         T += A;
                     }
                 }
-                uint32_t hits = 0;
-#pragma unroll
-                for (int jj = 0; jj < kGroup; ++jj) hits |= __builtin_amdgcn_ubfe(bw[jj], iB[jj], 1) << jj;  // bit (iB & 31) of the word
-                if (__any(hits != 0)) {  // one branch per group when nothing hits (sparse automata)
-#pragma unroll
-                    for (int jj = 0; jj < kGroup; ++jj) {
-                        const int j = grp * kGroup + jj;
-                        const bool hit = (hits >> jj) & 1u;
-                        const unsigned long long m = __ballot(hit);
-                        if (m != 0) {  // wave-uniform
-                            if (hit)
-                                ring[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), q_n))] =
-                                    uint2{iB[jj] | ((kx[K + j + 1] | (kx[K + j + 2] << 5)) << 20), v32 + j};
-                            q_n += __popcll(m);
-                            if (q_n >= 64u) process_batch();
+                // a hit is queued with the classes of the next two bytes; the slot comes from the wave ballot
+                auto queue_hit = [&](int jj, bool hit) {
+                    const int j = grp * kGroup + jj;
+                    const unsigned long long m = __ballot(hit);
+                    if (m != 0) {  // wave-uniform
+                        if (hit) {
+                            const uint32_t nx = kx[K + j + 1] | (kx[K + j + 2] << 5);
+                            ring[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), q_n))] =
+                                uint2{iB[jj] | (nx << 20), v32 + j};
                         }
+                        q_n = __builtin_amdgcn_readfirstlane(q_n + __popcll(m));
+                        if (q_n >= 64u) process_batch();
+                    }
+                };
+                if (DENSE) {  // B hits on most steps anyway: no point in testing the group first
+#pragma unroll
+                    for (int jj = 0; jj < kGroup; ++jj) queue_hit(jj, __builtin_amdgcn_ubfe(bw[jj], iB[jj], 1) != 0);
+                } else {
+                    uint32_t hits = 0;
+#pragma unroll
+                    for (int jj = 0; jj < kGroup; ++jj) hits |= __builtin_amdgcn_ubfe(bw[jj], iB[jj], 1) << jj;  // bit (iB & 31) of the word
+                    if (__any(hits != 0)) {  // one branch per group when nothing hits (sparse automata)
+#pragma unroll
+                        for (int jj = 0; jj < kGroup; ++jj) queue_hit(jj, (hits >> jj) & 1u);
                     }
                 }
             }
@@ -297,25 +322,25 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     gram_reduce(tot_cnt, tot_s1, tot_s2, reinterpret_cast<unsigned long long *>(smem), a.result);
 }
 
-template <int K, bool S, int TPB, bool PIPE, bool RL>
+template <int K, bool S, int TPB, bool DENSE, bool RL>
 static hipError_t launch_rl(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
     if (dev.lds_bytes > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram_count_kernel<K, S, TPB, PIPE, RL>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram_count_kernel<K, S, TPB, DENSE, RL>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dev.lds_bytes));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((gram_count_kernel<K, S, TPB, PIPE, RL>), dim3(blocks), dim3(threads), dev.lds_bytes, stream, dev, a);
+    hipLaunchKernelGGL((gram_count_kernel<K, S, TPB, DENSE, RL>), dim3(blocks), dim3(threads), dev.lds_bytes, stream, dev, a);
     return hipGetLastError();
 }
-template <int K, bool S, int TPB, bool PIPE>
+template <int K, bool S, int TPB, bool DENSE>
 static hipError_t launch_pipe(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
-    return dev.rank_in_lds ? launch_rl<K, S, TPB, PIPE, true>(dev, a, blocks, threads, stream)
-                           : launch_rl<K, S, TPB, PIPE, false>(dev, a, blocks, threads, stream);
+    return dev.rank_in_lds ? launch_rl<K, S, TPB, DENSE, true>(dev, a, blocks, threads, stream)
+                           : launch_rl<K, S, TPB, DENSE, false>(dev, a, blocks, threads, stream);
 }
 template <int K, bool S, int TPB>
 static hipError_t launch_tpb(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
-    return a.pipeline ? launch_pipe<K, S, TPB, true>(dev, a, blocks, threads, stream)
-                      : launch_pipe<K, S, TPB, false>(dev, a, blocks, threads, stream);
+    return a.dense ? launch_pipe<K, S, TPB, true>(dev, a, blocks, threads, stream)
+                   : launch_pipe<K, S, TPB, false>(dev, a, blocks, threads, stream);
 }
 
 // Three register budgets: 1024-thread workgroups (128 VGPRs, 4 waves/SIMD), 768 (168 VGPRs,
