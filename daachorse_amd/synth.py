@@ -19,6 +19,7 @@ SEEDS = {
     "cfg2_pat": 0xDAAC0002, "cfg2_hay": 0xDAAC0012, "cfg2_dense": 0xDAAC0022,
     "cfg3_pat": 0xDAAC0003, "cfg3_hay": 0xDAAC0013, "cfg3_dense": 0xDAAC0023,
     "cfg4_hay": 0xDAAC0014,
+    "cfg5_pat": 0xDAAC0005, "cfg5_dense": 0xDAAC0025,
 }
 
 ALPHA_ABCD = b"abcd"
@@ -134,6 +135,58 @@ def patterns_cfg3(n=100_000, seed=SEEDS["cfg3_pat"]):
                 if len(out) == n:
                     break
     return out
+
+
+# cfg5: a CJK-like vocabulary.  Code points: hiragana, katakana, then CJK unified ideographs; every one is
+# 3 bytes in UTF-8.  Characters are drawn with Zipf-like weights (kana and the first ideographs dominate).
+_CFG5_CODEPOINTS = list(range(0x3041, 0x3097)) + list(range(0x30A1, 0x30F7)) + list(range(0x4E00, 0x4E00 + 2228))
+_CFG5_LENGTHS = [(1, 2), (2, 25), (3, 30), (4, 22), (5, 12), (6, 6), (7, 2), (8, 1)]  # characters, percent
+
+
+def patterns_cfg5(n=50_000, seed=SEEDS["cfg5_pat"]):
+    """n distinct UTF-8 'words' (bytes), 1..8 characters of 3 bytes each, value = index"""
+    cps = np.array(_CFG5_CODEPOINTS, dtype=np.int64)
+    weights = (1_000_000 / (np.arange(len(cps)) + 12.0)).astype(np.int64)
+    cum_chr = np.cumsum(weights)
+    cum_len = np.cumsum([w for _, w in _CFG5_LENGTHS])
+    len_of = np.array([l for l, _ in _CFG5_LENGTHS])
+    enc = [chr(int(c)).encode("utf-8") for c in cps]
+    seen, out, j = set(), [], 0
+    batch = 1 << 15
+    while len(out) < n:
+        idx = np.arange(j, j + batch, dtype=np.uint64)
+        j += batch
+        zl = zstream(seed, idx * np.uint64(5))
+        lengths = len_of[np.searchsorted(cum_len, (zl % np.uint64(cum_len[-1])).astype(np.int64), side="right")]
+        # 8 character draws per word, 32 bits each (4 stream words)
+        sh = (np.arange(2, dtype=np.uint64) * np.uint64(32))[None, :]
+        raw = np.concatenate([(zstream(seed, idx * np.uint64(5) + np.uint64(t))[:, None] >> sh) & np.uint64(0xFFFFFFFF)
+                              for t in (1, 2, 3, 4)], axis=1)
+        draw = ((raw * np.uint64(cum_chr[-1])) >> np.uint64(32)).astype(np.int64)
+        chars = np.searchsorted(cum_chr, draw, side="right")
+        for row, length in zip(chars, lengths):
+            w = b"".join(enc[c] for c in row[:length])
+            if w not in seen:
+                seen.add(w)
+                out.append(w)
+                if len(out) == n:
+                    break
+    return out
+
+
+def cfg5_text_block(words, nbytes, seed=SEEDS["cfg5_dense"], word_share=0.8):
+    """about nbytes of UTF-8 text (numpy uint8, whole characters): dictionary words (word_share of the draws) run
+    together with stray characters of the same vocabulary, no separators — every byte belongs to a 3-byte character"""
+    rng = np.random.default_rng(seed)
+    cps = [chr(c).encode("utf-8") for c in _CFG5_CODEPOINTS]
+    avg = word_share * float(np.mean([len(w) for w in words])) + (1 - word_share) * 3
+    n_items = int(nbytes / avg) + 1
+    pick = rng.integers(0, len(words), size=n_items)
+    stray = rng.integers(0, len(cps), size=n_items)
+    is_word = rng.random(n_items) < word_share
+    text = b"".join(words[i] if w else cps[c] for i, c, w in zip(pick.tolist(), stray.tolist(), is_word.tolist()))
+    text = text[:nbytes - nbytes % 3]
+    return np.frombuffer(text, dtype=np.uint8)
 
 
 # --------------------------------------------------------------------------------- device generators
