@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libdaachorse_amd.so")
 
 SOURCES = ["pma.cpp", "repack.cpp", "gram.cpp", "builder.cpp", "charwise.cpp", "charwise_builder.cpp", "api.hip", "scan_kernels.hip",
            "gram_kernels.hip", "restart_kernels.hip", "charwise_kernels.hip", "synth.hip"]
-HEADERS = ["pma.hpp", "repack.hpp", "gram.hpp", "charwise.hpp", "build_common.hpp", "device_tables.hpp", os.path.join("..", "..", "include", "daachorse_amd.h"),
+HEADERS = ["pma.hpp", "repack.hpp", "gram.hpp", "charwise.hpp", "build_common.hpp", "device_tables.hpp", "chain_scan.hpp", os.path.join("..", "..", "include", "daachorse_amd.h"),
            os.path.join("..", "..", "include", "daac_synth.h")]
 
 

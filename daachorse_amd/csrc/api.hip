@@ -36,6 +36,8 @@ struct Options {
     std::atomic<int64_t> gram_slab{2048};
     std::atomic<int64_t> gram_dense{-1};        // -1 = decide per automaton
     std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
+    std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
+    std::atomic<int64_t> chain_rounds{24};
 };
 static Options g_opt;
 
@@ -298,6 +300,7 @@ daac_status diverged() {
 }
 
 struct Plan {
+    ChainArgs chain{};      // restart scans whose chain has been resolved (chain.x_prev != nullptr): the emit pass runs
     bool tier;
     bool charwise = false;  // the charwise engine (scan_kernel<CharEngine> / char_restart_kernel)
     bool restart = false;   // find_iter / leftmost_find_iter: the restart scanners (DARRAY tables)
@@ -366,6 +369,10 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
 }
 
 hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, hipStream_t s, unsigned long long *next_begin = nullptr) {
+    if (pl.restart && pl.chain.x_prev != nullptr) {
+        return pl.charwise ? launch_char_chain(t->chr, pl.a, pl.chain, 2, kmode, pl.leftmost, next_begin, pl.blocks, s)
+                           : launch_chain(t->da, pl.a, pl.chain, 2, kmode, pl.leftmost, next_begin, pl.blocks, s);
+    }
     if (pl.charwise) {
         return pl.restart ? launch_char_restart_scan(t->chr, pl.a, kmode, pl.leftmost, next_begin, pl.blocks, pl.threads, s)
                           : launch_char_scan(t->chr, pl.a, kmode, heads, pl.blocks, pl.threads, s);
@@ -373,6 +380,54 @@ hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, 
     if (pl.restart) return launch_restart_scan(t->da, pl.a, kmode, pl.leftmost, next_begin, pl.blocks, pl.threads, s);
     return pl.tier ? launch_tier_scan(t->tier, pl.a, kmode, heads, pl.blocks, pl.threads, s)
                    : launch_darray_scan(t->da, pl.a, kmode, heads, pl.blocks, pl.threads, s);
+}
+
+// Resolves where the chain of a restart iterator enters every segment (chain_scan.hpp): speculative exits,
+// then rounds of reconciliation until no exit moves.  On success pl.chain names the final exits and the
+// emit passes may run; otherwise ("" in the pattern set, a link that would not end, no convergence) pl.chain
+// stays empty and the sync-point scanners of restart_kernels.hip / charwise_kernels.hip do the scan.
+struct ChainBuffers {
+    void *buf = nullptr;
+    ~ChainBuffers() { if (buf) (void)hipFree(buf); }
+};
+
+daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, hipStream_t stream, ChainBuffers &cb) {
+    pl.chain = ChainArgs{};
+    if (!pl.restart || pma->root_has_output() || g_opt.restart_chain.load() == 0 || pl.a.nseg == 0) return DAAC_OK;
+    const uint64_t n = pl.a.nseg;
+    HIP_TRY(hipMalloc(&cb.buf, (3 * n + 2) * sizeof(unsigned long long)));
+    unsigned long long *x_spec = static_cast<unsigned long long *>(cb.buf), *xa = x_spec + n, *xb = xa + n;
+    unsigned int *flags = reinterpret_cast<unsigned int *>(xb + n);
+    HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned int), stream));
+    ChainArgs c{};
+    c.cap = std::max<uint64_t>(4096, 8 * pl.a.seg_bytes);
+    c.flags = flags;
+    c.x_out = x_spec;
+    auto run = [&](int pass) {
+        return pl.charwise ? launch_char_chain(t->chr, pl.a, c, pass, 0, pl.leftmost, nullptr, pl.blocks, stream)
+                           : launch_chain(t->da, pl.a, c, pass, 0, pl.leftmost, nullptr, pl.blocks, stream);
+    };
+    HIP_TRY(run(0));
+    const unsigned long long *prev = x_spec;
+    const int max_rounds = static_cast<int>(std::max<int64_t>(1, g_opt.chain_rounds.load()));
+    for (int round = 0; round < max_rounds; ++round) {
+        unsigned long long *out = (round & 1) ? xb : xa;
+        c.x_spec = x_spec; c.x_prev = prev; c.x_out = out;
+        HIP_TRY(hipMemsetAsync(flags, 0, sizeof(unsigned int), stream));
+        HIP_TRY(run(1));
+        unsigned int f[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(f, flags, sizeof(f), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (f[1] != 0) return DAAC_OK;  // a link ran away: not this method's text
+        prev = out;
+        if (f[0] == 0) {                // nothing moved: `out` holds the true exits
+            pl.chain = c;
+            pl.chain.x_prev = out;
+            pl.chain.x_out = nullptr;
+            return DAAC_OK;
+        }
+    }
+    return DAAC_OK;
 }
 
 // Scans [begin, end) of a haystack whose byte 0 is at `dev_hay` (device pointer; only bytes
@@ -402,6 +457,8 @@ daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int
     unsigned long long *d_next = d_counts + pl.a.nseg + 1;
     HIP_TRY(hipMemsetAsync(d_next, 0, 2 * sizeof(unsigned long long), stream));
     pl.a.flags = d_next + 1;
+    ChainBuffers chain_buffers;
+    if ((st = chain_resolve(pma, t, pl, stream, chain_buffers)) != DAAC_OK) return st;
     HIP_TRY(launch(t, pl, 1, heads, stream, d_next));
     HIP_TRY(launch_exclusive_scan(d_counts, pl.a.nseg, d_counts + pl.a.nseg, stream));
     unsigned long long total = 0, nbf[2] = {0, 0};
@@ -620,6 +677,8 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
     if (!d_res) { HIP_TRY(hipMalloc(&own, 3 * sizeof(unsigned long long))); d_res = static_cast<unsigned long long *>(own); }
     std::unique_ptr<void, void (*)(void *)> g2(own, [](void *p) { if (p) (void)hipFree(p); });
     pl.a.result = d_res;
+    ChainBuffers chain_buffers;
+    if (pl.a.nseg != 0 && (st = chain_resolve(pma, t, pl, stream, chain_buffers)) != DAAC_OK) return st;
     HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
     void *flagbuf = nullptr;
     if (pl.leftmost && pma->root_has_output()) {  // the one scan that can hit the non-terminating corner
@@ -797,6 +856,8 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_slab") g_opt.gram_slab = value;
     else if (n == "gram_dense") g_opt.gram_dense = value;
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
+    else if (n == "restart_chain") g_opt.restart_chain = value;
+    else if (n == "chain_rounds") g_opt.chain_rounds = value;
     else { set_error("unknown option: " + n); return DAAC_ERR_INVALID_ARGUMENT; }
     return DAAC_OK;
 }

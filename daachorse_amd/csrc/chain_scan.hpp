@@ -1,0 +1,194 @@
+// Speculate / reconcile / emit: the parallel form of the restart iterators (FindIterator and
+// LeftmostFindIterator of the reference, bytewise and charwise) for gfx950.
+//
+// Both iterators are a CHAIN: from a position r at ROOT they scan to the next match (s, e), report
+// it and continue from e.  What they report after r depends on nothing but r, so the haystack can
+// be cut wherever the chain passes — but where it passes is only known by following it.  Instead:
+//
+//   1. speculate   every lane follows the chain of its segment [lo, hi) as if it started fresh at
+//                  lo, and records where that chain leaves the segment (its first position >= hi);
+//   2. reconcile   the chain really enters segment k where segment k-1 was left.  A lane follows the
+//                  true entry and its speculative chain in lockstep; as soon as both stand on the
+//                  same position they are one chain from there on, so the speculative exit is the
+//                  true exit.  Different starting points fall in step after a few matches, so one
+//                  or two rounds settle every segment (a round re-reads only a few links per lane);
+//   3. emit        with the true entries known the segments are independent: count, or count per
+//                  segment -> exclusive scan -> write, as for the overlapping scan.
+//
+// A link also ends, without a match, once it is past its segment and the automaton is back at ROOT
+// with nothing pending: a fresh start there is indistinguishable from going on (this keeps links
+// short in text with few matches).  A link that neither matches nor returns to ROOT for `cap` bytes
+// past its segment raises the overflow flag, and the driver falls back to the sync-point scanners
+// (restart_kernels.hip), as it does for automata that contain the empty pattern.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_tables.hpp"
+
+namespace daac {
+
+// T supplies the automaton: State, root(), symbol_at(pos, clen), step_plain / step_leftmost, opos(), is_root().
+template <class T, bool LEFTMOST>
+struct ChainWalker {
+    const T &t;
+    uint64_t len;
+    uint64_t cap;
+    bool overflow = false;
+
+    // One link of the chain from position r (reference bytewise/iter.rs:87-112 / 272-340, charwise/iter.rs:
+    // 133-156 / 325-399, one call of next()); returns the next chain position, > r.
+    template <class Emit>
+    __device__ __forceinline__ uint64_t link(uint64_t r, uint64_t hi, Emit &&emit) {
+        typename T::State st = t.root();
+        uint64_t pos = r;
+        uint32_t clen;
+        if (!LEFTMOST) {
+            for (;;) {
+                if (pos >= len) return len;
+                const uint32_t sym = t.symbol_at(pos, clen);
+                pos += clen;
+                t.step_plain(st, sym);
+                if (t.opos(st) != 0) { emit(t.opos(st), pos); return pos; }
+                if (pos >= hi) {
+                    if (t.is_root(st)) return pos;
+                    if (pos - hi > cap) { overflow = true; return pos; }
+                }
+            }
+        } else {
+            uint32_t best = 0;       // last_output_pos
+            uint64_t best_end = r;   // self.pos
+            for (;;) {
+                if (pos >= len) {
+                    if (best != 0) { emit(best, best_end); return best_end; }
+                    return len;
+                }
+                const uint32_t sym = t.symbol_at(pos, clen);
+                t.step_leftmost(st, sym);
+                if (t.is_root(st)) {
+                    if (best != 0) { emit(best, best_end); return best_end; }
+                    pos += clen;
+                    if (pos >= hi) return pos;
+                } else {
+                    pos += clen;
+                    if (t.opos(st) != 0) { best = t.opos(st); best_end = pos; }
+                    else if (best == 0 && pos >= hi && pos - hi > cap) { overflow = true; return pos; }
+                }
+            }
+        }
+    }
+
+    template <class Emit>
+    __device__ __forceinline__ uint64_t run(uint64_t entry, uint64_t hi, Emit &&emit) {
+        uint64_t r = entry;
+        while (r < hi && !overflow) r = link(r, hi, emit);
+        return r;
+    }
+};
+
+struct ChainNoEmit {
+    __device__ __forceinline__ void operator()(uint32_t, uint64_t) const {}
+};
+
+// pass 1: exits of the speculative chains
+template <class T, bool LEFTMOST>
+__device__ __forceinline__ void chain_spec_body(const T &t, const ScanArgs &a, const ChainArgs &c) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    ChainWalker<T, LEFTMOST> w{t, a.total_len, c.cap};
+    for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
+        const uint64_t lo = a.begin + seg * a.seg_bytes;
+        const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
+        c.x_out[seg] = w.run(seg == 0 ? lo : t.boundary_at_or_after(lo), hi, ChainNoEmit{});
+    }
+    if (w.overflow) c.flags[1] = 1u;
+}
+
+// pass 2 (repeated until nothing changes): exits given the previous round's exits as entries
+template <class T, bool LEFTMOST>
+__device__ __forceinline__ void chain_fix_body(const T &t, const ScanArgs &a, const ChainArgs &c) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    ChainWalker<T, LEFTMOST> w{t, a.total_len, c.cap};
+    bool changed = false;
+    for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
+        const uint64_t lo = a.begin + seg * a.seg_bytes;
+        const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
+        const uint64_t spec_exit = c.x_spec[seg];
+        uint64_t exit = spec_exit;
+        if (seg != 0) {
+            const uint64_t entry = c.x_prev[seg - 1];
+            uint64_t s = t.boundary_at_or_after(lo);
+            if (entry >= hi) {
+                exit = entry;               // the chain jumps over this segment
+            } else if (entry != s) {
+                uint64_t x = entry;         // the true chain; s follows the speculative one
+                bool merged = false;
+                while (x < hi && !w.overflow) {
+                    while (s < x && s < hi && !w.overflow) s = w.link(s, hi, ChainNoEmit{});
+                    if (s == x) { merged = true; break; }
+                    x = w.link(x, hi, ChainNoEmit{});
+                }
+                if (!merged) exit = x;
+            }
+        }
+        if (exit != c.x_prev[seg]) changed = true;
+        c.x_out[seg] = exit;
+    }
+    if (changed) c.flags[0] = 1u;
+    if (w.overflow) c.flags[1] = 1u;
+}
+
+// pass 3: the segments with their true entries.  KMODE 0: totals, 1: per-segment counts, 2: write
+template <class T, bool LEFTMOST, int KMODE>
+__device__ __forceinline__ void chain_emit_body(const T &t, const ScanArgs &a, const ChainArgs &c, const uint32_t *outputs,
+                                                unsigned long long *next_begin, unsigned long long *scratch) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    ChainWalker<T, LEFTMOST> w{t, a.total_len, c.cap};
+    unsigned long long tot_cnt = 0;
+    uint32_t tot_s1 = 0, tot_s2 = 0;
+    for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
+        const uint64_t lo = a.begin + seg * a.seg_bytes;
+        const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
+        const uint64_t entry = seg == 0 ? lo : c.x_prev[seg - 1];
+        unsigned long long cnt = 0;
+        uint32_t s1 = 0, s2 = 0;
+        daac_match *o = nullptr;
+        if (KMODE == 2) o = a.out + a.seg_counts[seg];
+        auto emit = [&](uint32_t opos, uint64_t end) {
+            const uint32_t *r = outputs + 3u * (opos - 1u);
+            const uint32_t value = r[0], length = r[1];
+            if (KMODE == 2) {
+                daac_match m;
+                m.start = end - length; m.end = end; m.value = value; m._pad = 0;
+                *o++ = m;
+            } else {
+                uint64_t z = (static_cast<uint64_t>(value) << 32) | length;  // h of the checksum definition
+                z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+                z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+                const uint32_t h = static_cast<uint32_t>(z ^ (z >> 31));
+                cnt += 1; s1 += h; s2 += h * static_cast<uint32_t>(end);
+            }
+        };
+        const uint64_t exit = w.run(entry, hi, emit);
+        if (hi == a.len && next_begin) *next_begin = exit > a.len ? exit : a.len;  // where a following window starts
+        if (KMODE == 0) { tot_cnt += cnt; tot_s1 += s1; tot_s2 += s2; }
+        else if (KMODE == 1) a.seg_counts[seg] = cnt;
+    }
+    if (w.overflow) c.flags[1] = 1u;
+    if (KMODE == 0) {
+        unsigned long long cc = tot_cnt, x1 = tot_s1, x2 = tot_s2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { cc += __shfl_down(cc, off, 64); x1 += __shfl_down(x1, off, 64); x2 += __shfl_down(x2, off, 64); }
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) { scratch[wave * 3] = cc; scratch[wave * 3 + 1] = x1; scratch[wave * 3 + 2] = x2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long r0 = 0, r1 = 0, r2 = 0;
+            for (int v = 0; v < static_cast<int>((blockDim.x + 63) >> 6); ++v) { r0 += scratch[v * 3]; r1 += scratch[v * 3 + 1]; r2 += scratch[v * 3 + 2]; }
+            if (r0 | r1 | r2) { atomicAdd(a.result, r0); atomicAdd(a.result + 1, r1); atomicAdd(a.result + 2, r2); }
+        }
+    }
+}
+
+}  // namespace daac

@@ -11,6 +11,7 @@
 
 #include <cstdint>
 
+#include "chain_scan.hpp"
 #include "device_tables.hpp"
 
 namespace daac {
@@ -23,13 +24,22 @@ __device__ __forceinline__ uint64_t cw_mix64(uint64_t z) {
 
 struct CwState { uint32_t idx, base, fail, opos; };
 
-struct CharTables {
+struct CwTables {
+    using State = CwState;
     const CharDev &d;
     uint4 root_rec;
     const uint8_t *__restrict__ hay;
     uint64_t len;  // real end of the haystack: nothing at or beyond it is read
 
     __device__ __forceinline__ CwState root() const { return CwState{0, root_rec.x, root_rec.z, root_rec.w}; }
+    // the automaton as chain_scan.hpp wants it
+    __device__ __forceinline__ uint32_t symbol_at(uint64_t pos, uint32_t &clen) const { return scalar_at(pos, clen); }
+    __device__ __forceinline__ uint32_t opos(const CwState &st) const { return st.opos; }
+    __device__ __forceinline__ bool is_root(const CwState &st) const { return st.idx == 0; }
+    __device__ __forceinline__ uint64_t boundary_at_or_after(uint64_t x) const {
+        while (x < len && (hay[x] & 0xc0u) == 0x80u) ++x;
+        return x;
+    }
 
     // One scalar at byte `pos` (a character boundary of well-formed UTF-8; charwise/iter.rs:64-98).
     // A sequence cut by the end of the haystack is completed with zero payload bits, never read past.
@@ -99,7 +109,7 @@ struct CharTables {
 template <bool LEFTMOST, int KMODE>
 __global__ __launch_bounds__(256) void char_restart_kernel(const CharDev dev, const ScanArgs a, unsigned long long *next_begin) {
     __shared__ unsigned long long scratch[3 * 4];
-    const CharTables T{dev, dev.states[0], a.hay, a.total_len};
+    const CwTables T{dev, dev.states[0], a.hay, a.total_len};
     const uint8_t *__restrict__ hay = a.hay;
     const uint64_t len = a.total_len;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -239,6 +249,28 @@ __global__ __launch_bounds__(256) void char_restart_kernel(const CharDev dev, co
             if (r0 | r1 | r2) { atomicAdd(a.result, r0); atomicAdd(a.result + 1, r1); atomicAdd(a.result + 2, r2); }
         }
     }
+}
+
+// ---- speculate / reconcile / emit (chain_scan.hpp) over the charwise double array -------------------------
+template <bool LEFTMOST, int PASS, int KMODE>
+__global__ __launch_bounds__(256) void char_chain_kernel(const CharDev dev, const ScanArgs a, const ChainArgs c, unsigned long long *next_begin) {
+    __shared__ unsigned long long scratch[3 * 4];
+    const CwTables T{dev, dev.states[0], a.hay, a.total_len};
+    if (PASS == 0) chain_spec_body<CwTables, LEFTMOST>(T, a, c);
+    else if (PASS == 1) chain_fix_body<CwTables, LEFTMOST>(T, a, c);
+    else chain_emit_body<CwTables, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
+}
+
+hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
+                             unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
+    const dim3 g(blocks), b(256);
+#define DAAC_CC(L, P, M) hipLaunchKernelGGL((char_chain_kernel<L, P, M>), g, b, 0, stream, dev, a, c, next_begin)
+    if (pass == 0) { if (leftmost) DAAC_CC(true, 0, 0); else DAAC_CC(false, 0, 0); }
+    else if (pass == 1) { if (leftmost) DAAC_CC(true, 1, 0); else DAAC_CC(false, 1, 0); }
+    else if (leftmost) { if (kmode == 0) DAAC_CC(true, 2, 0); else if (kmode == 1) DAAC_CC(true, 2, 1); else DAAC_CC(true, 2, 2); }
+    else { if (kmode == 0) DAAC_CC(false, 2, 0); else if (kmode == 1) DAAC_CC(false, 2, 1); else DAAC_CC(false, 2, 2); }
+#undef DAAC_CC
+    return hipGetLastError();
 }
 
 hipError_t launch_char_restart_scan(const CharDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,

@@ -60,6 +60,15 @@ struct ScanArgs {
     unsigned long long *flags;       // optional, 1 x u64: bit 0 = the reference would not terminate on this input
 };
 
+// Passes of the restart scanners in their speculate / reconcile / emit form (chain_scan.hpp)
+struct ChainArgs {
+    const unsigned long long *x_spec;  // per segment: exit of the speculative chain
+    const unsigned long long *x_prev;  // per segment: exit as of the previous round
+    unsigned long long *x_out;         // per segment: exit computed by this pass
+    unsigned int *flags;               // [0] = some exit changed this round, [1] = a link overflowed
+    uint64_t cap;                      // bytes a link may run past its segment without match or ROOT
+};
+
 // GRAM engine tables (see gram.hpp).  Everything up to `drec` is staged into LDS.
 struct GramDev {
     const uint8_t *cls;       // 256
@@ -105,6 +114,11 @@ hipError_t launch_char_scan(const CharDev &dev, const ScanArgs &a, int mode, boo
                             hipStream_t stream);
 hipError_t launch_char_restart_scan(const CharDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,
                                     uint32_t blocks, uint32_t threads, hipStream_t stream);
+// pass 0 = speculate, 1 = reconcile (one round), 2 = emit in `kmode` (0 totals, 1 per-segment counts, 2 write)
+hipError_t launch_chain(const DArrayDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
+                        unsigned long long *next_begin, uint32_t blocks, hipStream_t stream);
+hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
+                             unsigned long long *next_begin, uint32_t blocks, hipStream_t stream);
 hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned long long *total, hipStream_t stream);
 
 }  // namespace daac

@@ -24,6 +24,7 @@
 
 #include <cstdint>
 
+#include "chain_scan.hpp"
 #include "device_tables.hpp"
 
 namespace daac {
@@ -37,8 +38,17 @@ __device__ __forceinline__ uint64_t rs_mix64(uint64_t z) {
 struct RsState { uint32_t idx, base, opos_ch; };
 
 struct RestartTables {
+    using State = RsState;
     const DArrayDev &d;
     const uint4 *l_root;  // 256 x {child, child.base, child.opos_ch, 0} in LDS
+    const uint8_t *__restrict__ hay = nullptr;
+
+    // the automaton as chain_scan.hpp wants it
+    __device__ __forceinline__ RsState root() const { return RsState{0, 0, 0}; }
+    __device__ __forceinline__ uint32_t symbol_at(uint64_t pos, uint32_t &clen) const { clen = 1; return hay[pos]; }
+    __device__ __forceinline__ uint32_t opos(const RsState &st) const { return st.opos_ch >> 8; }
+    __device__ __forceinline__ bool is_root(const RsState &st) const { return st.idx == 0; }
+    __device__ __forceinline__ uint64_t boundary_at_or_after(uint64_t x) const { return x; }
 
     // classic delta (failure links never stop): reference src/bytewise.rs:1063-1088 over fail_plain
     __device__ __forceinline__ void step_plain(RsState &st, uint32_t c) const {
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) void restart_scan_kernel(const DArrayDev dev, 
     __shared__ unsigned long long scratch[3 * 4];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root[i];
     __syncthreads();
-    const RestartTables T{dev, l_root};
+    const RestartTables T{dev, l_root, a.hay};
     const uint8_t *__restrict__ hay = a.hay;
     const uint64_t len = a.total_len;  // real end of the haystack; a.len is the nominal end of this window
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
@@ -232,6 +242,31 @@ __global__ __launch_bounds__(256) void restart_scan_kernel(const DArrayDev dev, 
             if (r0 | r1 | r2) { atomicAdd(a.result, r0); atomicAdd(a.result + 1, r1); atomicAdd(a.result + 2, r2); }
         }
     }
+}
+
+// ---- speculate / reconcile / emit (chain_scan.hpp) over the bytewise double array -------------------------
+template <bool LEFTMOST, int PASS, int KMODE>
+__global__ __launch_bounds__(256) void chain_kernel(const DArrayDev dev, const ScanArgs a, const ChainArgs c, unsigned long long *next_begin) {
+    __shared__ uint4 l_root[256];
+    __shared__ unsigned long long scratch[3 * 4];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root[i];
+    __syncthreads();
+    const RestartTables T{dev, l_root, a.hay};
+    if (PASS == 0) chain_spec_body<RestartTables, LEFTMOST>(T, a, c);
+    else if (PASS == 1) chain_fix_body<RestartTables, LEFTMOST>(T, a, c);
+    else chain_emit_body<RestartTables, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
+}
+
+hipError_t launch_chain(const DArrayDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
+                        unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
+    const dim3 g(blocks), b(256);
+#define DAAC_CH(L, P, M) hipLaunchKernelGGL((chain_kernel<L, P, M>), g, b, 0, stream, dev, a, c, next_begin)
+    if (pass == 0) { if (leftmost) DAAC_CH(true, 0, 0); else DAAC_CH(false, 0, 0); }
+    else if (pass == 1) { if (leftmost) DAAC_CH(true, 1, 0); else DAAC_CH(false, 1, 0); }
+    else if (leftmost) { if (kmode == 0) DAAC_CH(true, 2, 0); else if (kmode == 1) DAAC_CH(true, 2, 1); else DAAC_CH(true, 2, 2); }
+    else { if (kmode == 0) DAAC_CH(false, 2, 0); else if (kmode == 1) DAAC_CH(false, 2, 1); else DAAC_CH(false, 2, 2); }
+#undef DAAC_CH
+    return hipGetLastError();
 }
 
 hipError_t launch_restart_scan(const DArrayDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,

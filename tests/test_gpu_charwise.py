@@ -42,6 +42,7 @@ def _reset_options():
     yield
     da.set_option("seg_bytes", 0)
     da.set_option("iter_window", 64 << 20)
+    da.set_option("restart_chain", 1)
 
 
 def _pair(patterns, kind=0, values=None):
@@ -118,11 +119,14 @@ def _words(rng, n, alphabet, max_chars):
     return ["".join(alphabet[i] for i in rng.integers(0, len(alphabet), size=int(rng.integers(1, max_chars + 1)))) for _ in range(n)]
 
 
+@pytest.mark.parametrize("chain", [1, 0])
 @pytest.mark.parametrize("alpha", sorted(ALPHABETS))
-def test_fuzz_multibyte_all_iterators(alpha):
-    """random dictionaries and text; 16- and 48-byte lanes cut characters, halos start inside characters"""
+def test_fuzz_multibyte_all_iterators(alpha, chain):
+    """random dictionaries and text; 16- and 48-byte lanes cut characters, halos start inside characters;
+    the restart iterators both ways (chain = 1: speculate / reconcile / emit, 0: sync-point scanners)"""
     rng = np.random.default_rng(len(alpha) * 7 + 1)
     A = ALPHABETS[alpha]
+    da.set_option("restart_chain", chain)
     for trial in range(10):
         pats = _words(rng, int(rng.integers(1, 60)), A, 5)
         text = "".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(0, 3000))))

@@ -60,6 +60,8 @@ def _reset_options():
     yield
     da.set_option("seg_bytes", 0)
     da.set_option("iter_window", 64 << 20)
+    da.set_option("restart_chain", 1)
+    da.set_option("chain_rounds", 24)
 
 
 def test_golden_vectors_overlapping(vectors):
@@ -288,12 +290,17 @@ def test_shard_tail_counts_add_up():
         assert (tot_c, ddist.join_checksum(tot_1, tot_2)) == whole, cuts
 
 
+@pytest.mark.parametrize("chain", [1, 0, 2])
 @pytest.mark.parametrize("seg_bytes", [16, 64, 0])
-def test_fuzz_find_and_leftmost(seg_bytes):
+def test_fuzz_find_and_leftmost(seg_bytes, chain):
     """find_iter / leftmost_find_iter against the literal iterators of the oracle: tiny alphabets (few
-    sync points, long chains across segments), periodic texts that never synchronise, separators."""
+    sync points, long chains across segments), periodic texts that never synchronise, separators.
+    chain = 1: speculate / reconcile / emit; 0: the sync-point scanners; 2: one reconciliation round only,
+    so that texts whose chains do not fall in step at once exercise the fallback."""
     rng = np.random.default_rng(4321 + seg_bytes)
     da.set_option("seg_bytes", seg_bytes)
+    da.set_option("restart_chain", 1 if chain else 0)
+    da.set_option("chain_rounds", 1 if chain == 2 else 24)
     for it in range(50):
         npat = int(rng.integers(1, 7))
         pats = [bytes(rng.integers(97, 100, size=int(rng.integers(1, 6))).astype(np.uint8)) for _ in range(npat)]
