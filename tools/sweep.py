@@ -23,9 +23,12 @@ def main():
     ap.add_argument("--mib", type=int, default=1024)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--grid", default="engine=tiered,darray")
+    ap.add_argument("--mode", default="overlapping", choices=["overlapping", "find", "leftmost"])
     args = ap.parse_args()
     pats = synth.patterns_cfg3() if args.workload == "cfg3" else synth.patterns_cfg2()
-    blob = da.DoubleArrayAhoCorasick.new(pats).serialize()
+    kind = da.MatchKind.LeftmostLongest if args.mode == "leftmost" else da.MatchKind.Standard
+    mode = {"overlapping": ScanMode.FindOverlapping, "find": ScanMode.Find, "leftmost": ScanMode.LeftmostFind}[args.mode]
+    blob = da.DoubleArrayAhoCorasickBuilder().match_kind(kind).build(pats).serialize()
     n = args.mib << 20
     hay = torch.empty(n, dtype=torch.uint8, device="cuda")
     if args.haystack == "sparse":
@@ -41,7 +44,7 @@ def main():
         keys.append(k)
         vals.append(v.split(","))
     ref = None
-    defaults = {"gram_rank_in_lds": -1, "gram_dense": -1, "gram_region": 16384, "gram_lds_budget": 161792, "gram_slab": 2048, "seg_bytes": 0, "lds_budget": 96 * 1024, "dense_depth": -1, "rows_share_pct": 45, "blocks_per_cu": 0, "threads": 1024}
+    defaults = {"gram_rank_in_lds": -1, "gram_dense": -1, "gram_region": 16384, "gram_lds_budget": 161792, "gram_slab": 2048, "restart_chain": 1, "seg_bytes": 0, "lds_budget": 96 * 1024, "dense_depth": -1, "rows_share_pct": 45, "blocks_per_cu": 0, "threads": 1024}
     for combo in itertools.product(*vals):
         cfg = dict(zip(keys, combo))
         for k, v in defaults.items():
@@ -51,12 +54,12 @@ def main():
         try:
             pma.upload(0)
             info = pma.info()
-            pma.scan_count(ScanMode.FindOverlapping, hay, engine=eng, stream=stream, result_dev=res.data_ptr())
+            pma.scan_count(mode, hay, engine=eng, stream=stream, result_dev=res.data_ptr())
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.reps):
-                pma.scan_count(ScanMode.FindOverlapping, hay, engine=eng, stream=stream, result_dev=res.data_ptr())
+                pma.scan_count(mode, hay, engine=eng, stream=stream, result_dev=res.data_ptr())
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.reps
