@@ -2,7 +2,8 @@
 //
 // The reference is a Rust crate; no Rust toolchain exists in this image, so the host side that a
 // crate user would touch is mirrored here in C++ with the crate's names, argument meaning and
-// error behaviour (reference src/bytewise.rs, src/bytewise/builder.rs, src/bytewise/iter.rs):
+// error behaviour (reference src/bytewise.rs, src/bytewise/builder.rs, src/bytewise/iter.rs and their
+// src/charwise* twins):
 //
 //     auto pma = daachorse::DoubleArrayAhoCorasick::new_({"bcd", "ab", "a"}).value();
 //     for (auto it = pma.find_overlapping_iter("abcd"); auto m = it.next();)
@@ -99,29 +100,52 @@ public:
     }
 
 private:
-    friend class DoubleArrayAhoCorasick;
+    template <class F>
+    friend class BasicAhoCorasick;
     MatchIterator(daac_iter *it, std::unique_ptr<std::string> hay) : hay_(std::move(hay)), it_(it) {}
     std::unique_ptr<std::string> hay_;  // the haystack lives (at a stable address) as long as the iterator (the crate's `P`)
     std::unique_ptr<daac_iter, detail::IterDeleter> it_;
 };
 
-class DoubleArrayAhoCorasickBuilder;
+namespace detail {
+// Which pair of C entry points builds / parses the automaton behind a handle (the scans are shared).
+struct Bytewise {  // src/bytewise.rs, src/bytewise/builder.rs
+    static daac_status parse(const uint8_t *b, size_t n, daac_pma **h, size_t *used) { return daac_bytewise_from_serialized(b, n, h, used); }
+    static daac_status build(const uint8_t *b, const uint64_t *o, const uint32_t *v, size_t n, uint8_t k, uint32_t f, daac_pma **h) {
+        return daac_bytewise_build(b, o, v, n, k, f, h);
+    }
+};
+struct Charwise {  // src/charwise.rs, src/charwise/builder.rs
+    static daac_status parse(const uint8_t *b, size_t n, daac_pma **h, size_t *used) { return daac_charwise_from_serialized(b, n, h, used); }
+    static daac_status build(const uint8_t *b, const uint64_t *o, const uint32_t *v, size_t n, uint8_t k, uint32_t f, daac_pma **h) {
+        return daac_charwise_build(b, o, v, n, k, f, h);
+    }
+};
+}  // namespace detail
 
-class DoubleArrayAhoCorasick {  // src/bytewise.rs:54-68
+template <class Flavor>
+class BasicBuilder;
+
+// DoubleArrayAhoCorasick<u32> (src/bytewise.rs:54-68) and CharwiseDoubleArrayAhoCorasick<u32>
+// (src/charwise.rs:59-65): the same surface; charwise haystacks and patterns are UTF-8, positions are bytes.
+template <class Flavor>
+class BasicAhoCorasick {
 public:
-    // bytewise.rs:103-110 / 154-161 (`new` is a keyword in C++)
-    static Result<DoubleArrayAhoCorasick> new_(const std::vector<std::string> &patterns);
-    static Result<DoubleArrayAhoCorasick> with_values(const std::vector<std::pair<std::string, uint32_t>> &patvals);
+    // bytewise.rs:103-110 / 154-161, charwise.rs:87-94 / 139-146 (`new` is a keyword in C++)
+    static Result<BasicAhoCorasick> new_(const std::vector<std::string> &patterns) { return BasicBuilder<Flavor>().build(patterns); }
+    static Result<BasicAhoCorasick> with_values(const std::vector<std::pair<std::string, uint32_t>> &patvals) {
+        return BasicBuilder<Flavor>().build_with_values(patvals);
+    }
 
-    // bytewise.rs:868-964: (automaton, bytes consumed)
-    static Result<std::pair<DoubleArrayAhoCorasick, size_t>> deserialize(std::string_view source) {
+    // bytewise.rs:868-964, charwise.rs:896-952: (automaton, bytes consumed)
+    static Result<std::pair<BasicAhoCorasick, size_t>> deserialize(std::string_view source) {
         daac_pma *h = nullptr;
         size_t consumed = 0;
-        const daac_status st = daac_bytewise_from_serialized(reinterpret_cast<const uint8_t *>(source.data()), source.size(), &h, &consumed);
+        const daac_status st = Flavor::parse(reinterpret_cast<const uint8_t *>(source.data()), source.size(), &h, &consumed);
         if (st != DAAC_OK) return detail::make_error(st);
-        return std::make_pair(DoubleArrayAhoCorasick(h), consumed);
+        return std::make_pair(BasicAhoCorasick(h), consumed);
     }
-    std::string serialize() const {  // bytewise.rs:801-820
+    std::string serialize() const {  // bytewise.rs:801-820, charwise.rs:831-848
         uint8_t *buf = nullptr;
         size_t len = 0;
         if (daac_pma_serialize(h_.get(), &buf, &len) != DAAC_OK) throw PanicError(daac_last_error());
@@ -147,8 +171,8 @@ public:
     daac_pma *raw() const { return h_.get(); }
 
 private:
-    friend class DoubleArrayAhoCorasickBuilder;
-    explicit DoubleArrayAhoCorasick(daac_pma *h) : h_(h) {}
+    friend class BasicBuilder<Flavor>;
+    explicit BasicAhoCorasick(daac_pma *h) : h_(h) {}
     daac_info info() const {
         daac_info i;
         daac_pma_info(h_.get(), &i);
@@ -166,16 +190,17 @@ private:
     std::unique_ptr<daac_pma, detail::PmaDeleter> h_;
 };
 
-class DoubleArrayAhoCorasickBuilder {  // src/bytewise/builder.rs:21-244
+template <class Flavor>
+class BasicBuilder {  // src/bytewise/builder.rs:21-244, src/charwise/builder.rs:20-239
 public:
-    DoubleArrayAhoCorasickBuilder &match_kind(MatchKind k) { kind_ = k; return *this; }
-    DoubleArrayAhoCorasickBuilder &num_free_blocks(uint32_t n) {
-        if (n < 1) throw PanicError("assertion failed: n >= 1");  // builder.rs:113
+    BasicBuilder &match_kind(MatchKind k) { kind_ = k; return *this; }
+    BasicBuilder &num_free_blocks(uint32_t n) {
+        if (n < 1) throw PanicError("assertion failed: n >= 1");  // builder.rs:113 / :131
         nfb_ = n;
         return *this;
     }
-    Result<DoubleArrayAhoCorasick> build(const std::vector<std::string> &patterns) const { return run(patterns, nullptr); }
-    Result<DoubleArrayAhoCorasick> build_with_values(const std::vector<std::pair<std::string, uint32_t>> &patvals) const {
+    Result<BasicAhoCorasick<Flavor>> build(const std::vector<std::string> &patterns) const { return run(patterns, nullptr); }
+    Result<BasicAhoCorasick<Flavor>> build_with_values(const std::vector<std::pair<std::string, uint32_t>> &patvals) const {
         std::vector<std::string> pats;
         std::vector<uint32_t> vals;
         for (const auto &pv : patvals) { pats.push_back(pv.first); vals.push_back(pv.second); }
@@ -183,25 +208,23 @@ public:
     }
 
 private:
-    Result<DoubleArrayAhoCorasick> run(const std::vector<std::string> &pats, const std::vector<uint32_t> *vals) const {
+    Result<BasicAhoCorasick<Flavor>> run(const std::vector<std::string> &pats, const std::vector<uint32_t> *vals) const {
         std::string blob;
         std::vector<uint64_t> offs{0};
         for (const auto &p : pats) { blob += p; offs.push_back(blob.size()); }
         daac_pma *h = nullptr;
-        const daac_status st = daac_bytewise_build(reinterpret_cast<const uint8_t *>(blob.data()), offs.data(), vals ? vals->data() : nullptr,
-                                                   pats.size(), static_cast<uint8_t>(kind_), nfb_, &h);
+        const daac_status st = Flavor::build(reinterpret_cast<const uint8_t *>(blob.data()), offs.data(), vals ? vals->data() : nullptr,
+                                             pats.size(), static_cast<uint8_t>(kind_), nfb_, &h);
         if (st != DAAC_OK) return detail::make_error(st);
-        return DoubleArrayAhoCorasick(h);
+        return BasicAhoCorasick<Flavor>(h);
     }
     MatchKind kind_ = MatchKind::Standard;
     uint32_t nfb_ = 16;
 };
 
-inline Result<DoubleArrayAhoCorasick> DoubleArrayAhoCorasick::new_(const std::vector<std::string> &patterns) {
-    return DoubleArrayAhoCorasickBuilder().build(patterns);
-}
-inline Result<DoubleArrayAhoCorasick> DoubleArrayAhoCorasick::with_values(const std::vector<std::pair<std::string, uint32_t>> &patvals) {
-    return DoubleArrayAhoCorasickBuilder().build_with_values(patvals);
-}
+using DoubleArrayAhoCorasick = BasicAhoCorasick<detail::Bytewise>;
+using DoubleArrayAhoCorasickBuilder = BasicBuilder<detail::Bytewise>;
+using CharwiseDoubleArrayAhoCorasick = BasicAhoCorasick<detail::Charwise>;
+using CharwiseDoubleArrayAhoCorasickBuilder = BasicBuilder<detail::Charwise>;
 
 }  // namespace daachorse

@@ -29,6 +29,14 @@ int main(int argc, char **argv) {
     CHECK(again.second == blob.size() && again.first.serialize() == blob);
     CHECK(DoubleArrayAhoCorasick::deserialize(std::string(21, '\0')).is_err());  // src/bytewise.rs:1496-1507
     CHECK(DoubleArrayAhoCorasickBuilder().num_free_blocks(0xffffffffu).build({"pattern"}).is_err());  // tests/invalid_option_test.rs
+    // the charwise twin (README.md:171-193): same surface, UTF-8 patterns, blobs of its own format
+    auto cw = CharwiseDoubleArrayAhoCorasick::new_({"全世界", "世界", "に"}).unwrap();
+    CHECK(cw.match_kind() == MatchKind::Standard);
+    const std::string cblob = cw.serialize();
+    auto cagain = CharwiseDoubleArrayAhoCorasick::deserialize(cblob).unwrap();
+    CHECK(cagain.second == cblob.size() && cagain.first.serialize() == cblob);
+    CHECK(DoubleArrayAhoCorasick::deserialize(cblob).is_err());
+    CHECK(CharwiseDoubleArrayAhoCorasickBuilder().build({"\xff\xfe"}).is_err());  // not UTF-8
     if (!gpu) { std::printf("OK host\n"); return 0; }
 
     CHECK(same(pma.find_overlapping_iter("abcd").collect(), {Match(0, 1, 2), Match(0, 2, 1), Match(1, 4, 0)}));  // README.md:57-71
@@ -51,6 +59,14 @@ int main(int argc, char **argv) {
     panicked = false;
     try { pma.leftmost_find_iter(""); } catch (const PanicError &e) { panicked = std::string(e.what()) == "Error: match_kind must be leftmost."; }
     CHECK(panicked);  // tests/matchkind_mismatch_test.rs:65-71
+    auto cit = cw.find_iter("全世界中に");  // README.md:184-192, byte offsets
+    m = cit.next();
+    CHECK(m && m->start() == 0 && m->end() == 9 && m->value() == 0);
+    m = cit.next();
+    CHECK(m && m->start() == 12 && m->end() == 15 && m->value() == 2);
+    CHECK(!cit.next());
+    auto cll = CharwiseDoubleArrayAhoCorasickBuilder().match_kind(MatchKind::LeftmostLongest).build({"世界", "全世界", "世"}).unwrap();
+    CHECK(same(cll.leftmost_find_iter("全世界中に世").collect(), {Match(0, 9, 1), Match(15, 18, 2)}));
     std::printf("OK gpu\n");
     return 0;
 }
