@@ -52,11 +52,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world != 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # one process per GPU; DAAC_DIST_BACKEND=gloo lets the control flow be exercised on a single-GPU box
+    backend = os.environ.get("DAAC_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
+
+    def reduce_counts(t):
+        if backend == "nccl":
+            dist.all_reduce(t)
+        else:  # host-side reduction for backends without device tensors
+            c = t.cpu()
+            dist.all_reduce(c)
+            t.copy_(c)
 
     for kv in args.opt:
         k, v = kv.split("=")
@@ -95,7 +109,7 @@ def main():
     def step():
         pma.scan_count(ScanMode.FindOverlapping, hay, engine=engine, stream=stream, result_dev=result.data_ptr())
         if dist is not None:
-            dist.all_reduce(result)  # RCCL over xGMI: the trivial match-count reduction
+            reduce_counts(result)  # RCCL over xGMI: the trivial match-count reduction
 
     for _ in range(args.warmup):
         step()
@@ -109,20 +123,22 @@ def main():
         pma.scan_count(ScanMode.FindOverlapping, hay, engine=engine, stream=stream, result_dev=result.data_ptr())
         b.record()
         if dist is not None:
-            dist.all_reduce(result)
+            reduce_counts(result)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]  # memset + scan kernel on the launch stream
     from daachorse_amd import dist as ddist
-    elapsed = ddist.max_over_ranks(elapsed, device="cuda")
+    elapsed = ddist.max_over_ranks(elapsed, device="cuda" if backend == "nccl" else None)
     total_count = int(result[0].item())
     checksum = ((int(result[1].item()) & 0xFFFFFFFF) << 32) | (int(result[2].item()) & 0xFFFFFFFF)
 
+    if dist is not None:  # every rank leaves the group together; rank 0 reports on its own
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return
 
     total_bytes = nbytes * world
@@ -158,7 +174,7 @@ def main():
             pass
 
     # ---- materialising scan of a prefix (reported, not the metric) -----------------------------------
-    if args.materialize_mib > 0:
+    if args.materialize_mib > 0 and world == 1:
         n = min(nbytes, args.materialize_mib << 20)
         pma.scan(ScanMode.FindOverlapping, hay[:n], engine=mat_engine)
         torch.cuda.synchronize()
@@ -169,7 +185,7 @@ def main():
                               "note": "count pass + scan + write pass + D2H of 24-byte tuples"}
 
     # ---- CPU baseline: the C restatement of the reference CPU path, on a bounded prefix ----------------
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:
         from oracle import oracle as orc
         o = orc.OraclePma.deserialize(pma.serialize())
         cores = os.cpu_count() or 1
@@ -193,8 +209,6 @@ def main():
                                "parity_with_gpu_on_sample": bool(gpu_cc == cN)}
         del c1
     print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
