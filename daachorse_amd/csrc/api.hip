@@ -347,7 +347,7 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
     uint64_t S = static_cast<uint64_t>(g_opt.seg_bytes.load());
     if (S == 0) {
         S = (len + lanes - 1) / lanes;
-        const uint64_t min_seg = std::max<uint64_t>(256, 16ull * halo);
+        const uint64_t min_seg = std::max<uint64_t>(pl.restart ? 1024 : 256, 16ull * halo);  // restart scans keep 56 B of chain state per segment
         S = std::max(S, min_seg);
     }
     S = (std::max<uint64_t>(S, 16) + 15) & ~15ull;
@@ -369,9 +369,10 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
 }
 
 hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, hipStream_t s, unsigned long long *next_begin = nullptr) {
-    if (pl.restart && pl.chain.x_prev != nullptr) {
-        return pl.charwise ? launch_char_chain(t->chr, pl.a, pl.chain, 2, kmode, pl.leftmost, next_begin, pl.blocks, s)
-                           : launch_chain(t->da, pl.a, pl.chain, 2, kmode, pl.leftmost, next_begin, pl.blocks, s);
+    if (pl.restart && pl.chain.x_prev != nullptr) {  // totals and per-segment counts are sums of tallies; only writing re-scans
+        const int pass = kmode == 2 ? 2 : 3;
+        return pl.charwise ? launch_char_chain(t->chr, pl.a, pl.chain, pass, kmode, pl.leftmost, next_begin, pl.blocks, s)
+                           : launch_chain(t->da, pl.a, pl.chain, pass, kmode, pl.leftmost, next_begin, pl.blocks, s);
     }
     if (pl.charwise) {
         return pl.restart ? launch_char_restart_scan(t->chr, pl.a, kmode, pl.leftmost, next_begin, pl.blocks, pl.threads, s)
@@ -395,13 +396,16 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
     pl.chain = ChainArgs{};
     if (!pl.restart || pma->root_has_output() || g_opt.restart_chain.load() == 0 || pl.a.nseg == 0) return DAAC_OK;
     const uint64_t n = pl.a.nseg;
-    HIP_TRY(hipMalloc(&cb.buf, (3 * n + 2) * sizeof(unsigned long long)));
-    unsigned long long *x_spec = static_cast<unsigned long long *>(cb.buf), *xa = x_spec + n, *xb = xa + n;
+    HIP_TRY(hipMalloc(&cb.buf, (3 * n + 2) * sizeof(unsigned long long) + 2 * n * sizeof(uint4)));
+    uint4 *tallies = static_cast<uint4 *>(cb.buf);  // 16-byte records first (alignment), then the exits
+    unsigned long long *x_spec = reinterpret_cast<unsigned long long *>(tallies + 2 * n), *xa = x_spec + n, *xb = xa + n;
     unsigned int *flags = reinterpret_cast<unsigned int *>(xb + n);
     HIP_TRY(hipMemsetAsync(flags, 0, 2 * sizeof(unsigned int), stream));
     ChainArgs c{};
     c.cap = std::max<uint64_t>(4096, 8 * pl.a.seg_bytes);
     c.flags = flags;
+    c.tally_spec = tallies;
+    c.tally_delta = tallies + n;
     c.x_out = x_spec;
     auto run = [&](int pass) {
         return pl.charwise ? launch_char_chain(t->chr, pl.a, c, pass, 0, pl.leftmost, nullptr, pl.blocks, stream)

@@ -12,8 +12,10 @@
 //                  same position they are one chain from there on, so the speculative exit is the
 //                  true exit.  Different starting points fall in step after a few matches, so one
 //                  or two rounds settle every segment (a round re-reads only a few links per lane);
-//   3. emit        with the true entries known the segments are independent: count, or count per
-//                  segment -> exclusive scan -> write, as for the overlapping scan.
+//   3. emit        with the true entries known the segments are independent.  Counts need no third pass:
+//                  the speculative pass tallies what it reports and reconciliation records what the true
+//                  chain reports differently before the two meet; materialising runs count per segment ->
+//                  exclusive scan -> one write pass, as for the overlapping scan.
 //
 // A link also ends, without a match, once it is past its segment and the automaton is back at ROOT
 // with nothing pending: a fresh start there is indistinguishable from going on (this keeps links
@@ -92,22 +94,45 @@ struct ChainNoEmit {
     __device__ __forceinline__ void operator()(uint32_t, uint64_t) const {}
 };
 
+// {count, S1, S2} of the matches a chain reports (the checksum definition of the oracle)
+struct ChainTally {
+    const uint32_t *outputs;
+    unsigned long long cnt = 0;
+    uint32_t s1 = 0, s2 = 0;
+    __device__ __forceinline__ void operator()(uint32_t opos, uint64_t end) {
+        const uint32_t *r = outputs + 3u * (opos - 1u);
+        uint64_t z = (static_cast<uint64_t>(r[0]) << 32) | r[1];
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        const uint32_t h = static_cast<uint32_t>(z ^ (z >> 31));
+        cnt += 1; s1 += h; s2 += h * static_cast<uint32_t>(end);
+    }
+    __device__ __forceinline__ uint4 packed() const { return uint4{static_cast<uint32_t>(cnt), static_cast<uint32_t>(cnt >> 32), s1, s2}; }
+};
+__device__ __forceinline__ uint4 tally_sub(const uint4 &a, const uint4 &b) {  // a - b, field by field
+    const unsigned long long ca = (static_cast<unsigned long long>(a.y) << 32) | a.x, cb = (static_cast<unsigned long long>(b.y) << 32) | b.x;
+    const unsigned long long c = ca - cb;
+    return uint4{static_cast<uint32_t>(c), static_cast<uint32_t>(c >> 32), a.z - b.z, a.w - b.w};
+}
+
 // pass 1: exits of the speculative chains
 template <class T, bool LEFTMOST>
-__device__ __forceinline__ void chain_spec_body(const T &t, const ScanArgs &a, const ChainArgs &c) {
+__device__ __forceinline__ void chain_spec_body(const T &t, const ScanArgs &a, const ChainArgs &c, const uint32_t *outputs) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     ChainWalker<T, LEFTMOST> w{t, a.total_len, c.cap};
     for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
         const uint64_t lo = a.begin + seg * a.seg_bytes;
         const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
-        c.x_out[seg] = w.run(seg == 0 ? lo : t.boundary_at_or_after(lo), hi, ChainNoEmit{});
+        ChainTally tally{outputs};
+        c.x_out[seg] = w.run(seg == 0 ? lo : t.boundary_at_or_after(lo), hi, tally);
+        c.tally_spec[seg] = tally.packed();
     }
     if (w.overflow) c.flags[1] = 1u;
 }
 
 // pass 2 (repeated until nothing changes): exits given the previous round's exits as entries
 template <class T, bool LEFTMOST>
-__device__ __forceinline__ void chain_fix_body(const T &t, const ScanArgs &a, const ChainArgs &c) {
+__device__ __forceinline__ void chain_fix_body(const T &t, const ScanArgs &a, const ChainArgs &c, const uint32_t *outputs) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     ChainWalker<T, LEFTMOST> w{t, a.total_len, c.cap};
     bool changed = false;
@@ -116,27 +141,64 @@ __device__ __forceinline__ void chain_fix_body(const T &t, const ScanArgs &a, co
         const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
         const uint64_t spec_exit = c.x_spec[seg];
         uint64_t exit = spec_exit;
+        uint4 delta{0u, 0u, 0u, 0u};        // true chain minus speculative chain, in reported matches
         if (seg != 0) {
             const uint64_t entry = c.x_prev[seg - 1];
             uint64_t s = t.boundary_at_or_after(lo);
             if (entry >= hi) {
-                exit = entry;               // the chain jumps over this segment
+                exit = entry;               // the chain jumps over this segment: nothing of it is reported
+                delta = tally_sub(delta, c.tally_spec[seg]);
             } else if (entry != s) {
                 uint64_t x = entry;         // the true chain; s follows the speculative one
+                ChainTally of_true{outputs}, of_spec{outputs};
                 bool merged = false;
                 while (x < hi && !w.overflow) {
-                    while (s < x && s < hi && !w.overflow) s = w.link(s, hi, ChainNoEmit{});
+                    while (s < x && s < hi && !w.overflow) s = w.link(s, hi, of_spec);
                     if (s == x) { merged = true; break; }
-                    x = w.link(x, hi, ChainNoEmit{});
+                    x = w.link(x, hi, of_true);
                 }
-                if (!merged) exit = x;
+                if (merged) {
+                    delta = tally_sub(of_true.packed(), of_spec.packed());  // they differ only before they met
+                } else {
+                    exit = x;
+                    delta = tally_sub(of_true.packed(), c.tally_spec[seg]);
+                }
             }
         }
         if (exit != c.x_prev[seg]) changed = true;
         c.x_out[seg] = exit;
+        c.tally_delta[seg] = delta;
     }
     if (changed) c.flags[0] = 1u;
     if (w.overflow) c.flags[1] = 1u;
+}
+
+// the tallies of the speculative pass, corrected by the last reconciliation round.  KMODE 0: totals, 1: per-segment counts
+template <int KMODE>
+__device__ __forceinline__ void chain_sum_body(const ScanArgs &a, const ChainArgs &c, unsigned long long *next_begin, unsigned long long *scratch) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long tot_cnt = 0;
+    uint32_t tot_s1 = 0, tot_s2 = 0;
+    for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
+        const uint4 p = c.tally_spec[seg], d = c.tally_delta[seg];
+        const unsigned long long cnt = ((static_cast<unsigned long long>(p.y) << 32) | p.x) + ((static_cast<unsigned long long>(d.y) << 32) | d.x);
+        if (KMODE == 1) a.seg_counts[seg] = cnt;
+        else { tot_cnt += cnt; tot_s1 += p.z + d.z; tot_s2 += p.w + d.w; }
+        if (next_begin && seg + 1 == a.nseg) *next_begin = c.x_prev[seg] > a.len ? c.x_prev[seg] : a.len;  // where a following window starts
+    }
+    if (KMODE == 0) {
+        unsigned long long cc = tot_cnt, x1 = tot_s1, x2 = tot_s2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { cc += __shfl_down(cc, off, 64); x1 += __shfl_down(x1, off, 64); x2 += __shfl_down(x2, off, 64); }
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) { scratch[wave * 3] = cc; scratch[wave * 3 + 1] = x1; scratch[wave * 3 + 2] = x2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long r0 = 0, r1 = 0, r2 = 0;
+            for (int v = 0; v < static_cast<int>((blockDim.x + 63) >> 6); ++v) { r0 += scratch[v * 3]; r1 += scratch[v * 3 + 1]; r2 += scratch[v * 3 + 2]; }
+            if (r0 | r1 | r2) { atomicAdd(a.result, r0); atomicAdd(a.result + 1, r1); atomicAdd(a.result + 2, r2); }
+        }
+    }
 }
 
 // pass 3: the segments with their true entries.  KMODE 0: totals, 1: per-segment counts, 2: write

@@ -256,8 +256,9 @@ template <bool LEFTMOST, int PASS, int KMODE>
 __global__ __launch_bounds__(256) void char_chain_kernel(const CharDev dev, const ScanArgs a, const ChainArgs c, unsigned long long *next_begin) {
     __shared__ unsigned long long scratch[3 * 4];
     const CwTables T{dev, dev.states[0], a.hay, a.total_len};
-    if (PASS == 0) chain_spec_body<CwTables, LEFTMOST>(T, a, c);
-    else if (PASS == 1) chain_fix_body<CwTables, LEFTMOST>(T, a, c);
+    if (PASS == 0) chain_spec_body<CwTables, LEFTMOST>(T, a, c, dev.outputs);
+    else if (PASS == 1) chain_fix_body<CwTables, LEFTMOST>(T, a, c, dev.outputs);
+    else if (PASS == 3) chain_sum_body<KMODE>(a, c, next_begin, scratch);
     else chain_emit_body<CwTables, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
 }
 
@@ -267,6 +268,7 @@ hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainA
 #define DAAC_CC(L, P, M) hipLaunchKernelGGL((char_chain_kernel<L, P, M>), g, b, 0, stream, dev, a, c, next_begin)
     if (pass == 0) { if (leftmost) DAAC_CC(true, 0, 0); else DAAC_CC(false, 0, 0); }
     else if (pass == 1) { if (leftmost) DAAC_CC(true, 1, 0); else DAAC_CC(false, 1, 0); }
+    else if (pass == 3) { if (kmode == 0) DAAC_CC(false, 3, 0); else DAAC_CC(false, 3, 1); }
     else if (leftmost) { if (kmode == 0) DAAC_CC(true, 2, 0); else if (kmode == 1) DAAC_CC(true, 2, 1); else DAAC_CC(true, 2, 2); }
     else { if (kmode == 0) DAAC_CC(false, 2, 0); else if (kmode == 1) DAAC_CC(false, 2, 1); else DAAC_CC(false, 2, 2); }
 #undef DAAC_CC

@@ -66,6 +66,8 @@ struct ChainArgs {
     const unsigned long long *x_prev;  // per segment: exit as of the previous round
     unsigned long long *x_out;         // per segment: exit computed by this pass
     unsigned int *flags;               // [0] = some exit changed this round, [1] = a link overflowed
+    uint4 *tally_spec;                 // per segment {count lo, count hi, S1, S2} of the speculative chain
+    uint4 *tally_delta;                // per segment: what the true chain reports more (mod 2^64 / 2^32) than the speculative one
     uint64_t cap;                      // bytes a link may run past its segment without match or ROOT
 };
 
@@ -114,7 +116,8 @@ hipError_t launch_char_scan(const CharDev &dev, const ScanArgs &a, int mode, boo
                             hipStream_t stream);
 hipError_t launch_char_restart_scan(const CharDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,
                                     uint32_t blocks, uint32_t threads, hipStream_t stream);
-// pass 0 = speculate, 1 = reconcile (one round), 2 = emit in `kmode` (0 totals, 1 per-segment counts, 2 write)
+// pass 0 = speculate, 1 = reconcile (one round), 2 = emit in `kmode` (2 = write), 3 = sum up the tallies in `kmode`
+// (0 totals, 1 per-segment counts)
 hipError_t launch_chain(const DArrayDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
                         unsigned long long *next_begin, uint32_t blocks, hipStream_t stream);
 hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,

@@ -252,8 +252,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const DArrayDev dev, const S
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root[i];
     __syncthreads();
     const RestartTables T{dev, l_root, a.hay};
-    if (PASS == 0) chain_spec_body<RestartTables, LEFTMOST>(T, a, c);
-    else if (PASS == 1) chain_fix_body<RestartTables, LEFTMOST>(T, a, c);
+    if (PASS == 0) chain_spec_body<RestartTables, LEFTMOST>(T, a, c, dev.outputs);
+    else if (PASS == 1) chain_fix_body<RestartTables, LEFTMOST>(T, a, c, dev.outputs);
+    else if (PASS == 3) chain_sum_body<KMODE>(a, c, next_begin, scratch);
     else chain_emit_body<RestartTables, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
 }
 
@@ -263,6 +264,7 @@ hipError_t launch_chain(const DArrayDev &dev, const ScanArgs &a, const ChainArgs
 #define DAAC_CH(L, P, M) hipLaunchKernelGGL((chain_kernel<L, P, M>), g, b, 0, stream, dev, a, c, next_begin)
     if (pass == 0) { if (leftmost) DAAC_CH(true, 0, 0); else DAAC_CH(false, 0, 0); }
     else if (pass == 1) { if (leftmost) DAAC_CH(true, 1, 0); else DAAC_CH(false, 1, 0); }
+    else if (pass == 3) { if (kmode == 0) DAAC_CH(false, 3, 0); else DAAC_CH(false, 3, 1); }
     else if (leftmost) { if (kmode == 0) DAAC_CH(true, 2, 0); else if (kmode == 1) DAAC_CH(true, 2, 1); else DAAC_CH(true, 2, 2); }
     else { if (kmode == 0) DAAC_CH(false, 2, 0); else if (kmode == 1) DAAC_CH(false, 2, 1); else DAAC_CH(false, 2, 2); }
 #undef DAAC_CH
