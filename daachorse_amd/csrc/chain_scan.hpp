@@ -32,13 +32,30 @@
 
 namespace daac {
 
-// T supplies the automaton: State, root(), symbol_at(pos, clen), step_plain / step_leftmost, opos(), is_root().
+// A lane's window on the haystack: the aligned 16-byte granule around the last byte it asked for.  A chain
+// moves through the text byte by byte (and steps back a little after a leftmost match), so 15 of 16 requests
+// are served from registers instead of the memory pipeline, where 64 lanes asking for 64 different lines cost
+// 64 cycles each time.  A granule never crosses a page, so reading all of it is safe at either end of a buffer.
+struct HayWindow {
+    uintptr_t base = ~static_cast<uintptr_t>(0);
+    uint4 w;
+    __device__ __forceinline__ uint32_t byte_at(const uint8_t *p) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(p), b = addr & ~static_cast<uintptr_t>(15);
+        if (b != base) { base = b; w = *reinterpret_cast<const uint4 *>(b); }
+        const uint32_t k = static_cast<uint32_t>(addr) & 15u;
+        const uint32_t word = (k & 8u) ? ((k & 4u) ? w.w : w.z) : ((k & 4u) ? w.y : w.x);
+        return (word >> ((k & 3u) * 8u)) & 0xffu;
+    }
+};
+
+// T supplies the automaton: State, root(), symbol_at(window, pos, clen), step_plain / step_leftmost, opos(), is_root().
 template <class T, bool LEFTMOST>
 struct ChainWalker {
     const T &t;
     uint64_t len;
     uint64_t cap;
     bool overflow = false;
+    HayWindow win;
 
     // One link of the chain from position r (reference bytewise/iter.rs:87-112 / 272-340, charwise/iter.rs:
     // 133-156 / 325-399, one call of next()); returns the next chain position, > r.
@@ -50,7 +67,7 @@ struct ChainWalker {
         if (!LEFTMOST) {
             for (;;) {
                 if (pos >= len) return len;
-                const uint32_t sym = t.symbol_at(pos, clen);
+                const uint32_t sym = t.symbol_at(win, pos, clen);
                 pos += clen;
                 t.step_plain(st, sym);
                 if (t.opos(st) != 0) { emit(t.opos(st), pos); return pos; }
@@ -67,7 +84,7 @@ struct ChainWalker {
                     if (best != 0) { emit(best, best_end); return best_end; }
                     return len;
                 }
-                const uint32_t sym = t.symbol_at(pos, clen);
+                const uint32_t sym = t.symbol_at(win, pos, clen);
                 t.step_leftmost(st, sym);
                 if (t.is_root(st)) {
                     if (best != 0) { emit(best, best_end); return best_end; }

@@ -33,7 +33,16 @@ struct CwTables {
 
     __device__ __forceinline__ CwState root() const { return CwState{0, root_rec.x, root_rec.z, root_rec.w}; }
     // the automaton as chain_scan.hpp wants it
-    __device__ __forceinline__ uint32_t symbol_at(uint64_t pos, uint32_t &clen) const { return scalar_at(pos, clen); }
+    // one scalar through the lane's haystack window (same decoding as scalar_at below)
+    __device__ __forceinline__ uint32_t symbol_at(HayWindow &win, uint64_t pos, uint32_t &clen) const {
+        const uint32_t b0 = win.byte_at(hay + pos);
+        if (b0 < 0x80u) { clen = 1; return b0; }
+        const uint32_t n = b0 < 0xe0u ? 2u : b0 < 0xf0u ? 3u : 4u;
+        uint32_t cp = b0 < 0xe0u ? (b0 & 0x1fu) : b0 < 0xf0u ? (b0 & 0x0fu) : (b0 & 0x07u);
+        for (uint32_t k = 1; k < n; ++k) cp = (cp << 6) | (pos + k < len ? (win.byte_at(hay + pos + k) & 0x3fu) : 0u);
+        clen = n;
+        return cp;
+    }
     __device__ __forceinline__ uint32_t opos(const CwState &st) const { return st.opos; }
     __device__ __forceinline__ bool is_root(const CwState &st) const { return st.idx == 0; }
     __device__ __forceinline__ uint64_t boundary_at_or_after(uint64_t x) const {

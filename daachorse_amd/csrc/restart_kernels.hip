@@ -45,7 +45,7 @@ struct RestartTables {
 
     // the automaton as chain_scan.hpp wants it
     __device__ __forceinline__ RsState root() const { return RsState{0, 0, 0}; }
-    __device__ __forceinline__ uint32_t symbol_at(uint64_t pos, uint32_t &clen) const { clen = 1; return hay[pos]; }
+    __device__ __forceinline__ uint32_t symbol_at(HayWindow &win, uint64_t pos, uint32_t &clen) const { clen = 1; return win.byte_at(hay + pos); }
     __device__ __forceinline__ uint32_t opos(const RsState &st) const { return st.opos_ch >> 8; }
     __device__ __forceinline__ bool is_root(const RsState &st) const { return st.idx == 0; }
     __device__ __forceinline__ uint64_t boundary_at_or_after(uint64_t x) const { return x; }
