@@ -38,6 +38,8 @@ struct Options {
     std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
+    std::atomic<int64_t> char_map_lds{0};       // charwise chain scans: stage the code mapper in LDS when it fits (measured
+                                                // slower on cfg5: 88 vs 105 GB/s, the lanes it costs matter more than the gather)
 };
 static Options g_opt;
 
@@ -155,6 +157,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         c.n = static_cast<uint32_t>(ct.states.size());
         c.root_flag = ct.root_flag;
         c.leftmost = !pma->chost.is_standard();
+        c.map_in_lds = g_opt.char_map_lds.load() != 0 && c.table_len * 2u <= 48u * 1024u && pma->chost.alphabet_size < 0xffffu;
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipSetDevice(prev));
         *out = t.get();
@@ -862,6 +865,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;
     else if (n == "chain_rounds") g_opt.chain_rounds = value;
+    else if (n == "char_map_lds") g_opt.char_map_lds = value;
     else { set_error("unknown option: " + n); return DAAC_ERR_INVALID_ARGUMENT; }
     return DAAC_OK;
 }

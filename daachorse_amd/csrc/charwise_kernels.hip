@@ -24,12 +24,15 @@ __device__ __forceinline__ uint64_t cw_mix64(uint64_t z) {
 
 struct CwState { uint32_t idx, base, fail, opos; };
 
-struct CwTables {
+// MAPLDS: the code mapper is staged in LDS as u16 (0xffff = unmapped) — one L2 gather less per character
+template <bool MAPLDS>
+struct CwTablesT {
     using State = CwState;
     const CharDev &d;
     uint4 root_rec;
     const uint8_t *__restrict__ hay;
     uint64_t len;  // real end of the haystack: nothing at or beyond it is read
+    const uint16_t *l_map = nullptr;
 
     __device__ __forceinline__ CwState root() const { return CwState{0, root_rec.x, root_rec.z, root_rec.w}; }
     // the automaton as chain_scan.hpp wants it
@@ -61,7 +64,13 @@ struct CwTables {
         clen = n;
         return cp;
     }
-    __device__ __forceinline__ uint32_t code_of(uint32_t cp) const { return cp < d.table_len ? d.table[cp] : 0xffffffffu; }
+    __device__ __forceinline__ uint32_t code_of(uint32_t cp) const {
+        if (MAPLDS) {
+            const uint32_t c = cp < d.table_len ? l_map[cp] : 0xffffu;
+            return c == 0xffffu ? 0xffffffffu : c;
+        }
+        return cp < d.table_len ? d.table[cp] : 0xffffffffu;
+    }
     __device__ __forceinline__ void load(CwState &st, uint32_t slot, bool plain) const {
         const uint4 r = d.states[slot];
         st = CwState{slot, r.x, (plain && d.fail_plain) ? d.fail_plain[slot] : r.z, r.w};
@@ -113,6 +122,7 @@ struct CwTables {
         return st.idx == 0 ? pos : len;
     }
 };
+using CwTables = CwTablesT<false>;
 
 // KMODE 0: totals {count, S1, S2}; 1: per-segment counts; 2: write matches at out + seg_counts[seg]
 template <bool LEFTMOST, int KMODE>
@@ -261,20 +271,32 @@ __global__ __launch_bounds__(256) void char_restart_kernel(const CharDev dev, co
 }
 
 // ---- speculate / reconcile / emit (chain_scan.hpp) over the charwise double array -------------------------
-template <bool LEFTMOST, int PASS, int KMODE>
-__global__ __launch_bounds__(256) void char_chain_kernel(const CharDev dev, const ScanArgs a, const ChainArgs c, unsigned long long *next_begin) {
-    __shared__ unsigned long long scratch[3 * 4];
-    const CwTables T{dev, dev.states[0], a.hay, a.total_len};
-    if (PASS == 0) chain_spec_body<CwTables, LEFTMOST>(T, a, c, dev.outputs);
-    else if (PASS == 1) chain_fix_body<CwTables, LEFTMOST>(T, a, c, dev.outputs);
+template <bool LEFTMOST, int PASS, int KMODE, bool MAPLDS>
+__global__ __launch_bounds__(MAPLDS ? 512 : 256) void char_chain_kernel(const CharDev dev, const ScanArgs a, const ChainArgs c,
+                                                                         unsigned long long *next_begin) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t l_map[];
+    __shared__ unsigned long long scratch[3 * 8];
+    if (MAPLDS && PASS != 3) {
+        for (uint32_t i = threadIdx.x; i < dev.table_len; i += blockDim.x) {
+            const uint32_t code = dev.table[i];
+            l_map[i] = code == 0xffffffffu ? 0xffffu : static_cast<uint16_t>(code);
+        }
+        __syncthreads();
+    }
+    const CwTablesT<MAPLDS> T{dev, dev.states[0], a.hay, a.total_len, l_map};
+    if (PASS == 0) chain_spec_body<CwTablesT<MAPLDS>, LEFTMOST>(T, a, c, dev.outputs);
+    else if (PASS == 1) chain_fix_body<CwTablesT<MAPLDS>, LEFTMOST>(T, a, c, dev.outputs);
     else if (PASS == 3) chain_sum_body<KMODE>(a, c, next_begin, scratch);
-    else chain_emit_body<CwTables, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
+    else chain_emit_body<CwTablesT<MAPLDS>, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
 }
 
-hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
-                             unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
-    const dim3 g(blocks), b(256);
-#define DAAC_CC(L, P, M) hipLaunchKernelGGL((char_chain_kernel<L, P, M>), g, b, 0, stream, dev, a, c, next_begin)
+template <bool MAPLDS>
+static hipError_t launch_char_chain_ml(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
+                                       unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
+    // with the mapper in LDS three 512-thread workgroups share a CU (<= 48 KB each)
+    const dim3 g(MAPLDS ? (blocks * 3u + 7u) / 8u : blocks), b(MAPLDS ? 512 : 256);
+    const uint32_t lds = MAPLDS && pass != 3 ? ((dev.table_len * 2u + 15u) & ~15u) : 0u;
+#define DAAC_CC(L, P, M) hipLaunchKernelGGL((char_chain_kernel<L, P, M, MAPLDS>), g, b, lds, stream, dev, a, c, next_begin)
     if (pass == 0) { if (leftmost) DAAC_CC(true, 0, 0); else DAAC_CC(false, 0, 0); }
     else if (pass == 1) { if (leftmost) DAAC_CC(true, 1, 0); else DAAC_CC(false, 1, 0); }
     else if (pass == 3) { if (kmode == 0) DAAC_CC(false, 3, 0); else DAAC_CC(false, 3, 1); }
@@ -282,6 +304,14 @@ hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainA
     else { if (kmode == 0) DAAC_CC(false, 2, 0); else if (kmode == 1) DAAC_CC(false, 2, 1); else DAAC_CC(false, 2, 2); }
 #undef DAAC_CC
     return hipGetLastError();
+}
+
+hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
+                             unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
+    // u16 codes, at most 48 KB of LDS: otherwise the mapper stays in L2
+    const bool map_lds = dev.map_in_lds != 0;
+    return map_lds ? launch_char_chain_ml<true>(dev, a, c, pass, kmode, leftmost, next_begin, blocks, stream)
+                   : launch_char_chain_ml<false>(dev, a, c, pass, kmode, leftmost, next_begin, blocks, stream);
 }
 
 hipError_t launch_char_restart_scan(const CharDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,

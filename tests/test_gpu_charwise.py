@@ -43,6 +43,7 @@ def _reset_options():
     da.set_option("seg_bytes", 0)
     da.set_option("iter_window", 64 << 20)
     da.set_option("restart_chain", 1)
+    da.set_option("char_map_lds", 0)
 
 
 def _pair(patterns, kind=0, values=None):
@@ -189,8 +190,11 @@ def _dictionary(rng, n):
     return sorted(words), base, freq
 
 
-def test_dictionary_scale_text():
-    """config-5-shaped case: a 20 k-word dictionary, 2 MB of text made of dictionary words and noise"""
+@pytest.mark.parametrize("map_lds", [0, 1])
+def test_dictionary_scale_text(map_lds):
+    """config-5-shaped case: a 20 k-word dictionary, 2 MB of text made of dictionary words and noise
+    (map_lds = 1: the chain scanners with the code mapper staged in LDS; read when the automaton is uploaded)"""
+    da.set_option("char_map_lds", map_lds)
     rng = np.random.default_rng(5)
     words, base, freq = _dictionary(rng, 20000)
     parts = []
