@@ -111,7 +111,7 @@ struct ChainNoEmit {
     __device__ __forceinline__ void operator()(uint32_t, uint64_t) const {}
 };
 
-// {count, S1, S2} of the matches a chain reports (the checksum definition of the oracle)
+// {count, S1, S2} of the matches a chain reports (the checksum of include/daachorse_amd.h, daac_scan_count)
 struct ChainTally {
     const uint32_t *outputs;
     unsigned long long cnt = 0;
