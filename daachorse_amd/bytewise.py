@@ -91,6 +91,24 @@ class _Haystack:
         self.len = a.size
 
 
+class _MatchList:
+    """Owns a daac_matches handle and exposes its (page-locked) tuples to numpy without a copy."""
+
+    def __init__(self, handle, n):
+        self._h = handle
+        ptr = _ffi.lib().daac_matches_data(handle)
+        self.__array_interface__ = {"data": (ptr, True), "shape": (n,), "typestr": "|V%d" % MATCH_DTYPE.itemsize,
+                                    "descr": MATCH_DTYPE.descr, "version": 3}
+
+    def __del__(self):
+        try:
+            if self._h:
+                _ffi.lib().daac_matches_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class _LazyIter:
     """Iterator<Item = Match<u32>> over daac_iter_* (bytewise/iter.rs next())."""
 
@@ -217,13 +235,10 @@ class DoubleArrayAhoCorasick:
         out = C.c_void_p()
         _ffi.check(_ffi.lib().daac_scan(self._h, int(mode), int(engine), h.ptr, h.len, h.is_device, stream, C.byref(out)))
         n = _ffi.lib().daac_matches_count(out)
-        if n:
-            buf = (C.c_char * (n * MATCH_DTYPE.itemsize)).from_address(_ffi.lib().daac_matches_data(out))
-            res = np.frombuffer(buf, dtype=MATCH_DTYPE).copy()
-        else:
-            res = np.zeros(0, dtype=MATCH_DTYPE)
-        _ffi.lib().daac_matches_free(out)
-        return res
+        if n == 0:
+            _ffi.lib().daac_matches_free(out)
+            return np.zeros(0, dtype=MATCH_DTYPE)
+        return np.asarray(_MatchList(out, n))  # read-only view of the library's buffer, freed with the array
 
     def scan_count(self, mode, haystack, engine=Engine.Auto, stream=None, result_dev=None, begin=0):
         """-> (count, checksum) of the matches with end in (begin, len]; with `result_dev` (device

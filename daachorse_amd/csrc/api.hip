@@ -111,8 +111,62 @@ struct daac_pma {
     }
 };
 
+// Host-side list of match tuples.  Page-locked memory: the device writes tuples at HBM speed and a pageable
+// destination (plus its zero fill) turned the copy back into the slowest part of a materialising scan.
+// One released page-locked block is kept for the next list (pinning a GB costs ~50 ms, unpinning ~60 ms).
+struct PinnedSpare {
+    std::mutex mu;
+    void *p = nullptr;
+    size_t cap = 0;  // in tuples
+    // never freed at exit: the HIP runtime may already be gone when static destructors run
+};
+static PinnedSpare g_spare;
+
+struct MatchBuf {
+    daac_match *p = nullptr;
+    size_t n = 0, cap = 0;
+    bool pinned = false;
+    MatchBuf() = default;
+    MatchBuf(const MatchBuf &) = delete;
+    MatchBuf &operator=(const MatchBuf &) = delete;
+    ~MatchBuf() { release(); }
+    void release() {
+        if (p && pinned) {
+            std::lock_guard<std::mutex> g(g_spare.mu);
+            if (cap > g_spare.cap) { std::swap(g_spare.p, reinterpret_cast<void *&>(p)); std::swap(g_spare.cap, cap); }
+        }
+        if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); }
+        p = nullptr; n = cap = 0;
+    }
+    void clear() { n = 0; }
+    size_t size() const { return n; }
+    bool reserve(size_t want) {  // contents are not kept
+        if (want <= cap) return true;
+        release();
+        const size_t c = std::max<size_t>(want, 4096);
+        void *q = nullptr;
+        {
+            std::lock_guard<std::mutex> g(g_spare.mu);
+            if (g_spare.p && g_spare.cap >= want && g_spare.cap <= 4 * c) {
+                p = static_cast<daac_match *>(g_spare.p);
+                cap = g_spare.cap;
+                pinned = true;
+                g_spare.p = nullptr;
+                g_spare.cap = 0;
+                return true;
+            }
+        }
+        if (hipHostMalloc(&q, c * sizeof(daac_match), hipHostMallocDefault) == hipSuccess) pinned = true;
+        else { (void)hipGetLastError(); q = std::malloc(c * sizeof(daac_match)); pinned = false; }
+        if (!q) return false;
+        p = static_cast<daac_match *>(q);
+        cap = c;
+        return true;
+    }
+};
+
 struct daac_matches {
-    std::vector<daac_match> v;
+    MatchBuf v;
 };
 
 // --------------------------------------------------------------------------------------- upload
@@ -444,7 +498,7 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
 // `next_begin` of the previous window), `total_len` is the real end of the haystack, and the scan runs
 // on to the first sync point >= end, which is returned in *next_begin.
 daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int engine, const uint8_t *dev_hay, uint64_t begin,
-                                   uint64_t end, uint64_t total_len, hipStream_t stream, std::vector<daac_match> &out,
+                                   uint64_t end, uint64_t total_len, hipStream_t stream, MatchBuf &out,
                                    uint64_t *next_begin) {
     Plan pl;
     bool heads = false;
@@ -487,8 +541,9 @@ daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int
     std::unique_ptr<void, void (*)(void *)> g2(d_out, [](void *p) { (void)hipFree(p); });
     pl.a.out = d_out;
     HIP_TRY(launch(t, pl, 2, heads, stream, nullptr));
-    out.resize(total);
-    HIP_TRY(hipMemcpyAsync(out.data(), d_out, total * sizeof(daac_match), hipMemcpyDeviceToHost, stream));
+    if (!out.reserve(total)) { set_error("out of host memory for the match list"); return DAAC_ERR_AUTOMATON_SCALE; }
+    out.n = total;
+    HIP_TRY(hipMemcpyAsync(out.p, d_out, total * sizeof(daac_match), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return DAAC_OK;
 }
@@ -765,7 +820,7 @@ daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, s
 }
 
 size_t daac_matches_count(const daac_matches *m) { return m ? m->v.size() : 0; }
-const daac_match *daac_matches_data(const daac_matches *m) { return m && !m->v.empty() ? m->v.data() : nullptr; }
+const daac_match *daac_matches_data(const daac_matches *m) { return m && m->v.size() != 0 ? m->v.p : nullptr; }
 void daac_matches_free(daac_matches *m) { delete m; }
 
 }  // extern "C"
@@ -782,7 +837,7 @@ struct daac_iter {
     bool started = false, done = false;
     bool restart = false;          // find_iter / leftmost_find_iter: windows end at sync points
     void *owned_dev = nullptr;     // host haystack staged once (restart modes read past a window's nominal end)
-    std::vector<daac_match> buf;
+    MatchBuf buf;
     size_t pos = 0;
 };
 
@@ -816,7 +871,7 @@ daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *h
 int daac_iter_next(daac_iter *it, daac_match *m) {
     if (!it || !m) return -DAAC_ERR_INVALID_ARGUMENT;
     for (;;) {
-        if (it->pos < it->buf.size()) { *m = it->buf[it->pos++]; return 1; }
+        if (it->pos < it->buf.size()) { *m = it->buf.p[it->pos++]; return 1; }
         if (it->done) return 0;
         DeviceTables *t = nullptr;
         daac_status st = get_tables(it->pma, &t);
