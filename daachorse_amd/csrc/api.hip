@@ -275,7 +275,8 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             if (tt.N < (1u << 28) && build_gram_tables(h, tt, static_cast<uint32_t>(g_opt.gram_lds_budget.load()), gt)) {
                 GramDev &g = t->gram;
                 const U32x2 *combo; const U32x4 *drec; const U32x2 *dhit;
-                if ((st = t->put(gt.cls, g.cls)) != DAAC_OK) return st;
+                std::vector<uint32_t> cls32(gt.cls.begin(), gt.cls.end());
+                if ((st = t->put(cls32, g.cls32)) != DAAC_OK) return st;
                 if ((st = t->put(gt.cid, g.cid)) != DAAC_OK) return st;
                 if ((st = t->put(gt.combo, combo)) != DAAC_OK) return st;
                 if ((st = t->put(gt.bbits, g.bbits)) != DAAC_OK) return st;
@@ -289,10 +290,12 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 g.dhit = reinterpret_cast<const uint2 *>(dhit);
                 auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
                 g.has_short = gt.has_short;
-                g.off_cid = 256;
+                // LDS layout: [classes as u32 x 256][B bitmap][CID][COMBO][rank directory][hit stacks]; the first two sit at
+                // fixed offsets so that the kernel addresses them with immediates
+                g.off_bbits = 1024;
+                g.off_cid = g.off_bbits + p16(gt.bbits.size() * 4);
                 g.off_combo = g.off_cid + (gt.has_short ? p16(gt.cid.size() * 2) : 0u);   // not staged when unused
-                g.off_bbits = g.off_combo + (gt.has_short ? p16(gt.combo.size() * 8) : 0u);
-                g.off_brank = g.off_bbits + p16(gt.bbits.size() * 4);
+                g.off_brank = g.off_combo + (gt.has_short ? p16(gt.combo.size() * 8) : 0u);
                 // Without the rank directory two workgroups may fit one CU (<= 80 KB each); worth it when
                 // the level is small, i.e. B hits are rare whatever the text.
                 g.rank_in_lds = !(g.off_brank + 16u * 1024u <= 80u * 1024u && gt.dhit.size() <= 8192);

@@ -74,7 +74,7 @@ struct ChainArgs {
 
 // GRAM engine tables (see gram.hpp).  Everything up to `drec` is staged into LDS.
 struct GramDev {
-    const uint8_t *cls;       // 256
+    const uint32_t *cls32;    // 256 byte classes, one u32 each (a byte select + shift addresses them in one instruction)
     const uint16_t *cid;      // C^K: K-gram -> combination id (0 = no pattern ends here)
     const uint2 *combo;       // per id {count, hsum}
     const uint32_t *bbits;    // (K+1)-gram trie-prefix bitmap
@@ -83,7 +83,7 @@ struct GramDev {
     const uint4 *drec;        // N x {cmap, first_child, own_cnt, own_hsum}  (HBM / L2)
     const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}          (HBM / L2)
     const uint32_t *cfirst;   // depth-(K+1) states by rank: id of the first child     (HBM / L2)
-    uint32_t off_cid, off_combo, off_bbits, off_brank, off_bsuper, off_scratch, lds_bytes;  // cls at 0
+    uint32_t off_cid, off_combo, off_bbits, off_brank, off_bsuper, off_scratch, lds_bytes;  // cls32 at 0, bbits at 1024
     uint32_t K, C, CC, CCC;
     uint32_t level_start, unused_byte, has_short;
     uint32_t rank_in_lds;     // brank/bsuper staged in LDS (else read from L2 on hits)

@@ -86,7 +86,7 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
             cid[g] = it->second;
         }
         if (!ok) continue;
-        const uint64_t bytes = 256 + pad16(ngram * 2) + pad16(combo.size() * 8) + pad16(bwords * 4 + 8) + pad16((bwords + 1) / 2) +
+        const uint64_t bytes = 1024 + pad16(ngram * 2) + pad16(combo.size() * 8) + pad16(bwords * 4 + 8) + pad16((bwords + 1) / 2) +
                                pad16(((bwords + 7) / 8) * 4) + 64;
         if (bytes > lds_budget) continue;
         K = cand;

@@ -27,6 +27,8 @@ typedef uint32_t g_u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kGroup = 4;     // positions whose LDS reads are issued together (lgkmcnt tracks at most 15 reads)
 constexpr uint32_t kRing = 128;  // entries of a wave's hit stack in LDS (at most 63 left over + 64 new)
 constexpr int kPrefetch = 1;  // haystack chunks in flight per lane beyond the current one
+constexpr uint32_t kOffBbits = 1024;  // LDS layout: 256 classes as u32, then the B bitmap (api.hip)
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 
 // 24-bit multiply-adds, spelled out: left to itself hipcc turns some `__umul24(a, b) + c` of the gram
 // indices into the quarter-rate v_mad_u64_u32.
@@ -71,21 +73,26 @@ __device__ __forceinline__ void gram_reduce(unsigned long long cnt, uint32_t s1,
 template <int K, bool HAS_SHORT, int TPB, bool DENSE, bool RANK_LDS>
 __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const GramArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gram_copy(smem, g.cls, 256);
+    gram_copy(smem, g.cls32, 1024);
+    gram_copy(smem + kOffBbits, g.bbits, g.off_cid - kOffBbits);
     if (HAS_SHORT) {
         gram_copy(smem + g.off_cid, g.cid, g.off_combo - g.off_cid);
-        gram_copy(smem + g.off_combo, g.combo, g.off_bbits - g.off_combo);
+        gram_copy(smem + g.off_combo, g.combo, g.off_brank - g.off_combo);
     }
-    gram_copy(smem + g.off_bbits, g.bbits, g.off_brank - g.off_bbits);
     if (RANK_LDS) {
         gram_copy(smem + g.off_brank, g.brank, g.off_bsuper - g.off_brank);
         gram_copy(smem + g.off_bsuper, g.bsuper, g.off_scratch - g.off_bsuper);
     }
     __syncthreads();
-    const uint8_t *l_cls = reinterpret_cast<const uint8_t *>(smem);
+    // classes and bitmap words are read through absolute LDS addresses (the dynamic segment starts where the
+    // static one ends; this kernel has none): a byte select + shift is the whole address of a class
+    // (spelled as the literal 0 so that it folds into the instructions; checked once per workgroup)
+    constexpr uint32_t lds0 = 0;
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+    auto cls_of = [&](uint32_t byte) -> uint32_t { return *reinterpret_cast<lds_cu32 *>(static_cast<uintptr_t>(lds0 + byte * 4u)); };
     const uint16_t *l_cid = reinterpret_cast<const uint16_t *>(smem + g.off_cid);
     const uint2 *l_combo = reinterpret_cast<const uint2 *>(smem + g.off_combo);
-    const uint32_t *l_bbits = reinterpret_cast<const uint32_t *>(smem + g.off_bbits);
+    const uint32_t *l_bbits = reinterpret_cast<const uint32_t *>(smem + kOffBbits);
     // the rank directory of B is only touched on hits: small automata keep it in L2 so that two
     // workgroups fit one CU's LDS
     // (compile-time choice: a run-time select would turn these into generic pointers and flat loads)
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         return r;
     };
     auto class_at = [&](uint64_t p) -> uint32_t {  // class of the byte at virtual position p
-        return (p >= a.lead && p < a.vlen) ? l_cls[hay[p]] : 0u;
+        return (p >= a.lead && p < a.vlen) ? cls_of(hay[p]) : 0u;
     };
     // offset within its level of the depth-(K+1) state whose gram index is `ib` (its B bit is set):
     // popcount directory = u32 per 256 bits + u8 per 64 bits + the bits below inside the 64-bit pair
@@ -229,12 +236,22 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             for (int i = 0; i < kPrefetch; ++i) pf[i] = pf[i + 1];
             pf[kPrefetch] = (sb + 1024ull * (kPrefetch + 1) < rend) ? load_chunk(v + 1024ull * (kPrefetch + 1)) : uint4{ub4, ub4, ub4, ub4};
 
-            // ---- byte classes of this lane's 16 positions plus K to the left and 1 to the right ----
+            // the two bytes after this wave's 1 KiB (lane 63 needs their classes): lane 0's share of the chunk that
+            // is already in flight or, on the last step of a region, two wave-uniform loads
+            uint32_t after2;
+            if (sb + 1024 < rend) {
+                after2 = __builtin_amdgcn_readfirstlane(pf[0].x);
+            } else {
+                const uint64_t p0 = sb + 1024, p1 = sb + 1025;
+                after2 = ((p0 >= a.lead && p0 < a.vlen) ? hay[p0] : g.unused_byte) | (((p1 >= a.lead && p1 < a.vlen) ? hay[p1] : g.unused_byte) << 8);
+            }
+
+            // ---- byte classes of this lane's 16 positions plus K to the left and 2 to the right ----
             uint32_t kx[K + 18];
             {
                 const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll
-                for (int b = 0; b < 16; ++b) kx[K + b] = l_cls[(w[b >> 2] >> (8 * (b & 3))) & 0xffu];
+                for (int b = 0; b < 16; ++b) kx[K + b] = cls_of((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
             }
             uint32_t pk = 0;
 #pragma unroll
@@ -245,7 +262,9 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
 #pragma unroll
             for (int i = 0; i < K; ++i) kx[i] = (left >> (8 * i)) & 0xffu;
             uint32_t right = __shfl_down(kx[K] | (kx[K + 1] << 5), 1, 64);  // the two classes after this lane's 16
-            if (lane == 63) right = class_at(sb + 1024) | (class_at(sb + 1025) << 5);
+            uint32_t right63 = cls_of(after2 & 0xffu) | (cls_of((after2 >> 8) & 0xffu) << 5);  // same address in every lane: a broadcast
+            asm volatile("" : "+v"(right63));  // keep the two reads out of a lane-63-only branch: the step stays one basic block
+            right = lane == 63 ? right63 : right;
             kx[K + 16] = right & 31u;
             kx[K + 17] = right >> 5;
 
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
 #pragma unroll
                 for (int jj = 0; jj < kGroup; ++jj) {
                     if (HAS_SHORT) id[jj] = l_cid[iW[jj]];
-                    bw[jj] = l_bbits[__builtin_amdgcn_ubfe(iB[jj], 5, 27)];
+                    bw[jj] = *reinterpret_cast<lds_cu32 *>(static_cast<uintptr_t>(lds0 + kOffBbits + ((iB[jj] >> 3) & ~3u)));
                 }
                 if (HAS_SHORT) {
 #pragma unroll

@@ -259,7 +259,7 @@ def test_cfg3_100k_patterns():
     for eng in ENGINES + [Engine.Gram, Engine.Auto]:
         assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want_cc, eng
     # a small K (tables squeezed into a few KB of LDS) must give the same answer
-    da.set_option("gram_lds_budget", 8192)
+    da.set_option("gram_lds_budget", 9216)
     p2, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
     assert p2.upload().info().gram_k == 2
     assert p2.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want_cc
