@@ -43,6 +43,12 @@ __device__ __forceinline__ uint32_t mad_i24(uint32_t a, int32_t b_uniform, uint3
     return d;
 }
 
+__device__ __forceinline__ uint32_t lshl_or(uint32_t a, uint32_t shift, uint32_t c) {  // (a << shift) | c in one instruction
+    uint32_t d;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(shift), "v"(c));
+    return d;
+}
+
 __device__ __forceinline__ unsigned long long gram_wave_sum(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -307,12 +313,13 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                     const int j = grp * kGroup + jj;
                     const unsigned long long m = __ballot(hit);
                     if (m != 0) {  // wave-uniform
+                        const uint32_t q_s = __builtin_amdgcn_readfirstlane(q_n);  // the fill level lives in a scalar register
                         if (hit) {
-                            const uint32_t nx = kx[K + j + 1] | (kx[K + j + 2] << 5);
-                            ring[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), q_n))] =
-                                uint2{iB[jj] | (nx << 20), v32 + j};
+                            const uint32_t nx = lshl_or(kx[K + j + 2], 5, kx[K + j + 1]);
+                            ring[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), q_s))] =
+                                uint2{lshl_or(nx, 20, iB[jj]), v32 + j};
                         }
-                        q_n = __builtin_amdgcn_readfirstlane(q_n + __popcll(m));
+                        q_n = q_s + static_cast<uint32_t>(__popcll(m));
                         if (q_n >= 64u) process_batch();
                     }
                 };
