@@ -370,3 +370,39 @@ def test_cpp_facade_on_gpu(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "cpp_facade_test.cpp"),
                            "-L" + libdir, "-ldaachorse_amd", "-Wl,-rpath," + libdir])
     assert subprocess.check_output([exe, "gpu"]).decode().strip() == "OK gpu"
+
+
+def test_concurrent_scans_share_one_handle():
+    """Handles are immutable after upload: several host threads scan through one handle, each on its own HIP
+    stream (include/daachorse_amd.h conventions); all four iterators, materialising and counting."""
+    import threading
+    import torch
+    pats = synth.patterns_cfg3(3000)
+    o, p = _pma(pats)
+    ol, pl = _pma(pats, kind="LeftmostLongest")
+    hay = synth.wordsoup_haystack(400_000, synth.SEEDS["cfg3_dense"], pats, 20)
+    dev = torch.from_numpy(hay).cuda()
+    want = {"ov": o.find_overlapping_iter(hay), "find": o.find_iter(hay), "lm": ol.leftmost_find_iter(hay)}
+    p.upload(0)
+    pl.upload(0)
+    errors = []
+
+    def worker(tid):
+        try:
+            s = torch.cuda.Stream()
+            for rep in range(6):
+                assert _same(p.scan(ScanMode.FindOverlapping, dev, stream=s.cuda_stream), want["ov"])
+                assert p.scan_count(ScanMode.FindOverlapping, dev, stream=s.cuda_stream) == (len(want["ov"]), orc.matches_checksum(want["ov"]))
+                assert _same(p.scan(ScanMode.Find, dev, stream=s.cuda_stream), want["find"])
+                assert pl.scan_count(ScanMode.LeftmostFind, dev, stream=s.cuda_stream) == (len(want["lm"]), orc.matches_checksum(want["lm"]))
+                assert [(m.start(), m.end()) for m, _ in zip(p.find_iter(hay[:5000]), range(50))] == \
+                    [(int(x["start"]), int(x["end"])) for x in o.find_iter(hay[:5000])[:50]]
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
