@@ -272,7 +272,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             t->tier_ok = true;
             // GRAM count engine, derived from the tier tables
             GramTables gt;
-            if (tt.N < (1u << 28) && build_gram_tables(h, tt, static_cast<uint32_t>(g_opt.gram_lds_budget.load()), gt)) {
+            if (tt.N < (1u << 27) && build_gram_tables(h, tt, static_cast<uint32_t>(g_opt.gram_lds_budget.load()), gt)) {
                 GramDev &g = t->gram;
                 const U32x2 *combo; const U32x4 *drec; const U32x2 *dhit;
                 std::vector<uint32_t> cls32(gt.cls.begin(), gt.cls.end());
@@ -774,8 +774,8 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         ga.dense = g_opt.gram_dense.load() >= 0 ? g_opt.gram_dense.load() != 0
                                                 : static_cast<uint64_t>(t->gram.n_deep) * 100 > static_cast<uint64_t>(t->gram.CCC) * (t->gram.K == 3 ? t->gram.C : 1);
         void *wq = nullptr;
-        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * sizeof(uint4), stream));
-        ga.wq = static_cast<uint4 *>(wq);
+        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * sizeof(uint2), stream));
+        ga.wq = static_cast<uint2 *>(wq);
         const hipError_t le = launch_gram_scan(t->gram, ga, blocks, threads, stream);
         HIP_TRY(hipFreeAsync(wq, stream));
         HIP_TRY(le);

@@ -97,7 +97,7 @@ struct GramArgs {
     uint64_t region_bytes;   // contiguous bytes a wave takes at a time (multiple of 1024)
     uint64_t nregions;
     unsigned long long *result;  // {count, S1, S2}
-    uint4 *wq;                   // per-wave walker slabs: {position lo, position hi | class after next << 8, state, 0}
+    uint2 *wq;                   // per-wave walker slabs: {position lo, state | class after next << 27}
     uint32_t wq_slab;            // entries per wave
     uint32_t dense;              // B hits are frequent: queue them position by position without testing the group first
 };

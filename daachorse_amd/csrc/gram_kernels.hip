@@ -1,18 +1,19 @@
 // GRAM engine kernels (gfx950): count + checksum of the find_overlapping stream without a state
 // chain.  See gram.hpp for the method.  One wavefront streams 1 KiB per step with fully coalesced
-// 16-byte loads (kept PF steps ahead, so enough bytes are in flight to cover HBM latency); every
-// position is independent, so there is no halo and no warm-up:
+// 16-byte non-temporal loads (one chunk ahead per lane; sixteen waves per CU keep enough bytes in flight);
+// every position is independent, so there is no halo and no warm-up:
 //
 //   per position p (all in LDS): class of the byte, CID[last K classes] -> COMBO[id] = count and
 //   h32 sum of every pattern of length <= K ending here, B_{K+1} bit -> "a longer pattern may start
-//   K bytes back".  Positions whose B bit is set are rare enough (16 % on the 100k-word automaton)
+//   K bytes back".  Positions whose B bit is set are rare enough (11 % on the 100k-word automaton)
 //   that handling them in place would waste most lanes, so the wave COMPACTS them: a wave ballot
-//   gives every hit a slot in a 128-entry ring in LDS, and whenever 64 are queued all 64 lanes take
+//   gives every hit a slot in a 128-entry stack in LDS, and whenever 64 are queued all 64 lanes take
 //   one each: rank directory -> depth-(K+1) state -> its 8-byte {child bitmap, own h32 sum} record,
 //   the ONLY HBM/L2 access of the fast pass, consumed one batch later so its latency hides behind
-//   LDS work.  Branches that go on past depth K+1 are rarer still; their positions go to the wave's
-//   slab in HBM (ballot-compacted, no atomics) and are finished 64 at a time by a goto-only trie
-//   walk whenever the slab fills up and at the end of the wave's work.
+//   LDS work.  Branches that go on past depth K+1 are rarer still (0.6 %); the state they reach and the
+//   class of the byte after next go to the wave's slab in HBM (ballot-compacted, no atomics) and are
+//   finished 64 at a time by a goto-only trie walk whenever the slab fills up and at the end of the
+//   wave's work, without touching the haystack again unless a branch survives two more levels.
 //
 // Roofline: HBM bytes of haystack (1 B read per byte); integer/bit work only, no MFMA.
 #include <hip/hip_runtime.h>
@@ -112,11 +113,12 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     const uint32_t ub4 = g.unused_byte * 0x01010101u;
     const uint8_t *__restrict__ hay = a.hay_al;
     const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
-    // this wave's slab of pending walkers: {virtual position p of the last byte of a (K+1)-gram (lo, hi),
-    // class of the byte at p + 2 (<< 8 in .y), the depth-(K+2) state reached on the byte at p + 1}
-    uint4 *__restrict__ slab =
+    // this wave's slab of pending walkers: {low 32 bits of the virtual position p of the last byte of a
+    // (K+1)-gram, the depth-(K+2) state reached on the byte at p + 1 | class of the byte at p + 2 << 27};
+    // all entries of a slab share the bits of p above 2^32 (slab_hi): it is emptied before they change
+    uint2 *__restrict__ slab =
         a.wq + (static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * a.wq_slab;
-    uint32_t wq_n = 0;  // wave-uniform
+    uint32_t wq_n = 0, slab_hi = 0;  // wave-uniform
 
     unsigned long long tot_cnt = 0;
     uint32_t tot_s1 = 0, tot_s2 = 0;
@@ -154,10 +156,10 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     // that survive yet another level (2e-4 of the positions on the 100k-word automaton).
     auto drain = [&]() {
         for (uint32_t i = lane; i < wq_n; i += 64) {
-            const uint4 e = slab[i];
-            uint64_t vnext = ((static_cast<uint64_t>(e.y & 0xffu) << 32) | e.x) + 2;  // the state consumed the byte before vnext
-            uint4 r = g.drec[e.z];                 // {cmap, first_child, own_cnt, own_hsum}
-            uint32_t kn = e.y >> 8;
+            const uint2 e = slab[i];
+            uint64_t vnext = ((static_cast<uint64_t>(slab_hi) << 32) | e.x) + 2;  // the state consumed the byte before vnext
+            uint4 r = g.drec[e.y & 0x07ffffffu];   // {cmap, first_child, own_cnt, own_hsum}
+            uint32_t kn = e.y >> 27;
             for (;;) {
                 tot_cnt += r.z;                   // its own patterns end at vnext - lead
                 tot_s1 += r.w;
@@ -178,7 +180,6 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     uint2 pend = uint2{0u, 0u};                 // record read for the previous batch, not yet consumed
     uint32_t pend_item = 0, pend_pos = 0, pend_rank = 0;
     bool pend_valid = false;                    // wave-uniform
-    uint64_t v_now = 0;                         // a recent 64-bit position of this wave (to widen pend_pos)
     auto consume_pending = [&]() {
         if (!pend_valid) return;
         pend_valid = false;
@@ -189,15 +190,10 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         const uint32_t k1 = (pend_item >> 20) & 31u;
         const bool go = (r.x >> k1) & 1u;
         const unsigned long long m = __ballot(go);
-        if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker (needs the full position)
-            if (go) {
-                uint64_t vp = (v_now & ~0xffffffffull) | pend_pos;
-                if (vp > v_now + (1ull << 31)) vp -= 1ull << 32;
-                else if (vp + (1ull << 31) < v_now) vp += 1ull << 32;
-                const uint32_t child = g.cfirst[pend_rank] + __popc(r.x & ((1u << k1) - 1u));
+        if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker (same slab epoch: see the step loop)
+            if (go)
                 slab[wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
-                    uint4{static_cast<uint32_t>(vp), static_cast<uint32_t>(vp >> 32) | ((pend_item >> 25) << 8), child, 0u};
-            }
+                    uint2{pend_pos, (g.cfirst[pend_rank] + __popc(r.x & ((1u << k1) - 1u))) | ((pend_item >> 25) << 27)};
             wq_n += __popcll(m);
         }
     };
@@ -218,8 +214,13 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         pend_valid = true;
     };
 
-    for (uint64_t region = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6); region < a.nregions;
-         region += nwaves) {
+    // Regions (multiples of 1 KiB) never straddle a multiple of 4 GiB.  The wave works through its regions one
+    // 4 GiB epoch at a time and retires everything queued before moving on, so that every position in the hit
+    // stack, the pending batch and the walker slab shares its bits above 2^32 (slab_hi).
+    uint64_t region = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    while (region < a.nregions) {
+      slab_hi = static_cast<uint32_t>((region * a.region_bytes) >> 32);
+      for (; region < a.nregions && static_cast<uint32_t>((region * a.region_bytes) >> 32) == slab_hi; region += nwaves) {
         const uint64_t rbase = region * a.region_bytes;
         const uint64_t rend = rbase + a.region_bytes < a.vlen ? rbase + a.region_bytes : a.vlen;
         // classes of the K bytes before the region, oldest in the low byte
@@ -235,7 +236,6 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         for (uint64_t sb = rbase; sb < rend; sb += 1024) {
             if (wq_n + 256u > a.wq_slab) drain();  // a step retires at most a few batches of 64 walkers
             const uint64_t v = sb + lane * 16;
-            v_now = sb;
             const uint32_t v32 = static_cast<uint32_t>(v);
             const uint4 cur = pf[0];
 #pragma unroll
@@ -341,10 +341,11 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             tot_s1 += A;
             tot_s2 += A * (e0 + 16u) - T;
         }
+      }
+      while (q_n != 0) process_batch();
+      consume_pending();
+      drain();
     }
-    while (q_n != 0) process_batch();
-    consume_pending();
-    drain();
     gram_reduce(tot_cnt, tot_s1, tot_s2, reinterpret_cast<unsigned long long *>(smem), a.result);
 }
 

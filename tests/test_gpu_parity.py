@@ -406,3 +406,28 @@ def test_concurrent_scans_share_one_handle():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_gram_haystack_beyond_4_gib():
+    """BASELINE-sized property: positions above 2^32 (the walker slabs change epoch at every multiple of 4 GiB,
+    checksums use the low 32 bits of `end`).  5 GiB + 5 bytes of word soup at an unaligned address, GRAM
+    against the oracle (128 host threads); the two halves of the haystack must also add up."""
+    import os
+    import torch
+    pats = synth.patterns_cfg3(20000)
+    o, p = _pma(pats)
+    n = (5 << 30) + 5
+    buf = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
+    dev = buf[3:3 + n]
+    synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20)
+    got = p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram)
+    host = dev.cpu().numpy()
+    want = o.overlapping_count(host, threads=min(128, os.cpu_count() or 1))
+    assert got == want
+    cut = (4 << 30) - 7  # tail shard through the materialising engines' count mode
+    head = p.scan_count(ScanMode.FindOverlapping, dev[:cut], engine=Engine.Gram)
+    tail = p.scan_count(ScanMode.FindOverlapping, dev, begin=cut)
+    from daachorse_amd import dist as ddist
+    h1, h2 = ddist.split_checksum(head[1])
+    t1, t2 = ddist.split_checksum(tail[1])
+    assert (head[0] + tail[0], ddist.join_checksum(h1 + t1, h2 + t2)) == want
