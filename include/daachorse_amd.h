@@ -177,7 +177,18 @@ int daac_iter_next(daac_iter *it, daac_match *m); /* 1 = Some(m), 0 = None, <0 =
 void daac_iter_close(daac_iter *it);
 
 /* ---- tuning knobs (optional) ----------------------------------------------------------------- */
-/* name/value pairs for experiments: "seg_bytes", "lds_budget", "dense_depth", "blocks_per_cu" ... */
+/* Process-wide name/value pairs for experiments; defaults in parentheses.  Options that shape the device tables
+ * ("lds_budget", "dense_depth", "rows_share_pct", "gram_lds_budget", "gram_rank_in_lds", "char_map_lds") are read
+ * when an automaton is uploaded, the others at every scan.
+ *   seg_bytes (0 = auto)        bytes of haystack per lane-segment of the segment scanners
+ *   threads (1024), blocks_per_cu (0 = auto)   launch shape of the overlapping scanners
+ *   lds_budget (98304), dense_depth (-1 = auto), rows_share_pct (45)   TIERED re-pack
+ *   gram_lds_budget (161792), gram_region (16384), gram_slab (2048), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto)
+ *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
+ *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners
+ *   char_map_lds (0)            charwise chain scans: code mapper staged in LDS when it fits
+ *   iter_window (64 MiB)        haystack bytes per window of the lazy iterator
+ *   max_result_bytes (8 GiB)    largest match list daac_scan may materialise */
 daac_status daac_set_option(const char *name, int64_t value);
 
 #ifdef __cplusplus
