@@ -158,8 +158,11 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         for (uint32_t i = lane; i < wq_n; i += 64) {
             const uint2 e = slab[i];
             uint64_t vnext = ((static_cast<uint64_t>(slab_hi) << 32) | e.x) + 2;  // the state consumed the byte before vnext
-            uint4 r = g.drec[e.y & 0x07ffffffu];   // {cmap, first_child, own_cnt, own_hsum}
+            uint4 r = g.drec[e.y & 0x07ffffffu];  // {cmap, first_child, own_cnt, own_hsum}
             uint32_t kn = e.y >> 27;
+            // bytes ahead of the walk, four per read: on text made of dictionary words a walker lives for several
+            // levels, and every separate byte read is one more uncoalesced request to the memory pipeline
+            uint32_t ahead = 0, n_ahead = 0;
             for (;;) {
                 tot_cnt += r.z;                   // its own patterns end at vnext - lead
                 tot_s1 += r.w;
@@ -167,7 +170,18 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                 if (((r.x >> kn) & 1u) == 0) break;
                 r = g.drec[r.y + __popc(r.x & ((1u << kn) - 1u))];
                 ++vnext;
-                kn = class_at(vnext);
+                if (n_ahead == 0) {
+                    if (vnext >= a.lead && vnext + 4 <= a.vlen) {
+                        __builtin_memcpy(&ahead, hay + vnext, 4);  // one (unaligned) dword
+                    } else {
+                        ahead = 0;
+                        for (int b = 3; b >= 0; --b) ahead = (ahead << 8) | ((vnext + b >= a.lead && vnext + b < a.vlen) ? hay[vnext + b] : g.unused_byte);
+                    }
+                    n_ahead = 4;
+                }
+                kn = cls_of(ahead & 0xffu);
+                ahead >>= 8;
+                --n_ahead;
             }
         }
         wq_n = 0;
