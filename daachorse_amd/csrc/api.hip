@@ -494,6 +494,14 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
     return DAAC_OK;
 }
 
+// {count, S1, S2} of a shard scanned with shard-relative ends -> absolute ends, plus tuples counted on the host
+__global__ void shard_fixup_kernel(unsigned long long *r, unsigned long long begin32, unsigned long long c, unsigned long long s1,
+                                   unsigned long long s2) {
+    r[2] += (r[1] & 0xffffffffull) * begin32 + s2;
+    r[1] += s1;
+    r[0] += c;
+}
+
 // Scans [begin, end) of a haystack whose byte 0 is at `dev_hay` (device pointer; only bytes
 // >= begin - halo are dereferenced) and returns the matches with end in (begin, end] — plus
 // ROOT's list at end = 0 when begin == 0 — in reference order.
@@ -719,7 +727,7 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
     daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
     if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
-    const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len < (1ull << 35) && begin == 0 &&
+    const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len - begin < (1ull << 35) &&
                           (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && t->gram_ok));
     if (engine == DAAC_ENGINE_GRAM && (!use_gram || !t->gram_ok)) {
         set_error("GRAM engine not available for this automaton / mode");
@@ -752,11 +760,15 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         pl.a.flags = static_cast<unsigned long long *>(flagbuf);
     }
     std::unique_ptr<void, void (*)(void *)> g3(flagbuf, [](void *p) { if (p) (void)hipFree(p); });
-    if (use_gram && len != 0) {
+    if (use_gram && len != begin) {
+        // A shard [begin, len) is scanned as a haystack of its own: that counts every occurrence lying inside it,
+        // with ends relative to `begin`.  What is missing are the occurrences that start before `begin` and end
+        // after it (at most Lmax - 1 bytes in); they are added below from a materialising scan of that sliver.
+        const uint8_t *sub = dev_hay + begin;
         GramArgs ga{};
-        ga.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dev_hay) & 15u);
-        ga.hay_al = dev_hay - ga.lead;
-        ga.vlen = ga.lead + static_cast<uint64_t>(len);
+        ga.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sub) & 15u);
+        ga.hay_al = sub - ga.lead;
+        ga.vlen = ga.lead + static_cast<uint64_t>(len - begin);
         uint64_t region = static_cast<uint64_t>(g_opt.gram_region.load());
         region = std::max<uint64_t>(1024, region & ~1023ull);
         ga.region_bytes = region;
@@ -779,6 +791,26 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         const hipError_t le = launch_gram_scan(t->gram, ga, blocks, threads, stream);
         HIP_TRY(hipFreeAsync(wq, stream));
         HIP_TRY(le);
+        if (begin != 0) {
+            unsigned long long add[3] = {0, 0, 0};
+            const uint64_t sliver_end = std::min<uint64_t>(len, begin + pl.a.halo);
+            if (sliver_end > begin) {
+                MatchBuf edge;
+                if ((st = scan_range_materialize(pma, t, DAAC_FIND_OVERLAPPING, DAAC_ENGINE_AUTO, dev_hay, begin, sliver_end, len, stream, edge,
+                                                 nullptr)) != DAAC_OK)
+                    return st;
+                for (size_t i = 0; i < edge.size(); ++i) {
+                    const daac_match &m = edge.p[i];
+                    if (m.start >= begin) continue;  // lies inside the shard: already counted
+                    const uint32_t h = match_hash32(m.value, static_cast<uint32_t>(m.end - m.start));
+                    add[0] += 1; add[1] += h; add[2] += static_cast<uint32_t>(h * static_cast<uint32_t>(m.end));
+                }
+            }
+            // ends were relative to `begin`: S2 += low32(begin) * S1, then the sliver's tuples
+            hipLaunchKernelGGL(shard_fixup_kernel, dim3(1), dim3(1), 0, stream, d_res, static_cast<unsigned long long>(begin & 0xffffffffull), add[0],
+                               add[1], add[2]);
+            HIP_TRY(hipGetLastError());
+        }
     } else if (pl.a.nseg != 0) {
         HIP_TRY(launch(t, pl, 0, heads, stream));
     }

@@ -50,7 +50,7 @@ typedef enum {
     DAAC_FIND_OVERLAPPING_NO_SUFFIX = 3  /* FindOverlappingNoSuffixIterator  iter.rs:180-244 */
 } daac_scan_mode;
 
-/* Which device engine to use.  AUTO picks GRAM for daac_scan_count(FIND_OVERLAPPING) and TIERED
+/* Which device engine to use.  AUTO picks GRAM for daac_scan_count[_range](FIND_OVERLAPPING) and TIERED
  * for everything else when the automaton qualifies, DARRAY otherwise. */
 typedef enum {
     DAAC_ENGINE_AUTO = 0,
