@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on one MI355X: many small automata / haystacks / segment sizes, all four iterators of
+both automaton flavours against the CPU oracle (test infrastructure).  usage: python tools/stress.py [seconds] [seed] [gram]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import daachorse_amd as da
+from daachorse_amd import ScanMode
+from oracle import oracle as orc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+APIS = {0: [("find_overlapping_iter", ScanMode.FindOverlapping), ("find_overlapping_no_suffix_iter", ScanMode.FindOverlappingNoSuffix),
+            ("find_iter", ScanMode.Find)], 1: [("leftmost_find_iter", ScanMode.LeftmostFind)], 2: [("leftmost_find_iter", ScanMode.LeftmostFind)]}
+ALPHAS = [list("ab"), list("abc"), list("abcde"), [chr(c) for c in range(0x3041, 0x3046)], list("aé世") + ["\U0001F600"]]
+
+
+def sev(m):
+    return [(int(x["start"]), int(x["end"]), int(x["value"])) for x in m]
+
+
+t0 = time.time()
+cases = checks = 0
+while time.time() - t0 < budget and not (len(sys.argv) > 3 and sys.argv[3] == "gram"):
+    A = ALPHAS[int(rng.integers(0, len(ALPHAS)))]
+    multibyte = any(len(c.encode()) > 1 for c in A)
+    npat = int(rng.integers(1, 40))
+    pats = ["".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(1, 7)))) for _ in range(npat)]
+    if rng.random() < 0.15 and not (multibyte and len({len(c.encode()) for c in A}) > 1):
+        pats.insert(int(rng.integers(0, len(pats) + 1)), "")
+    text = "".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(0, 6000))))
+    if rng.random() < 0.2:
+        text = (pats[0] + pats[-1]) * int(rng.integers(1, 300))  # periodic: chains that never fall in step
+    charwise = multibyte or rng.random() < 0.4
+    kind = int(rng.integers(0, 3))
+    da.set_option("seg_bytes", int(rng.choice([0, 16, 32, 48, 256, 1024])))
+    da.set_option("restart_chain", int(rng.random() < 0.8))
+    da.set_option("chain_rounds", int(rng.choice([1, 2, 24])))
+    da.set_option("iter_window", int(rng.choice([4096, 64 << 20])))
+    if charwise:
+        o = orc.OracleCharwisePma.build(pats, kind=kind)
+        p, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(o.serialize())
+    else:
+        o = orc.OraclePma.build(pats, kind=kind)
+        p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    cases += 1
+    for api, mode in APIS[kind]:
+        try:
+            want = getattr(o, api)(text)
+        except orc.OracleError as e:
+            assert e.code == 6
+            try:
+                p.scan(mode, text)
+                raise SystemExit(f"expected Unsupported: {pats!r} {text[:80]!r} {api}")
+            except da.DaachorseError as e2:
+                assert e2.code == 6
+            continue
+        got = p.scan(mode, text)
+        ctx = (charwise, kind, api, pats, text[:200], len(text))
+        assert sev(got) == sev(want), ctx
+        assert p.scan_count(mode, text) == (len(want), orc.matches_checksum(want)), ctx
+        if len(text) < 3000:
+            assert [(m.start(), m.end(), m.value()) for m in getattr(p, api)(text)] == sev(want), ctx
+        checks += 1
+if cases:
+    print(f"stress ok: {cases} automata, {checks} iterator checks in {time.time() - t0:.0f} s (seed {seed})")
+
+
+def gram_soak(seconds, seed):
+    """count + checksum of the GRAM engine (and TIERED / DARRAY) against the oracle on random dictionaries"""
+    import torch
+    from daachorse_amd import Engine
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    n_auto = n_gram = 0
+    while time.time() - t0 < seconds:
+        nsym = int(rng.integers(2, 27))
+        syms = rng.choice(np.arange(97, 123), size=nsym, replace=False).astype(np.uint8)
+        npat = int(rng.choice([1, 5, 50, 500, 5000]))
+        lo, hi = int(rng.integers(1, 5)), int(rng.integers(5, 14))
+        pats = [bytes(syms[rng.integers(0, nsym, size=int(rng.integers(lo, hi + 1)))]) for _ in range(npat)]
+        noise = rng.choice(np.concatenate([syms, np.frombuffer(b" .,\n", dtype=np.uint8)]), size=int(rng.integers(1000, 3_000_000)))
+        hay = noise.astype(np.uint8)
+        for _ in range(int(rng.integers(0, 200))):  # plant some patterns
+            w = np.frombuffer(pats[int(rng.integers(0, npat))], dtype=np.uint8)
+            at = int(rng.integers(0, max(1, len(hay) - len(w))))
+            hay[at:at + len(w)] = w[:len(hay) - at]
+        o = orc.OraclePma.build(pats)
+        da.set_option("gram_lds_budget", int(rng.choice([158 * 1024, 40 * 1024, 9216])))
+        p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+        dev = torch.from_numpy(hay).cuda()[int(rng.integers(0, 16)):]
+        want = o.overlapping_count(dev.cpu().numpy(), threads=8)
+        n_auto += 1
+        for eng in (Engine.Auto, Engine.Tiered, Engine.DArray, Engine.Gram):
+            try:
+                got = p.scan_count(ScanMode.FindOverlapping, dev, engine=eng)
+            except da.DaachorseError as e:
+                assert e.code == 6 and eng in (Engine.Gram, Engine.Tiered), (eng, str(e))
+                continue
+            assert got == want, (eng, nsym, npat, lo, hi, len(hay), got, want)
+            n_gram += eng == Engine.Gram
+        begin = int(rng.integers(1, len(dev)))
+        head = p.scan_count(ScanMode.FindOverlapping, dev[:begin])
+        tail = p.scan_count(ScanMode.FindOverlapping, dev, begin=begin)
+        s = lambda c: ((c >> 32) & 0xFFFFFFFF, c & 0xFFFFFFFF)
+        tot = (head[0] + tail[0], (((s(head[1])[0] + s(tail[1])[0]) & 0xFFFFFFFF) << 32) | ((s(head[1])[1] + s(tail[1])[1]) & 0xFFFFFFFF))
+        assert tot == want, ("shards", begin, tot, want)
+    da.set_option("gram_lds_budget", 158 * 1024)
+    print(f"gram soak ok: {n_auto} automata ({n_gram} on the GRAM engine) in {time.time() - t0:.0f} s (seed {seed})")
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "gram":
+    gram_soak(budget, seed + 1000)
