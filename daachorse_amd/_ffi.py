@@ -70,13 +70,16 @@ def lib():
     L.daac_iter_next.argtypes = [vp, P(Match)]
     L.daac_iter_next.restype = C.c_int
     L.daac_iter_close.argtypes = [vp]
+    L.daac_stream_open.argtypes = [vp, C.c_int, C.c_int, vp, P(vp)]
+    L.daac_stream_feed.argtypes = [vp, u8p, sz, C.c_int, P(vp)]
+    L.daac_stream_close.argtypes = [vp]
     L.daac_set_option.argtypes = [C.c_char_p, C.c_int64]
     L.daac_synth_uniform.argtypes = [vp, sz, C.c_uint64, vp, C.c_uint32, C.c_uint64, vp]
     L.daac_synth_wordsoup.argtypes = [vp, sz, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32,
                                       vp, C.c_uint32, C.c_uint64, vp]
     for name in ("daac_bytewise_from_serialized", "daac_bytewise_from_parts", "daac_bytewise_build", "daac_charwise_from_serialized",
                  "daac_charwise_build", "daac_pma_serialize",
-                 "daac_pma_info", "daac_pma_upload", "daac_scan", "daac_scan_count", "daac_scan_count_range", "daac_iter_open", "daac_set_option",
+                 "daac_pma_info", "daac_pma_upload", "daac_scan", "daac_scan_count", "daac_scan_count_range", "daac_iter_open", "daac_stream_open", "daac_stream_feed", "daac_set_option",
                  "daac_synth_uniform", "daac_synth_wordsoup"):
         getattr(L, name).restype = C.c_int
     _lib = L

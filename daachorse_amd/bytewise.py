@@ -140,6 +140,35 @@ class _LazyIter:
             pass
 
 
+class _Stepper:
+    """FindStepper / FindOverlappingStepper (bytewise/iter.rs:344-475, charwise/iter.rs:403-534) fed chunk by chunk:
+    `feed(chunk)` returns the matches decided so far, positions counted from the first byte ever fed."""
+
+    def __init__(self, pma, mode, engine, stream):
+        self._pma = pma
+        self._stream = stream
+        self._s = C.c_void_p()
+        _ffi.check(_ffi.lib().daac_stream_open(pma._h, int(mode), int(engine), stream, C.byref(self._s)))
+
+    def feed(self, chunk):
+        h = _Haystack(chunk)
+        out = C.c_void_p()
+        _ffi.check(_ffi.lib().daac_stream_feed(self._s, h.ptr, h.len, h.is_device, C.byref(out)))
+        n = _ffi.lib().daac_matches_count(out)
+        if n == 0:
+            _ffi.lib().daac_matches_free(out)
+            return np.zeros(0, dtype=MATCH_DTYPE)
+        return np.asarray(_MatchList(out, n))
+
+    def __del__(self):
+        try:
+            if self._s:
+                _ffi.lib().daac_stream_close(self._s)
+                self._s = None
+        except Exception:
+            pass
+
+
 class DoubleArrayAhoCorasick:
     """DoubleArrayAhoCorasick<u32> (reference src/bytewise.rs:54-68)."""
 
@@ -227,6 +256,16 @@ class DoubleArrayAhoCorasick:
 
     def leftmost_find_iter(self, haystack, engine=Engine.Auto, stream=None):
         return _LazyIter(self, ScanMode.LeftmostFind, haystack, engine, stream)
+
+    # ---- steppers for haystacks that arrive in pieces (bytewise.rs:238-251, 353-375; iter.rs:344-475) ------------------
+    def find_stepper(self, engine=Engine.Auto, stream=None):
+        return _Stepper(self, ScanMode.Find, engine, stream)
+
+    def find_overlapping_stepper(self, engine=Engine.Auto, stream=None):
+        return _Stepper(self, ScanMode.FindOverlapping, engine, stream)
+
+    def find_overlapping_no_suffix_stepper(self, engine=Engine.Auto, stream=None):
+        return _Stepper(self, ScanMode.FindOverlappingNoSuffix, engine, stream)
 
     # ---- eager forms (`.collect()` / `.count()` on the iterators) ---------------------------------------------
     def scan(self, mode, haystack, engine=Engine.Auto, stream=None):

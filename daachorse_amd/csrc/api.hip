@@ -937,6 +937,138 @@ void daac_iter_close(daac_iter *it) {
     delete it;
 }
 
+}  // extern "C"
+
+// ------------------------------------------------------------------------------ chunk-fed steppers
+struct daac_stream {
+    daac_pma *pma;
+    int mode, engine;
+    hipStream_t stream;
+    uint64_t consumed = 0;   // bytes fed so far
+    uint64_t resume = 0;     // FIND: where the chain restarts (>= kept_from)
+    uint64_t kept_from = 0;  // stream offset of byte 0 of `kept`
+    void *kept = nullptr;    // device copy of stream bytes [kept_from, consumed)
+    bool started = false;
+    ~daac_stream() { if (kept) (void)hipFree(kept); }
+};
+
+// first character boundary at or after `pos` (charwise streams); the bytes are on the device
+static daac_status boundary_at_or_after(const uint8_t *dev_virt, uint64_t pos, uint64_t end, hipStream_t stream, uint64_t *out) {
+    uint8_t b[4] = {0, 0, 0, 0};
+    const uint64_t n = std::min<uint64_t>(4, end > pos ? end - pos : 0);
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(b, dev_virt + pos, n, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    uint64_t k = 0;
+    while (k < n && (b[k] & 0xc0u) == 0x80u) ++k;
+    *out = pos + k;
+    return DAAC_OK;
+}
+
+// end of the last complete character of [.., end) (charwise streams hold an incomplete tail back)
+static daac_status last_complete_char_end(const uint8_t *dev_virt, uint64_t from, uint64_t end, hipStream_t stream, uint64_t *out) {
+    const uint64_t n = std::min<uint64_t>(4, end - from);
+    uint8_t b[4] = {0, 0, 0, 0};
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(b, dev_virt + end - n, n, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    *out = end;
+    for (uint64_t back = 1; back <= n; ++back) {  // the last lead byte within 4 bytes of the end
+        const uint8_t c = b[n - back];
+        if ((c & 0xc0u) == 0x80u) continue;
+        const uint64_t need = c < 0x80u ? 1 : c < 0xe0u ? 2 : c < 0xf0u ? 3 : 4;
+        if (need > back) *out = end - back;       // that character is not complete yet
+        break;
+    }
+    return DAAC_OK;
+}
+
+extern "C" {
+
+daac_status daac_stream_open(daac_pma *pma, int mode, int engine, void *stream, daac_stream **out) {
+    if (!pma || !out) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    if (mode == DAAC_LEFTMOST_FIND) {
+        set_error("the reference has no stepper for leftmost automata (a leftmost match needs the text after it)");
+        return DAAC_ERR_UNSUPPORTED;
+    }
+    daac_status st = check_mode_kind(pma, mode);
+    if (st != DAAC_OK) return st;
+    if (pma->charwise ? (engine != DAAC_ENGINE_AUTO && engine != DAAC_ENGINE_DARRAY) : engine == DAAC_ENGINE_GRAM) {
+        set_error("engine cannot serve a stepper");
+        return DAAC_ERR_UNSUPPORTED;
+    }
+    daac_stream *s = new daac_stream;
+    s->pma = pma; s->mode = mode; s->engine = engine;
+    s->stream = static_cast<hipStream_t>(stream);
+    *out = s;
+    return DAAC_OK;
+}
+
+daac_status daac_stream_feed(daac_stream *s, const uint8_t *chunk, size_t len, int chunk_is_device, daac_matches **out) {
+    if (!s || !out || (len && !chunk)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    std::unique_ptr<daac_matches> m(new daac_matches);
+    if (len == 0 && s->started) { *out = m.release(); return DAAC_OK; }
+    DeviceTables *t = nullptr;
+    daac_status st = get_tables(s->pma, &t);
+    if (st != DAAC_OK) return st;
+    const uint64_t halo = s->pma->halo();
+    const bool find = s->mode == DAAC_FIND;
+    const uint64_t total = s->consumed + len;
+    // what of the old bytes the next scan can still look at: FIND restarts at `resume`, the overlapping scans
+    // warm up over the halo
+    const uint64_t keep = find ? s->resume : (s->consumed > halo ? s->consumed - halo : 0);
+    void *fresh = nullptr;
+    HIP_TRY(hipMalloc(&fresh, total - keep + 32));
+    std::unique_ptr<void, void (*)(void *)> guard(fresh, [](void *p) { (void)hipFree(p); });
+    uint8_t *nb = static_cast<uint8_t *>(fresh);
+    if (s->consumed > keep)
+        HIP_TRY(hipMemcpyAsync(nb, static_cast<const uint8_t *>(s->kept) + (keep - s->kept_from), s->consumed - keep, hipMemcpyDeviceToDevice, s->stream));
+    if (len) HIP_TRY(hipMemcpyAsync(nb + (s->consumed - keep), chunk, len, chunk_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->stream));
+    const uint8_t *virt = nb - keep;  // address stream byte 0 would have
+    if (!find) {
+        // FindOverlappingStepper / no-suffix: everything that ends inside this chunk (and ROOT's list at 0 on the first)
+        if ((st = scan_range_materialize(s->pma, t, s->mode, s->engine, virt, s->consumed, total, total, s->stream, m->v, nullptr)) != DAAC_OK) return st;
+    } else {
+        // FindStepper: the chain goes on from `resume` as if the text ended here; what it has not decided yet is
+        // re-read with the next chunk (a charwise stream also holds an incomplete last character back)
+        uint64_t end = total;
+        if (s->pma->charwise && (st = last_complete_char_end(virt, s->resume, total, s->stream, &end)) != DAAC_OK) return st;
+        if (end < s->resume) end = s->resume;
+        if ((st = scan_range_materialize(s->pma, t, s->mode, s->engine, virt, s->resume, end, end, s->stream, m->v, nullptr)) != DAAC_OK) return st;
+        uint64_t r = m->v.size() ? m->v.p[m->v.size() - 1].end : s->resume;
+        if (s->pma->root_has_output()) {
+            r = end;  // "" among the patterns: one report per position, nothing is ever pending
+        } else if (end > halo && r < end - halo) {
+            // nothing matched for more than a halo: a fresh start `halo` bytes back reaches the same state
+            r = end - halo;
+            if (s->pma->charwise && (st = boundary_at_or_after(virt, r, end, s->stream, &r)) != DAAC_OK) return st;
+        }
+        s->resume = r;
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->started) {
+        // what ends at position 0 ("" among the patterns) was reported by the first call, even an empty one
+        size_t skip = 0;
+        while (skip < m->v.n && m->v.p[skip].end == 0) ++skip;
+        if (skip) { std::memmove(m->v.p, m->v.p + skip, (m->v.n - skip) * sizeof(daac_match)); m->v.n -= skip; }
+    }
+    if (s->kept) (void)hipFree(s->kept);
+    s->kept = guard.release();
+    s->kept_from = keep;
+    s->consumed = total;
+    s->started = true;
+    *out = m.release();
+    return DAAC_OK;
+}
+
+void daac_stream_close(daac_stream *s) { delete s; }
+
+}  // extern "C"
+
+extern "C" {
+
 daac_status daac_set_option(const char *name, int64_t value) {
     if (!name) { set_error("null option name"); return DAAC_ERR_INVALID_ARGUMENT; }
     const std::string n(name);

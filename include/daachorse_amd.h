@@ -176,6 +176,19 @@ daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *h
 int daac_iter_next(daac_iter *it, daac_match *m); /* 1 = Some(m), 0 = None, <0 = -daac_status */
 void daac_iter_close(daac_iter *it);
 
+/* Chunk-fed steppers = FindOverlappingStepper / FindStepper (bytewise/iter.rs:344-475, charwise/iter.rs:403-534)
+ * and the *_from_iter entry points (bytewise.rs:238-251, 353-375) for haystacks that arrive piecewise: feed the
+ * text chunk by chunk (any sizes, cuts may fall inside UTF-8 characters); every call returns the matches it can
+ * already decide — for the overlapping modes everything ending inside the chunk, for DAAC_FIND the chain up to
+ * the end of the data — in stream coordinates, so that the concatenation over all calls is exactly what the
+ * iterator reports on the concatenated text.  The library keeps at most max-pattern-length bytes (DAAC_FIND: the
+ * undecided tail) of earlier chunks on the device.  Modes: DAAC_FIND_OVERLAPPING, DAAC_FIND,
+ * DAAC_FIND_OVERLAPPING_NO_SUFFIX (the reference has no leftmost stepper: a leftmost match needs lookahead). */
+typedef struct daac_stream daac_stream;
+daac_status daac_stream_open(daac_pma *pma, int mode, int engine, void *stream, daac_stream **out);
+daac_status daac_stream_feed(daac_stream *s, const uint8_t *chunk, size_t len, int chunk_is_device, daac_matches **out);
+void daac_stream_close(daac_stream *s);
+
 /* ---- tuning knobs (optional) ----------------------------------------------------------------- */
 /* Process-wide name/value pairs for experiments; defaults in parentheses.  Options that shape the device tables
  * ("lds_budget", "dense_depth", "rows_share_pct", "gram_lds_budget", "gram_rank_in_lds", "char_map_lds") are read
