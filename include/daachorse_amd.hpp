@@ -107,6 +107,29 @@ private:
     std::unique_ptr<daac_iter, detail::IterDeleter> it_;
 };
 
+// FindStepper / FindOverlappingStepper (src/bytewise/iter.rs:344-475, src/charwise/iter.rs:403-534), fed a chunk
+// at a time: feed() returns the matches decided so far, positions counted from the first byte ever fed.
+class Stepper {
+public:
+    std::vector<Match> feed(std::string_view chunk) {
+        daac_matches *m = nullptr;
+        const daac_status st = daac_stream_feed(s_.get(), reinterpret_cast<const uint8_t *>(chunk.data()), chunk.size(), 0, &m);
+        if (st != DAAC_OK) throw PanicError(std::string("device scan failed: ") + daac_last_error());
+        std::vector<Match> out;
+        const daac_match *p = daac_matches_data(m);
+        for (size_t i = 0, n = daac_matches_count(m); i < n; ++i) out.emplace_back(p[i].start, p[i].end, p[i].value);
+        daac_matches_free(m);
+        return out;
+    }
+
+private:
+    template <class F>
+    friend class BasicAhoCorasick;
+    struct Closer { void operator()(daac_stream *s) const { daac_stream_close(s); } };
+    explicit Stepper(daac_stream *s) : s_(s) {}
+    std::unique_ptr<daac_stream, Closer> s_;
+};
+
 namespace detail {
 // Which pair of C entry points builds / parses the automaton behind a handle (the scans are shared).
 struct Bytewise {  // src/bytewise.rs, src/bytewise/builder.rs
@@ -165,6 +188,10 @@ public:
         return open(DAAC_LEFTMOST_FIND, std::move(haystack), "Error: match_kind must be leftmost.");
     }
 
+    // bytewise.rs:238-251, 353-375 / charwise.rs: steppers for text that arrives in pieces
+    Stepper find_stepper() const { return open_stepper(DAAC_FIND); }
+    Stepper find_overlapping_stepper() const { return open_stepper(DAAC_FIND_OVERLAPPING); }
+
     MatchKind match_kind() const { return static_cast<MatchKind>(info().match_kind); }
     size_t num_states() const { return info().num_states; }
     size_t heap_bytes() const { return info().heap_bytes; }
@@ -177,6 +204,13 @@ private:
         daac_info i;
         daac_pma_info(h_.get(), &i);
         return i;
+    }
+    Stepper open_stepper(int mode) const {
+        daac_stream *st = nullptr;
+        const daac_status rc = daac_stream_open(h_.get(), mode, DAAC_ENGINE_AUTO, nullptr, &st);
+        if (rc == DAAC_ERR_MATCH_KIND) throw PanicError("Error: match_kind must be standard.");
+        if (rc != DAAC_OK) throw PanicError(std::string("device scan failed: ") + daac_last_error());
+        return Stepper(st);
     }
     MatchIterator open(int mode, std::string hay, const char *panic_msg) const {
         auto keep = std::make_unique<std::string>(std::move(hay));

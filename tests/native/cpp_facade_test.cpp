@@ -67,6 +67,11 @@ int main(int argc, char **argv) {
     CHECK(!cit.next());
     auto cll = CharwiseDoubleArrayAhoCorasickBuilder().match_kind(MatchKind::LeftmostLongest).build({"世界", "全世界", "世"}).unwrap();
     CHECK(same(cll.leftmost_find_iter("全世界中に世").collect(), {Match(0, 9, 1), Match(15, 18, 2)}));
+    auto stepper = pma.find_overlapping_stepper();  // the text in three pieces, a pattern across each cut
+    std::vector<Match> fed;
+    for (const char *piece : {"a", "bc", "d"})
+        for (const Match &x : stepper.feed(piece)) fed.push_back(x);
+    CHECK(same(fed, {Match(0, 1, 2), Match(0, 2, 1), Match(1, 4, 0)}));
     std::printf("OK gpu\n");
     return 0;
 }
