@@ -34,6 +34,7 @@ struct Options {
     std::atomic<int64_t> gram_lds_budget{158 * 1024};
     std::atomic<int64_t> gram_region{16 * 1024};
     std::atomic<int64_t> gram_slab{2048};
+    std::atomic<int64_t> gram_ppl{0};           // 0 = auto (32 positions per lane for automata without short patterns), 16, 32
     std::atomic<int64_t> gram_dense{-1};        // -1 = decide per automaton
     std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
@@ -770,7 +771,8 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         ga.hay_al = sub - ga.lead;
         ga.vlen = ga.lead + static_cast<uint64_t>(len - begin);
         uint64_t region = static_cast<uint64_t>(g_opt.gram_region.load());
-        region = std::max<uint64_t>(1024, region & ~1023ull);
+        region = std::max<uint64_t>(2048, region & ~2047ull);
+        ga.ppl = (!t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;
         ga.result = d_res;
@@ -1084,6 +1086,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_region") g_opt.gram_region = value;
     else if (n == "gram_slab") g_opt.gram_slab = value;
     else if (n == "gram_dense") g_opt.gram_dense = value;
+    else if (n == "gram_ppl") g_opt.gram_ppl = value;
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;
     else if (n == "chain_rounds") g_opt.chain_rounds = value;

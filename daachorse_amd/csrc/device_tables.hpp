@@ -99,6 +99,7 @@ struct GramArgs {
     unsigned long long *result;  // {count, S1, S2}
     uint2 *wq;                   // per-wave walker slabs: {position lo, state | class after next << 27}
     uint32_t wq_slab;            // entries per wave
+    uint32_t ppl;                // positions per lane and step: 16 or 32 (region_bytes is a multiple of 64 * ppl)
     uint32_t dense;              // B hits are frequent: queue them position by position without testing the group first
 };
 

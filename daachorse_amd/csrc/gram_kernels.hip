@@ -77,7 +77,9 @@ __device__ __forceinline__ void gram_reduce(unsigned long long cnt, uint32_t s1,
     }
 }
 
-template <int K, bool HAS_SHORT, int TPB, bool DENSE, bool RANK_LDS>
+// P = positions (bytes) a lane takes per step: 16, or 32 for automata without short patterns (their step is so
+// cheap that the per-step work — neighbour exchange, prefetch bookkeeping — and the load latency show)
+template <int K, bool HAS_SHORT, int TPB, bool DENSE, bool RANK_LDS, int P>
 __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const GramArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gram_copy(smem, g.cls32, 1024);
@@ -242,51 +244,63 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
 #pragma unroll
         for (int i = 0; i < K; ++i) carry |= (rbase >= static_cast<uint64_t>(K - i) ? class_at(rbase - (K - i)) : 0u) << (8 * i);
 
-        uint4 pf[kPrefetch + 1];
+        constexpr int Q = P / 16;               // 16-byte loads per lane and step
+        constexpr uint64_t SB = 64ull * P;      // bytes a wave takes per step
+        uint4 pf[kPrefetch + 1][Q];
 #pragma unroll
         for (int i = 0; i <= kPrefetch; ++i)
-            pf[i] = (rbase + 1024ull * i < rend) ? load_chunk(rbase + 1024ull * i + lane * 16) : uint4{ub4, ub4, ub4, ub4};
-
-        for (uint64_t sb = rbase; sb < rend; sb += 1024) {
-            if (wq_n + 256u > a.wq_slab) drain();  // a step retires at most a few batches of 64 walkers
-            const uint64_t v = sb + lane * 16;
-            const uint32_t v32 = static_cast<uint32_t>(v);
-            const uint4 cur = pf[0];
 #pragma unroll
-            for (int i = 0; i < kPrefetch; ++i) pf[i] = pf[i + 1];
-            pf[kPrefetch] = (sb + 1024ull * (kPrefetch + 1) < rend) ? load_chunk(v + 1024ull * (kPrefetch + 1)) : uint4{ub4, ub4, ub4, ub4};
+            for (int h = 0; h < Q; ++h)
+                pf[i][h] = (rbase + SB * i < rend) ? load_chunk(rbase + SB * i + lane * P + 16 * h) : uint4{ub4, ub4, ub4, ub4};
 
-            // the two bytes after this wave's 1 KiB (lane 63 needs their classes): lane 0's share of the chunk that
+        for (uint64_t sb = rbase; sb < rend; sb += SB) {
+            if (wq_n + 16u * P > a.wq_slab) drain();  // a step retires at most a few batches of 64 walkers
+            const uint64_t v = sb + lane * P;
+            const uint32_t v32 = static_cast<uint32_t>(v);
+            uint4 cur[Q];
+#pragma unroll
+            for (int h = 0; h < Q; ++h) cur[h] = pf[0][h];
+#pragma unroll
+            for (int i = 0; i < kPrefetch; ++i)
+#pragma unroll
+                for (int h = 0; h < Q; ++h) pf[i][h] = pf[i + 1][h];
+#pragma unroll
+            for (int h = 0; h < Q; ++h)
+                pf[kPrefetch][h] = (sb + SB * (kPrefetch + 1) < rend) ? load_chunk(v + SB * (kPrefetch + 1) + 16 * h) : uint4{ub4, ub4, ub4, ub4};
+
+            // the two bytes after this wave's share (lane 63 needs their classes): lane 0's part of the chunk that
             // is already in flight or, on the last step of a region, two wave-uniform loads
             uint32_t after2;
-            if (sb + 1024 < rend) {
-                after2 = __builtin_amdgcn_readfirstlane(pf[0].x);
+            if (sb + SB < rend) {
+                after2 = __builtin_amdgcn_readfirstlane(pf[0][0].x);
             } else {
-                const uint64_t p0 = sb + 1024, p1 = sb + 1025;
+                const uint64_t p0 = sb + SB, p1 = sb + SB + 1;
                 after2 = ((p0 >= a.lead && p0 < a.vlen) ? hay[p0] : g.unused_byte) | (((p1 >= a.lead && p1 < a.vlen) ? hay[p1] : g.unused_byte) << 8);
             }
 
-            // ---- byte classes of this lane's 16 positions plus K to the left and 2 to the right ----
-            uint32_t kx[K + 18];
+            // ---- byte classes of this lane's P positions plus K to the left and 2 to the right ----
+            uint32_t kx[K + P + 2];
             {
-                const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+                uint32_t w[4 * Q];
 #pragma unroll
-                for (int b = 0; b < 16; ++b) kx[K + b] = cls_of((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
+                for (int h = 0; h < Q; ++h) { w[4 * h] = cur[h].x; w[4 * h + 1] = cur[h].y; w[4 * h + 2] = cur[h].z; w[4 * h + 3] = cur[h].w; }
+#pragma unroll
+                for (int b = 0; b < P; ++b) kx[K + b] = cls_of((w[b >> 2] >> (8 * (b & 3))) & 0xffu);
             }
             uint32_t pk = 0;
 #pragma unroll
-            for (int i = 0; i < K; ++i) pk |= kx[16 + i] << (8 * i);  // this lane's last K classes, oldest low
+            for (int i = 0; i < K; ++i) pk |= kx[P + i] << (8 * i);  // this lane's last K classes, oldest low
             uint32_t left = __shfl_up(pk, 1, 64);
             if (lane == 0) left = carry;
             carry = __shfl(pk, 63, 64);
 #pragma unroll
             for (int i = 0; i < K; ++i) kx[i] = (left >> (8 * i)) & 0xffu;
-            uint32_t right = __shfl_down(kx[K] | (kx[K + 1] << 5), 1, 64);  // the two classes after this lane's 16
+            uint32_t right = __shfl_down(kx[K] | (kx[K + 1] << 5), 1, 64);  // the two classes after this lane's P
             uint32_t right63 = cls_of(after2 & 0xffu) | (cls_of((after2 >> 8) & 0xffu) << 5);  // same address in every lane: a broadcast
             asm volatile("" : "+v"(right63));  // keep the two reads out of a lane-63-only branch: the step stays one basic block
             right = lane == 63 ? right63 : right;
-            kx[K + 16] = right & 31u;
-            kx[K + 17] = right >> 5;
+            kx[K + P] = right & 31u;
+            kx[K + P + 1] = right >> 5;
 
             // ---- per group of kGroup positions: LDS work of every position independently (all reads of
             // the group in flight before the first is consumed), then the B hits are queued ---------------
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             uint32_t wprev = mad_u24(kx[0], C, kx[1]);                               // K classes ending before position 0
             if (K == 3) wprev = mad_u24(wprev, C, kx[2]);
 #pragma unroll
-            for (int grp = 0; grp < 16 / kGroup; ++grp) {
+            for (int grp = 0; grp < P / kGroup; ++grp) {
                 uint32_t iW[kGroup], iB[kGroup], bw[kGroup], id[kGroup];
                 uint2 co[kGroup];
 #pragma unroll
@@ -350,10 +364,10 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                     }
                 }
             }
-            // sum_j hs_j * (e0 + j):  A * (e0 + 16) - T
+            // sum_j hs_j * (e0 + j):  A * (e0 + P) - T
             tot_cnt += ccnt;
             tot_s1 += A;
-            tot_s2 += A * (e0 + 16u) - T;
+            tot_s2 += A * (e0 + static_cast<uint32_t>(P)) - T;
         }
       }
       while (q_n != 0) process_batch();
@@ -363,15 +377,21 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     gram_reduce(tot_cnt, tot_s1, tot_s2, reinterpret_cast<unsigned long long *>(smem), a.result);
 }
 
-template <int K, bool S, int TPB, bool DENSE, bool RL>
-static hipError_t launch_rl(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
+template <int K, bool S, int TPB, bool DENSE, bool RL, int P>
+static hipError_t launch_p(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
     if (dev.lds_bytes > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram_count_kernel<K, S, TPB, DENSE, RL>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram_count_kernel<K, S, TPB, DENSE, RL, P>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(dev.lds_bytes));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((gram_count_kernel<K, S, TPB, DENSE, RL>), dim3(blocks), dim3(threads), dev.lds_bytes, stream, dev, a);
+    hipLaunchKernelGGL((gram_count_kernel<K, S, TPB, DENSE, RL, P>), dim3(blocks), dim3(threads), dev.lds_bytes, stream, dev, a);
     return hipGetLastError();
+}
+template <int K, bool S, int TPB, bool DENSE, bool RL>
+static hipError_t launch_rl(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
+    // 32 positions per lane only where the step is light: no short patterns, 1024-thread workgroups
+    if (!S && TPB == 1024 && a.ppl == 32) return launch_p<K, S, TPB, DENSE, RL, (!S && TPB == 1024) ? 32 : 16>(dev, a, blocks, threads, stream);
+    return launch_p<K, S, TPB, DENSE, RL, 16>(dev, a, blocks, threads, stream);
 }
 template <int K, bool S, int TPB, bool DENSE>
 static hipError_t launch_pipe(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream) {
