@@ -397,7 +397,11 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
         return DAAC_ERR_UNSUPPORTED;
     }
     pl.tier = !pl.charwise && !pl.restart && (engine == DAAC_ENGINE_TIERED || (engine == DAAC_ENGINE_AUTO && t->tier_ok));
-    const uint32_t halo = pma->halo();
+    uint32_t halo = pma->halo();
+    // The sync-point scanners decide "is the classic state ROOT here" from a warm-up over the halo, and every lane
+    // must reach the same verdict as a lane that has been following the text for longer: Lmax whole bytes, so that a
+    // pattern of maximal length ending exactly at the cut is seen too.
+    if (pl.restart) halo = std::max(halo, pma->max_pattern_len());
     uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
     threads = std::min(1024u, std::max(64u, threads & ~63u));
     uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());

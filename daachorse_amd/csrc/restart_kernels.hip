@@ -9,7 +9,8 @@
 // to the next can be scanned as if it were a haystack of its own.
 //
 // One lane per segment [lo, hi):
-//   p = first sync point >= lo   (classic automaton warmed up over the (Lmax-1)-byte halo, then
+//   p = first sync point >= lo   (classic automaton warmed up over Lmax bytes — enough to land on the state a
+//                                 lane that followed the text from further back is in, whatever its depth — then
 //                                 advanced until it sits at ROOT); the lane owns nothing if p >= hi
 //   q = first sync point >= hi   (same procedure) — the next owner starts exactly there
 //   then the reference's loop, literally, over [p, q), positions offset by p.

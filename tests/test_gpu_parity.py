@@ -334,6 +334,23 @@ def test_fuzz_find_and_leftmost(seg_bytes, chain):
             assert p.scan_count(mode, hay) == (len(want), orc.matches_checksum(want)), (kind, pats)
 
 
+def test_sync_point_verdicts_do_not_depend_on_the_warm_up():
+    """Regression (found by tools/stress.py): text that never returns to ROOT, a pattern of maximal length ending
+    exactly at a segment cut.  A lane warming up over Lmax - 1 bytes saw ROOT there, a lane that had followed the
+    text did not, and their regions overlapped."""
+    da.set_option("restart_chain", 0)
+    for pats, unit in ((["cab", "cbabab"], "cabcbabab"), (["ab", "abcabc", "cabca"], "abcabc"), (["aaaa", "a"], "aaaa")):
+        text = (unit * 400).encode()
+        for kind, api, mode in (("LeftmostLongest", "leftmost_find_iter", ScanMode.LeftmostFind), ("LeftmostFirst", "leftmost_find_iter", ScanMode.LeftmostFind),
+                                ("Standard", "find_iter", ScanMode.Find)):
+            o, p = _pma(pats, kind=kind)
+            want = getattr(o, api)(text)
+            for seg in (16, 32, 48, 64, 0):
+                da.set_option("seg_bytes", seg)
+                assert _same(p.scan(mode, text), want), (pats, kind, seg)
+                assert p.scan_count(mode, text) == (len(want), orc.matches_checksum(want)), (pats, kind, seg)
+
+
 def test_find_and_leftmost_dictionaries():
     """cfg2 / cfg3-style automata, all three kinds, MiB-sized sparse and dense haystacks, lazy windows."""
     import torch
