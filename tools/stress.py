@@ -66,6 +66,15 @@ while time.time() - t0 < budget and not (len(sys.argv) > 3 and sys.argv[3] == "g
         assert p.scan_count(mode, text) == (len(want), orc.matches_checksum(want)), ctx
         if len(text) < 3000:
             assert [(m.start(), m.end(), m.value()) for m in getattr(p, api)(text)] == sev(want), ctx
+        if kind == 0 and rng.random() < 0.5:  # the same through a chunk-fed stepper, random cuts (also inside characters)
+            raw = text.encode()
+            cuts = sorted(int(x) for x in rng.integers(0, len(raw) + 1, size=int(rng.integers(0, 6))))
+            st = getattr(p, api.replace("_iter", "_stepper"))()
+            fed, prev = [], 0
+            for c in cuts + [len(raw)]:
+                fed += sev(st.feed(raw[prev:c]))
+                prev = c
+            assert fed == sev(want), ("stepper", cuts) + ctx
         checks += 1
 if cases:
     print(f"stress ok: {cases} automata, {checks} iterator checks in {time.time() - t0:.0f} s (seed {seed})")
