@@ -30,12 +30,21 @@ while time.time() - t0 < budget and not (len(sys.argv) > 3 and sys.argv[3] == "g
     A = ALPHAS[int(rng.integers(0, len(ALPHAS)))]
     multibyte = any(len(c.encode()) > 1 for c in A)
     npat = int(rng.integers(1, 40))
-    pats = ["".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(1, 7)))) for _ in range(npat)]
+    maxlen = int(rng.choice([3, 7, 7, 15, 40]))
+    pats = ["".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(1, maxlen + 1)))) for _ in range(npat)]
+    if rng.random() < 0.3:  # families with common prefixes / suffixes
+        pats += [pats[0] + q for q in pats[:5]] + [q + pats[-1] for q in pats[:5]]
     if rng.random() < 0.15 and not (multibyte and len({len(c.encode()) for c in A}) > 1):
         pats.insert(int(rng.integers(0, len(pats) + 1)), "")
     text = "".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(0, 6000))))
     if rng.random() < 0.2:
         text = (pats[0] + pats[-1]) * int(rng.integers(1, 300))  # periodic: chains that never fall in step
+    elif rng.random() < 0.4:  # text made of patterns and pieces of patterns: deep states, long failure chains
+        parts = []
+        for _ in range(int(rng.integers(1, 800))):
+            w = pats[int(rng.integers(0, len(pats)))]
+            parts.append(w[:int(rng.integers(0, len(w) + 1))] if rng.random() < 0.5 else w)
+        text = "".join(parts)
     charwise = multibyte or rng.random() < 0.4
     kind = int(rng.integers(0, 3))
     da.set_option("seg_bytes", int(rng.choice([0, 16, 32, 48, 256, 1024])))
@@ -95,6 +104,10 @@ def gram_soak(seconds, seed):
         pats = [bytes(syms[rng.integers(0, nsym, size=int(rng.integers(lo, hi + 1)))]) for _ in range(npat)]
         noise = rng.choice(np.concatenate([syms, np.frombuffer(b" .,\n", dtype=np.uint8)]), size=int(rng.integers(1000, 3_000_000)))
         hay = noise.astype(np.uint8)
+        if rng.random() < 0.5:  # text made of the patterns themselves (deep trie walks, many walkers)
+            idx = rng.integers(0, npat, size=max(1, len(hay) // max(1, (lo + hi) // 2 + 1)))
+            sep = b" " if rng.random() < 0.5 else b""
+            hay = np.frombuffer(sep.join(pats[i] for i in idx.tolist())[:len(hay)] or b"x", dtype=np.uint8).copy()
         for _ in range(int(rng.integers(0, 200))):  # plant some patterns
             w = np.frombuffer(pats[int(rng.integers(0, npat))], dtype=np.uint8)
             at = int(rng.integers(0, max(1, len(hay) - len(w))))
