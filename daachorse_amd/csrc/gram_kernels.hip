@@ -254,7 +254,8 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                 pf[i][h] = (rbase + SB * i < rend) ? load_chunk(rbase + SB * i + lane * P + 16 * h) : uint4{ub4, ub4, ub4, ub4};
 
         for (uint64_t sb = rbase; sb < rend; sb += SB) {
-            if (wq_n + 16u * P > a.wq_slab) drain();  // a step retires at most a few batches of 64 walkers
+            // every position of the step can queue a walker, and so can the batch still in flight from the step before
+            if (wq_n + 64u * P + 64u > a.wq_slab) drain();
             const uint64_t v = sb + lane * P;
             const uint32_t v32 = static_cast<uint32_t>(v);
             uint4 cur[Q];

@@ -448,3 +448,21 @@ def test_gram_haystack_beyond_4_gib():
     h1, h2 = ddist.split_checksum(head[1])
     t1, t2 = ddist.split_checksum(tail[1])
     assert (head[0] + tail[0], ddist.join_checksum(h1 + t1, h2 + t2)) == want
+
+
+def test_gram_text_made_of_patterns_overflows_nothing():
+    """Regression (found by tools/stress.py): text in which EVERY position continues deep in the trie queues a
+    walker per position — more than the slab margin of a step allowed for, so entries spilled into the
+    neighbouring wave's slab.  Pattern-made text over small alphabets, both positions-per-lane variants."""
+    import torch
+    rng = np.random.default_rng(1051)
+    for nsym, npat, lo, hi, sep in ((4, 500, 4, 8, b" "), (7, 5, 2, 7, b""), (3, 40, 5, 12, b""), (2, 6, 3, 9, b"")):
+        syms = np.arange(97, 97 + nsym, dtype=np.uint8)
+        pats = [bytes(syms[rng.integers(0, nsym, size=int(rng.integers(lo, hi + 1)))]) for _ in range(npat)]
+        idx = rng.integers(0, npat, size=200_000)
+        hay = np.frombuffer(sep.join(pats[i] for i in idx.tolist())[:900_000], dtype=np.uint8).copy()
+        o, p = _pma(pats)
+        dev = torch.from_numpy(hay).cuda()[1:]
+        want = o.overlapping_count(dev.cpu().numpy(), threads=8)
+        for eng in (Engine.Auto, Engine.Tiered, Engine.DArray):
+            assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want, (nsym, npat, eng)

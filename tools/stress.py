@@ -113,7 +113,8 @@ def gram_soak(seconds, seed):
             at = int(rng.integers(0, max(1, len(hay) - len(w))))
             hay[at:at + len(w)] = w[:len(hay) - at]
         o = orc.OraclePma.build(pats)
-        da.set_option("gram_lds_budget", int(rng.choice([158 * 1024, 40 * 1024, 9216])))
+        da_budget = int(rng.choice([158 * 1024, 40 * 1024, 9216]))
+        da.set_option("gram_lds_budget", da_budget)
         p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
         dev = torch.from_numpy(hay).cuda()[int(rng.integers(0, 16)):]
         want = o.overlapping_count(dev.cpu().numpy(), threads=8)
@@ -124,6 +125,10 @@ def gram_soak(seconds, seed):
             except da.DaachorseError as e:
                 assert e.code == 6 and eng in (Engine.Gram, Engine.Tiered), (eng, str(e))
                 continue
+            if got != want:
+                os.makedirs("gpurun_out", exist_ok=True)
+                np.savez(f"gpurun_out/gram_fail_{seed}_{n_auto}.npz", hay=dev.cpu().numpy(), blob=np.frombuffer(o.serialize(), dtype=np.uint8),
+                         budget=np.array([da_budget]), eng=np.array([int(eng)]))
             assert got == want, (eng, nsym, npat, lo, hi, len(hay), got, want)
             n_gram += eng == Engine.Gram
         begin = int(rng.integers(1, len(dev)))
