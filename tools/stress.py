@@ -115,6 +115,13 @@ def gram_soak(seconds, seed):
         o = orc.OraclePma.build(pats)
         da_budget = int(rng.choice([158 * 1024, 40 * 1024, 9216]))
         da.set_option("gram_lds_budget", da_budget)
+        da.set_option("gram_region", int(rng.choice([2048, 16384, 65536])))
+        da.set_option("gram_slab", int(rng.choice([0, 4096, 20000])))
+        da.set_option("threads", int(rng.choice([1024, 1024, 768, 512, 256, 64])))
+        da.set_option("blocks_per_cu", int(rng.choice([0, 0, 1, 2])))
+        da.set_option("gram_ppl", int(rng.choice([0, 16])))
+        da.set_option("gram_dense", int(rng.choice([-1, 0, 1])))
+        da.set_option("seg_bytes", int(rng.choice([0, 0, 64, 4096])))
         p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
         dev = torch.from_numpy(hay).cuda()[int(rng.integers(0, 16)):]
         want = o.overlapping_count(dev.cpu().numpy(), threads=8)
@@ -137,7 +144,9 @@ def gram_soak(seconds, seed):
         s = lambda c: ((c >> 32) & 0xFFFFFFFF, c & 0xFFFFFFFF)
         tot = (head[0] + tail[0], (((s(head[1])[0] + s(tail[1])[0]) & 0xFFFFFFFF) << 32) | ((s(head[1])[1] + s(tail[1])[1]) & 0xFFFFFFFF))
         assert tot == want, ("shards", begin, tot, want)
-    da.set_option("gram_lds_budget", 158 * 1024)
+    for k, v in (("gram_lds_budget", 158 * 1024), ("gram_region", 16384), ("gram_slab", 4096), ("threads", 1024), ("blocks_per_cu", 0),
+                 ("gram_ppl", 0), ("gram_dense", -1), ("seg_bytes", 0)):
+        da.set_option(k, v)
     print(f"gram soak ok: {n_auto} automata ({n_gram} on the GRAM engine) in {time.time() - t0:.0f} s (seed {seed})")
 
 
