@@ -45,6 +45,12 @@ while time.time() - t0 < budget and not (len(sys.argv) > 3 and sys.argv[3] == "g
             w = pats[int(rng.integers(0, len(pats)))]
             parts.append(w[:int(rng.integers(0, len(w) + 1))] if rng.random() < 0.5 else w)
         text = "".join(parts)
+    if rng.random() < 0.04:  # now and then something bigger: thousands of patterns, megabytes of text
+        big = [chr(c) for c in (range(0x61, 0x61 + 12) if not multibyte else range(0x3041, 0x3041 + 40))]
+        pats = list({"".join(big[i] for i in rng.integers(0, len(big), size=int(rng.integers(2, 9)))) for _ in range(3000)})
+        words = [pats[i] for i in rng.integers(0, len(pats), size=200_000)]
+        text = ("" if rng.random() < 0.5 else " ").join(words)[:int(rng.integers(100_000, 1_500_000))]
+        A = big
     charwise = multibyte or rng.random() < 0.4
     kind = int(rng.integers(0, 3))
     da.set_option("seg_bytes", int(rng.choice([0, 16, 32, 48, 256, 1024])))
