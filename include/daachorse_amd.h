@@ -162,8 +162,12 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
                             uint64_t *result_dev);
 
 /* The same over the tail of a haystack: counts the matches with end in (begin, len] — what one
- * shard of a haystack split across devices contributes.  Bytes before begin - (Lmax - 1) are never
- * read (they need not be resident), byte 0 of the haystack is still `hay`. */
+ * shard of a haystack split across devices contributes.  Bytes before begin - Lmax are never read (they need
+ * not be resident), byte 0 of the haystack is still `hay`.  For the overlapping modes any `begin` works (charwise:
+ * also inside a character).  DAAC_FIND / DAAC_LEFTMOST_FIND are chains through their own matches: there `begin`
+ * must be a position where the iterator restarts (0, or the end of a match it reported), and the call reports
+ * what the iterator reports from there on.  These two modes settle the chain before counting and synchronise
+ * the stream even when `result_dev` is given. */
 daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin,
                                   int hay_is_device, void *stream, uint64_t *count, uint64_t *checksum,
                                   uint64_t *result_dev);
