@@ -39,8 +39,8 @@ struct Options {
     std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
-    std::atomic<int64_t> char_map_lds{0};       // charwise chain scans: stage the code mapper in LDS when it fits (measured
-                                                // slower on cfg5: 88 vs 105 GB/s, the lanes it costs matter more than the gather)
+    std::atomic<int64_t> char_map_lds{0};       // charwise chain scans: stage the populated stretch of the code mapper in LDS
+                                                // (off: measured slower on cfg5, 88 vs 104 GB/s — the stretch is L1-resident anyway)
 };
 static Options g_opt;
 
@@ -212,7 +212,20 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         c.n = static_cast<uint32_t>(ct.states.size());
         c.root_flag = ct.root_flag;
         c.leftmost = !pma->chost.is_standard();
-        c.map_in_lds = g_opt.char_map_lds.load() != 0 && c.table_len * 2u <= 48u * 1024u && pma->chost.alphabet_size < 0xffffu;
+        // Stage [map_lo, table_len) of the mapper in LDS when that stretch is small: map_lo = the lowest start for which
+        // it fits 32 KB, moved up to the first mapped code point at or above it (CJK text: the table is dense from the
+        // kana up, ASCII below stays in L2).
+        {
+            const uint32_t cap = 16u * 1024u;  // u16 entries
+            uint32_t lo = c.table_len > cap ? c.table_len - cap : 0u;
+            while (lo < c.table_len && ct.table[lo] == kInvalidCode) ++lo;
+            c.map_lo = lo;
+            uint32_t staged = 0;
+            for (uint32_t i = lo; i < c.table_len; ++i) staged += ct.table[i] != kInvalidCode;
+            // worth it only if most of the alphabet lives in the stretch
+            c.map_in_lds = g_opt.char_map_lds.load() != 0 && lo < c.table_len && pma->chost.alphabet_size < 0xffffu &&
+                           staged * 4u >= pma->chost.alphabet_size * 3u;
+        }
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipSetDevice(prev));
         *out = t.get();

@@ -24,7 +24,8 @@ __device__ __forceinline__ uint64_t cw_mix64(uint64_t z) {
 
 struct CwState { uint32_t idx, base, fail, opos; };
 
-// MAPLDS: the code mapper is staged in LDS as u16 (0xffff = unmapped) — one L2 gather less per character
+// MAPLDS: the populated stretch [map_lo, table_len) of the code mapper is staged in LDS as u16 (0xffff = unmapped):
+// one L2 round trip less per character; code points below map_lo (ASCII in CJK text) still go to the L2 copy
 template <bool MAPLDS>
 struct CwTablesT {
     using State = CwState;
@@ -66,7 +67,9 @@ struct CwTablesT {
     }
     __device__ __forceinline__ uint32_t code_of(uint32_t cp) const {
         if (MAPLDS) {
-            const uint32_t c = cp < d.table_len ? l_map[cp] : 0xffffu;
+            if (cp >= d.table_len) return 0xffffffffu;
+            if (cp < d.map_lo) return d.table[cp];
+            const uint32_t c = l_map[cp - d.map_lo];
             return c == 0xffffu ? 0xffffffffu : c;
         }
         return cp < d.table_len ? d.table[cp] : 0xffffffffu;
@@ -277,9 +280,9 @@ __global__ __launch_bounds__(MAPLDS ? 512 : 256) void char_chain_kernel(const Ch
     extern __shared__ __attribute__((aligned(16))) uint16_t l_map[];
     __shared__ unsigned long long scratch[3 * 8];
     if (MAPLDS && PASS != 3) {
-        for (uint32_t i = threadIdx.x; i < dev.table_len; i += blockDim.x) {
+        for (uint32_t i = dev.map_lo + threadIdx.x; i < dev.table_len; i += blockDim.x) {
             const uint32_t code = dev.table[i];
-            l_map[i] = code == 0xffffffffu ? 0xffffu : static_cast<uint16_t>(code);
+            l_map[i - dev.map_lo] = code == 0xffffffffu ? 0xffffu : static_cast<uint16_t>(code);
         }
         __syncthreads();
     }
@@ -293,9 +296,9 @@ __global__ __launch_bounds__(MAPLDS ? 512 : 256) void char_chain_kernel(const Ch
 template <bool MAPLDS>
 static hipError_t launch_char_chain_ml(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
                                        unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
-    // with the mapper in LDS three 512-thread workgroups share a CU (<= 48 KB each)
-    const dim3 g(MAPLDS ? (blocks * 3u + 7u) / 8u : blocks), b(MAPLDS ? 512 : 256);
-    const uint32_t lds = MAPLDS && pass != 3 ? ((dev.table_len * 2u + 15u) & ~15u) : 0u;
+    // with the mapper in LDS (<= 32 KB) four 512-thread workgroups share a CU: the same 2048 lanes as without
+    const dim3 g(MAPLDS ? (blocks + 1u) / 2u : blocks), b(MAPLDS ? 512 : 256);
+    const uint32_t lds = MAPLDS && pass != 3 ? (((dev.table_len - dev.map_lo) * 2u + 15u) & ~15u) : 0u;
 #define DAAC_CC(L, P, M) hipLaunchKernelGGL((char_chain_kernel<L, P, M, MAPLDS>), g, b, lds, stream, dev, a, c, next_begin)
     if (pass == 0) { if (leftmost) DAAC_CC(true, 0, 0); else DAAC_CC(false, 0, 0); }
     else if (pass == 1) { if (leftmost) DAAC_CC(true, 1, 0); else DAAC_CC(false, 1, 0); }
@@ -308,7 +311,7 @@ static hipError_t launch_char_chain_ml(const CharDev &dev, const ScanArgs &a, co
 
 hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
                              unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
-    // u16 codes, at most 48 KB of LDS: otherwise the mapper stays in L2
+    // u16 codes of the populated stretch, at most 32 KB of LDS: otherwise the mapper stays in L2
     const bool map_lds = dev.map_in_lds != 0;
     return map_lds ? launch_char_chain_ml<true>(dev, a, c, pass, kmode, leftmost, next_begin, blocks, stream)
                    : launch_char_chain_ml<false>(dev, a, c, pass, kmode, leftmost, next_begin, blocks, stream);

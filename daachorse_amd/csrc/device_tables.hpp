@@ -44,7 +44,8 @@ struct CharDev {
     const uint2 *osum;           // per output record {chain count, chain sum of h32}
     const uint32_t *outputs;     // n_outputs x {value, length, parent}
     uint32_t table_len, n, root_flag, leftmost;
-    uint32_t map_in_lds;         // the mapper fits a CU's LDS as u16 codes (table_len * 2 <= 48 KB, alphabet < 65535)
+    uint32_t map_in_lds;         // the populated stretch of the mapper fits LDS as u16 codes ((table_len - map_lo) * 2 <= 32 KB)
+    uint32_t map_lo;             // first code point worth staging (the dense tail of the table starts here)
 };
 
 struct ScanArgs {
