@@ -12,9 +12,6 @@ import daachorse_amd as da
 from daachorse_amd import ScanMode
 from oracle import oracle as orc
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(seed)
 APIS = {0: [("find_overlapping_iter", ScanMode.FindOverlapping), ("find_overlapping_no_suffix_iter", ScanMode.FindOverlappingNoSuffix),
             ("find_iter", ScanMode.Find)], 1: [("leftmost_find_iter", ScanMode.LeftmostFind)], 2: [("leftmost_find_iter", ScanMode.LeftmostFind)]}
 ALPHAS = [list("ab"), list("abc"), list("abcde"), [chr(c) for c in range(0x3041, 0x3046)], list("aé世") + ["\U0001F600"]]
@@ -24,75 +21,84 @@ def sev(m):
     return [(int(x["start"]), int(x["end"]), int(x["value"])) for x in m]
 
 
-t0 = time.time()
-cases = checks = 0
-while time.time() - t0 < budget and not (len(sys.argv) > 3 and sys.argv[3] == "gram"):
-    A = ALPHAS[int(rng.integers(0, len(ALPHAS)))]
-    multibyte = any(len(c.encode()) > 1 for c in A)
-    npat = int(rng.integers(1, 40))
-    maxlen = int(rng.choice([3, 7, 7, 15, 40]))
-    pats = ["".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(1, maxlen + 1)))) for _ in range(npat)]
-    if rng.random() < 0.3:  # families with common prefixes / suffixes
-        pats += [pats[0] + q for q in pats[:5]] + [q + pats[-1] for q in pats[:5]]
-    if rng.random() < 0.15 and not (multibyte and len({len(c.encode()) for c in A}) > 1):
-        pats.insert(int(rng.integers(0, len(pats) + 1)), "")
-    text = "".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(0, 6000))))
-    if rng.random() < 0.2:
-        text = (pats[0] + pats[-1]) * int(rng.integers(1, 300))  # periodic: chains that never fall in step
-    elif rng.random() < 0.4:  # text made of patterns and pieces of patterns: deep states, long failure chains
-        parts = []
-        for _ in range(int(rng.integers(1, 800))):
-            w = pats[int(rng.integers(0, len(pats)))]
-            parts.append(w[:int(rng.integers(0, len(w) + 1))] if rng.random() < 0.5 else w)
-        text = "".join(parts)
-    if rng.random() < 0.04:  # now and then something bigger: thousands of patterns, megabytes of text
-        big = [chr(c) for c in (range(0x61, 0x61 + 12) if not multibyte else range(0x3041, 0x3041 + 40))]
-        pats = list({"".join(big[i] for i in rng.integers(0, len(big), size=int(rng.integers(2, 9)))) for _ in range(3000)})
-        words = [pats[i] for i in rng.integers(0, len(pats), size=200_000)]
-        text = ("" if rng.random() < 0.5 else " ").join(words)[:int(rng.integers(100_000, 1_500_000))]
-        A = big
-    charwise = multibyte or rng.random() < 0.4
-    kind = int(rng.integers(0, 3))
-    da.set_option("seg_bytes", int(rng.choice([0, 16, 32, 48, 256, 1024])))
-    da.set_option("restart_chain", int(rng.random() < 0.8))
-    da.set_option("chain_rounds", int(rng.choice([1, 2, 24])))
-    da.set_option("iter_window", int(rng.choice([4096, 64 << 20])))
-    if charwise:
-        o = orc.OracleCharwisePma.build(pats, kind=kind)
-        p, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(o.serialize())
-    else:
-        o = orc.OraclePma.build(pats, kind=kind)
-        p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
-    cases += 1
-    for api, mode in APIS[kind]:
-        try:
-            want = getattr(o, api)(text)
-        except orc.OracleError as e:
-            assert e.code == 6
+
+
+def iter_soak(budget, seed):
+    """all iterators and steppers of both automaton flavours against the oracle, random everything"""
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    cases = checks = 0
+    while time.time() - t0 < budget:
+        A = ALPHAS[int(rng.integers(0, len(ALPHAS)))]
+        multibyte = any(len(c.encode()) > 1 for c in A)
+        npat = int(rng.integers(1, 40))
+        maxlen = int(rng.choice([3, 7, 7, 15, 40]))
+        pats = ["".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(1, maxlen + 1)))) for _ in range(npat)]
+        if rng.random() < 0.3:  # families with common prefixes / suffixes
+            pats += [pats[0] + q for q in pats[:5]] + [q + pats[-1] for q in pats[:5]]
+        if rng.random() < 0.15 and not (multibyte and len({len(c.encode()) for c in A}) > 1):
+            pats.insert(int(rng.integers(0, len(pats) + 1)), "")
+        text = "".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(0, 6000))))
+        if rng.random() < 0.2:
+            text = (pats[0] + pats[-1]) * int(rng.integers(1, 300))  # periodic: chains that never fall in step
+        elif rng.random() < 0.4:  # text made of patterns and pieces of patterns: deep states, long failure chains
+            parts = []
+            for _ in range(int(rng.integers(1, 800))):
+                w = pats[int(rng.integers(0, len(pats)))]
+                parts.append(w[:int(rng.integers(0, len(w) + 1))] if rng.random() < 0.5 else w)
+            text = "".join(parts)
+        if rng.random() < 0.04:  # now and then something bigger: thousands of patterns, megabytes of text
+            big = [chr(c) for c in (range(0x61, 0x61 + 12) if not multibyte else range(0x3041, 0x3041 + 40))]
+            pats = list({"".join(big[i] for i in rng.integers(0, len(big), size=int(rng.integers(2, 9)))) for _ in range(3000)})
+            words = [pats[i] for i in rng.integers(0, len(pats), size=200_000)]
+            text = ("" if rng.random() < 0.5 else " ").join(words)[:int(rng.integers(100_000, 1_500_000))]
+            A = big
+        charwise = multibyte or rng.random() < 0.4
+        kind = int(rng.integers(0, 3))
+        da.set_option("seg_bytes", int(rng.choice([0, 16, 32, 48, 256, 1024])))
+        da.set_option("restart_chain", int(rng.random() < 0.8))
+        da.set_option("chain_rounds", int(rng.choice([1, 2, 24])))
+        da.set_option("iter_window", int(rng.choice([4096, 64 << 20])))
+        if charwise:
+            o = orc.OracleCharwisePma.build(pats, kind=kind)
+            p, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(o.serialize())
+        else:
+            o = orc.OraclePma.build(pats, kind=kind)
+            p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+        cases += 1
+        for api, mode in APIS[kind]:
             try:
-                p.scan(mode, text)
-                raise SystemExit(f"expected Unsupported: {pats!r} {text[:80]!r} {api}")
-            except da.DaachorseError as e2:
-                assert e2.code == 6
-            continue
-        got = p.scan(mode, text)
-        ctx = (charwise, kind, api, pats, text[:200], len(text))
-        assert sev(got) == sev(want), ctx
-        assert p.scan_count(mode, text) == (len(want), orc.matches_checksum(want)), ctx
-        if len(text) < 3000:
-            assert [(m.start(), m.end(), m.value()) for m in getattr(p, api)(text)] == sev(want), ctx
-        if kind == 0 and rng.random() < 0.5:  # the same through a chunk-fed stepper, random cuts (also inside characters)
-            raw = text.encode()
-            cuts = sorted(int(x) for x in rng.integers(0, len(raw) + 1, size=int(rng.integers(0, 6))))
-            st = getattr(p, api.replace("_iter", "_stepper"))()
-            fed, prev = [], 0
-            for c in cuts + [len(raw)]:
-                fed += sev(st.feed(raw[prev:c]))
-                prev = c
-            assert fed == sev(want), ("stepper", cuts) + ctx
-        checks += 1
-if cases:
-    print(f"stress ok: {cases} automata, {checks} iterator checks in {time.time() - t0:.0f} s (seed {seed})")
+                want = getattr(o, api)(text)
+            except orc.OracleError as e:
+                assert e.code == 6
+                try:
+                    p.scan(mode, text)
+                    raise SystemExit(f"expected Unsupported: {pats!r} {text[:80]!r} {api}")
+                except da.DaachorseError as e2:
+                    assert e2.code == 6
+                continue
+            got = p.scan(mode, text)
+            ctx = (charwise, kind, api, pats, text[:200], len(text))
+            assert sev(got) == sev(want), ctx
+            assert p.scan_count(mode, text) == (len(want), orc.matches_checksum(want)), ctx
+            if len(text) < 3000:
+                assert [(m.start(), m.end(), m.value()) for m in getattr(p, api)(text)] == sev(want), ctx
+            if kind == 0 and rng.random() < 0.5:  # the same through a chunk-fed stepper, random cuts (also inside characters)
+                raw = text.encode()
+                cuts = sorted(int(x) for x in rng.integers(0, len(raw) + 1, size=int(rng.integers(0, 6))))
+                st = getattr(p, api.replace("_iter", "_stepper"))()
+                fed, prev = [], 0
+                for c in cuts + [len(raw)]:
+                    fed += sev(st.feed(raw[prev:c]))
+                    prev = c
+                assert fed == sev(want), ("stepper", cuts) + ctx
+            checks += 1
+    if cases:
+        print(f"stress ok: {cases} automata, {checks} iterator checks in {time.time() - t0:.0f} s (seed {seed})")
+
+
+    for k, v in (("seg_bytes", 0), ("restart_chain", 1), ("chain_rounds", 24), ("iter_window", 64 << 20)):
+        da.set_option(k, v)
 
 
 def gram_soak(seconds, seed):
@@ -156,5 +162,10 @@ def gram_soak(seconds, seed):
     print(f"gram soak ok: {n_auto} automata ({n_gram} on the GRAM engine) in {time.time() - t0:.0f} s (seed {seed})")
 
 
-if len(sys.argv) > 3 and sys.argv[3] == "gram":
-    gram_soak(budget, seed + 1000)
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "gram":
+        gram_soak(budget, seed + 1000)
+    else:
+        iter_soak(budget, seed)
