@@ -800,8 +800,8 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / t->gram.lds_bytes));
         const uint32_t blocks = static_cast<uint32_t>(
             std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (ga.nregions + wpb - 1) / wpb)));
-        // room for what one step can queue at worst (64 * ppl + 64 walkers) on top of a useful fill level
-        ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(2 * (64 * ga.ppl + 64), g_opt.gram_slab.load()));
+        // room for what one step can queue at worst (64 * ppl + 128 walkers) on top of a useful fill level
+        ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(2 * (64 * ga.ppl + 128), g_opt.gram_slab.load()));
         // more than ~1 % of the (K+1)-grams are trie prefixes: some lane of the wave hits on nearly every position
         ga.dense = g_opt.gram_dense.load() >= 0 ? g_opt.gram_dense.load() != 0
                                                 : static_cast<uint64_t>(t->gram.n_deep) * 100 > static_cast<uint64_t>(t->gram.CCC) * (t->gram.K == 3 ? t->gram.C : 1);

@@ -254,8 +254,9 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                 pf[i][h] = (rbase + SB * i < rend) ? load_chunk(rbase + SB * i + lane * P + 16 * h) : uint4{ub4, ub4, ub4, ub4};
 
         for (uint64_t sb = rbase; sb < rend; sb += SB) {
-            // every position of the step can queue a walker, and so can the batch still in flight from the step before
-            if (wq_n + 64u * P + 64u > a.wq_slab) drain();
+            // a walker is queued when its hit is retired, and a step can retire every hit it makes (64 * P) plus what
+            // the step before left in the stack (< 64) and in flight (64)
+            if (wq_n + 64u * P + 128u > a.wq_slab) drain();
             const uint64_t v = sb + lane * P;
             const uint32_t v32 = static_cast<uint32_t>(v);
             uint4 cur[Q];

@@ -466,3 +466,23 @@ def test_gram_text_made_of_patterns_overflows_nothing():
         want = o.overlapping_count(dev.cpu().numpy(), threads=8)
         for eng in (Engine.Auto, Engine.Tiered, Engine.DArray):
             assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want, (nsym, npat, eng)
+    # second defect of the same family: every position hits AND continues, so a step retires its own 64 * P hits plus
+    # what the previous step left in the stack and in flight (K = 2 tables, 16 positions per lane, smallest slab)
+    syms = np.frombuffer(b"acinrs", dtype=np.uint8)
+    pats = [bytes(syms[rng.integers(0, 6, size=int(rng.integers(4, 9)))]) for _ in range(5000)]
+    hay = np.frombuffer(b"".join(pats[i] for i in rng.integers(0, 5000, size=60_000).tolist())[:300_000], dtype=np.uint8).copy()
+    da.set_option("gram_lds_budget", 9216)
+    da.set_option("gram_ppl", 16)
+    da.set_option("gram_slab", 0)
+    try:
+        o, p = _pma(pats)
+        dev = torch.from_numpy(hay).cuda()[13:]
+        want = o.overlapping_count(dev.cpu().numpy(), threads=8)
+        assert p.upload().info().gram_k == 2
+        assert p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want
+        da.set_option("gram_ppl", 0)
+        assert p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want
+    finally:
+        da.set_option("gram_lds_budget", 158 * 1024)
+        da.set_option("gram_ppl", 0)
+        da.set_option("gram_slab", 4096)

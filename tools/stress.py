@@ -127,13 +127,11 @@ def gram_soak(seconds, seed):
         o = orc.OraclePma.build(pats)
         da_budget = int(rng.choice([158 * 1024, 40 * 1024, 9216]))
         da.set_option("gram_lds_budget", da_budget)
-        da.set_option("gram_region", int(rng.choice([2048, 16384, 65536])))
-        da.set_option("gram_slab", int(rng.choice([0, 4096, 20000])))
-        da.set_option("threads", int(rng.choice([1024, 1024, 768, 512, 256, 64])))
-        da.set_option("blocks_per_cu", int(rng.choice([0, 0, 1, 2])))
-        da.set_option("gram_ppl", int(rng.choice([0, 16])))
-        da.set_option("gram_dense", int(rng.choice([-1, 0, 1])))
-        da.set_option("seg_bytes", int(rng.choice([0, 0, 64, 4096])))
+        opts = {"gram_region": int(rng.choice([2048, 16384, 65536])), "gram_slab": int(rng.choice([0, 4096, 20000])),
+                "threads": int(rng.choice([1024, 1024, 768, 512, 256, 64])), "blocks_per_cu": int(rng.choice([0, 0, 1, 2])),
+                "gram_ppl": int(rng.choice([0, 16])), "gram_dense": int(rng.choice([-1, 0, 1])), "seg_bytes": int(rng.choice([0, 0, 64, 4096]))}
+        for k, v in opts.items():
+            da.set_option(k, v)
         p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
         dev = torch.from_numpy(hay).cuda()[int(rng.integers(0, 16)):]
         want = o.overlapping_count(dev.cpu().numpy(), threads=8)
@@ -148,7 +146,7 @@ def gram_soak(seconds, seed):
                 os.makedirs("gpurun_out", exist_ok=True)
                 np.savez(f"gpurun_out/gram_fail_{seed}_{n_auto}.npz", hay=dev.cpu().numpy(), blob=np.frombuffer(o.serialize(), dtype=np.uint8),
                          budget=np.array([da_budget]), eng=np.array([int(eng)]))
-            assert got == want, (eng, nsym, npat, lo, hi, len(hay), got, want)
+            assert got == want, (eng, nsym, npat, lo, hi, len(hay), got, want, opts, da_budget)
             n_gram += eng == Engine.Gram
         begin = int(rng.integers(1, len(dev)))
         head = p.scan_count(ScanMode.FindOverlapping, dev[:begin])
