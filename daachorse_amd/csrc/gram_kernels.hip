@@ -109,6 +109,9 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     const uint32_t *l_bsuper = reinterpret_cast<const uint32_t *>(smem + g.off_bsuper);
 
     const uint32_t lane = threadIdx.x & 63;
+    // the wave's index, as a scalar: everything derived from it (regions, step bounds, fill levels of the hit stack
+    // and the slab) then lives in SGPRs and the loops branch on SCC instead of masking lanes
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t C = g.C;
     const uint32_t PK = K == 3 ? g.CCC : g.CC;   // C^K
     const int32_t negPK = -static_cast<int32_t>(PK);
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     // (K+1)-gram, the depth-(K+2) state reached on the byte at p + 1 | class of the byte at p + 2 << 27};
     // all entries of a slab share the bits of p above 2^32 (slab_hi): it is emptied before they change
     uint2 *__restrict__ slab =
-        a.wq + (static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * a.wq_slab;
+        a.wq + (static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg) * a.wq_slab;
     uint32_t wq_n = 0, slab_hi = 0;  // wave-uniform
 
     unsigned long long tot_cnt = 0;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
 
     // ---- the hit ring: entry = {gram index | classes of the next two bytes << 20 / << 25, low 32 bits of the position}
     // (a stack: batches are taken from the top, so no wrap-around arithmetic; order does not matter)
-    uint2 *ring = reinterpret_cast<uint2 *>(smem + g.off_scratch) + (threadIdx.x >> 6) * kRing;
+    uint2 *ring = reinterpret_cast<uint2 *>(smem + g.off_scratch) + wave_in_wg * kRing;
     uint32_t q_n = 0;                           // wave-uniform
     uint2 pend = uint2{0u, 0u};                 // record read for the previous batch, not yet consumed
     uint32_t pend_item = 0, pend_pos = 0, pend_rank = 0;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         const unsigned long long m = __ballot(go);
         if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker (same slab epoch: see the step loop)
             if (go)
-                slab[wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
+                (slab + wq_n)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
                     uint2{pend_pos, (g.cfirst[pend_rank] + __popc(r.x & ((1u << k1) - 1u))) | ((pend_item >> 25) << 27)};
             wq_n += __popcll(m);
         }
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     // Regions (multiples of 1 KiB) never straddle a multiple of 4 GiB.  The wave works through its regions one
     // 4 GiB epoch at a time and retires everything queued before moving on, so that every position in the hit
     // stack, the pending batch and the walker slab shares its bits above 2^32 (slab_hi).
-    uint64_t region = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint64_t region = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg;
     while (region < a.nregions) {
       slab_hi = static_cast<uint32_t>((region * a.region_bytes) >> 32);
       for (; region < a.nregions && static_cast<uint32_t>((region * a.region_bytes) >> 32) == slab_hi; region += nwaves) {
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
             for (int i = 0; i < kPrefetch; ++i)
 #pragma unroll
                 for (int h = 0; h < Q; ++h) pf[i][h] = pf[i + 1][h];
+            consume_pending();  // before the next chunk is requested: loads retire in order, the batch's records must not queue behind it
 #pragma unroll
             for (int h = 0; h < Q; ++h)
                 pf[kPrefetch][h] = (sb + SB * (kPrefetch + 1) < rend) ? load_chunk(v + SB * (kPrefetch + 1) + 16 * h) : uint4{ub4, ub4, ub4, ub4};
@@ -343,10 +347,10 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                     const int j = grp * kGroup + jj;
                     const unsigned long long m = __ballot(hit);
                     if (m != 0) {  // wave-uniform
-                        const uint32_t q_s = __builtin_amdgcn_readfirstlane(q_n);  // the fill level lives in a scalar register
+                        const uint32_t q_s = q_n;  // wave-uniform (a scalar register: everything it is computed from is)
                         if (hit) {
                             const uint32_t nx = lshl_or(kx[K + j + 2], 5, kx[K + j + 1]);
-                            ring[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), q_s))] =
+                            (ring + q_s)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] =
                                 uint2{lshl_or(nx, 20, iB[jj]), v32 + j};
                         }
                         q_n = q_s + static_cast<uint32_t>(__popcll(m));
