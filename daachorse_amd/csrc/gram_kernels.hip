@@ -218,6 +218,10 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     };
     // takes up to 64 queued hits, one per lane: issue their record reads, retire the previous batch
     auto process_batch = [&]() {
+        // a wave with records in flight runs at raised priority until it has retired them at the top of its next
+        // step: the four waves of a SIMD stop marching in phase (measured +3-4 %; either polarity works, a static
+        // per-wave priority does not)
+        __builtin_amdgcn_s_setprio(2);
         consume_pending();
         const uint32_t n = q_n < 64u ? q_n : 64u;
         q_n -= n;
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
 #pragma unroll
                 for (int h = 0; h < Q; ++h) pf[i][h] = pf[i + 1][h];
             consume_pending();  // before the next chunk is requested: loads retire in order, the batch's records must not queue behind it
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int h = 0; h < Q; ++h)
                 pf[kPrefetch][h] = (sb + SB * (kPrefetch + 1) < rend) ? load_chunk(v + SB * (kPrefetch + 1) + 16 * h) : uint4{ub4, ub4, ub4, ub4};
