@@ -77,10 +77,12 @@ def lib():
     L.daac_synth_uniform.argtypes = [vp, sz, C.c_uint64, vp, C.c_uint32, C.c_uint64, vp]
     L.daac_synth_wordsoup.argtypes = [vp, sz, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32,
                                       vp, C.c_uint32, C.c_uint64, vp]
+    L.daac_synth_zipf_text.argtypes = [vp, sz, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_uint64, vp]
     for name in ("daac_bytewise_from_serialized", "daac_bytewise_from_parts", "daac_bytewise_build", "daac_charwise_from_serialized",
                  "daac_charwise_build", "daac_pma_serialize",
                  "daac_pma_info", "daac_pma_upload", "daac_scan", "daac_scan_count", "daac_scan_count_range", "daac_iter_open", "daac_stream_open", "daac_stream_feed", "daac_set_option",
-                 "daac_synth_uniform", "daac_synth_wordsoup"):
+                 "daac_synth_uniform", "daac_synth_wordsoup", "daac_synth_zipf_text"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -80,6 +80,49 @@ __global__ __launch_bounds__(256) void synth_wordsoup_kernel(uint8_t *out, uint6
     }
 }
 
+// Zipf text (cfg5): the haystack is a sequence of `slot`-byte slots of whole UTF-8 characters.  Character k
+// of slot s is drawn from zz = mix64(z(s) + k + 1): an ASCII byte ascii_lo + ((zz >> 8 & 0xffffff) * ascii_n >> 24) when
+// (zz & 0xff) < ascii_256, otherwise the 3-byte code point cps[i], i = first index with cum[i] > ((zz >> 32) * cum[n-1]) >> 32.
+// A slot is filled while 3 bytes are left; the last 1-2 bytes are ASCII draws of the same stream.
+__global__ __launch_bounds__(256) void synth_zipf_text_kernel(uint8_t *out, uint64_t len, uint64_t seed, const uint32_t *cps,
+                                                                const uint32_t *cum, uint32_t n_sym, uint32_t ascii_256,
+                                                                uint32_t ascii_lo, uint32_t ascii_n, uint32_t slot, uint64_t off) {
+    const uint64_t s0 = off / slot;
+    const uint64_t nslots = (off + len + slot - 1) / slot - s0;
+    const uint64_t total = cum[n_sym - 1];
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < nslots;
+         t += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint64_t s = s0 + t;
+        const uint64_t z = synth_z(seed, s);
+        const uint64_t first = s * slot;
+        uint32_t j = 0;
+        for (uint32_t k = 0; j < slot; ++k) {
+            const uint64_t zz = synth_mix64(z + k + 1);
+            uint8_t b[3];
+            uint32_t nb = 1;
+            if (slot - j < 3 || (zz & 0xffu) < ascii_256) {
+                b[0] = static_cast<uint8_t>(ascii_lo + ((((zz >> 8) & 0xffffffu) * ascii_n) >> 24));
+            } else {
+                const uint32_t u = static_cast<uint32_t>(((zz >> 32) * total) >> 32);
+                uint32_t lo = 0, hi = n_sym - 1;  // first index with cum[i] > u
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (cum[mid] > u) hi = mid; else lo = mid + 1;
+                }
+                const uint32_t cp = cps[lo];  // U+0800 .. U+FFFF
+                b[0] = static_cast<uint8_t>(0xe0u | (cp >> 12));
+                b[1] = static_cast<uint8_t>(0x80u | ((cp >> 6) & 0x3fu));
+                b[2] = static_cast<uint8_t>(0x80u | (cp & 0x3fu));
+                nb = 3;
+            }
+            for (uint32_t q = 0; q < nb; ++q, ++j) {
+                const uint64_t i = first + j;
+                if (i >= off && i < off + len) out[i - off] = b[q];
+            }
+        }
+    }
+}
+
 }  // namespace daac
 
 using namespace daac;
@@ -134,4 +177,31 @@ extern "C" daac_status daac_synth_wordsoup(uint8_t *dev_out, size_t len, uint64_
     (void)hipFree(d_words);
     (void)hipFree(d_offs);
     return e == hipSuccess ? DAAC_OK : synth_fail(e, "synth_wordsoup");
+}
+
+extern "C" daac_status daac_synth_zipf_text(uint8_t *dev_out, size_t len, uint64_t seed, const uint32_t *codepoints, const uint32_t *cum_weights,
+                                            uint32_t n_symbols, uint32_t ascii_256, uint32_t ascii_lo, uint32_t ascii_n, uint32_t slot_bytes,
+                                            uint64_t index_offset, void *stream) {
+    if (!codepoints || !cum_weights || n_symbols == 0 || slot_bytes < 3 || ascii_n == 0 || ascii_lo + ascii_n > 128 || ascii_256 > 256) {
+        set_error("bad zipf text parameters");
+        return DAAC_ERR_INVALID_ARGUMENT;
+    }
+    for (uint32_t i = 0; i < n_symbols; ++i)
+        if (codepoints[i] < 0x800u || codepoints[i] > 0xffffu || (codepoints[i] >= 0xd800u && codepoints[i] < 0xe000u) ||
+            (i && cum_weights[i] <= cum_weights[i - 1])) { set_error("code points must be 3-byte scalars with increasing cumulative weights"); return DAAC_ERR_INVALID_ARGUMENT; }
+    if (len == 0) return DAAC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint32_t *d = nullptr;
+    hipError_t e;
+    if ((e = hipMalloc(reinterpret_cast<void **>(&d), 2 * static_cast<size_t>(n_symbols) * sizeof(uint32_t))) != hipSuccess) return synth_fail(e, "hipMalloc");
+    e = hipMemcpyAsync(d, codepoints, n_symbols * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + n_symbols, cum_weights, n_symbols * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(synth_zipf_text_kernel, dim3(4096), dim3(256), 0, s, dev_out, static_cast<uint64_t>(len), seed, d, d + n_symbols,
+                           n_symbols, ascii_256, ascii_lo, ascii_n, slot_bytes, index_offset);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    return e == hipSuccess ? DAAC_OK : synth_fail(e, "synth_zipf_text");
 }

@@ -137,20 +137,27 @@ def patterns_cfg3(n=100_000, seed=SEEDS["cfg3_pat"]):
     return out
 
 
-# cfg5: a CJK-like vocabulary.  Code points: hiragana, katakana, then CJK unified ideographs; every one is
-# 3 bytes in UTF-8.  Characters are drawn with Zipf-like weights (kana and the first ideographs dominate).
-_CFG5_CODEPOINTS = list(range(0x3041, 0x3097)) + list(range(0x30A1, 0x30F7)) + list(range(0x4E00, 0x4E00 + 2228))
-_CFG5_LENGTHS = [(1, 2), (2, 25), (3, 30), (4, 22), (5, 12), (6, 6), (7, 2), (8, 1)]  # characters, percent
+# cfg5: 50 000 distinct UTF-8 patterns of 2-8 scalars drawn with Zipf(1.0) ranks from a 6 000-symbol
+# alphabet (hiragana, katakana, then CJK unified ideographs from U+4E00; all 3 bytes in UTF-8), no empty pattern;
+# the haystack is i.i.d. scalars of the same distribution plus 10 % ASCII (1-byte) characters, cut at a character boundary.
+CFG5_CODEPOINTS = np.array(list(range(0x3041, 0x3097)) + list(range(0x30A1, 0x30F7)) + list(range(0x4E00, 0x4E00 + 6000 - 172)),
+                           dtype=np.uint32)
+CFG5_WEIGHTS = ((1 << 20) // (np.arange(len(CFG5_CODEPOINTS), dtype=np.int64) + 1)).astype(np.uint32)  # Zipf(1.0): weight 1 / rank
+CFG5_CUM = np.cumsum(CFG5_WEIGHTS.astype(np.uint64)).astype(np.uint32)
+CFG5_SLOT = 48           # bytes per slot of the text stream: every multiple is a character boundary
+CFG5_ASCII_256 = 26      # 26 / 256 = 10 % of the scalars are ASCII
+CFG5_ASCII = (0x20, 95)  # printable ASCII 0x20 .. 0x7E
+_CFG5_LENGTHS = [(2, 27), (3, 30), (4, 22), (5, 12), (6, 6), (7, 2), (8, 1)]  # scalars, percent
+SEEDS["cfg5_hay"] = 0xDAAC0015
 
 
 def patterns_cfg5(n=50_000, seed=SEEDS["cfg5_pat"]):
-    """n distinct UTF-8 'words' (bytes), 1..8 characters of 3 bytes each, value = index"""
-    cps = np.array(_CFG5_CODEPOINTS, dtype=np.int64)
-    weights = (1_000_000 / (np.arange(len(cps)) + 12.0)).astype(np.int64)
-    cum_chr = np.cumsum(weights)
+    """n distinct UTF-8 patterns (bytes) of 2..8 three-byte scalars, Zipf(1.0) over CFG5_CODEPOINTS, value = index"""
+    assert len(CFG5_CODEPOINTS) == 6000
+    total = np.uint64(CFG5_CUM[-1])
     cum_len = np.cumsum([w for _, w in _CFG5_LENGTHS])
     len_of = np.array([l for l, _ in _CFG5_LENGTHS])
-    enc = [chr(int(c)).encode("utf-8") for c in cps]
+    enc = [chr(int(c)).encode("utf-8") for c in CFG5_CODEPOINTS]
     seen, out, j = set(), [], 0
     batch = 1 << 15
     while len(out) < n:
@@ -158,12 +165,11 @@ def patterns_cfg5(n=50_000, seed=SEEDS["cfg5_pat"]):
         j += batch
         zl = zstream(seed, idx * np.uint64(5))
         lengths = len_of[np.searchsorted(cum_len, (zl % np.uint64(cum_len[-1])).astype(np.int64), side="right")]
-        # 8 character draws per word, 32 bits each (4 stream words)
+        # 8 scalar draws per pattern, 32 bits each (4 stream words)
         sh = (np.arange(2, dtype=np.uint64) * np.uint64(32))[None, :]
         raw = np.concatenate([(zstream(seed, idx * np.uint64(5) + np.uint64(t))[:, None] >> sh) & np.uint64(0xFFFFFFFF)
                               for t in (1, 2, 3, 4)], axis=1)
-        draw = ((raw * np.uint64(cum_chr[-1])) >> np.uint64(32)).astype(np.int64)
-        chars = np.searchsorted(cum_chr, draw, side="right")
+        chars = np.searchsorted(CFG5_CUM, ((raw * total) >> np.uint64(32)).astype(np.uint32), side="right")
         for row, length in zip(chars, lengths):
             w = b"".join(enc[c] for c in row[:length])
             if w not in seen:
@@ -174,19 +180,46 @@ def patterns_cfg5(n=50_000, seed=SEEDS["cfg5_pat"]):
     return out
 
 
-def cfg5_text_block(words, nbytes, seed=SEEDS["cfg5_dense"], word_share=0.8):
-    """about nbytes of UTF-8 text (numpy uint8, whole characters): dictionary words (word_share of the draws) run
-    together with stray characters of the same vocabulary, no separators — every byte belongs to a 3-byte character"""
-    rng = np.random.default_rng(seed)
-    cps = [chr(c).encode("utf-8") for c in _CFG5_CODEPOINTS]
-    avg = word_share * float(np.mean([len(w) for w in words])) + (1 - word_share) * 3
-    n_items = int(nbytes / avg) + 1
-    pick = rng.integers(0, len(words), size=n_items)
-    stray = rng.integers(0, len(cps), size=n_items)
-    is_word = rng.random(n_items) < word_share
-    text = b"".join(words[i] if w else cps[c] for i, c, w in zip(pick.tolist(), stray.tolist(), is_word.tolist()))
-    text = text[:nbytes - nbytes % 3]
-    return np.frombuffer(text, dtype=np.uint8)
+def zipf_text(n, seed=SEEDS["cfg5_hay"], offset=0, codepoints=CFG5_CODEPOINTS, cum=CFG5_CUM, ascii_256=CFG5_ASCII_256,
+              ascii=CFG5_ASCII, slot=CFG5_SLOT):
+    """bytes offset .. offset+n of the Zipf text stream (see include/daac_synth.h), numpy uint8"""
+    s0, s1 = offset // slot, (offset + n + slot - 1) // slot
+    z = zstream(seed, np.arange(s0, s1, dtype=np.uint64))
+    ns = len(z)
+    out = np.zeros((ns, slot + 3), dtype=np.uint8)
+    pos = np.zeros(ns, dtype=np.int64)
+    total = np.uint64(cum[-1])
+    rows = np.arange(ns)
+    k = 0
+    while True:
+        live = pos < slot
+        if not live.any():
+            break
+        with np.errstate(over="ignore"):
+            zz = mix64(z + np.uint64(k + 1))
+        k += 1
+        is_ascii = ((slot - pos) < 3) | ((zz & np.uint64(0xFF)) < np.uint64(ascii_256))
+        a = (ascii[0] + ((((zz >> np.uint64(8)) & np.uint64(0xFFFFFF)) * np.uint64(ascii[1])) >> np.uint64(24))).astype(np.uint8)
+        u = (((zz >> np.uint64(32)) * total) >> np.uint64(32)).astype(np.uint32)
+        cp = codepoints[np.searchsorted(cum, u, side="right")].astype(np.uint32)
+        b0 = np.where(is_ascii, a, (0xE0 | (cp >> 12)).astype(np.uint8))
+        b1 = (0x80 | ((cp >> 6) & 0x3F)).astype(np.uint8)
+        b2 = (0x80 | (cp & 0x3F)).astype(np.uint8)
+        r = rows[live]
+        out[r, pos[live]] = b0[live]
+        wide = live & ~is_ascii
+        r = rows[wide]
+        out[r, pos[wide] + 1] = b1[wide]
+        out[r, pos[wide] + 2] = b2[wide]
+        pos = np.where(live, pos + np.where(is_ascii, 1, 3), pos)
+    flat = np.ascontiguousarray(out[:, :slot]).reshape(-1)
+    lo = offset - s0 * slot
+    return np.ascontiguousarray(flat[lo:lo + n])
+
+
+def cfg5_haystack_bytes(nominal=1 << 30):
+    """the configured size cut down to a character boundary (a whole number of slots)"""
+    return nominal - nominal % CFG5_SLOT
 
 
 # --------------------------------------------------------------------------------- device generators
@@ -209,4 +242,13 @@ def device_wordsoup(tensor, seed, words, slot_bytes, pad=b" ", noise_256=77, alp
     blob = np.frombuffer(b"".join(words), dtype=np.uint8)
     _ffi.check(_ffi.lib().daac_synth_wordsoup(tensor.data_ptr(), tensor.numel(), C.c_uint64(seed), blob.ctypes.data, offs.ctypes.data,
                                               len(words), slot_bytes, pad[0], noise_256, ap, an, C.c_uint64(offset), stream))
+    return tensor
+
+
+def device_zipf_text(tensor, seed=SEEDS["cfg5_hay"], offset=0, codepoints=CFG5_CODEPOINTS, cum=CFG5_CUM, ascii_256=CFG5_ASCII_256,
+                     ascii=CFG5_ASCII, slot=CFG5_SLOT, stream=None):
+    cps = np.ascontiguousarray(codepoints, dtype=np.uint32)
+    cw = np.ascontiguousarray(cum, dtype=np.uint32)
+    _ffi.check(_ffi.lib().daac_synth_zipf_text(tensor.data_ptr(), tensor.numel(), C.c_uint64(seed), cps.ctypes.data, cw.ctypes.data, len(cps),
+                                               ascii_256, ascii[0], ascii[1], slot, C.c_uint64(offset), stream))
     return tensor

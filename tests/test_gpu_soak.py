@@ -1,6 +1,6 @@
 """A short slice of the randomised soak (tools/stress.py) inside the GPU suite: random automata, haystacks, segment /
-window / chain / chunk settings and launch geometry against the CPU oracle — every run draws the same cases (fixed
-seeds), longer runs with other seeds are for spare GPU minutes."""
+window / chain / chunk settings and launch geometry against the CPU oracle — every run draws the same, fixed NUMBER of cases from fixed
+seeds (count-boxed, not time-boxed), longer runs with other seeds are for spare GPU minutes."""
 import importlib.util
 import os
 
@@ -19,8 +19,8 @@ def _stress():
 
 
 def test_iterators_and_steppers_soak():
-    _stress().iter_soak(8.0, 2024)
+    _stress().iter_soak(0.0, 2024, max_cases=150)
 
 
 def test_count_engines_soak():
-    _stress().gram_soak(8.0, 2025)
+    _stress().gram_soak(0.0, 2025, max_cases=40)

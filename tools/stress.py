@@ -23,12 +23,13 @@ def sev(m):
 
 
 
-def iter_soak(budget, seed):
-    """all iterators and steppers of both automaton flavours against the oracle, random everything"""
+def iter_soak(budget, seed, max_cases=None):
+    """all iterators and steppers of both automaton flavours against the oracle, random everything.
+    `max_cases` set: exactly that many automata whatever the box's speed (the GPU suite); else `budget` seconds."""
     rng = np.random.default_rng(seed)
     t0 = time.time()
     cases = checks = 0
-    while time.time() - t0 < budget:
+    while (cases < max_cases) if max_cases is not None else (time.time() - t0 < budget):
         A = ALPHAS[int(rng.integers(0, len(ALPHAS)))]
         multibyte = any(len(c.encode()) > 1 for c in A)
         npat = int(rng.integers(1, 40))
@@ -101,14 +102,15 @@ def iter_soak(budget, seed):
         da.set_option(k, v)
 
 
-def gram_soak(seconds, seed):
-    """count + checksum of the GRAM engine (and TIERED / DARRAY) against the oracle on random dictionaries"""
+def gram_soak(seconds, seed, max_cases=None):
+    """count + checksum of the GRAM engine (and TIERED / DARRAY) against the oracle on random dictionaries.
+    `max_cases` set: exactly that many automata whatever the box's speed (the GPU suite); else `seconds`."""
     import torch
     from daachorse_amd import Engine
     rng = np.random.default_rng(seed)
     t0 = time.time()
     n_auto = n_gram = 0
-    while time.time() - t0 < seconds:
+    while (n_auto < max_cases) if max_cases is not None else (time.time() - t0 < seconds):
         nsym = int(rng.integers(2, 27))
         syms = rng.choice(np.arange(97, 123), size=nsym, replace=False).astype(np.uint8)
         npat = int(rng.choice([1, 5, 50, 500, 5000]))
