@@ -74,6 +74,8 @@ def lib():
     L.daac_stream_feed.argtypes = [vp, u8p, sz, C.c_int, P(vp)]
     L.daac_stream_close.argtypes = [vp]
     L.daac_set_option.argtypes = [C.c_char_p, C.c_int64]
+    L.daac_last_engine.argtypes = []
+    L.daac_last_engine.restype = C.c_int
     L.daac_synth_uniform.argtypes = [vp, sz, C.c_uint64, vp, C.c_uint32, C.c_uint64, vp]
     L.daac_synth_wordsoup.argtypes = [vp, sz, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32,
                                       vp, C.c_uint32, C.c_uint64, vp]
@@ -92,6 +94,11 @@ def check(status):
     if status != 0:
         msg = lib().daac_last_error()
         raise DaachorseError(status, msg.decode("utf-8", "replace") if msg else "")
+
+
+def last_engine():
+    """daac_engine that served this thread's most recent scan"""
+    return lib().daac_last_engine()
 
 
 def set_option(name, value):

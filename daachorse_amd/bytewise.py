@@ -83,7 +83,9 @@ class _Haystack:
                 self.ptr = None
             return
         if isinstance(h, np.ndarray):
-            a = np.ascontiguousarray(h, dtype=np.uint8)
+            if h.dtype.itemsize != 1:  # a value cast would scan something else than the caller's bytes
+                raise DaachorseError(1, "haystack array must have a 1-byte dtype (uint8)")
+            a = np.ascontiguousarray(h).view(np.uint8)
         else:
             a = np.frombuffer(_as_bytes(h), dtype=np.uint8)
         self.keep = a
@@ -217,7 +219,9 @@ class DoubleArrayAhoCorasick:
             return a, len(a)
         st, n_st = arr(states, 3)
         ls, n_ls = arr(leftmost_states, 2)
-        fl, _ = arr(fails, 1)
+        fl, n_fl = arr(fails, 1)
+        if n_fl != n_ls:  # the C ABI copies n_lstates entries from `fails` (bytewise.rs:61-63: the two arrays are parallel)
+            raise DaachorseError(1, "`fails` must have one entry per leftmost state")
         ou, n_ou = arr(outputs, 3)
         h = C.c_void_p()
         p = lambda a: a.ctypes.data if a is not None and a.size else None

@@ -43,6 +43,7 @@ struct Options {
                                                 // (off: measured slower on cfg5, 88 vs 104 GB/s — the stretch is L1-resident anyway)
 };
 static Options g_opt;
+static thread_local int g_last_engine = DAAC_ENGINE_AUTO;  // engine of this thread's most recent scan (daac_last_engine)
 
 static daac_status hip_fail(hipError_t e, const char *what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -177,6 +178,10 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     int prev = 0;
     HIP_TRY(hipGetDevice(&prev));
     HIP_TRY(hipSetDevice(device));
+    struct DeviceGuard {  // the caller's current device comes back on every return path, errors included
+        int prev;
+        ~DeviceGuard() { (void)hipSetDevice(prev); }
+    } device_guard{prev};
     std::unique_ptr<DeviceTables> t(new DeviceTables);
     t->device = device;
     hipDeviceProp_t prop;
@@ -227,7 +232,6 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                            staged * 4u >= pma->chost.alphabet_size * 3u;
         }
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipSetDevice(prev));
         *out = t.get();
         pma->dev[device] = std::move(t);
         return DAAC_OK;
@@ -335,7 +339,6 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         }
     }
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipSetDevice(prev));
     *out = t.get();
     pma->dev[device] = std::move(t);
     return DAAC_OK;
@@ -534,6 +537,7 @@ daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int
     daac_status st = make_plan(pma, t, mode, engine, begin, end, pl, heads);
     if (st != DAAC_OK) return st;
     out.clear();
+    g_last_engine = pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY;
     if (next_begin) *next_begin = end;
     // an empty range still has to report ROOT's list at end = 0: run one (empty) segment
     if (pl.a.nseg == 0) { if (begin != 0) return DAAC_OK; pl.a.nseg = 1; }
@@ -595,6 +599,7 @@ daac_status stage_window(const uint8_t *host_hay, uint64_t copy_from, uint64_t e
 extern "C" {
 
 const char *daac_last_error(void) { return last_error_cstr(); }
+int daac_last_engine(void) { return g_last_engine; }
 void daac_free(void *p) { std::free(p); }
 
 daac_status daac_bytewise_from_serialized(const uint8_t *blob, size_t len, daac_pma **out, size_t *consumed) {
@@ -610,6 +615,10 @@ daac_status daac_bytewise_from_parts(const uint32_t *states, size_t n_states, co
                                      size_t n_lstates, const uint32_t *outputs, size_t n_outputs, uint8_t match_kind,
                                      uint32_t num_states, daac_pma **out) {
     if (!out || match_kind > 2) { set_error("bad argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    if ((n_states && !states) || (n_lstates && (!lstates || !fails)) || (n_outputs && !outputs)) {
+        set_error("null array with a non-zero count (`fails` must hold n_lstates entries)");
+        return DAAC_ERR_INVALID_ARGUMENT;
+    }
     std::unique_ptr<daac_pma> p(new daac_pma);
     HostPma &h = p->host;
     h.match_kind = match_kind;
@@ -778,6 +787,7 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         pl.a.flags = static_cast<unsigned long long *>(flagbuf);
     }
     std::unique_ptr<void, void (*)(void *)> g3(flagbuf, [](void *p) { if (p) (void)hipFree(p); });
+    g_last_engine = use_gram ? DAAC_ENGINE_GRAM : (pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY);
     if (use_gram && len != begin) {
         // A shard [begin, len) is scanned as a haystack of its own: that counts every occurrence lying inside it,
         // with ends relative to `begin`.  What is missing are the occurrences that start before `begin` and end
@@ -787,8 +797,9 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         ga.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sub) & 15u);
         ga.hay_al = sub - ga.lead;
         ga.vlen = ga.lead + static_cast<uint64_t>(len - begin);
-        uint64_t region = static_cast<uint64_t>(g_opt.gram_region.load());
-        region = std::max<uint64_t>(2048, region & ~2047ull);
+        // a power of two >= 2 KiB: regions then never straddle a multiple of 4 GiB (the kernel keeps 32-bit positions per epoch)
+        uint64_t region = 2048;
+        while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, g_opt.gram_region.load())) && region < (1ull << 30)) region *= 2;
         ga.ppl = (!t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;

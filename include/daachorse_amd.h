@@ -93,6 +93,9 @@ typedef struct daac_iter daac_iter;       /* lazy iterator façade */
 
 const char *daac_last_error(void);
 void daac_free(void *p);
+/* daac_engine that served this thread's most recent scan (AUTO resolves to GRAM / TIERED / DARRAY per request:
+ * e.g. GRAM declines ranges of 32 GiB and more and automata whose tables do not fit LDS). */
+int daac_last_engine(void);
 
 /* ---- construction / (de)serialisation ------------------------------------------------------ */
 
@@ -104,7 +107,8 @@ daac_status daac_bytewise_from_serialized(const uint8_t *blob, size_t len, daac_
 /* Takes the automaton's arrays directly (what a Rust shim has in hand without serialising):
  * `states` = n_states x {base, fail, opos_ch} (State<u32>, bytewise.rs:1131-1137) or, for leftmost
  * kinds, `lstates` = n x {base, opos_ch} + `fails` (bytewise.rs:61-63); `outputs` = n_outputs x
- * {value, length, parent} (lib.rs:213-218).  Same validation as deserialize. */
+ * {value, length, parent} (lib.rs:213-218).  Same validation as deserialize.  `fails` must hold n_lstates entries;
+ * a NULL array with a non-zero count is DAAC_ERR_INVALID_ARGUMENT. */
 daac_status daac_bytewise_from_parts(const uint32_t *states, size_t n_states,
                                      const uint32_t *lstates, const uint32_t *fails, size_t n_lstates,
                                      const uint32_t *outputs, size_t n_outputs,
@@ -156,7 +160,10 @@ void daac_matches_free(daac_matches *m);
  * (`.count()` on the iterator).  checksum = (S1 << 32) | S2 with, over all matches,
  *   h = low32(mix64(value << 32 | length)),  S1 = sum h,  S2 = sum h * low32(end)   (mod 2^32).
  * Asynchronous on `stream` when `result_dev` != NULL: the 3 x u64 {count, S1, S2} are left in
- * device memory there and count/checksum may be NULL; otherwise the call synchronises. */
+ * device memory there and count/checksum may be NULL; otherwise the call synchronises.
+ * Device haystacks are read in whole aligned 16-byte granules: up to 15 bytes before `hay` and after `hay + len`
+ * (inside the same 16-byte granules as the first / last byte) are loaded and masked out, never interpreted.  Any
+ * hipMalloc'ed buffer satisfies this (allocations are 256-byte granular); a sub-range of a larger allocation always does. */
 daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len,
                             int hay_is_device, void *stream, uint64_t *count, uint64_t *checksum,
                             uint64_t *result_dev);
@@ -200,7 +207,7 @@ void daac_stream_close(daac_stream *s);
  *   seg_bytes (0 = auto)        bytes of haystack per lane-segment of the segment scanners
  *   threads (1024), blocks_per_cu (0 = auto)   launch shape of the overlapping scanners
  *   lds_budget (98304), dense_depth (-1 = auto), rows_share_pct (45)   TIERED re-pack
- *   gram_lds_budget (161792), gram_region (16384), gram_slab (4096), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto),
+ *   gram_lds_budget (161792), gram_region (16384; rounded down to a power of two >= 2048), gram_slab (4096), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto),
  *   gram_ppl (0 = auto: 32 positions per lane and step for automata without short patterns, else 16)
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners

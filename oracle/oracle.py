@@ -31,6 +31,15 @@ def build_lib(force=False):
     return _LIB_PATH
 
 
+def build_native_lib():
+    """The same sources with -O3 -march=native, compiled on the machine that runs it (never shipped: a binary tuned to
+    one host's CPU may not start on another).  Used by bench.py's cpu_baseline leg (DAAC_ORACLE_NATIVE=1)."""
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), f"liboracle_native_{os.getuid()}.so")
+    subprocess.check_call(["make", "-C", _HERE, "-B", "native", f"NATIVE_OUT={out}"], stdout=subprocess.DEVNULL)
+    return out
+
+
 class _Pma(C.Structure):
     _fields_ = [
         ("states", C.c_void_p), ("n_states", C.c_size_t),
@@ -58,8 +67,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build_lib()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(build_native_lib() if os.environ.get("DAAC_ORACLE_NATIVE") == "1" else build_lib())
         P = C.POINTER
         L.orc_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint32, P(P(_Pma))]
         L.orc_build.restype = C.c_int

@@ -75,3 +75,49 @@ def test_shard_ranges_cover_exactly():
             edges = [shard_range(total, r, world, align=4096) for r in range(world)]
             assert edges[0][0] == 0 and edges[-1][1] == total
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+
+
+def _run_bench(extra, env_extra=None, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 prints the one line
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks (torchrun on 127.0.0.1), reduces over
+    them and prints n_gpus = 2.  --plumbing: no device and no scan, only launch + rendezvous + reduction + the line."""
+    line = _run_bench(["--gpus", "2", "--plumbing", "--steps", "2", "--warmup", "1", "--scaling", "strong"])
+    assert line["n_gpus"] == 2 and line["plumbing_only"] is True and line["value"] is None and line["scaling"] == "strong"
+    assert line["reduced"] == [3, ((30 << 32) | 300)]  # sums over ranks 0 and 1 of {r + 1, 10 (r + 1), 100 (r + 1)}
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DAAC_BENCH_OVERSUBSCRIBE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0 and "hipGetDeviceCount" in (out.stderr + out.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_weak_and_strong():
+    """the real step under the self-launcher: two ranks share the box's GPU (oversubscribed, gloo for the reduce).
+    Strong scaling must reproduce the single-rank count + checksum of the same haystack exactly."""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu", "--no-dense", "--materialize-mib", "0", "--workload", "cfg2"]
+    env = {"DAAC_DIST_BACKEND": "gloo", "DAAC_BENCH_OVERSUBSCRIBE": "1"}
+    one = _run_bench(["--gpus", "1", "--bytes", str(96 << 20)] + common)
+    strong = _run_bench(["--gpus", "2", "--scaling", "strong", "--bytes", str(96 << 20)] + common, env)
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
+    assert strong["match_count"] == one["match_count"] and strong["match_checksum"] == one["match_checksum"]
+    assert strong["config"]["haystack_bytes_job"] == 96 << 20 and strong["config"]["engine_used"] == "gram"
+    weak = _run_bench(["--gpus", "2", "--bytes", str(32 << 20)] + common, env)
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["haystack_bytes_job"] == 64 << 20
+    assert weak["value"] > 0 and weak["match_count"] > 0

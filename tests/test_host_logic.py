@@ -73,6 +73,32 @@ def test_from_parts_equals_blob():
     assert a.serialize() == o.serialize()
 
 
+def test_from_parts_rejects_short_or_missing_arrays():
+    """the C ABI copies n_lstates entries from `fails`: a short array must not be read past its end"""
+    import ctypes as C
+    from daachorse_amd import _ffi
+    o = orc.OraclePma.build(["he", "she", "his", "hers"], kind="LeftmostLongest")
+    with pytest.raises(da.DaachorseError) as ei:
+        da.DoubleArrayAhoCorasick.from_parts(1, o.num_states, o.outputs(), leftmost_states=o.leftmost_states(), fails=o.fails()[:-1])
+    assert ei.value.code == 1
+    h = C.c_void_p()
+    ls = np.ascontiguousarray(o.leftmost_states(), dtype=np.uint32)
+    ou = np.ascontiguousarray(o.outputs(), dtype=np.uint32)
+    st = _ffi.lib().daac_bytewise_from_parts(None, 0, ls.ctypes.data, None, len(ls), ou.ctypes.data, len(ou), 1, o.num_states, C.byref(h))
+    assert st == 1 and not h.value  # NULL `fails` with a non-zero count
+    st = _ffi.lib().daac_bytewise_from_parts(None, 5, None, None, 0, ou.ctypes.data, len(ou), 0, o.num_states, C.byref(h))
+    assert st == 1 and not h.value
+
+
+def test_numpy_haystack_must_be_bytes():
+    """a non-uint8 array is rejected, not value-cast (torch tensors are checked the same way)"""
+    p = da.DoubleArrayAhoCorasick.new(["ab"])
+    for bad in (np.arange(8, dtype=np.int32), np.ones(4, dtype=np.float32)):
+        with pytest.raises(da.DaachorseError) as ei:
+            p.scan_count(da.ScanMode.FindOverlapping, bad)
+        assert ei.value.code == 1
+
+
 @pytest.fixture(scope="module")
 def repack_check(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("native") / "repack_check")
