@@ -29,7 +29,9 @@ class Info(C.Structure):
                 ("num_classes", C.c_uint32), ("tier_dense_states", C.c_uint32), ("tier_lds_states", C.c_uint32),
                 ("tier_lds_bytes", C.c_uint32), ("tiered_available", C.c_uint8), ("gram_available", C.c_uint8),
                 ("gram_k", C.c_uint32), ("gram_lds_bytes", C.c_uint32),
-                ("charwise", C.c_uint8), ("alphabet_size", C.c_uint32)]
+                ("charwise", C.c_uint8), ("alphabet_size", C.c_uint32),
+                ("gram2_available", C.c_uint8), ("gram2_exact", C.c_uint8), ("gram2_k", C.c_uint32),
+                ("gram2_lds_count", C.c_uint32), ("gram2_lds_exact", C.c_uint32)]
 
 
 def lib():
@@ -73,6 +75,8 @@ def lib():
     L.daac_stream_open.argtypes = [vp, C.c_int, C.c_int, vp, P(vp)]
     L.daac_stream_feed.argtypes = [vp, u8p, sz, C.c_int, P(vp)]
     L.daac_stream_close.argtypes = [vp]
+    L.daac_scan_count_only_range.argtypes = [vp, C.c_int, C.c_int, u8p, sz, sz, C.c_int, vp, P(C.c_uint64), vp]
+    L.daac_scan_count_only_range.restype = C.c_int
     L.daac_set_option.argtypes = [C.c_char_p, C.c_int64]
     L.daac_last_engine.argtypes = []
     L.daac_last_engine.restype = C.c_int

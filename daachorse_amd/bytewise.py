@@ -283,6 +283,19 @@ class DoubleArrayAhoCorasick:
             return np.zeros(0, dtype=MATCH_DTYPE)
         return np.asarray(_MatchList(out, n))  # read-only view of the library's buffer, freed with the array
 
+    def count(self, mode, haystack, engine=Engine.Auto, stream=None, result_dev=None, begin=0):
+        """`.count()` of the iterator: the number of matches with end in (begin, len], no checksum; with `result_dev`
+        (device pointer to 3 x u64, the count goes to [0]) the call is asynchronous and returns None."""
+        h = _Haystack(haystack)
+        if result_dev is not None:
+            _ffi.check(_ffi.lib().daac_scan_count_only_range(self._h, int(mode), int(engine), h.ptr, h.len, begin, h.is_device, stream,
+                                                             None, result_dev))
+            return None
+        cnt = C.c_uint64()
+        _ffi.check(_ffi.lib().daac_scan_count_only_range(self._h, int(mode), int(engine), h.ptr, h.len, begin, h.is_device, stream,
+                                                         C.byref(cnt), None))
+        return cnt.value
+
     def scan_count(self, mode, haystack, engine=Engine.Auto, stream=None, result_dev=None, begin=0):
         """-> (count, checksum) of the matches with end in (begin, len]; with `result_dev` (device
         pointer to 3 x u64 = count, S1, S2) the call is asynchronous and returns None."""

@@ -15,6 +15,7 @@
 #include "charwise.hpp"
 #include "device_tables.hpp"
 #include "gram.hpp"
+#include "gram2.hpp"
 #include "pma.hpp"
 #include "repack.hpp"
 
@@ -37,6 +38,9 @@ struct Options {
     std::atomic<int64_t> gram_ppl{0};           // 0 = auto (32 positions per lane for automata without short patterns), 16, 32
     std::atomic<int64_t> gram_dense{-1};        // -1 = decide per automaton
     std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
+    std::atomic<int64_t> gram_version{0};       // 0 = the second table set where it applies (else v1), 1 = v1 only, 2 = v2 only
+    std::atomic<int64_t> gram2_dpp{1};
+    std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
     std::atomic<int64_t> char_map_lds{0};       // charwise chain scans: stage the populated stretch of the code mapper in LDS
@@ -66,6 +70,8 @@ struct DeviceTables {
     TierTables tier_host_meta;  // sizes only (vectors cleared after upload)
     bool gram_ok = false;
     GramDev gram{};
+    bool gram2_ok = false;     // second table set (gram2.hpp)
+    Gram2Dev gram2{};
     CharDev chr{};  // charwise automata only
 
     ~DeviceTables() {
@@ -336,6 +342,73 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             // keep the sizes for daac_pma_info
             tt.rows16.clear(); tt.rows32.clear(); tt.bcmap.clear(); tt.bfail.clear(); tt.grec.clear(); tt.ssum.clear(); tt.sopos.clear(); tt.old_of_new.clear();
             t->tier_host_meta = tt;
+        }
+    }
+    // GRAM engine, second table set: built from the automaton itself
+    {
+        Gram2Tables g2;
+        const uint32_t ring_bytes = 16u * 128u * 8u;  // one 128-entry x 8-byte hit ring per wave of a 1024-thread workgroup
+        const int64_t budget = g_opt.gram_lds_budget.load() - static_cast<int64_t>(ring_bytes);
+        if (budget > 0 && build_gram2_tables(h, static_cast<uint32_t>(budget), g2)) {
+            Gram2Dev &d = t->gram2;
+            auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
+            const U32x4 *drec; const U32x2 *dhit;
+            if ((st = t->put(g2.cls, d.cls)) != DAAC_OK) return st;
+            if ((st = t->put(g2.m, d.m)) != DAAC_OK) return st;
+            if (g2.s16) {
+                std::vector<uint16_t> s16(g2.sdir.begin(), g2.sdir.end());
+                const uint16_t *ps;
+                if ((st = t->put(s16, ps)) != DAAC_OK) return st;
+                d.sdir = ps;
+                d.s_bytes = p16(s16.size() * 2);
+            } else {
+                const uint32_t *ps;
+                if ((st = t->put(g2.sdir, ps)) != DAAC_OK) return st;
+                d.sdir = ps;
+                d.s_bytes = p16(g2.sdir.size() * 4);
+            }
+            // CID entries are the LDS addresses of their H words (H sits at a fixed offset)
+            std::vector<uint16_t> cid(g2.cid4.size());
+            bool exact_ok = g2.exact_available && kGram2OffH + g2.hsum.size() * 4 <= 65536;
+            for (size_t i = 0; i < cid.size(); ++i) cid[i] = static_cast<uint16_t>(kGram2OffH + g2.cid4[i]);
+            if ((st = t->put(cid, d.cid4)) != DAAC_OK) return st;
+            if ((st = t->put(g2.hsum, d.hsum)) != DAAC_OK) return st;
+            if ((st = t->put(g2.drec, drec)) != DAAC_OK) return st;
+            if ((st = t->put(g2.dhit, dhit)) != DAAC_OK) return st;
+            if ((st = t->put(g2.cfirst, d.cfirst)) != DAAC_OK) return st;
+            d.drec = reinterpret_cast<const uint4 *>(drec);
+            d.dhit = reinterpret_cast<const uint2 *>(dhit);
+            d.m_bytes = p16(g2.m.size() * 4);
+            d.cid_bytes = p16(cid.size() * 2);
+            d.h_bytes = p16(g2.hsum.size() * 4);
+            d.off_m_count = kGram2OffM;
+            d.off_s_count = d.off_m_count + d.m_bytes;
+            d.off_ring_count = d.off_s_count + d.s_bytes;
+            d.lds_count = d.off_ring_count + ring_bytes;
+            d.rfull = nullptr;
+            d.rfull_ok = 0;
+            if (g2.s16) {  // per-word directory for count-only launches (they have the LDS for it)
+                std::vector<uint16_t> rf(g2.m.size());
+                uint32_t run = 0;
+                for (size_t i = 0; i < g2.m.size(); ++i) { rf[i] = static_cast<uint16_t>(run); run += static_cast<uint32_t>(__builtin_popcount(g2.m[i] & kGram2MaskBits)); }
+                if ((st = t->put(rf, d.rfull)) != DAAC_OK) return st;
+                d.rfull_bytes = p16(rf.size() * 2);
+                d.off_ring_rfull = d.off_s_count + d.rfull_bytes;
+                d.lds_rfull = d.off_ring_rfull + ring_bytes;
+                d.rfull_ok = d.lds_rfull <= static_cast<uint32_t>(g_opt.gram_lds_budget.load()) && g_opt.gram2_rfull.load() != 0;
+            }
+            d.off_m_exact = kGram2OffH + d.h_bytes;
+            d.off_s_exact = d.off_m_exact + d.m_bytes;
+            d.off_cid = d.off_s_exact + d.s_bytes;
+            d.off_ring_exact = d.off_cid + d.cid_bytes;
+            d.lds_exact = d.off_ring_exact + ring_bytes;
+            // the hit queue keeps the LDS address of an M word in 17 bits
+            if (d.off_m_exact + d.m_bytes > (1u << 17) || d.lds_exact > 160u * 1024u) exact_ok = false;
+            d.K = g2.K; d.C = g2.C; d.s16 = g2.s16; d.unused_byte = g2.unused_byte;
+            d.n_deep = static_cast<uint32_t>(g2.dhit.size());
+            d.exact_ok = exact_ok;
+            d.xlane_dpp = g_opt.gram2_dpp.load() != 0;
+            t->gram2_ok = d.off_m_count + d.m_bytes <= (1u << 17) && d.lds_count <= 160u * 1024u;
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -725,10 +798,18 @@ daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
             info->tier_lds_states = t->tier.NB;
             info->tier_lds_bytes = t->tier.lds_bytes;
         }
-        info->gram_available = t->gram_ok;
+        info->gram_available = t->gram_ok || t->gram2_ok;
         if (t->gram_ok) {
             info->gram_k = t->gram.K;
             info->gram_lds_bytes = t->gram.lds_bytes;
+        }
+        info->gram2_available = t->gram2_ok;
+        if (t->gram2_ok) {
+            info->gram2_k = t->gram2.K;
+            info->gram2_exact = t->gram2.exact_ok;
+            info->gram2_lds_count = t->gram2.lds_count;
+            info->gram2_lds_exact = t->gram2.lds_exact;
+            if (!t->gram_ok) { info->gram_k = t->gram2.K; info->gram_lds_bytes = t->gram2.lds_count; }
         }
     }
     return DAAC_OK;
@@ -743,9 +824,9 @@ daac_status daac_pma_upload(daac_pma *pma, int device) {
     return upload_locked(pma, device, &t);
 }
 
-daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin, int hay_is_device,
-                                  void *stream_, uint64_t *count, uint64_t *checksum, uint64_t *result_dev) {
-    if (!pma || (len && !hay) || (!result_dev && (!count || !checksum)) || begin > len) {
+static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin, int hay_is_device,
+                                   void *stream_, uint64_t *count, uint64_t *checksum, uint64_t *result_dev, bool want_checksum) {
+    if (!pma || (len && !hay) || (!result_dev && (!count || (want_checksum && !checksum))) || begin > len) {
         set_error("bad argument");
         return DAAC_ERR_INVALID_ARGUMENT;
     }
@@ -754,12 +835,18 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
     daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
     if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
+    // which GRAM table set serves this request: the second one where it applies (count only: always; with checksum: when
+    // CID/H fit next to M), else the first
+    const int64_t gv = g_opt.gram_version.load();
+    const bool g2_can = t->gram2_ok && (!want_checksum || t->gram2.exact_ok) && gv != 1;
+    const bool g1_can = t->gram_ok && gv != 2;
     const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len - begin < (1ull << 35) &&
-                          (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && t->gram_ok));
-    if (engine == DAAC_ENGINE_GRAM && (!use_gram || !t->gram_ok)) {
+                          (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (g2_can || g1_can)));
+    if (engine == DAAC_ENGINE_GRAM && (!use_gram || !(g2_can || g1_can))) {
         set_error("GRAM engine not available for this automaton / mode");
         return DAAC_ERR_UNSUPPORTED;
     }
+    const bool use_g2 = use_gram && g2_can;
     Plan pl;
     bool heads = false;
     if ((st = make_plan(pma, t, mode, use_gram ? DAAC_ENGINE_AUTO : engine, begin, len, pl, heads)) != DAAC_OK) return st;
@@ -800,7 +887,7 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         // a power of two >= 2 KiB: regions then never straddle a multiple of 4 GiB (the kernel keeps 32-bit positions per epoch)
         uint64_t region = 2048;
         while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, g_opt.gram_region.load())) && region < (1ull << 30)) region *= 2;
-        ga.ppl = (!t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
+        ga.ppl = (!use_g2 && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;
         ga.result = d_res;
@@ -808,18 +895,22 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
         threads = std::min(1024u, std::max(64u, threads & ~63u));
         const uint32_t wpb = threads / 64;
         uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
-        if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / t->gram.lds_bytes));
+        const uint32_t gram_lds = use_g2 ? gram2_lds_bytes(t->gram2, want_checksum) : t->gram.lds_bytes;
+        if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / gram_lds));
         const uint32_t blocks = static_cast<uint32_t>(
             std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (ga.nregions + wpb - 1) / wpb)));
         // room for what one step can queue at worst (64 * ppl + 128 walkers) on top of a useful fill level
         ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(2 * (64 * ga.ppl + 128), g_opt.gram_slab.load()));
         // more than ~1 % of the (K+1)-grams are trie prefixes: some lane of the wave hits on nearly every position
-        ga.dense = g_opt.gram_dense.load() >= 0 ? g_opt.gram_dense.load() != 0
-                                                : static_cast<uint64_t>(t->gram.n_deep) * 100 > static_cast<uint64_t>(t->gram.CCC) * (t->gram.K == 3 ? t->gram.C : 1);
+        {
+            const uint64_t n_deep = use_g2 ? t->gram2.n_deep : t->gram.n_deep, C = use_g2 ? t->gram2.C : t->gram.C, K = use_g2 ? t->gram2.K : t->gram.K;
+            ga.dense = g_opt.gram_dense.load() >= 0 ? g_opt.gram_dense.load() != 0 : n_deep * 100 > C * C * C * (K == 3 ? C : 1);
+        }
         void *wq = nullptr;
         HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * sizeof(uint2), stream));
         ga.wq = static_cast<uint2 *>(wq);
-        const hipError_t le = launch_gram_scan(t->gram, ga, blocks, threads, stream);
+        const hipError_t le = use_g2 ? launch_gram2_scan(t->gram2, ga, want_checksum, blocks, threads, stream)
+                                     : launch_gram_scan(t->gram, ga, blocks, threads, stream);
         HIP_TRY(hipFreeAsync(wq, stream));
         HIP_TRY(le);
         if (begin != 0) {
@@ -860,9 +951,19 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
     return DAAC_OK;
 }
 
+daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin, int hay_is_device,
+                                  void *stream, uint64_t *count, uint64_t *checksum, uint64_t *result_dev) {
+    return scan_count_impl(pma, mode, engine, hay, len, begin, hay_is_device, stream, count, checksum, result_dev, true);
+}
+
 daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream,
                             uint64_t *count, uint64_t *checksum, uint64_t *result_dev) {
-    return daac_scan_count_range(pma, mode, engine, hay, len, 0, hay_is_device, stream, count, checksum, result_dev);
+    return scan_count_impl(pma, mode, engine, hay, len, 0, hay_is_device, stream, count, checksum, result_dev, true);
+}
+
+daac_status daac_scan_count_only_range(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin, int hay_is_device,
+                                       void *stream, uint64_t *count, uint64_t *result_dev) {
+    return scan_count_impl(pma, mode, engine, hay, len, begin, hay_is_device, stream, count, nullptr, result_dev, false);
 }
 
 daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
@@ -1116,6 +1217,9 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_slab") g_opt.gram_slab = value;
     else if (n == "gram_dense") g_opt.gram_dense = value;
     else if (n == "gram_ppl") g_opt.gram_ppl = value;
+    else if (n == "gram_version") g_opt.gram_version = value;
+    else if (n == "gram2_dpp") g_opt.gram2_dpp = value;
+    else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;
     else if (n == "chain_rounds") g_opt.chain_rounds = value;

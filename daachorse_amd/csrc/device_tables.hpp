@@ -106,6 +106,29 @@ struct GramArgs {
 
 hipError_t launch_gram_scan(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream);
 
+// GRAM engine, second table set (see gram2.hpp).  LDS layout, count only: [0,256) classes | M at 512 | S | hit rings;
+// with checksum: [0,256) classes | H at 512 | M | S | CID | hit rings.
+constexpr uint32_t kGram2OffH = 512;
+struct Gram2Dev {
+    const uint8_t *cls;       // 256 byte classes
+    const uint32_t *m;        // C^K words: continuation bits 1..29, short-pattern count in bits 30-31
+    const void *sdir;         // per 4 words of m: set continuation bits before the group (u16 or u32 entries)
+    const uint16_t *rfull;    // per word of m: set continuation bits before it (only when there are fewer than 65536)
+    const uint16_t *cid4;     // C^K: LDS address of the context's H entry (kGram2OffH + 4 * id)
+    const uint32_t *hsum;     // per id: sum of h32
+    const uint4 *drec;        // N x {cmap, first_child, own_cnt, own_hsum}  (HBM / L2)
+    const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}
+    const uint32_t *cfirst;   // depth-(K+1) states by rank: id of the first child
+    uint32_t m_bytes, s_bytes, cid_bytes, h_bytes;  // multiples of 16
+    uint32_t off_m_count, off_s_count, off_ring_count, lds_count;
+    uint32_t rfull_bytes, off_ring_rfull, lds_rfull, rfull_ok;  // count only, with the per-word directory in place of `sdir`
+    uint32_t off_m_exact, off_s_exact, off_cid, off_ring_exact, lds_exact;
+    uint32_t K, C, s16, unused_byte, n_deep, exact_ok;
+    uint32_t xlane_dpp;       // neighbour exchange through DPP wave shifts (else ds_bpermute)
+};
+uint32_t gram2_lds_bytes(const Gram2Dev &dev, bool exact);
+hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool exact, uint32_t blocks, uint32_t threads, hipStream_t stream);
+
 hipError_t launch_tier_scan(const TierDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,
                             hipStream_t stream);
 hipError_t launch_darray_scan(const DArrayDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,

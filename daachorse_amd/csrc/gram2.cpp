@@ -1,0 +1,180 @@
+// GRAM engine, second table set (host side) — see gram2.hpp.
+#include "gram2.hpp"
+
+#include <algorithm>
+#include <map>
+
+namespace daac {
+
+namespace {
+uint64_t ipow(uint64_t b, uint32_t e) {
+    uint64_t r = 1;
+    while (e--) r *= b;
+    return r;
+}
+constexpr uint32_t kNone = 0xffffffffu;
+}  // namespace
+
+bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out) {
+    out = Gram2Tables{};
+    if (!p.is_standard()) return false;
+    const uint32_t n = static_cast<uint32_t>(p.states.size());
+    if (n == 0 || n >= (1u << 27)) return false;
+    // "" as a pattern makes every position (and end = 0) a match: left to the AC engines
+    if (output_pos_of(p.states[kRoot].opos_ch) != 0) return false;
+
+    // ---- breadth-first renumbering over the double array: children of a state are contiguous, byte-ascending ----
+    std::vector<uint32_t> new_of_old(n, kNone), old_of_new{kRoot}, depth{0}, first_child, nchild;
+    std::vector<uint8_t> label{0};
+    new_of_old[kRoot] = 0;
+    bool used[256] = {false};
+    for (uint32_t s = 0; s < old_of_new.size(); ++s) {
+        const uint32_t base = p.states[old_of_new[s]].base;
+        first_child.push_back(static_cast<uint32_t>(old_of_new.size()));
+        uint32_t cnt = 0;
+        if (base != 0) {
+            for (uint32_t c = 0; c < 256; ++c) {
+                const uint32_t t = base ^ c;
+                if (t >= n || t == kRoot || check_of(p.states[t].opos_ch) != c) continue;
+                if (new_of_old[t] != kNone) return false;  // not a tree
+                new_of_old[t] = static_cast<uint32_t>(old_of_new.size());
+                old_of_new.push_back(t);
+                depth.push_back(depth[s] + 1);
+                label.push_back(static_cast<uint8_t>(c));
+                used[c] = true;
+                ++cnt;
+            }
+        }
+        nchild.push_back(cnt);
+    }
+    const uint32_t N = static_cast<uint32_t>(old_of_new.size());
+
+    // ---- byte classes (ascending byte order, so that class order = child order) ----
+    out.cls.assign(256, 0);
+    uint32_t C = 1;
+    uint8_t rep[32] = {0};
+    int unused = -1;
+    for (uint32_t c = 0; c < 256; ++c) {
+        if (used[c]) {
+            if (C >= 30) return false;  // bits 1..29 of an M word are continuation bits
+            rep[C] = static_cast<uint8_t>(c);
+            out.cls[c] = static_cast<uint8_t>(C++);
+        } else if (unused < 0) {
+            unused = static_cast<int>(c);
+        }
+    }
+    if (unused < 0 || C < 2) return false;
+    rep[0] = static_cast<uint8_t>(unused);
+
+    // ---- per state: child bitmap, own patterns (list entries as long as the state is deep), class string ----
+    std::vector<uint32_t> cmap(N, 0), own_cnt(N, 0), own_hs(N, 0);
+    std::vector<uint64_t> gram(N, 0);
+    for (uint32_t s = 0; s < N; ++s) {
+        for (uint32_t j = 0; j < nchild[s]; ++j) {
+            const uint32_t ch = first_child[s] + j, k = out.cls[label[ch]];
+            cmap[s] |= 1u << k;
+            gram[ch] = depth[ch] <= 6 ? gram[s] * C + k : 0;
+        }
+        uint32_t op = output_pos_of(p.states[old_of_new[s]].opos_ch);
+        while (op != 0 && p.outputs[op - 1].length == depth[s]) {
+            own_cnt[s]++;
+            own_hs[s] += match_hash32(p.outputs[op - 1].value, p.outputs[op - 1].length);
+            op = p.outputs[op - 1].parent;
+        }
+    }
+
+    // output-list aggregates per output record (the `parent` chain always points to a smaller index)
+    std::vector<OutSum> osum(p.outputs.size());
+    for (size_t i = 0; i < p.outputs.size(); ++i) {
+        const OutputRec &o = p.outputs[i];
+        OutSum s{1u, match_hash32(o.value, o.length)};
+        if (o.parent != 0) { s.cnt += osum[o.parent - 1].cnt; s.hsum += osum[o.parent - 1].hsum; }
+        osum[i] = s;
+    }
+
+    auto pad16 = [](uint64_t x) { return static_cast<uint32_t>((x + 15) & ~15ull); };
+    for (uint32_t K : {3u, 2u}) {
+        const uint64_t ngram = ipow(C, K);
+        if (ngram * 4 >= (1ull << 17)) continue;  // the queue entry keeps the byte offset of the M word in 17 bits
+        // depth-(K+1) states: regular own patterns, lexicographic numbering (rank == offset within the level)
+        bool ok = true;
+        uint32_t n_deep = 0, level_start = N;
+        uint64_t prev = 0;
+        for (uint32_t s = 0; s < N && ok; ++s) {
+            if (depth[s] != K + 1) continue;
+            if (own_cnt[s] != (own_hs[s] != 0 ? 1u : 0u)) ok = false;
+            if (n_deep == 0) level_start = s; else if (gram[s] <= prev) ok = false;
+            prev = gram[s];
+            ++n_deep;
+        }
+        if (!ok) continue;
+        const uint32_t nm = static_cast<uint32_t>((ngram + 3) & ~3ull);
+        std::vector<uint32_t> m(nm, 0);
+        std::vector<uint16_t> cid4(nm, 0);
+        std::vector<uint32_t> hs{0};
+        std::map<uint32_t, uint32_t> id_of;  // hsum -> id
+        bool exact_ok = true, has_short = false;
+        for (uint32_t g = 0; g < ngram && ok; ++g) {
+            uint32_t st = kRoot;
+            for (uint32_t i = 0; i < K; ++i) st = p.next_state(st, rep[(g / static_cast<uint32_t>(ipow(C, K - 1 - i))) % C]);
+            const uint32_t op = output_pos_of(p.states[st].opos_ch);
+            if (op == 0) continue;
+            const OutSum o = osum[op - 1];
+            if (o.cnt > 3) { ok = false; break; }  // two count bits per word
+            has_short = true;
+            m[g] |= o.cnt << 30;
+            if (o.hsum != 0) {  // a zero sum needs no table entry (id 0 adds nothing)
+                auto it = id_of.find(o.hsum);
+                if (it == id_of.end()) {
+                    it = id_of.emplace(o.hsum, static_cast<uint32_t>(hs.size())).first;
+                    hs.push_back(o.hsum);
+                }
+                if (it->second >= 16384) exact_ok = false; else cid4[g] = static_cast<uint16_t>(4 * it->second);
+            }
+        }
+        if (!ok) continue;
+        for (uint32_t s = level_start; s < level_start + n_deep; ++s) {
+            const uint32_t g = static_cast<uint32_t>(gram[s] / C), d = static_cast<uint32_t>(gram[s] % C);
+            m[g] |= 1u << d;  // d >= 1: class 0 labels no edge
+        }
+        std::vector<uint32_t> sdir(nm / 4, 0);
+        uint32_t run = 0;
+        for (uint32_t g = 0; g < nm; ++g) {
+            if ((g & 3) == 0) sdir[g >> 2] = run;
+            run += static_cast<uint32_t>(__builtin_popcount(m[g] & kGram2MaskBits));
+        }
+        if (run != n_deep) continue;  // cannot happen for a consistent trie
+        const bool s16 = n_deep < 65536;
+        const uint64_t lds_count = kGram2OffM + pad16(static_cast<uint64_t>(nm) * 4) + pad16(static_cast<uint64_t>(nm / 4) * (s16 ? 2 : 4));
+        const uint64_t lds_exact = lds_count + pad16(static_cast<uint64_t>(nm) * 2) + pad16(hs.size() * 4);
+        if (lds_count > lds_budget) continue;
+        out.K = K;
+        out.m = std::move(m);
+        out.sdir = std::move(sdir);
+        out.cid4 = std::move(cid4);
+        out.hsum = std::move(hs);
+        out.s16 = s16;
+        out.has_short = has_short;
+        out.level_start = level_start;
+        out.lds_count = static_cast<uint32_t>(lds_count);
+        out.lds_exact = static_cast<uint32_t>(lds_exact);
+        out.exact_available = exact_ok && lds_exact <= lds_budget;
+        out.dhit.clear();
+        out.cfirst.clear();
+        for (uint32_t s = level_start; s < level_start + n_deep; ++s) {
+            out.dhit.push_back(U32x2{cmap[s], own_hs[s]});
+            out.cfirst.push_back(first_child[s]);
+        }
+        break;
+    }
+    if (out.K == 0) return false;
+    out.C = C;
+    out.N = N;
+    out.unused_byte = rep[0];
+    out.drec.resize(N);
+    for (uint32_t s = 0; s < N; ++s) out.drec[s] = U32x4{cmap[s], first_child[s], own_cnt[s], own_hs[s]};
+    out.available = true;
+    return true;
+}
+
+}  // namespace daac

@@ -85,6 +85,11 @@ typedef struct {
     uint32_t gram_lds_bytes;
     uint8_t charwise;            /* 1: a CharwiseDoubleArrayAhoCorasick (src/charwise.rs), 0: bytewise */
     uint32_t alphabet_size;      /* charwise: number of distinct code points in the patterns (mapper.rs:10-13) */
+    uint8_t gram2_available;     /* the GRAM engine's second table set (one LDS lookup per position) serves this automaton */
+    uint8_t gram2_exact;         /* ... also with the checksum (CID/H fit next to M) */
+    uint32_t gram2_k;
+    uint32_t gram2_lds_count;    /* LDS bytes per workgroup, count only / with checksum */
+    uint32_t gram2_lds_exact;
 } daac_info;
 
 typedef struct daac_pma daac_pma;         /* an automaton (host copy + per-device re-pack) */
@@ -168,6 +173,12 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
                             int hay_is_device, void *stream, uint64_t *count, uint64_t *checksum,
                             uint64_t *result_dev);
 
+/* `.count()` alone: the number of matches with end in (begin, len], no checksum.  With `result_dev` the count is left in
+ * result_dev[0] (3 x u64 as above; [1] and [2] are not meaningful) and the call is asynchronous.  The GRAM engine serves
+ * this with one LDS lookup per haystack byte; every other engine runs its count + checksum scan and drops the checksum. */
+daac_status daac_scan_count_only_range(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin,
+                                       int hay_is_device, void *stream, uint64_t *count, uint64_t *result_dev);
+
 /* The same over the tail of a haystack: counts the matches with end in (begin, len] — what one
  * shard of a haystack split across devices contributes.  Bytes before begin - Lmax are never read (they need
  * not be resident), byte 0 of the haystack is still `hay`.  For the overlapping modes any `begin` works (charwise:
@@ -209,6 +220,7 @@ void daac_stream_close(daac_stream *s);
  *   lds_budget (98304), dense_depth (-1 = auto), rows_share_pct (45)   TIERED re-pack
  *   gram_lds_budget (161792), gram_region (16384; rounded down to a power of two >= 2048), gram_slab (4096), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto),
  *   gram_ppl (0 = auto: 32 positions per lane and step for automata without short patterns, else 16)
+ *   gram_version (0 = second table set where it applies, 1 = first only, 2 = second only), gram2_dpp (1: DPP wave shifts)
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners
  *   char_map_lds (0)            charwise chain scans: code mapper staged in LDS when it fits

@@ -39,14 +39,23 @@ def _check_counts(p, mode, hay, want):
     expect = (len(want), orc.matches_checksum(want))
     for eng in ENGINES + [Engine.Auto]:
         assert p.scan_count(mode, hay, engine=eng) == expect, eng
+        assert p.count(mode, hay, engine=eng) == expect[0], eng  # `.count()` alone
     if mode == ScanMode.FindOverlapping:
-        try:
-            got = p.scan_count(mode, hay, engine=Engine.Gram)
-        except da.DaachorseError as e:
-            assert e.code == 6
-            return False
-        assert got == expect, "gram"
-        return True
+        served = False
+        for version in (1, 2, 0):  # first table set, second, the default choice
+            da.set_option("gram_version", version)
+            try:
+                got = p.scan_count(mode, hay, engine=Engine.Gram)
+                assert got == expect, ("gram", version)
+                served = True
+            except da.DaachorseError as e:
+                assert e.code == 6
+            try:
+                assert p.count(mode, hay, engine=Engine.Gram) == expect[0], ("gram count", version)
+            except da.DaachorseError as e:
+                assert e.code == 6
+        da.set_option("gram_version", 0)
+        return served
     return False
 
 
@@ -62,6 +71,8 @@ def _reset_options():
     da.set_option("iter_window", 64 << 20)
     da.set_option("restart_chain", 1)
     da.set_option("chain_rounds", 24)
+    da.set_option("gram_version", 0)
+    da.set_option("gram2_dpp", 1)
 
 
 def test_golden_vectors_overlapping(vectors):
@@ -264,6 +275,47 @@ def test_cfg3_100k_patterns():
     assert p2.upload().info().gram_k == 2
     assert p2.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want_cc
     da.set_option("gram_lds_budget", 158 * 1024)
+
+
+def test_gram2_tables_on_the_device():
+    """the GRAM engine's second table set (gram2.hpp: one M word per position) against the oracle: count alone and count +
+    checksum, K = 3 and K = 2, both neighbour-exchange paths, unaligned haystacks, shards, dense and sparse text"""
+    import torch
+    rng = np.random.default_rng(77)
+    pats3 = synth.patterns_cfg3(30000)
+    cases = [(synth.patterns_cfg1(), synth.uniform_haystack(70001, 5, synth.ALPHA_ABCD)),
+             (synth.patterns_cfg2(500), synth.uniform_haystack(1 << 20, 6, synth.ALPHA_LOWER)),
+             (pats3, synth.uniform_haystack(3 << 20, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)),
+             (pats3, synth.wordsoup_haystack(3 << 20, synth.SEEDS["cfg3_dense"], pats3, 20)),
+             (["ab", "ab", "b", "abab", "bababab"], np.frombuffer(b"abababbab" * 3000, dtype=np.uint8))]
+    for pats, hay in cases:
+        o, p = _pma(pats)
+        info = p.upload().info()
+        assert info.gram2_available and info.gram2_exact
+        dev = torch.from_numpy(np.concatenate([np.zeros(5, dtype=np.uint8), hay])).cuda()[5:]  # not 16-byte aligned
+        want = o.overlapping_count(hay, threads=8)
+        for dpp, budget in ((1, 158 * 1024), (0, 158 * 1024), (1, 24 * 1024)):
+            da.set_option("gram2_dpp", dpp)
+            da.set_option("gram_lds_budget", budget)
+            q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+            da.set_option("gram_version", 2)
+            try:
+                assert q.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want, (len(pats), dpp, budget)
+                assert q.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want[0], (len(pats), dpp, budget)
+                assert da.last_engine() == int(Engine.Gram)
+                cut = int(rng.integers(1, len(hay)))
+                head, tail = q.count(ScanMode.FindOverlapping, dev[:cut]), q.count(ScanMode.FindOverlapping, dev, begin=cut)
+                assert head + tail == want[0], cut
+            finally:
+                da.set_option("gram_version", 0)
+                da.set_option("gram2_dpp", 1)
+                da.set_option("gram_lds_budget", 158 * 1024)
+        if budget == 24 * 1024 and len(pats) > 1000:
+            assert q.info().gram2_k == 2
+    # declined automata: the request falls through to the other engines / an error for engine = GRAM with version 2
+    o, p = _pma(["", "a"])
+    assert not p.upload().info().gram2_available
+    assert p.count(ScanMode.FindOverlapping, b"aaa") == 7
 
 
 def test_shard_tail_counts_add_up():

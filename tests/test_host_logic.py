@@ -174,6 +174,48 @@ def test_gram_tables_reproduce_the_match_stream(gram_check, tmp_path):
     assert subprocess.check_output([gram_check, str(blob), "160000", str(h)]).decode().startswith("UNAVAILABLE")
 
 
+@pytest.fixture(scope="module")
+def gram2_check(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("native") / "gram2_check")
+    csrc = os.path.join(ROOT, "daachorse_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "gram2_check.cpp"),
+                           os.path.join(csrc, "pma.cpp"), os.path.join(csrc, "repack.cpp"), os.path.join(csrc, "gram2.cpp")])
+    return exe
+
+
+def test_gram2_tables_reproduce_the_match_stream(gram2_check, tmp_path):
+    """the second GRAM table set (one M word per position: continuation bits + short-pattern count; CID -> H for the
+    checksum) evaluated with the kernel's rules == literal automaton walk; K = 3 and K = 2; duplicates decline"""
+    rng = np.random.default_rng(3)
+    cases = [(["a", "ab", "bab", "bc", "bca", "c", "caa", "abcabcab", "bb"], b"abc", "OK"),
+             (["abcabcabd", "bcabd", "cab", "ab", "dddddddd"], b"abcd", "OK"),
+             (synth.patterns_cfg1(), synth.ALPHA_ABCD, "OK"),
+             (synth.patterns_cfg2(300), synth.ALPHA_LOWER, "OK"),
+             (synth.patterns_cfg3(20000), synth.ALPHA_LOWER_SPACE, "OK")]
+    for pats, alpha, want in cases:
+        blob = tmp_path / "a.blob"
+        blob.write_bytes(orc.OraclePma.build(pats).serialize())
+        h = tmp_path / "h.bin"
+        rng.choice(np.frombuffer(alpha, dtype=np.uint8), size=60000).tofile(h)
+        for budget in (160000, 9000):
+            out = subprocess.check_output([gram2_check, str(blob), str(budget), str(h)]).decode()
+            assert out.startswith(want), out
+    # word-soup text: deep walks
+    pats = synth.patterns_cfg3(20000)
+    blob.write_bytes(orc.OraclePma.build(pats).serialize())
+    synth.wordsoup_haystack(100000, synth.SEEDS["cfg3_dense"], pats, 20).tofile(h)
+    out = subprocess.check_output([gram2_check, str(blob), "160000", str(h)]).decode()
+    assert out.startswith("OK") and "K=3" in out, out
+    # "" as a pattern, four copies of one short pattern (count bits overflow), 31 distinct bytes: declined
+    for pats in (["", "a"], ["ab"] * 4 + ["abc"], [bytes([65 + i, 66 + i]) for i in range(31)]):
+        blob.write_bytes(orc.OraclePma.build(pats).serialize())
+        assert subprocess.check_output([gram2_check, str(blob), "160000", str(h)]).decode().startswith("UNAVAILABLE"), pats
+    # duplicates below the limit are fine
+    blob.write_bytes(orc.OraclePma.build(["ab", "ab", "b", "abab"]).serialize())
+    np.frombuffer(b"abababbab" * 50, dtype=np.uint8).tofile(h)
+    assert subprocess.check_output([gram2_check, str(blob), "160000", str(h)]).decode().startswith("OK")
+
+
 def test_synth_definitions_are_stable():
     """Seeds and generators are part of the benchmark definition: pin a few bytes/patterns."""
     h = synth.uniform_haystack(64, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs ONE configuration a few times (for rocprofv3): python tools/prof_one.py cfg3 sparse gram 1024 [mib]"""
+"""Runs ONE configuration a few times (for rocprofv3): python tools/prof_one.py cfg3 sparse gram 1024 [mib] [gram_version] [count_only]"""
 import os
 import sys
 
@@ -19,6 +19,8 @@ if hk == "sparse":
     synth.device_uniform(hay, synth.SEEDS[f"{wl}_hay"], synth.ALPHA_LOWER_SPACE if wl == "cfg3" else synth.ALPHA_PRINTABLE)
 else:
     synth.device_wordsoup(hay, synth.SEEDS[f"{wl}_dense"], pats, 20 if wl == "cfg3" else 13, noise_256=77 if wl == "cfg3" else 0)
-e = {"gram": Engine.Gram, "tiered": Engine.Tiered, "darray": Engine.DArray}[eng]
+e = {"gram": Engine.Gram, "tiered": Engine.Tiered, "darray": Engine.DArray, "auto": Engine.Auto}[eng]
+da.set_option("gram_version", int(sys.argv[6]) if len(sys.argv) > 6 else 0)
+count_only = len(sys.argv) > 7 and sys.argv[7] == "1"
 for _ in range(3):
-    print(pma.scan_count(ScanMode.FindOverlapping, hay, engine=e))
+    print(pma.count(ScanMode.FindOverlapping, hay, engine=e) if count_only else pma.scan_count(ScanMode.FindOverlapping, hay, engine=e))

@@ -131,7 +131,8 @@ def gram_soak(seconds, seed, max_cases=None):
         da.set_option("gram_lds_budget", da_budget)
         opts = {"gram_region": int(rng.choice([2048, 16384, 65536])), "gram_slab": int(rng.choice([0, 4096, 20000])),
                 "threads": int(rng.choice([1024, 1024, 768, 512, 256, 64])), "blocks_per_cu": int(rng.choice([0, 0, 1, 2])),
-                "gram_ppl": int(rng.choice([0, 16])), "gram_dense": int(rng.choice([-1, 0, 1])), "seg_bytes": int(rng.choice([0, 0, 64, 4096]))}
+                "gram_ppl": int(rng.choice([0, 16])), "gram_dense": int(rng.choice([-1, 0, 1])), "seg_bytes": int(rng.choice([0, 0, 64, 4096])),
+                "gram_version": int(rng.choice([0, 0, 1, 2])), "gram2_dpp": int(rng.choice([1, 1, 0]))}
         for k, v in opts.items():
             da.set_option(k, v)
         p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
@@ -149,6 +150,7 @@ def gram_soak(seconds, seed, max_cases=None):
                 np.savez(f"gpurun_out/gram_fail_{seed}_{n_auto}.npz", hay=dev.cpu().numpy(), blob=np.frombuffer(o.serialize(), dtype=np.uint8),
                          budget=np.array([da_budget]), eng=np.array([int(eng)]))
             assert got == want, (eng, nsym, npat, lo, hi, len(hay), got, want, opts, da_budget)
+            assert p.count(ScanMode.FindOverlapping, dev, engine=eng) == want[0], ("count", eng, nsym, npat, lo, hi, len(hay), opts, da_budget)
             n_gram += eng == Engine.Gram
         begin = int(rng.integers(1, len(dev)))
         head = p.scan_count(ScanMode.FindOverlapping, dev[:begin])
@@ -157,7 +159,7 @@ def gram_soak(seconds, seed, max_cases=None):
         tot = (head[0] + tail[0], (((s(head[1])[0] + s(tail[1])[0]) & 0xFFFFFFFF) << 32) | ((s(head[1])[1] + s(tail[1])[1]) & 0xFFFFFFFF))
         assert tot == want, ("shards", begin, tot, want)
     for k, v in (("gram_lds_budget", 158 * 1024), ("gram_region", 16384), ("gram_slab", 4096), ("threads", 1024), ("blocks_per_cu", 0),
-                 ("gram_ppl", 0), ("gram_dense", -1), ("seg_bytes", 0)):
+                 ("gram_ppl", 0), ("gram_dense", -1), ("seg_bytes", 0), ("gram_version", 0), ("gram2_dpp", 1)):
         da.set_option(k, v)
     print(f"gram soak ok: {n_auto} automata ({n_gram} on the GRAM engine) in {time.time() - t0:.0f} s (seed {seed})")
 

@@ -44,7 +44,7 @@ def main():
         keys.append(k)
         vals.append(v.split(","))
     ref = None
-    defaults = {"gram_rank_in_lds": -1, "gram_dense": -1, "gram_ppl": 0, "gram_region": 16384, "gram_lds_budget": 161792, "gram_slab": 4096, "restart_chain": 1, "seg_bytes": 0, "lds_budget": 96 * 1024, "dense_depth": -1, "rows_share_pct": 45, "blocks_per_cu": 0, "threads": 1024}
+    defaults = {"gram_version": 0, "gram2_dpp": 1, "gram_rank_in_lds": -1, "gram_dense": -1, "gram_ppl": 0, "gram_region": 16384, "gram_lds_budget": 161792, "gram_slab": 4096, "restart_chain": 1, "seg_bytes": 0, "lds_budget": 96 * 1024, "dense_depth": -1, "rows_share_pct": 45, "blocks_per_cu": 0, "threads": 1024}
     for combo in itertools.product(*vals):
         cfg = dict(zip(keys, combo))
         for k, v in defaults.items():
@@ -54,20 +54,25 @@ def main():
         try:
             pma.upload(0)
             info = pma.info()
-            pma.scan_count(mode, hay, engine=eng, stream=stream, result_dev=res.data_ptr())
+            count_only = int(cfg.get("count_only", 0)) != 0   # `.count()` alone (daac_scan_count_only_range)
+            run = (lambda: pma.count(mode, hay, engine=eng, stream=stream, result_dev=res.data_ptr())) if count_only else \
+                (lambda: pma.scan_count(mode, hay, engine=eng, stream=stream, result_dev=res.data_ptr()))
+            run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.reps):
-                pma.scan_count(mode, hay, engine=eng, stream=stream, result_dev=res.data_ptr())
+                run()
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.reps
             r = res.tolist()
             cc = (int(r[0]), int(r[1]) & 0xFFFFFFFF, int(r[2]) & 0xFFFFFFFF)
+            if count_only:
+                cc = (cc[0],) + (ref[1:] if ref else (0, 0))
             ok = ref is None or cc == ref
             ref = ref or cc
-            print(f"{cfg}  NA={info.tier_dense_states} NB={info.tier_lds_states} lds={info.tier_lds_bytes}  "
+            print(f"{cfg} used={da.last_engine()}  NA={info.tier_dense_states} NB={info.tier_lds_states} lds={info.tier_lds_bytes}  "
                   f"{ms:8.3f} ms  {n / ms / 1e6:9.1f} GB/s  frac={n / ms / 1e6 / 8000:.3f}  count={cc[0]} {'OK' if ok else 'MISMATCH'}", flush=True)
         except da.DaachorseError as e:
             print(f"{cfg}  ERROR {e}", flush=True)
