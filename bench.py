@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — haystack GB/s of the MI355X-native daachorse overlapping scan.
 
-One "step" = one find_overlapping scan (count + checksum, `daac_scan_count[_range]`) of this rank's part of the
-haystack, resident in HBM, with the 100 000-pattern bytewise automaton (BASELINE.json configs[2] = the
-configuration the metric is quoted on), plus the RCCL all-reduce of {count, S1, S2} when more than one GPU takes
-part.  No data-path collective exists: the automaton is replicated and the haystack is sharded.
+One "step" = one find_overlapping scan of this rank's part of the haystack, resident in HBM, with the 100 000-pattern
+bytewise automaton (BASELINE.json configs[2] = the configuration the metric is quoted on), plus the RCCL all-reduce of
+{count, S1, S2} when more than one GPU takes part.  No data-path collective exists: the automaton is replicated and the
+haystack is sharded.  The scan is `find_overlapping_iter(haystack).count()` (`daac_scan_count_only_range`, --op count,
+the default) or count + order-independent checksum of the (start, end, value) stream (`daac_scan_count_range`,
+--op checksum); the line carries both at N = 1 (`with_checksum`), each checked against the CPU oracle.
 
   --scaling weak    (default) every rank owns a 4 GiB haystack of its own (shard k seeded 0xDAAC0014 + k: cfg4)
   --scaling strong  ONE haystack of --bytes (default 4 GiB) split over the ranks with daac_scan_count_range: rank r
@@ -46,6 +48,8 @@ def parse_args(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--bytes", type=int, default=0, help="haystack bytes per GPU (weak) / in total (strong); default: the config's size")
     ap.add_argument("--engine", default="auto", choices=["auto", "gram", "tiered", "darray"])
+    ap.add_argument("--op", default="count", choices=["count", "checksum"],
+                    help="what a step computes: .count() of the iterator, or count + checksum of the match stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-dense", action="store_true", help="skip the extra dense-haystack object")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -209,7 +213,12 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     base32 = (lo - lead) & 0xFFFFFFFF
 
+    op = {"v": args.op}
+
     def scan_step():
+        if op["v"] == "count":
+            pma.count(ScanMode.FindOverlapping, hay, engine=engine, stream=stream, result_dev=result.data_ptr(), begin=lead)
+            return
         pma.scan_count(ScanMode.FindOverlapping, hay, engine=engine, stream=stream, result_dev=result.data_ptr(), begin=lead)
         if base32:  # ends were relative to this rank's buffer: S2 += S1 * (offset of the buffer in the haystack)  (mod 2^32)
             result[2] += (result[1] & 0xFFFFFFFF) * base32
@@ -240,7 +249,8 @@ def main():
     elapsed, avg_kernel_s = timed(args.steps, args.warmup)
     engine_used = ENGINE_NAMES.get(da.last_engine(), "?")
     total_count = int(result[0].item())
-    checksum = ((int(result[1].item()) & 0xFFFFFFFF) << 32) | (int(result[2].item()) & 0xFFFFFFFF)
+    checksum = ((int(result[1].item()) & 0xFFFFFFFF) << 32) | (int(result[2].item()) & 0xFFFFFFFF) if args.op == "checksum" else None
+    v2 = info.gram2_available and engine_used == "gram" and args.op == "count"
 
     if dist is not None:  # every rank leaves the group together; rank 0 reports on its own
         dist.barrier()
@@ -256,6 +266,7 @@ def main():
     out = {
         "metric": "haystack GB/s scanned (find_overlapping, 100k-pattern bytewise automaton)" if args.workload == "cfg3"
         else "haystack GB/s scanned (find_overlapping, 1000-pattern bytewise automaton)",
+        "op": "find_overlapping_iter(haystack).count()" if args.op == "count" else "count + checksum of the find_overlapping match stream",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u8/u32 integer", "data": "synthetic",
@@ -268,16 +279,16 @@ def main():
                    "matches_per_byte": round(total_count / job_bytes, 4), "host_build_seconds": round(build_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
-                     "kernel": "daac::gram_count_kernel" if gram else "daac::scan_kernel",
+                     "kernel": ("daac::gram2_kernel" if v2 else "daac::gram_count_kernel") if gram else "daac::scan_kernel",
                      "kernel_ms": round(avg_kernel_s * 1e3, 4),
                      "algorithmic_bytes_per_launch": nbytes},
-        "match_count": total_count, "match_checksum": f"{checksum:016x}",
+        "match_count": total_count, "match_checksum": f"{checksum:016x}" if checksum is not None else None,
     }
     pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(pmc):
         try:
             t = json.load(open(pmc))
-            out["roofline"]["traffic"] = t.get(f"{args.workload}_{args.haystack}_bytes_per_launch")
+            out["roofline"]["traffic"] = t.get(f"{args.workload}_{args.haystack}_{args.op}_bytes_per_launch", t.get(f"{args.workload}_{args.haystack}_bytes_per_launch"))
             out["roofline"]["traffic_source"] = "static: " + str(t.get("source", "profiles/hbm_traffic.json (rocprofv3 --pmc passes of an earlier run, "
                                                                             "2*FETCH_SIZE + WRITE_SIZE), not measured in this run"))
         except Exception:
@@ -332,15 +343,31 @@ def main():
         t0 = time.perf_counter()
         cN = o.overlapping_count(sample[:n], threads=best[0])
         dtN = time.perf_counter() - t0
-        gpu_cc = pma.scan_count(ScanMode.FindOverlapping, hay[:n], engine=engine)
+        gpu_cc = pma.scan_count(ScanMode.FindOverlapping, hay[:n], engine=engine)     # count + checksum kernel
+        gpu_c = pma.count(ScanMode.FindOverlapping, hay[:n], engine=engine)            # count-only kernel
         out["cpu_baseline"] = {"value": round(n / dtN / 1e9, 4), "unit": "GB/s", "cores": best[0], "kind": "port",
                                "sample": f"first {n >> 20} MiB of the same haystack, {best[0]} threads with (Lmax-1)-byte halos, "
                                          f"gcc -O3 -march=native",
                                "single_thread_GB/s": round(rate1 / 1e9, 4),
                                "cores_usable": usable, "cores_os": os.cpu_count(), "cgroup_cpu_max": quota,
                                "effective_parallelism": round(best[1] / rate1, 1), "scaling": ladder,
-                               "parity_with_gpu_on_sample": bool(gpu_cc == cN)}
+                               "parity_with_gpu_on_sample": bool(gpu_cc == cN and gpu_c == cN[0]),
+                               "parity_checked": "count (count-only kernel) and count + checksum (checksum kernel) of the sample vs the oracle"}
         del sample
+
+    # ---- the other op beside the primary one: same haystack, few steps; the two kernels must agree on the count -----------
+    if world == 1:
+        other = "checksum" if args.op == "count" else "count"
+        op["v"] = other
+        _, k_s = timed(max(3, args.steps // 4), 1)
+        oc = int(result[0].item())
+        ocs = ((int(result[1].item()) & 0xFFFFFFFF) << 32) | (int(result[2].item()) & 0xFFFFFFFF)
+        out["with_checksum" if other == "checksum" else "count_only"] = {
+            "op": other, "value": round(nbytes / k_s / 1e9, 2), "unit": "GB/s", "frac": round(nbytes / k_s / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel_ms": round(k_s * 1e3, 4), "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"),
+            "match_count": oc, "match_checksum": f"{ocs:016x}" if other == "checksum" else None,
+            "count_agrees_with_primary": bool(oc == total_count)}
+        op["v"] = args.op
 
     # ---- the dense haystack (cfg3 (ii): word soup) beside the primary number --------------------------
     if world == 1 and not args.no_dense and args.haystack == "sparse":

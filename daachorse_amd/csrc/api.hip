@@ -33,7 +33,7 @@ struct Options {
     std::atomic<int64_t> iter_window{64ll << 20};
     std::atomic<int64_t> max_result_bytes{8ll << 30};
     std::atomic<int64_t> gram_lds_budget{158 * 1024};
-    std::atomic<int64_t> gram_region{16 * 1024};
+    std::atomic<int64_t> gram_region{0};           // 0 = auto: 16 KiB for the first table set, 64 KiB for the second
     std::atomic<int64_t> gram_slab{4096};
     std::atomic<int64_t> gram_ppl{0};           // 0 = auto (32 positions per lane for automata without short patterns), 16, 32
     std::atomic<int64_t> gram_dense{-1};        // -1 = decide per automaton
@@ -838,8 +838,10 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     // which GRAM table set serves this request: the second one where it applies (count only: always; with checksum: when
     // CID/H fit next to M), else the first
     const int64_t gv = g_opt.gram_version.load();
-    const bool g2_can = t->gram2_ok && (!want_checksum || t->gram2.exact_ok) && gv != 1;
+    // (measured on cfg3: with the checksum both table sets spend three LDS lookups per position and the first is a little
+    // faster; `.count()` alone needs one lookup per position on the second and runs 20-25 % faster there)
     const bool g1_can = t->gram_ok && gv != 2;
+    const bool g2_can = t->gram2_ok && (!want_checksum || t->gram2.exact_ok) && gv != 1 && !(gv == 0 && want_checksum && g1_can);
     const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len - begin < (1ull << 35) &&
                           (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (g2_can || g1_can)));
     if (engine == DAAC_ENGINE_GRAM && (!use_gram || !(g2_can || g1_can))) {
@@ -886,7 +888,8 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         ga.vlen = ga.lead + static_cast<uint64_t>(len - begin);
         // a power of two >= 2 KiB: regions then never straddle a multiple of 4 GiB (the kernel keeps 32-bit positions per epoch)
         uint64_t region = 2048;
-        while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, g_opt.gram_region.load())) && region < (1ull << 30)) region *= 2;
+        const int64_t region_opt = g_opt.gram_region.load() > 0 ? g_opt.gram_region.load() : (use_g2 ? 65536 : 16384);
+        while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, region_opt)) && region < (1ull << 30)) region *= 2;
         ga.ppl = (!use_g2 && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;

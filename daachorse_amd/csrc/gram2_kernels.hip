@@ -26,7 +26,7 @@ namespace {
 typedef uint32_t g2_u32x4_t __attribute__((ext_vector_type(4)));
 // build-time knobs for A/B runs of library variants (tools/mkvar2.sh); the defaults are the measured best
 #ifndef G2_GROUP
-#define G2_GROUP 4
+#define G2_GROUP 8
 #endif
 #ifndef G2_GROUPED_BALLOT
 #define G2_GROUPED_BALLOT 1

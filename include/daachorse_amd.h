@@ -218,7 +218,7 @@ void daac_stream_close(daac_stream *s);
  *   seg_bytes (0 = auto)        bytes of haystack per lane-segment of the segment scanners
  *   threads (1024), blocks_per_cu (0 = auto)   launch shape of the overlapping scanners
  *   lds_budget (98304), dense_depth (-1 = auto), rows_share_pct (45)   TIERED re-pack
- *   gram_lds_budget (161792), gram_region (16384; rounded down to a power of two >= 2048), gram_slab (4096), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto),
+ *   gram_lds_budget (161792), gram_region (0 = auto: 16384 / 65536 for the first / second table set; rounded down to a power of two >= 2048), gram_slab (4096), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto),
  *   gram_ppl (0 = auto: 32 positions per lane and step for automata without short patterns, else 16)
  *   gram_version (0 = second table set where it applies, 1 = first only, 2 = second only), gram2_dpp (1: DPP wave shifts)
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)

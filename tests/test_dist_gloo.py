@@ -111,7 +111,7 @@ def test_bench_refuses_more_ranks_than_gpus():
 def test_bench_two_ranks_on_one_gpu_weak_and_strong():
     """the real step under the self-launcher: two ranks share the box's GPU (oversubscribed, gloo for the reduce).
     Strong scaling must reproduce the single-rank count + checksum of the same haystack exactly."""
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu", "--no-dense", "--materialize-mib", "0", "--workload", "cfg2"]
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu", "--no-dense", "--materialize-mib", "0", "--workload", "cfg2", "--op", "checksum"]
     env = {"DAAC_DIST_BACKEND": "gloo", "DAAC_BENCH_OVERSUBSCRIBE": "1"}
     one = _run_bench(["--gpus", "1", "--bytes", str(96 << 20)] + common)
     strong = _run_bench(["--gpus", "2", "--scaling", "strong", "--bytes", str(96 << 20)] + common, env)
@@ -121,3 +121,6 @@ def test_bench_two_ranks_on_one_gpu_weak_and_strong():
     weak = _run_bench(["--gpus", "2", "--bytes", str(32 << 20)] + common, env)
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["haystack_bytes_job"] == 64 << 20
     assert weak["value"] > 0 and weak["match_count"] > 0
+    # the default op (.count() alone) under strong scaling: same count, no checksum in the line
+    cnt = _run_bench(["--gpus", "2", "--scaling", "strong", "--bytes", str(96 << 20)] + common[:-2], env)
+    assert cnt["match_count"] == one["match_count"] and cnt["match_checksum"] is None and cnt["op"].endswith(".count()")

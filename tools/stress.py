@@ -158,7 +158,7 @@ def gram_soak(seconds, seed, max_cases=None):
         s = lambda c: ((c >> 32) & 0xFFFFFFFF, c & 0xFFFFFFFF)
         tot = (head[0] + tail[0], (((s(head[1])[0] + s(tail[1])[0]) & 0xFFFFFFFF) << 32) | ((s(head[1])[1] + s(tail[1])[1]) & 0xFFFFFFFF))
         assert tot == want, ("shards", begin, tot, want)
-    for k, v in (("gram_lds_budget", 158 * 1024), ("gram_region", 16384), ("gram_slab", 4096), ("threads", 1024), ("blocks_per_cu", 0),
+    for k, v in (("gram_lds_budget", 158 * 1024), ("gram_region", 0), ("gram_slab", 4096), ("threads", 1024), ("blocks_per_cu", 0),
                  ("gram_ppl", 0), ("gram_dense", -1), ("seg_bytes", 0), ("gram_version", 0), ("gram2_dpp", 1)):
         da.set_option(k, v)
     print(f"gram soak ok: {n_auto} automata ({n_gram} on the GRAM engine) in {time.time() - t0:.0f} s (seed {seed})")
