@@ -77,6 +77,11 @@ def lib():
     L.daac_stream_close.argtypes = [vp]
     L.daac_scan_count_only_range.argtypes = [vp, C.c_int, C.c_int, u8p, sz, sz, C.c_int, vp, P(C.c_uint64), vp]
     L.daac_scan_count_only_range.restype = C.c_int
+    L.daac_scan_device.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp), P(C.c_uint64)]
+    L.daac_scan_device.restype = C.c_int
+    L.daac_device_free.argtypes = [vp]
+    L.daac_device_to_host.argtypes = [vp, vp, sz]
+    L.daac_device_to_host.restype = C.c_int
     L.daac_set_option.argtypes = [C.c_char_p, C.c_int64]
     L.daac_last_engine.argtypes = []
     L.daac_last_engine.restype = C.c_int

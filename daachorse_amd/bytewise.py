@@ -111,6 +111,31 @@ class _MatchList:
             pass
 
 
+class DeviceMatches:
+    """`count` daac_match tuples (24 bytes each, MATCH_DTYPE) at device address `ptr`, in the reference's order"""
+
+    def __init__(self, ptr, count):
+        self.ptr, self.count = ptr, count
+
+    def to_numpy(self, first=0, n=None):
+        n = self.count - first if n is None else n
+        out = np.zeros(n, dtype=MATCH_DTYPE)
+        if n:
+            _ffi.check(_ffi.lib().daac_device_to_host(out.ctypes.data, self.ptr + first * MATCH_DTYPE.itemsize, n * MATCH_DTYPE.itemsize))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _ffi.lib().daac_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class _LazyIter:
     """Iterator<Item = Match<u32>> over daac_iter_* (bytewise/iter.rs next())."""
 
@@ -282,6 +307,13 @@ class DoubleArrayAhoCorasick:
             _ffi.lib().daac_matches_free(out)
             return np.zeros(0, dtype=MATCH_DTYPE)
         return np.asarray(_MatchList(out, n))  # read-only view of the library's buffer, freed with the array
+
+    def scan_device(self, mode, haystack, engine=Engine.Auto, stream=None):
+        """-> DeviceMatches: the match list left in device memory (daac_scan_device)"""
+        h = _Haystack(haystack)
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _ffi.check(_ffi.lib().daac_scan_device(self._h, int(mode), int(engine), h.ptr, h.len, h.is_device, stream, C.byref(ptr), C.byref(n)))
+        return DeviceMatches(ptr.value, n.value)
 
     def count(self, mode, haystack, engine=Engine.Auto, stream=None, result_dev=None, begin=0):
         """`.count()` of the iterator: the number of matches with end in (begin, len], no checksum; with `result_dev`

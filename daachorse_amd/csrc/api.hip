@@ -41,6 +41,9 @@ struct Options {
     std::atomic<int64_t> gram_version{0};       // 0 = the second table set where it applies (else v1), 1 = v1 only, 2 = v2 only
     std::atomic<int64_t> gram2_dpp{1};
     std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
+    std::atomic<int64_t> emit{1};               // materialising overlapping scans: GRAM tuple emission where it applies (0: segment scanners)
+    std::atomic<int64_t> emit_tiles{64};        // tiles of 1024 positions a wave takes at a time
+    std::atomic<int64_t> emit_rec_cap{256};     // deep-match records per wave and tile before the scan falls back
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
     std::atomic<int64_t> char_map_lds{0};       // charwise chain scans: stage the populated stretch of the code mapper in LDS
@@ -72,6 +75,8 @@ struct DeviceTables {
     GramDev gram{};
     bool gram2_ok = false;     // second table set (gram2.hpp)
     Gram2Dev gram2{};
+    bool emit_ok = false;      // tuple emission on the second table set (gram2_emit_kernels.hip)
+    Gram2EmitDev emit{};
     CharDev chr{};  // charwise automata only
 
     ~DeviceTables() {
@@ -409,6 +414,31 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             d.exact_ok = exact_ok;
             d.xlane_dpp = g_opt.gram2_dpp.load() != 0;
             t->gram2_ok = d.off_m_count + d.m_bytes <= (1u << 17) && d.lds_count <= 160u * 1024u;
+            if (t->gram2_ok && g2.emit_available) {
+                Gram2EmitDev &e = t->emit;
+                const U32x4 *erec; const U32x2 *ehit;
+                e.cls = d.cls;
+                e.sdir = d.sdir;
+                e.cfirst = d.cfirst;
+                if ((st = t->put(g2.me, e.me)) != DAAC_OK) return st;
+                if ((st = t->put(g2.v1, e.v1)) != DAAC_OK) return st;
+                if ((st = t->put(g2.v2, e.v2)) != DAAC_OK) return st;
+                if ((st = t->put(g2.v3, e.v3)) != DAAC_OK) return st;
+                if ((st = t->put(g2.erec, erec)) != DAAC_OK) return st;
+                if ((st = t->put(g2.ehit, ehit)) != DAAC_OK) return st;
+                e.erec = reinterpret_cast<const uint4 *>(erec);
+                e.ehit = reinterpret_cast<const uint2 *>(ehit);
+                e.m_bytes = d.m_bytes; e.s_bytes = d.s_bytes;
+                e.v1_bytes = p16(g2.v1.size() * 4); e.v2_bytes = p16(g2.v2.size() * 4);
+                e.off_s = kGram2OffM + e.m_bytes;
+                e.off_v1 = e.off_s + e.s_bytes;
+                e.off_v2 = e.off_v1 + e.v1_bytes;
+                e.off_ring = e.off_v2 + e.v2_bytes;
+                e.off_wave = e.off_ring + ring_bytes;
+                e.lds_bytes = e.off_wave + 16u * (2048u + 256u + 256u + 16u);
+                e.K = g2.K; e.C = g2.C; e.s16 = g2.s16; e.unused_byte = g2.unused_byte;
+                t->emit_ok = e.lds_bytes <= 160u * 1024u;
+            }
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -602,16 +632,128 @@ __global__ void shard_fixup_kernel(unsigned long long *r, unsigned long long beg
 // For the restart scanners (find_iter / leftmost_find_iter) `begin` must be a sync point (0, or the
 // `next_begin` of the previous window), `total_len` is the real end of the haystack, and the scan runs
 // on to the first sync point >= end, which is returned in *next_begin.
-daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int engine, const uint8_t *dev_hay, uint64_t begin,
-                                   uint64_t end, uint64_t total_len, hipStream_t stream, MatchBuf &out,
-                                   uint64_t *next_begin) {
+// a match list in device memory (daac_scan_device, and the first half of every materialising scan)
+struct DevMatches {
+    daac_match *p = nullptr;
+    uint64_t n = 0;
+    DevMatches() = default;
+    DevMatches(const DevMatches &) = delete;
+    DevMatches &operator=(const DevMatches &) = delete;
+    ~DevMatches() { if (p) (void)hipFree(p); }
+    daac_match *release() { daac_match *q = p; p = nullptr; n = 0; return q; }
+};
+
+// FindOverlappingIterator of a bytewise Standard automaton through the GRAM tuple emitter (gram2_emit_kernels.hip):
+// COUNT pass -> exclusive scan of the per-tile counts -> WRITE pass.  *served = false when the automaton / request does
+// not qualify or a wave ran out of record space (then nothing is returned and the segment scanners take over).
+daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t end, hipStream_t stream,
+                             DevMatches &out, bool *served) {
+    *served = false;
+    if (!t->emit_ok || g_opt.emit.load() == 0 || end <= begin) return DAAC_OK;
+    const Gram2EmitDev &e = t->emit;
+    const uint64_t halo = pma->halo();
+    // windows of at most 1 GiB of end positions: virtual positions inside a window fit 32 bits
+    const uint64_t kWin = 1ull << 30;
+    struct Win { uint64_t wb, we, from; uint32_t lead, vlen, emit_from, ntiles; uint64_t tile0; const uint8_t *hay_al; };
+    std::vector<Win> wins;
+    uint64_t tiles_total = 0;
+    for (uint64_t wb = begin; wb < end; wb += kWin) {
+        Win w{};
+        w.wb = wb; w.we = std::min(end, wb + kWin);
+        w.from = wb > halo ? wb - halo : 0;
+        const uint8_t *first = dev_hay + w.from;
+        w.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(first) & 15u);
+        w.hay_al = first - w.lead;
+        w.vlen = static_cast<uint32_t>(w.lead + (w.we - w.from));
+        w.emit_from = static_cast<uint32_t>(w.lead + (wb - w.from));
+        w.ntiles = (w.vlen + 1023u) / 1024u;
+        w.tile0 = tiles_total;
+        tiles_total += w.ntiles;
+        wins.push_back(w);
+    }
+    const uint32_t tpr = static_cast<uint32_t>(std::max<int64_t>(1, g_opt.emit_tiles.load()));
+    const uint32_t rec_cap = static_cast<uint32_t>(std::max<int64_t>(16, g_opt.emit_rec_cap.load()));
+    const uint32_t wq_slab = 2048;
+    // one launch geometry for all windows
+    uint64_t max_regions = 0;
+    for (const Win &w : wins) max_regions = std::max<uint64_t>(max_regions, (w.ntiles + tpr - 1) / tpr);
+    const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (max_regions + 15) / 16)));
+    const uint64_t nwaves = static_cast<uint64_t>(blocks) * 16;
+    unsigned long long *d_tiles = nullptr;
+    void *d_scratch = nullptr;
+    const size_t wq_bytes = nwaves * wq_slab * sizeof(uint2), rec_bytes = nwaves * 2ull * rec_cap * sizeof(uint4);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_tiles), (tiles_total + 2) * sizeof(unsigned long long)));
+    std::unique_ptr<void, void (*)(void *)> g1(d_tiles, [](void *p) { (void)hipFree(p); });
+    HIP_TRY(hipMalloc(&d_scratch, wq_bytes + rec_bytes + 16));
+    std::unique_ptr<void, void (*)(void *)> g2(d_scratch, [](void *p) { (void)hipFree(p); });
+    unsigned int *d_fail = reinterpret_cast<unsigned int *>(static_cast<char *>(d_scratch) + wq_bytes + rec_bytes);
+    HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(unsigned int), stream));
+    auto args_of = [&](const Win &w) {
+        EmitArgs a{};
+        a.hay_al = w.hay_al; a.lead = w.lead; a.vlen = w.vlen; a.emit_from = w.emit_from;
+        a.pos_base = w.from - w.lead + 1;  // (mod 2^64: a match ends one past its last byte)
+        a.tile_cnt = d_tiles + w.tile0;
+        a.wq = static_cast<uint2 *>(d_scratch); a.wq_slab = wq_slab;
+        a.recs = reinterpret_cast<uint4 *>(static_cast<char *>(d_scratch) + wq_bytes); a.rec_cap = rec_cap;
+        a.ntiles = w.ntiles; a.tiles_per_region = tpr; a.nregions = (w.ntiles + tpr - 1) / tpr;
+        a.fail = d_fail;
+        return a;
+    };
+    for (const Win &w : wins) HIP_TRY(launch_gram2_emit(e, args_of(w), false, blocks, stream));
+    HIP_TRY(launch_exclusive_scan(d_tiles, tiles_total, d_tiles + tiles_total, stream));
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_tiles + tiles_total, sizeof(total), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    g_last_engine = DAAC_ENGINE_GRAM;
+    if (total == 0) { *served = true; return DAAC_OK; }
+    if (total * sizeof(daac_match) > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+        set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
+        return DAAC_ERR_AUTOMATON_SCALE;
+    }
+    daac_match *d_out = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), total * sizeof(daac_match)));
+    out.p = d_out;
+    out.n = total;
+    for (const Win &w : wins) {
+        EmitArgs a = args_of(w);
+        a.out = d_out;
+        HIP_TRY(launch_gram2_emit(e, a, true, blocks, stream));
+    }
+    unsigned int fail = 0;
+    HIP_TRY(hipMemcpyAsync(&fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (fail != 0) {  // a wave met more deep matches in one tile than it has record space for: leave it to the segment scanners
+        (void)hipFree(out.release());
+        return DAAC_OK;
+    }
+    *served = true;
+    return DAAC_OK;
+}
+
+// Scans [begin, end) of a haystack whose byte 0 is at `dev_hay` (device pointer; only bytes
+// >= begin - halo are dereferenced) and leaves the matches with end in (begin, end] — plus
+// ROOT's list at end = 0 when begin == 0 — in device memory, in reference order.
+// For the restart scanners (find_iter / leftmost_find_iter) `begin` must be a sync point (0, or the
+// `next_begin` of the previous window), `total_len` is the real end of the haystack, and the scan runs
+// on to the first sync point >= end, which is returned in *next_begin.
+daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engine, const uint8_t *dev_hay, uint64_t begin,
+                              uint64_t end, uint64_t total_len, hipStream_t stream, DevMatches &out, uint64_t *next_begin) {
     Plan pl;
     bool heads = false;
-    daac_status st = make_plan(pma, t, mode, engine, begin, end, pl, heads);
+    const bool want_gram = engine == DAAC_ENGINE_GRAM;
+    daac_status st = make_plan(pma, t, mode, want_gram ? DAAC_ENGINE_AUTO : engine, begin, end, pl, heads);
     if (st != DAAC_OK) return st;
-    out.clear();
-    g_last_engine = pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY;
     if (next_begin) *next_begin = end;
+    if (!pma->charwise && mode == DAAC_FIND_OVERLAPPING && (engine == DAAC_ENGINE_AUTO || want_gram)) {
+        bool served = false;
+        if ((st = emit_overlapping(pma, t, dev_hay, begin, end, stream, out, &served)) != DAAC_OK) return st;
+        if (served) return DAAC_OK;
+    }
+    if (want_gram) {
+        set_error("the GRAM engine cannot emit tuples for this automaton / request");
+        return DAAC_ERR_UNSUPPORTED;
+    }
+    g_last_engine = pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY;
     // an empty range still has to report ROOT's list at end = 0: run one (empty) segment
     if (pl.a.nseg == 0) { if (begin != 0) return DAAC_OK; pl.a.nseg = 1; }
     pl.a.hay = dev_hay;
@@ -644,12 +786,25 @@ daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int
     }
     daac_match *d_out = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), total * sizeof(daac_match)));
-    std::unique_ptr<void, void (*)(void *)> g2(d_out, [](void *p) { (void)hipFree(p); });
+    out.p = d_out;
+    out.n = total;
     pl.a.out = d_out;
     HIP_TRY(launch(t, pl, 2, heads, stream, nullptr));
-    if (!out.reserve(total)) { set_error("out of host memory for the match list"); return DAAC_ERR_AUTOMATON_SCALE; }
-    out.n = total;
-    HIP_TRY(hipMemcpyAsync(out.p, d_out, total * sizeof(daac_match), hipMemcpyDeviceToHost, stream));
+    return DAAC_OK;
+}
+
+// The same, copied to the host (page-locked) for daac_scan / the lazy iterator / the steppers.
+daac_status scan_range_materialize(daac_pma *pma, DeviceTables *t, int mode, int engine, const uint8_t *dev_hay, uint64_t begin,
+                                   uint64_t end, uint64_t total_len, hipStream_t stream, MatchBuf &out,
+                                   uint64_t *next_begin) {
+    out.clear();
+    DevMatches dm;
+    const daac_status st = scan_range_device(pma, t, mode, engine, dev_hay, begin, end, total_len, stream, dm, next_begin);
+    if (st != DAAC_OK) return st;
+    if (dm.n == 0) return DAAC_OK;
+    if (!out.reserve(dm.n)) { set_error("out of host memory for the match list"); return DAAC_ERR_AUTOMATON_SCALE; }
+    out.n = dm.n;
+    HIP_TRY(hipMemcpyAsync(out.p, dm.p, dm.n * sizeof(daac_match), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return DAAC_OK;
 }
@@ -989,6 +1144,36 @@ daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, s
     return DAAC_OK;
 }
 
+daac_status daac_scan_device(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
+                             daac_match **dev_out, uint64_t *count) {
+    if (!pma || !dev_out || !count || (len && !hay)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    DeviceTables *t = nullptr;
+    daac_status st = check_mode_kind(pma, mode);
+    if (st != DAAC_OK) return st;
+    if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
+    void *staged = nullptr;
+    const uint8_t *dev_hay = hay;
+    if (!hay_is_device && len) {
+        if ((st = stage_window(hay, 0, len, stream, &staged, &dev_hay)) != DAAC_OK) return st;
+    }
+    std::unique_ptr<void, void (*)(void *)> g1(staged, [](void *p) { if (p) (void)hipFree(p); });
+    DevMatches dm;
+    if ((st = scan_range_device(pma, t, mode, engine, dev_hay, 0, len, len, stream, dm, nullptr)) != DAAC_OK) return st;
+    HIP_TRY(hipStreamSynchronize(stream));
+    *count = dm.n;
+    *dev_out = dm.release();
+    return DAAC_OK;
+}
+
+void daac_device_free(void *p) { if (p) (void)hipFree(p); }
+
+daac_status daac_device_to_host(void *dst, const void *dev_src, size_t bytes) {
+    if (bytes && (!dst || !dev_src)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    if (bytes) HIP_TRY(hipMemcpy(dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return DAAC_OK;
+}
+
 size_t daac_matches_count(const daac_matches *m) { return m ? m->v.size() : 0; }
 const daac_match *daac_matches_data(const daac_matches *m) { return m && m->v.size() != 0 ? m->v.p : nullptr; }
 void daac_matches_free(daac_matches *m) { delete m; }
@@ -1223,6 +1408,9 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_version") g_opt.gram_version = value;
     else if (n == "gram2_dpp") g_opt.gram2_dpp = value;
     else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
+    else if (n == "emit") g_opt.emit = value;
+    else if (n == "emit_tiles") g_opt.emit_tiles = value;
+    else if (n == "emit_rec_cap") g_opt.emit_rec_cap = value;
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;
     else if (n == "chain_rounds") g_opt.chain_rounds = value;

@@ -127,6 +127,38 @@ struct Gram2Dev {
     uint32_t xlane_dpp;       // neighbour exchange through DPP wave shifts (else ds_bpermute)
 };
 uint32_t gram2_lds_bytes(const Gram2Dev &dev, bool exact);
+
+// GRAM engine, tuple emission (gram2_emit_kernels.hip).  LDS: [0,256) classes | ME at 512 | S | V1 | V2 | hit rings | per-wave areas
+constexpr uint32_t kGram2OffM = 512;
+struct Gram2EmitDev {
+    const uint8_t *cls;
+    const uint32_t *me;       // C^K words: continuation bits 1..28, bit 28 + len = a pattern of length len ends after the context
+    const void *sdir;         // rank directory (as Gram2Dev::sdir)
+    const uint32_t *v1, *v2;  // values of the 1- and 2-gram patterns (staged in LDS)
+    const uint32_t *v3;       // values of the 3-gram patterns (L2)
+    const uint4 *erec;        // N x {cmap | own (bit 0), first_child, own_value, depth}
+    const uint2 *ehit;        // depth-(K+1) states by rank: {cmap | own, own_value}
+    const uint32_t *cfirst;
+    uint32_t m_bytes, s_bytes, v1_bytes, v2_bytes;
+    uint32_t off_s, off_v1, off_v2, off_ring, off_wave, lds_bytes;
+    uint32_t K, C, s16, unused_byte;
+};
+struct EmitArgs {
+    const uint8_t *hay_al;        // window address rounded down to 16 bytes ("virtual" positions count from here)
+    uint32_t lead;                // bytes between hay_al and the first byte of the window
+    uint32_t vlen;                // lead + window length
+    uint32_t emit_from;           // matches whose last byte lies at a virtual position >= this are reported
+    unsigned long long pos_base;  // end (in haystack coordinates) of a match whose last byte is at virtual position v = pos_base + v
+    unsigned long long *tile_cnt; // per tile of 1024 positions: tuple count (COUNT pass out) / exclusive offset (WRITE pass in)
+    daac_match *out;
+    uint4 *recs;                  // per wave two lists of rec_cap deep-match records {byte, length, value, -}
+    uint32_t rec_cap;
+    uint2 *wq;                    // per-wave walker slabs
+    uint32_t wq_slab;
+    uint32_t ntiles, tiles_per_region, nregions;
+    unsigned int *fail;           // set when a record list overflowed (the caller falls back to the segment scanners)
+};
+hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, bool write, uint32_t blocks, hipStream_t stream);
 hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool exact, uint32_t blocks, uint32_t threads, hipStream_t stream);
 
 hipError_t launch_tier_scan(const TierDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,

@@ -145,7 +145,7 @@ bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out)
         }
         if (run != n_deep) continue;  // cannot happen for a consistent trie
         const bool s16 = n_deep < 65536;
-        const uint64_t lds_count = kGram2OffM + pad16(static_cast<uint64_t>(nm) * 4) + pad16(static_cast<uint64_t>(nm / 4) * (s16 ? 2 : 4));
+        const uint64_t lds_count = kGram2OffMHost + pad16(static_cast<uint64_t>(nm) * 4) + pad16(static_cast<uint64_t>(nm / 4) * (s16 ? 2 : 4));
         const uint64_t lds_exact = lds_count + pad16(static_cast<uint64_t>(nm) * 2) + pad16(hs.size() * 4);
         if (lds_count > lds_budget) continue;
         out.K = K;
@@ -174,6 +174,45 @@ bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out)
     out.drec.resize(N);
     for (uint32_t s = 0; s < N; ++s) out.drec[s] = U32x4{cmap[s], first_child[s], own_cnt[s], own_hs[s]};
     out.available = true;
+
+    // ---- tuple emission tables ----
+    {
+        const uint32_t K = out.K;
+        uint32_t max_len = 0;
+        bool ok = C <= 29;
+        for (const OutputRec &o : p.outputs) max_len = std::max(max_len, o.length);
+        for (uint32_t s = 0; s < N && ok; ++s) ok = own_cnt[s] <= 1;
+        if (max_len > K + 16) ok = false;
+        out.max_len = max_len;
+        if (ok) {
+            const uint32_t ngram = static_cast<uint32_t>(ipow(C, K));
+            out.me.assign(out.m.size(), 0);
+            out.v1.assign(C, 0);
+            out.v2.assign(static_cast<size_t>(C) * C, 0);
+            if (K == 3) out.v3.assign(static_cast<size_t>(C) * C * C, 0);
+            for (uint32_t g = 0; g < ngram; ++g) {
+                uint32_t st = kRoot;
+                for (uint32_t i = 0; i < K; ++i) st = p.next_state(st, rep[(g / static_cast<uint32_t>(ipow(C, K - 1 - i))) % C]);
+                uint32_t word = out.m[g] & 0x1ffffffeu;  // continuation bits 1..28
+                for (uint32_t op = output_pos_of(p.states[st].opos_ch); op != 0; op = p.outputs[op - 1].parent) {
+                    const uint32_t len = p.outputs[op - 1].length, val = p.outputs[op - 1].value;
+                    word |= 1u << (28 + len);  // len in 1..K
+                    const uint32_t sub = g % static_cast<uint32_t>(ipow(C, len));  // the last `len` classes of the context
+                    (len == 1 ? out.v1 : len == 2 ? out.v2 : out.v3)[sub] = val;
+                }
+                out.me[g] = word;
+            }
+            out.erec.resize(N);
+            for (uint32_t s = 0; s < N; ++s) {
+                uint32_t val = 0;
+                if (own_cnt[s]) val = p.outputs[output_pos_of(p.states[old_of_new[s]].opos_ch) - 1].value;
+                out.erec[s] = U32x4{cmap[s] | (own_cnt[s] ? 1u : 0u), first_child[s], val, depth[s]};
+            }
+            out.ehit.clear();
+            for (uint32_t s = out.level_start; s < out.level_start + out.dhit.size(); ++s) out.ehit.push_back(U32x2{out.erec[s].x, out.erec[s].z});
+            out.emit_available = true;
+        }
+    }
     return true;
 }
 

@@ -25,6 +25,8 @@
 
 #include "repack.hpp"
 
+namespace daac { constexpr uint32_t kGram2OffMHost = 512; }  // LDS offset of M (= kGram2OffM of device_tables.hpp)
+
 namespace daac {
 
 struct Gram2Tables {
@@ -44,10 +46,19 @@ struct Gram2Tables {
     std::vector<U32x2> dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}; own_cnt == (own_hsum != 0)
     std::vector<uint32_t> cfirst;   // same order: first child id
     uint32_t lds_count = 0, lds_exact = 0;  // table bytes in LDS per mode (without the hit rings)
+
+    // ---- tuple emission (gram2_emit_kernels.hip): the same lookups, but every match has to come out as (start, end, value) ----
+    // Needs: no duplicate patterns (a context then holds at most one pattern per length), <= 29 classes (three flag bits
+    // in the word), patterns no longer than K + 16 bytes (one u16 of deep-match lengths per position).
+    bool emit_available = false;
+    uint32_t max_len = 0;
+    std::vector<uint32_t> me;       // C^K: continuation bits 1..28 as in m; bit 28 + len: a pattern of length len (1..3) ends after the context
+    std::vector<uint32_t> v1, v2, v3;  // value of the pattern that IS the 1-/2-/3-gram (C, C^2, C^3 entries; v3 only for K = 3)
+    std::vector<U32x4> erec;        // N: {cmap | own (bit 0), first_child, own_value, depth}
+    std::vector<U32x2> ehit;        // depth-(K+1) states by rank: {cmap | own (bit 0), own_value}
 };
 
 constexpr uint32_t kGram2MaskBits = 0x3fffffffu;  // continuation bits of an M word
-constexpr uint32_t kGram2OffM = 512;              // LDS layout: [0,256) classes, [256,512) 4 * class, M from 512
 
 // `lds_budget` = bytes the tables may take (rings excluded).  Returns false if the automaton does not qualify.
 bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out);

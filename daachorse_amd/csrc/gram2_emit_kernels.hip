@@ -1,0 +1,416 @@
+// GRAM engine, tuple emission (gfx950): the find_overlapping match stream as (start, end, value) tuples in the reference's
+// order (bytewise/iter.rs:133-176: by end, longest first), written to device memory without a state chain.
+//
+// Detection is that of gram2_kernels.hip (one M word per position, hits compacted into batches, walkers for the branches
+// that go on).  What emission adds is ORDER.  The haystack is cut into tiles of 1024 end positions, one wave-step each:
+//   * patterns of length <= K ending at a byte are three flag bits of its M word; their values are table lookups by the
+//     1-/2-/3-gram (v1, v2 in LDS, v3 in L2), longest first — already in order within a position;
+//   * longer ("deep") matches are found from their START by hits and walkers, so they arrive out of order.  Each sets bit
+//     (length - K - 1) in a u16 per end position of the tile (LDS) and is logged as a record {byte, length, value};
+//     at one position deep matches have distinct lengths (no duplicate patterns), so the number of set bits above
+//     its own gives a record its rank, and they all come before the short ones;
+//   * when the tile's walkers have run out, every lane knows the tuple count of each of its 16 positions; a wave scan gives
+//     the offsets; the lanes write their short matches, and the records are replayed into their slots.
+// Matches that start in one tile and end in the next are carried over in the wave's second record list; a wave begins a
+// region with a "prologue" pass over the tile before it (detection only) to pick up those that reach into its first tile.
+// Two launches: COUNT leaves the number of tuples per tile, an exclusive scan turns them into offsets, WRITE emits.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_tables.hpp"
+
+namespace daac {
+
+namespace {
+
+typedef uint32_t ge_u32x4_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t kERing = 128;        // entries of a wave's hit stack
+constexpr uint32_t kTile = 1024;        // end positions per wave-step
+constexpr uint32_t kWaveLds = 2048 + 256 + 256 + 16;  // per wave: dm[1024] u16, lanebase[64] u32, nsw[64] u32, counters
+typedef __attribute__((address_space(3))) const uint32_t ldse_cu32;
+typedef __attribute__((address_space(3))) const uint8_t ldse_cu8;
+
+__device__ __forceinline__ uint32_t epin(uint32_t x) {
+    asm("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ void ge_copy(void *dst, const void *src, uint32_t bytes) {
+    const uint4 *s = reinterpret_cast<const uint4 *>(src);
+    uint4 *d = reinterpret_cast<uint4 *>(dst);
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t &total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(x, off, 64);
+        if (lane >= static_cast<uint32_t>(off)) x += y;
+    }
+    total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+}  // namespace
+
+// K = context length; WRITE = emit tuples (else count per tile); S16 = rank directory entries are u16
+template <int K, bool WRITE, bool S16>
+__global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, const EmitArgs a) {
+    constexpr int P = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t offM = kGram2OffM, offS = g.off_s;
+    ge_copy(smem, g.cls, 256);
+    ge_copy(smem + offM, g.me, g.m_bytes);
+    ge_copy(smem + offS, g.sdir, g.s_bytes);
+    ge_copy(smem + g.off_v1, g.v1, g.v1_bytes);
+    ge_copy(smem + g.off_v2, g.v2, g.v2_bytes);
+    __syncthreads();
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+    auto cls_of = [&](uint32_t byte) -> uint32_t { return *reinterpret_cast<ldse_cu8 *>(static_cast<uintptr_t>(byte)); };
+    auto lds_u32 = [&](uint32_t addr) -> uint32_t { return *reinterpret_cast<ldse_cu32 *>(static_cast<uintptr_t>(addr)); };
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t C4 = g.C * 4u, CC4 = g.C * g.C * 4u;
+    const uint32_t ub4 = g.unused_byte * 0x01010101u;
+    const uint8_t *__restrict__ hay = a.hay_al;
+    const uint64_t wave_global = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg;
+    const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
+    uint2 *__restrict__ slab = a.wq + wave_global * a.wq_slab;
+    uint4 *__restrict__ rec_a = a.recs + wave_global * 2ull * a.rec_cap, *__restrict__ rec_b = rec_a + a.rec_cap;
+
+    // per-wave LDS: deep-match lengths per end position of the tile, lane offsets, short counts, list counters
+    char *wl = smem + g.off_wave + wave_in_wg * kWaveLds;
+    uint32_t *dm32 = reinterpret_cast<uint32_t *>(wl);            // 512 dwords = 1024 x u16
+    uint32_t *lb = reinterpret_cast<uint32_t *>(wl + 2048);       // 64
+    uint32_t *nsw = reinterpret_cast<uint32_t *>(wl + 2048 + 256);
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(wl + 2048 + 512);  // [0] records of this tile, [1] of the next
+
+    auto load_chunk = [&](uint32_t v) -> uint4 {
+        if (v >= a.vlen) return uint4{ub4, ub4, ub4, ub4};
+        const ge_u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const ge_u32x4_t *>(hay + v));
+        uint4 r{q.x, q.y, q.z, q.w};
+        if (v < a.lead || v + 16 > a.vlen) {
+            uint32_t w[4] = {r.x, r.y, r.z, r.w};
+            for (int b = 0; b < 16; ++b) {
+                const uint32_t p = v + b;
+                if (p < a.lead || p >= a.vlen) w[b >> 2] = (w[b >> 2] & ~(0xffu << (8 * (b & 3)))) | (g.unused_byte << (8 * (b & 3)));
+            }
+            r = uint4{w[0], w[1], w[2], w[3]};
+        }
+        return r;
+    };
+    auto byte_at = [&](uint32_t p) -> uint32_t { return (p >= a.lead && p < a.vlen) ? hay[p] : g.unused_byte; };
+
+    uint32_t wq_n = 0;                  // wave-uniform
+    uint32_t sb = 0;                    // first byte of the current tile (wave-uniform)
+    bool prologue = false;              // wave-uniform
+    uint4 *cur_list = rec_a, *next_list = rec_b;
+
+    // a deep match: `p` = its last byte, `len` its length, found while the wave works on tile [sb, sb + 1024)
+    auto log_deep = [&](uint32_t p, uint32_t len, uint32_t value) {
+        if (p < a.emit_from) return;
+        const bool here = p < sb + kTile;
+        if (here && prologue) return;   // belongs to the tile before this wave's region
+        if (WRITE) {
+            const uint32_t slot = atomicAdd(&ctr[here ? 0 : 1], 1u);
+            if (slot >= a.rec_cap) { atomicOr(a.fail, 1u); return; }
+            (here ? cur_list : next_list)[slot] = uint4{p, len, value, 0u};
+            if (here) atomicOr(&dm32[(p - sb) >> 1], 1u << ((len - (K + 1)) + 16u * ((p - sb) & 1u)));
+        } else {
+            atomicAdd(&ctr[here ? 0 : 1], 1u);
+        }
+    };
+
+    // walkers: {byte position p of the last byte of a (K+1)-gram, the depth-(K+2) state reached on the byte at p + 1 | class of
+    // the byte at p + 2 << 27}
+    // what one lane stored to the wave's slab / record lists is read back by another lane: the stores have to be out first
+    auto mem_settle = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    auto drain = [&]() {
+        mem_settle();
+        for (uint32_t i = lane; i < wq_n; i += 64) {
+            const uint2 e = slab[i];
+            uint32_t vnext = e.x + 2;   // the state consumed the byte before vnext
+            uint4 r = g.erec[e.y & 0x07ffffffu];  // {cmap | own, first_child, own_value, depth}
+            uint32_t kn = e.y >> 27;
+            uint32_t ahead = 0, n_ahead = 0;
+            for (;;) {
+                if (r.x & 1u) log_deep(vnext - 1, r.w, r.z);
+                if (((r.x >> kn) & 1u) == 0 || kn == 0) break;
+                r = g.erec[r.y + __popc(r.x & ((1u << kn) - 1u) & ~1u)];
+                ++vnext;
+                if (n_ahead == 0) {
+                    ahead = 0;
+                    for (int b = 3; b >= 0; --b) ahead = (ahead << 8) | byte_at(vnext + b);
+                    n_ahead = 4;
+                }
+                kn = cls_of(ahead & 0xffu);
+                ahead >>= 8;
+                --n_ahead;
+            }
+        }
+        wq_n = 0;
+    };
+
+    uint2 *ring = reinterpret_cast<uint2 *>(smem + g.off_ring) + wave_in_wg * kERing;
+    uint32_t q_n = 0;
+    uint2 pend = uint2{0u, 0u};
+    uint32_t pend_item = 0, pend_pos = 0, pend_rank = 0;
+    bool pend_valid = false;
+    auto consume_pending = [&]() {
+        if (!pend_valid) return;
+        pend_valid = false;
+        const uint2 r = pend;  // {cmap | own, own_value}; zero for idle lanes
+        if (r.x & 1u) log_deep(pend_pos, K + 1, r.y);
+        const uint32_t k1 = (pend_item >> 22) & 31u;
+        const bool go = k1 != 0 && ((r.x >> k1) & 1u);
+        const unsigned long long m = __ballot(go);
+        if (m != 0) {
+            if (go)
+                (slab + wq_n)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
+                    uint2{pend_pos, (g.cfirst[pend_rank] + __popc(r.x & ((1u << k1) - 1u) & ~1u)) | ((pend_item >> 27) << 27)};
+            wq_n += __popcll(m);
+        }
+    };
+    auto deep_rank = [&](uint32_t am, uint32_t d) -> uint32_t {
+        const uint32_t rel = am - offM;
+        const uint4 q = *reinterpret_cast<const uint4 *>(smem + offM + (rel & ~15u));
+        const uint32_t idx = (rel >> 2) & 3u;
+        const uint32_t base = S16 ? *reinterpret_cast<const uint16_t *>(smem + offS + ((rel >> 4) << 1))
+                                  : *reinterpret_cast<const uint32_t *>(smem + offS + ((rel >> 4) << 2));
+        constexpr uint32_t kBits = 0x1ffffffeu;
+        const uint32_t own = idx == 0 ? q.x : idx == 1 ? q.y : idx == 2 ? q.z : q.w;
+        uint32_t below = __popc(own & kBits & ((1u << d) - 1u));
+        below += idx > 0 ? __popc(q.x & kBits) : 0u;
+        below += idx > 1 ? __popc(q.y & kBits) : 0u;
+        below += idx > 2 ? __popc(q.z & kBits) : 0u;
+        return base + below;
+    };
+    auto process_batch = [&]() {
+        consume_pending();
+        const uint32_t n = q_n < 64u ? q_n : 64u;
+        q_n -= n;
+        pend = uint2{0u, 0u};
+        pend_item = 0;
+        if (lane < n) {
+            const uint2 it = ring[q_n + lane];
+            pend_item = it.x;
+            pend_pos = it.y;
+            pend_rank = deep_rank(it.x & 0x1ffffu, (it.x >> 17) & 31u);
+            pend = g.ehit[pend_rank];
+        }
+        pend_valid = true;
+    };
+
+    for (uint64_t region = wave_global; region < a.nregions; region += nwaves) {
+        const uint32_t t_begin = static_cast<uint32_t>(region) * a.tiles_per_region;
+        const uint32_t t_end = t_begin + a.tiles_per_region < a.ntiles ? t_begin + a.tiles_per_region : a.ntiles;
+        uint32_t t = t_begin > 0 ? t_begin - 1 : t_begin;
+        if (lane < 2) ctr[lane] = 0;
+        cur_list = rec_a;
+        next_list = rec_b;
+        q_n = 0;
+        wq_n = 0;
+        pend_valid = false;
+        // classes of the K bytes before the first tile, oldest in the low byte
+        uint32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) carry |= (t * kTile >= static_cast<uint32_t>(K - i) ? cls_of(byte_at(t * kTile - (K - i))) : 0u) << (8 * i);
+        uint4 pf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pf[i] = load_chunk((t + i) * kTile + lane * P);
+
+        for (; t < t_end; ++t) {
+            sb = t * kTile;
+            prologue = t < t_begin;
+            const uint32_t v = sb + lane * P;
+            const uint4 cur = pf[0];
+            pf[0] = pf[1];
+            pf[1] = load_chunk(v + 2 * kTile);
+            unsigned long long tile_base = 0;
+            if (WRITE && !prologue) tile_base = a.tile_cnt[t];  // exclusive offset of this tile's first tuple
+
+            // the two bytes after the tile (lane 63 needs their classes)
+            const uint32_t after2 = byte_at(sb + kTile) | (byte_at(sb + kTile + 1) << 8);
+
+            uint32_t kx[K + P + 2];
+            {
+                const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (int b = 0; b < P; ++b) {
+                    kx[K + b] = epin(cls_of((w[b >> 2] >> (8 * (b & 3))) & 0xffu));
+                    __builtin_assume(kx[K + b] < 32u);
+                }
+            }
+            uint32_t pk = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) pk |= kx[P + i] << (8 * i);
+            uint32_t left = __shfl_up(pk, 1, 64);
+            if (lane == 0) left = carry;
+            carry = __builtin_amdgcn_readlane(pk, 63);
+#pragma unroll
+            for (int i = 0; i < K; ++i) { kx[i] = (left >> (8 * i)) & 0xffu; __builtin_assume(kx[i] < 32u); }
+            const uint32_t right63 = cls_of(after2 & 0xffu) | (cls_of((after2 >> 8) & 0xffu) << 5);
+            uint32_t right = __shfl_down(kx[K] | (kx[K + 1] << 5), 1, 64);
+            right = lane == 63 ? right63 : right;
+            kx[K + P] = right & 31u;
+            kx[K + P + 1] = right >> 5;
+
+            // LDS address of the M word of the K-gram ending at j, j = -1 .. P-1
+            uint32_t am[P + 1];
+#pragma unroll
+            for (int j = -1; j < P; ++j) {
+                uint32_t x = epin((kx[K + j] << 2) + offM);
+                x = __umul24(kx[K + j - 1], C4) + x;
+                if (K == 3) x = __umul24(kx[K + j - 2], CC4) + epin(x);
+                am[j + 1] = x;
+            }
+            uint32_t tri[P];
+            tri[P - 1] = (((kx[K + P + 1] << 5) | kx[K + P]) << 5) | kx[K + P - 1];
+#pragma unroll
+            for (int j = P - 2; j >= 0; --j) tri[j] = (tri[j + 1] << 5) | kx[K + j];
+
+            // this tile's per-position deep lengths start empty; what the previous tile's walkers found for this one is replayed
+            if (WRITE) {
+                reinterpret_cast<uint4 *>(dm32)[lane * 2] = uint4{0u, 0u, 0u, 0u};
+                reinterpret_cast<uint4 *>(dm32)[lane * 2 + 1] = uint4{0u, 0u, 0u, 0u};
+                mem_settle();
+                const uint32_t ncur = min(*reinterpret_cast<volatile uint32_t *>(&ctr[0]), a.rec_cap);  // (a list that overflowed set a.fail: the scan is redone elsewhere)
+                for (uint32_t i = lane; i < ncur; i += 64) {
+                    const uint4 r = cur_list[i];
+                    atomicOr(&dm32[(r.x - sb) >> 1], 1u << ((r.y - (K + 1)) + 16u * ((r.x - sb) & 1u)));
+                }
+            }
+
+            // ---- detection: M words, short flags, hits ----
+            uint32_t flags = 0;       // 2 bits per position: number of short patterns ending there
+            uint32_t fl3[2] = {0, 0};  // 3 flag bits per position (10 positions per dword would do; two dwords of 8 keep it simple)
+            uint32_t mprev = lds_u32(am[0]);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const uint32_t mw = lds_u32(am[j + 1]);
+                uint32_t f = mw >> 29;
+                if (prologue || v + j < a.emit_from) f = 0;  // (bytes at and beyond vlen are class 0: no flags there)
+                fl3[j >> 3] |= f << (4 * (j & 7));
+                flags |= static_cast<uint32_t>(__popc(f)) << (2 * j);
+                const bool hit = __builtin_amdgcn_ubfe(mprev, kx[K + j], 1) != 0;
+                const unsigned long long m = __ballot(hit);
+                if (m != 0) {
+                    const uint32_t q_s = q_n;
+                    if (hit)
+                        (ring + q_s)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] =
+                            uint2{(tri[j] << 17) | am[j], v + j};
+                    q_n = q_s + static_cast<uint32_t>(__popcll(m));
+                    if (q_n >= 64u) process_batch();
+                }
+                mprev = mw;
+            }
+            // everything this tile's hits lead to has to be known before its tuples can be placed
+            while (q_n != 0) process_batch();
+            consume_pending();
+            drain();
+
+            if (!prologue) {
+                // ---- tuples per position: deep (bits of dm) + short (flags) ----
+                uint32_t nshort = 0;
+#pragma unroll
+                for (int j = 0; j < P; ++j) nshort += (flags >> (2 * j)) & 3u;
+                if (!WRITE) {
+                    uint32_t total;
+                    (void)wave_excl_scan(nshort, lane, total);
+                    if (lane == 0) a.tile_cnt[t] = static_cast<unsigned long long>(total) + *reinterpret_cast<volatile uint32_t *>(&ctr[0]);
+                } else {
+                    uint32_t dmw[8];
+                    {
+                        const uint4 d0 = reinterpret_cast<const uint4 *>(dm32)[lane * 2], d1 = reinterpret_cast<const uint4 *>(dm32)[lane * 2 + 1];
+                        dmw[0] = d0.x; dmw[1] = d0.y; dmw[2] = d0.z; dmw[3] = d0.w; dmw[4] = d1.x; dmw[5] = d1.y; dmw[6] = d1.z; dmw[7] = d1.w;
+                    }
+                    uint32_t ndeep = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) ndeep += __popc(dmw[w]);
+                    uint32_t total;
+                    const uint32_t lanebase = wave_excl_scan(nshort + ndeep, lane, total);
+                    lb[lane] = lanebase;
+                    nsw[lane] = flags;
+                    daac_match *__restrict__ out = a.out + tile_base;
+                    // deep matches: replay the records of this tile into their slots
+                    mem_settle();
+                    const uint32_t ncur = min(*reinterpret_cast<volatile uint32_t *>(&ctr[0]), a.rec_cap);  // (a list that overflowed set a.fail: the scan is redone elsewhere)
+                    for (uint32_t i = lane; i < ncur; i += 64) {
+                        const uint4 r = cur_list[i];
+                        const uint32_t rel = r.x - sb, L = rel >> 4, j = rel & 15u;
+                        const uint4 d0 = reinterpret_cast<const uint4 *>(dm32)[L * 2], d1 = reinterpret_cast<const uint4 *>(dm32)[L * 2 + 1];
+                        const uint32_t dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                        uint32_t before = 0;
+#pragma unroll
+                        for (uint32_t w = 0; w < 8; ++w) {
+                            const uint32_t keep = 2 * w + 1 < j ? 0xffffffffu : 2 * w < j ? 0xffffu : 0u;  // positions 2w, 2w+1 below j
+                            before += __popc(dw[w] & keep);
+                        }
+                        const uint32_t x = nsw[L] & ((1u << (2 * j)) - 1u);
+                        before += __popc(x & 0x55555555u) + 2u * __popc(x & 0xaaaaaaaau);
+                        const uint32_t here = (dw[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+                        const uint32_t longer = __popc(here >> (r.y - (K + 1) + 1));
+                        const unsigned long long end = a.pos_base + r.x;
+                        daac_match mt;
+                        mt.start = end - r.y; mt.end = end; mt.value = r.z; mt._pad = 0;
+                        out[lb[L] + before + longer] = mt;
+                    }
+                    // short matches: each lane walks its 16 positions
+                    uint32_t running = lanebase;
+                    const unsigned long long end0 = a.pos_base + v;
+#pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        running += __popc((dmw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                        const uint32_t f = (fl3[j >> 3] >> (4 * (j & 7))) & 7u;
+                        if (__ballot(f != 0) == 0) continue;
+                        const unsigned long long end = end0 + j;
+                        if (K == 3 && (f & 4u)) {
+                            daac_match mt;
+                            mt.start = end - 3; mt.end = end; mt.value = g.v3[(am[j + 1] - offM) >> 2]; mt._pad = 0;
+                            out[running++] = mt;
+                        }
+                        if (f & 2u) {
+                            daac_match mt;
+                            mt.start = end - 2; mt.end = end; mt.value = lds_u32(g.off_v2 + 4u * (kx[K + j - 1] * g.C + kx[K + j])); mt._pad = 0;
+                            out[running++] = mt;
+                        }
+                        if (f & 1u) {
+                            daac_match mt;
+                            mt.start = end - 1; mt.end = end; mt.value = lds_u32(g.off_v1 + 4u * kx[K + j]); mt._pad = 0;
+                            out[running++] = mt;
+                        }
+                    }
+                }
+            }
+            // the next tile's list becomes the current one
+            {
+                uint4 *tmp = cur_list; cur_list = next_list; next_list = tmp;
+                const uint32_t nn = *reinterpret_cast<volatile uint32_t *>(&ctr[1]);
+                if (lane == 0) { ctr[0] = nn; ctr[1] = 0; }
+            }
+        }
+    }
+}
+
+template <int K, bool WRITE>
+static hipError_t launch_e(const Gram2EmitDev &dev, const EmitArgs &a, uint32_t blocks, hipStream_t stream) {
+    hipError_t e;
+    if (dev.s16) {
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_emit_kernel<K, WRITE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(dev.lds_bytes))) != hipSuccess) return e;
+        hipLaunchKernelGGL((gram2_emit_kernel<K, WRITE, true>), dim3(blocks), dim3(1024), dev.lds_bytes, stream, dev, a);
+    } else {
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_emit_kernel<K, WRITE, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(dev.lds_bytes))) != hipSuccess) return e;
+        hipLaunchKernelGGL((gram2_emit_kernel<K, WRITE, false>), dim3(blocks), dim3(1024), dev.lds_bytes, stream, dev, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, bool write, uint32_t blocks, hipStream_t stream) {
+    if (dev.K == 3) return write ? launch_e<3, true>(dev, a, blocks, stream) : launch_e<3, false>(dev, a, blocks, stream);
+    return write ? launch_e<2, true>(dev, a, blocks, stream) : launch_e<2, false>(dev, a, blocks, stream);
+}
+
+}  // namespace daac

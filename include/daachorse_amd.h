@@ -56,7 +56,7 @@ typedef enum {
     DAAC_ENGINE_AUTO = 0,
     DAAC_ENGINE_TIERED = 1, /* re-packed bitmap-rank trie, top levels dense in LDS */
     DAAC_ENGINE_DARRAY = 2, /* the reference's own double array, hot/cold split   */
-    DAAC_ENGINE_GRAM = 3    /* count/checksum only: k-gram context tables in LDS, no state chain */
+    DAAC_ENGINE_GRAM = 3    /* k-gram context tables in LDS, no state chain: count / checksum, and tuples of FIND_OVERLAPPING */
 } daac_engine;
 
 /* Match<u32> (src/lib.rs:286-320): start() = end - length, end(), value() */
@@ -157,6 +157,16 @@ daac_status daac_pma_upload(daac_pma *pma, int device);
  * if hay_is_device != 0.  Matches come back in the reference's order. */
 daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len,
                       int hay_is_device, void *stream, daac_matches **out);
+/* The same with the match list left in DEVICE memory (for consumers that run on the GPU): `*dev_out` receives a device
+ * buffer of `*count` daac_match tuples in the reference's order (NULL when there are none), owned by the caller and
+ * released with daac_device_free.  For DAAC_FIND_OVERLAPPING on a bytewise Standard automaton whose tables fit (engine
+ * AUTO or GRAM) the tuples come from the GRAM emitter: per-tile counts, one exclusive scan, then every tuple is written
+ * once, straight to its final place; all other requests run the segment scanners (count, scan, write).  The call returns
+ * after the stream has finished.  daac_device_to_host copies (part of) such a list to host memory. */
+daac_status daac_scan_device(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len,
+                             int hay_is_device, void *stream, daac_match **dev_out, uint64_t *count);
+void daac_device_free(void *p);
+daac_status daac_device_to_host(void *dst, const void *dev_src, size_t bytes);
 size_t daac_matches_count(const daac_matches *m);
 const daac_match *daac_matches_data(const daac_matches *m); /* host memory, owned by `m` */
 void daac_matches_free(daac_matches *m);
@@ -221,6 +231,8 @@ void daac_stream_close(daac_stream *s);
  *   gram_lds_budget (161792), gram_region (0 = auto: 16384 / 65536 for the first / second table set; rounded down to a power of two >= 2048), gram_slab (4096), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto),
  *   gram_ppl (0 = auto: 32 positions per lane and step for automata without short patterns, else 16)
  *   gram_version (0 = second table set where it applies, 1 = first only, 2 = second only), gram2_dpp (1: DPP wave shifts)
+ *   emit (1)                    materialising overlapping scans through the GRAM tuple emitter where it applies (0: segment scanners);
+ *   emit_tiles (64), emit_rec_cap (256)   tiles of 1024 positions per wave region / deep-match records per wave and tile
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners
  *   char_map_lds (0)            charwise chain scans: code mapper staged in LDS when it fits

@@ -318,6 +318,70 @@ def test_gram2_tables_on_the_device():
     assert p.count(ScanMode.FindOverlapping, b"aaa") == 7
 
 
+def test_gram_tuple_emitter():
+    """daac_scan_device / daac_scan through the GRAM tuple emitter (gram2_emit_kernels.hip): bit-exact tuples in the
+    reference's order on texts that stress its seams — matches that straddle tile (1024 B) and region boundaries, lazy
+    windows that begin inside matches, unaligned device haystacks, both K, record-list overflow (falls back) — and the list
+    left in device memory equals the one copied to the host"""
+    import torch
+    rng = np.random.default_rng(123)
+    pats3 = synth.patterns_cfg3(30000)
+    long_pats = [b"abcdefghijklmnop", b"bcdefghijklmnopq", b"mnopqrs", b"ponmlkjihg", b"qrstuv", b"a", b"op", b"nop", b"lmnopqrstuvwxyzabc"]
+    cases = [(synth.patterns_cfg1(), synth.uniform_haystack(9000, 3, synth.ALPHA_ABCD)),
+             (long_pats, np.frombuffer((b"abcdefghijklmnopqrstuvwxyzabc" * 400)[:11000], dtype=np.uint8)),
+             (long_pats, synth.uniform_haystack(20000, 4, b"abcdefghijklmnopqrstuvwxyz")),
+             (synth.patterns_cfg2(500), synth.wordsoup_haystack(300000, 8, synth.patterns_cfg2(500), 13, noise_256=30)),
+             (pats3, synth.uniform_haystack((1 << 20) + 777, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)),
+             (pats3, synth.wordsoup_haystack(1 << 20, synth.SEEDS["cfg3_dense"], pats3, 20))]
+    try:
+        for pats, hay in cases:
+            o, _ = _pma(pats)
+            want = o.find_overlapping_iter(hay)
+            for tiles, budget, shift in ((64, 158 * 1024, 0), (1, 158 * 1024, 3), (2, 24 * 1024, 9)):
+                da.set_option("emit_tiles", tiles)
+                da.set_option("gram_lds_budget", budget)
+                p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+                dev = torch.from_numpy(np.concatenate([np.zeros(shift, dtype=np.uint8), hay])).cuda()[shift:]
+                got = p.scan(ScanMode.FindOverlapping, dev, engine=Engine.Gram)  # Engine.Gram: no silent fallback
+                assert _same(got, want), (len(pats), len(hay), tiles, budget)
+                dm = p.scan_device(ScanMode.FindOverlapping, dev)
+                assert da.last_engine() == int(Engine.Gram) and dm.count == len(want)
+                assert _same(dm.to_numpy(), want)
+                if len(want) > 100:
+                    mid = dm.to_numpy(first=len(want) // 2, n=50)
+                    assert _same(mid, want[len(want) // 2:len(want) // 2 + 50])
+                dm.free()
+            da.set_option("emit_tiles", 64)
+            da.set_option("gram_lds_budget", 158 * 1024)
+            # lazy windows begin wherever the previous one ended: inside matches, off the tile grid
+            p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+            da.set_option("iter_window", 4096 + 37)
+            sub = hay[:60000]
+            wsub = o.find_overlapping_iter(sub)
+            lazy = [(m.start(), m.end(), m.value()) for m in p.find_overlapping_iter(sub)]
+            assert lazy == [(int(x["start"]), int(x["end"]), int(x["value"])) for x in wsub]
+            da.set_option("iter_window", 64 << 20)
+        # more deep matches in one tile than a wave has record space for: the scan falls back and stays exact
+        pats = [b"a" * k for k in range(1, 17)]
+        hay = np.frombuffer(b"a" * 5000 + b"b" + b"a" * 3000, dtype=np.uint8)
+        o, p = _pma(pats)
+        want = o.find_overlapping_iter(hay)
+        got = p.scan(ScanMode.FindOverlapping, hay)
+        assert _same(got, want) and da.last_engine() != int(Engine.Gram)
+        da.set_option("emit_rec_cap", 1 << 14)
+        q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+        assert _same(q.scan(ScanMode.FindOverlapping, hay, engine=Engine.Gram), want)
+        # automata the emitter declines (duplicates): still served, by the segment scanners
+        o, p = _pma(["ab", "ab", "abc"])
+        assert _same(p.scan(ScanMode.FindOverlapping, b"xabcabab"), o.find_overlapping_iter(b"xabcabab"))
+        with pytest.raises(da.DaachorseError) as ei:
+            p.scan(ScanMode.FindOverlapping, b"xabcabab", engine=Engine.Gram)
+        assert ei.value.code == 6
+    finally:
+        for k, v in (("emit_tiles", 64), ("gram_lds_budget", 158 * 1024), ("iter_window", 64 << 20), ("emit_rec_cap", 256)):
+            da.set_option(k, v)
+
+
 def test_shard_tail_counts_add_up():
     """daac_scan_count_range: the matches with end in (begin, len] — what one device of a sharded
     haystack contributes.  Shards of one haystack must add up to the whole, at any split point."""

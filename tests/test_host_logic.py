@@ -216,6 +216,33 @@ def test_gram2_tables_reproduce_the_match_stream(gram2_check, tmp_path):
     assert subprocess.check_output([gram2_check, str(blob), "160000", str(h)]).decode().startswith("OK")
 
 
+def test_emit_tables_reproduce_the_tuple_stream(tmp_path):
+    """the tuple-emission tables (flag bits + value tables for short patterns, ehit / erec for deep ones) walked with the
+    emitter's rules give the literal automaton's (start, end, value) list, order included"""
+    exe = str(tmp_path / "emit_check")
+    csrc = os.path.join(ROOT, "daachorse_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "emit_check.cpp"),
+                           os.path.join(csrc, "pma.cpp"), os.path.join(csrc, "repack.cpp"), os.path.join(csrc, "gram2.cpp")])
+    rng = np.random.default_rng(4)
+    pats3 = synth.patterns_cfg3(20000)
+    cases = [(["a", "ab", "bab", "bc", "bca", "c", "caa", "abcabcab", "bb", "cabcabcab"], rng.choice(np.frombuffer(b"abc", dtype=np.uint8), size=30000)),
+             (synth.patterns_cfg1(), synth.uniform_haystack(5000, 1, synth.ALPHA_ABCD)),
+             (synth.patterns_cfg2(300), synth.wordsoup_haystack(60000, 9, synth.patterns_cfg2(300), 13, noise_256=40)),
+             (pats3, synth.uniform_haystack(100000, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)),
+             (pats3, synth.wordsoup_haystack(100000, synth.SEEDS["cfg3_dense"], pats3, 20))]
+    blob, h = tmp_path / "a.blob", tmp_path / "h.bin"
+    for pats, hay in cases:
+        blob.write_bytes(orc.OraclePma.build(pats).serialize())
+        np.asarray(hay, dtype=np.uint8).tofile(h)
+        for budget in (147000, 9000):
+            out = subprocess.check_output([exe, str(blob), str(budget), str(h)]).decode()
+            assert out.startswith("OK"), out
+    # duplicate patterns, patterns longer than K + 16 bytes: no emission tables (the segment scanners serve)
+    for pats in (["ab", "ab", "abc"], ["a" * 25, "ab"]):
+        blob.write_bytes(orc.OraclePma.build(pats).serialize())
+        assert subprocess.check_output([exe, str(blob), "147000", str(h)]).decode().startswith("UNAVAILABLE"), pats
+
+
 def test_synth_definitions_are_stable():
     """Seeds and generators are part of the benchmark definition: pin a few bytes/patterns."""
     h = synth.uniform_haystack(64, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
