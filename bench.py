@@ -176,13 +176,13 @@ def main():
         total_default = 4 << 30
         seed_sparse = synth.SEEDS["cfg4_hay"] + rank if (world > 1 and args.scaling == "weak") else synth.SEEDS["cfg3_hay"]
         seed_dense, alpha, slot, noise = synth.SEEDS["cfg3_dense"] + (rank if args.scaling == "weak" else 0), synth.ALPHA_LOWER_SPACE, 20, 77
-        wl_name = "100k-pattern bytewise automaton (words_100000-style), 4 GiB haystack, find_overlapping count+checksum"
+        wl_name = "cfg3: 100k-pattern bytewise automaton (words_100000-style), 4 GiB haystack per GPU, find_overlapping"
     else:
         patterns = synth.patterns_cfg2()
         total_default = 256 << 20
         seed_sparse = synth.SEEDS["cfg2_hay"] + (rank if args.scaling == "weak" else 0)
         seed_dense, alpha, slot, noise = synth.SEEDS["cfg2_dense"] + (rank if args.scaling == "weak" else 0), synth.ALPHA_PRINTABLE, 13, 0
-        wl_name = "1000-pattern bytewise automaton, 256 MiB random-ASCII haystack, find_overlapping count+checksum"
+        wl_name = "cfg2: 1000-pattern bytewise automaton, 256 MiB random-ASCII haystack per GPU, find_overlapping"
     t0 = time.time()
     pma = da.DoubleArrayAhoCorasick.new(patterns)
     build_s = time.time() - t0
@@ -275,6 +275,7 @@ def main():
                    "automaton_bytes": info.heap_bytes, "byte_classes": info.num_classes,
                    "lds_dense_states": info.tier_dense_states, "lds_states": info.tier_lds_states,
                    "lds_table_bytes": info.tier_lds_bytes, "gram_k": info.gram_k, "gram_lds_bytes": info.gram_lds_bytes,
+                   "gram2_lds_bytes_count": info.gram2_lds_count, "gram2_lds_bytes_checksum": info.gram2_lds_exact,
                    "parallelism": f"haystack-shard x{world} ({args.scaling})",
                    "matches_per_byte": round(total_count / job_bytes, 4), "host_build_seconds": round(build_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -294,8 +295,22 @@ def main():
         except Exception:
             pass
 
-    # ---- materialising scan of a prefix (reported, not the metric) -----------------------------------
+    # ---- tuples (reported, not the metric): device-resident list of a 1 GiB prefix, and a list copied to the host -----------
     if args.materialize_mib > 0 and world == 1:
+        da.set_option("max_result_bytes", 64 << 30)
+        n = min(nbytes, 1 << 30)
+        dm = pma.scan_device(ScanMode.FindOverlapping, hay[:n], engine=mat_engine)
+        dm.free()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dm = pma.scan_device(ScanMode.FindOverlapping, hay[:n], engine=mat_engine)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["tuples_device"] = {"bytes": n, "matches": int(dm.count), "seconds": round(dt, 4), "GB/s": round(n / dt / 1e9, 2),
+                                "tuple_GB/s": round(dm.count * 24 / dt / 1e9, 1), "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"),
+                                "note": "daac_scan_device: (start, end, value) tuples in reference order left in HBM; wall time of the call "
+                                        "(count pass, exclusive scan, allocation, write pass)"}
+        dm.free()
         n = min(nbytes, args.materialize_mib << 20)
         pma.scan(ScanMode.FindOverlapping, hay[:n], engine=mat_engine)
         torch.cuda.synchronize()
@@ -304,7 +319,7 @@ def main():
         dt = time.perf_counter() - t0
         out["materialize"] = {"bytes": n, "matches": int(len(m)), "seconds": round(dt, 4), "GB/s": round(n / dt / 1e9, 3),
                               "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"),
-                              "note": "device scan + D2H of 24-byte tuples into page-locked memory"}
+                              "note": "daac_scan: the same + D2H of the 24-byte tuples into page-locked memory (PCIe-bound)"}
         del m
 
     # ---- CPU baseline: the C restatement of the reference CPU path, on a bounded prefix ----------------
@@ -377,6 +392,32 @@ def main():
         out["dense"] = {"haystack": "dense (word soup)", "value": round(nbytes / k_s / 1e9, 2), "unit": "GB/s",
                         "frac": round(nbytes / k_s / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(k_s * 1e3, 4),
                         "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"), "matches_per_byte": round(cnt / nbytes, 4)}
+    # ---- a dictionary beyond 31 byte classes: the cfg3 words in mixed case + digits (60 pattern bytes) -----------------
+    if world == 1 and not args.no_dense and args.workload == "cfg3":
+        del hay
+        torch.cuda.empty_cache()
+        wp = da.DoubleArrayAhoCorasick.new(synth.patterns_cfg3_wide())
+        wp.upload(local_rank)
+        wn = 1 << 30
+        whay = torch.empty(wn, dtype=torch.uint8, device="cuda")
+        synth.device_uniform(whay, seed_sparse, synth.ALPHA_WIDE_SPACE)
+        wide = {"dictionary": "cfg3 words in lower / Capitalised / UPPER case, a quarter with a digit: 60 pattern bytes", "bytes": wn,
+                "byte_classes": None}
+        for name, fn in (("count", lambda: wp.count(ScanMode.FindOverlapping, whay, stream=stream, result_dev=result.data_ptr())),
+                         ("checksum", lambda: wp.scan_count(ScanMode.FindOverlapping, whay, stream=stream, result_dev=result.data_ptr()))):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            wide[name] = {"value": round(wn / ms / 1e6, 2), "unit": "GB/s", "frac": round(wn / ms / 1e6 / HBM_PEAK_GBS, 4),
+                          "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"), "match_count": int(result[0].item())}
+        wide["byte_classes"] = wp.info().num_classes
+        out["wide_alphabet"] = wide
     print(json.dumps(out))
 
 

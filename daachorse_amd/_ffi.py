@@ -31,7 +31,7 @@ class Info(C.Structure):
                 ("gram_k", C.c_uint32), ("gram_lds_bytes", C.c_uint32),
                 ("charwise", C.c_uint8), ("alphabet_size", C.c_uint32),
                 ("gram2_available", C.c_uint8), ("gram2_exact", C.c_uint8), ("gram2_k", C.c_uint32),
-                ("gram2_lds_count", C.c_uint32), ("gram2_lds_exact", C.c_uint32)]
+                ("gram2_lds_count", C.c_uint32), ("gram2_lds_exact", C.c_uint32), ("gram_wide", C.c_uint8)]
 
 
 def lib():

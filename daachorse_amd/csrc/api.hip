@@ -16,6 +16,7 @@
 #include "device_tables.hpp"
 #include "gram.hpp"
 #include "gram2.hpp"
+#include "gram2w.hpp"
 #include "pma.hpp"
 #include "repack.hpp"
 
@@ -75,6 +76,8 @@ struct DeviceTables {
     GramDev gram{};
     bool gram2_ok = false;     // second table set (gram2.hpp)
     Gram2Dev gram2{};
+    bool gramw_ok = false;     // wide alphabets (gram2w.hpp)
+    Gram2WDev gramw{};
     bool emit_ok = false;      // tuple emission on the second table set (gram2_emit_kernels.hip)
     Gram2EmitDev emit{};
     CharDev chr{};  // charwise automata only
@@ -439,6 +442,43 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 e.K = g2.K; e.C = g2.C; e.s16 = g2.s16; e.unused_byte = g2.unused_byte;
                 t->emit_ok = e.lds_bytes <= 160u * 1024u;
             }
+        }
+    }
+    // GRAM engine for wide alphabets: only where the 32-bit tables do not apply
+    if (!t->gram_ok && !t->gram2_ok) {
+        Gram2WTables gw;
+        const uint32_t ring_bytes = 16u * 128u * 8u;
+        const int64_t budget = g_opt.gram_lds_budget.load() - static_cast<int64_t>(ring_bytes);
+        if (budget > 0 && build_gram2w_tables(h, static_cast<uint32_t>(budget), gw)) {
+            Gram2WDev &d = t->gramw;
+            auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
+            const U32x4 *drec; const U32x4 *dhit; const uint64_t *pm;
+            if ((st = t->put(gw.cls, d.cls)) != DAAC_OK) return st;
+            if ((st = t->put(gw.m, pm)) != DAAC_OK) return st;
+            d.m = reinterpret_cast<const unsigned long long *>(pm);
+            if ((st = t->put(gw.sdir, d.sdir)) != DAAC_OK) return st;
+            std::vector<uint16_t> cid(gw.cid4.size());
+            for (size_t i = 0; i < cid.size(); ++i) cid[i] = static_cast<uint16_t>(kGram2OffH + gw.cid4[i]);
+            if ((st = t->put(cid, d.cid4)) != DAAC_OK) return st;
+            if ((st = t->put(gw.hsum, d.hsum)) != DAAC_OK) return st;
+            if ((st = t->put(gw.drec, drec)) != DAAC_OK) return st;
+            if ((st = t->put(gw.dhit, dhit)) != DAAC_OK) return st;
+            d.drec = reinterpret_cast<const uint4 *>(drec);
+            d.dhit = reinterpret_cast<const uint4 *>(dhit);
+            d.m_bytes = p16(gw.m.size() * 8); d.s_bytes = p16(gw.sdir.size() * 4);
+            d.cid_bytes = p16(cid.size() * 2); d.h_bytes = p16(gw.hsum.size() * 4);
+            d.off_m_count = kGram2OffM;
+            d.off_s_count = d.off_m_count + d.m_bytes;
+            d.off_ring_count = d.off_s_count + d.s_bytes;
+            d.lds_count = d.off_ring_count + ring_bytes;
+            d.off_m_exact = kGram2OffH + d.h_bytes;
+            d.off_s_exact = d.off_m_exact + d.m_bytes;
+            d.off_cid = d.off_s_exact + d.s_bytes;
+            d.off_ring_exact = d.off_cid + d.cid_bytes;
+            d.lds_exact = d.off_ring_exact + ring_bytes;
+            d.C = gw.C; d.unused_byte = gw.unused_byte; d.n_deep = static_cast<uint32_t>(gw.dhit.size());
+            d.exact_ok = gw.exact_available && kGram2OffH + gw.hsum.size() * 4 <= 65536 && d.lds_exact <= 160u * 1024u;
+            t->gramw_ok = d.lds_count <= 160u * 1024u;
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -958,6 +998,7 @@ daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
             info->gram_k = t->gram.K;
             info->gram_lds_bytes = t->gram.lds_bytes;
         }
+        if (t->gramw_ok) { info->gram_available = 1; info->gram_k = 2; info->gram_lds_bytes = t->gramw.lds_count; info->num_classes = t->gramw.C; info->gram_wide = 1; }
         info->gram2_available = t->gram2_ok;
         if (t->gram2_ok) {
             info->gram2_k = t->gram2.K;
@@ -997,13 +1038,15 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     // faster; `.count()` alone needs one lookup per position on the second and runs 20-25 % faster there)
     const bool g1_can = t->gram_ok && gv != 2;
     const bool g2_can = t->gram2_ok && (!want_checksum || t->gram2.exact_ok) && gv != 1 && !(gv == 0 && want_checksum && g1_can);
+    const bool gw_can = t->gramw_ok && (!want_checksum || t->gramw.exact_ok);  // wide alphabets: built only where the others are not
     const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len - begin < (1ull << 35) &&
-                          (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (g2_can || g1_can)));
-    if (engine == DAAC_ENGINE_GRAM && (!use_gram || !(g2_can || g1_can))) {
+                          (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (g2_can || g1_can || gw_can)));
+    if (engine == DAAC_ENGINE_GRAM && (!use_gram || !(g2_can || g1_can || gw_can))) {
         set_error("GRAM engine not available for this automaton / mode");
         return DAAC_ERR_UNSUPPORTED;
     }
     const bool use_g2 = use_gram && g2_can;
+    const bool use_gw = use_gram && !g2_can && !g1_can && gw_can;
     Plan pl;
     bool heads = false;
     if ((st = make_plan(pma, t, mode, use_gram ? DAAC_ENGINE_AUTO : engine, begin, len, pl, heads)) != DAAC_OK) return st;
@@ -1045,15 +1088,17 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         uint64_t region = 2048;
         const int64_t region_opt = g_opt.gram_region.load() > 0 ? g_opt.gram_region.load() : (use_g2 ? 65536 : 16384);
         while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, region_opt)) && region < (1ull << 30)) region *= 2;
-        ga.ppl = (!use_g2 && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
+        ga.ppl = (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;
         ga.result = d_res;
         uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
         threads = std::min(1024u, std::max(64u, threads & ~63u));
+        if (use_gw) threads = 1024;  // the wide kernel has one launch shape
         const uint32_t wpb = threads / 64;
         uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
-        const uint32_t gram_lds = use_g2 ? gram2_lds_bytes(t->gram2, want_checksum) : t->gram.lds_bytes;
+        const uint32_t gram_lds = use_gw ? (want_checksum ? t->gramw.lds_exact : t->gramw.lds_count)
+                                         : use_g2 ? gram2_lds_bytes(t->gram2, want_checksum) : t->gram.lds_bytes;
         if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / gram_lds));
         const uint32_t blocks = static_cast<uint32_t>(
             std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (ga.nregions + wpb - 1) / wpb)));
@@ -1061,14 +1106,16 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(2 * (64 * ga.ppl + 128), g_opt.gram_slab.load()));
         // more than ~1 % of the (K+1)-grams are trie prefixes: some lane of the wave hits on nearly every position
         {
-            const uint64_t n_deep = use_g2 ? t->gram2.n_deep : t->gram.n_deep, C = use_g2 ? t->gram2.C : t->gram.C, K = use_g2 ? t->gram2.K : t->gram.K;
+            const uint64_t n_deep = use_gw ? t->gramw.n_deep : use_g2 ? t->gram2.n_deep : t->gram.n_deep, C = use_gw ? t->gramw.C : use_g2 ? t->gram2.C : t->gram.C,
+                           K = use_gw ? 2 : use_g2 ? t->gram2.K : t->gram.K;
             ga.dense = g_opt.gram_dense.load() >= 0 ? g_opt.gram_dense.load() != 0 : n_deep * 100 > C * C * C * (K == 3 ? C : 1);
         }
         void *wq = nullptr;
         HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * sizeof(uint2), stream));
         ga.wq = static_cast<uint2 *>(wq);
-        const hipError_t le = use_g2 ? launch_gram2_scan(t->gram2, ga, want_checksum, blocks, threads, stream)
-                                     : launch_gram_scan(t->gram, ga, blocks, threads, stream);
+        const hipError_t le = use_gw ? launch_gram2w_scan(t->gramw, ga, want_checksum, blocks, stream)
+                              : use_g2 ? launch_gram2_scan(t->gram2, ga, want_checksum, blocks, threads, stream)
+                                       : launch_gram_scan(t->gram, ga, blocks, threads, stream);
         HIP_TRY(hipFreeAsync(wq, stream));
         HIP_TRY(le);
         if (begin != 0) {

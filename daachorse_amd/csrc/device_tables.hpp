@@ -128,6 +128,22 @@ struct Gram2Dev {
 };
 uint32_t gram2_lds_bytes(const Gram2Dev &dev, bool exact);
 
+// GRAM engine for 31 .. 62 byte classes (gram2w.hpp): K = 2, 64-bit M words and child bitmaps.  LDS layout as Gram2Dev.
+struct Gram2WDev {
+    const uint8_t *cls;
+    const unsigned long long *m;  // C^2 words: continuation bits 1..61, short-pattern count in bits 62-63
+    const uint32_t *sdir;         // per 4 words of m: set continuation bits before the group
+    const uint16_t *cid4;         // C^2: LDS address of the context's H entry
+    const uint32_t *hsum;
+    const uint4 *drec;            // N x {cmap lo, cmap hi, first_child, own_hsum}
+    const uint4 *dhit;            // depth-3 states by rank: {cmap lo, cmap hi, own_hsum, first_child}
+    uint32_t m_bytes, s_bytes, cid_bytes, h_bytes;
+    uint32_t off_m_count, off_s_count, off_ring_count, lds_count;
+    uint32_t off_m_exact, off_s_exact, off_cid, off_ring_exact, lds_exact;
+    uint32_t C, unused_byte, n_deep, exact_ok;
+};
+hipError_t launch_gram2w_scan(const Gram2WDev &dev, const GramArgs &a, bool exact, uint32_t blocks, hipStream_t stream);
+
 // GRAM engine, tuple emission (gram2_emit_kernels.hip).  LDS: [0,256) classes | ME at 512 | S | V1 | V2 | hit rings | per-wave areas
 constexpr uint32_t kGram2OffM = 512;
 struct Gram2EmitDev {

@@ -137,6 +137,25 @@ def patterns_cfg3(n=100_000, seed=SEEDS["cfg3_pat"]):
     return out
 
 
+# A 60-class variant of the cfg3 dictionary (dictionaries beyond 31 byte classes): the same words in lower,
+# Capitalised or UPPER case (by a hash of the index), a quarter of them followed by a digit 0-7.  26 + 26 + 8 = 60 pattern bytes.
+ALPHA_WIDE = ALPHA_LOWER + bytes(range(ord("A"), ord("Z") + 1)) + b"01234567"
+ALPHA_WIDE_SPACE = ALPHA_WIDE + b" "
+
+
+def patterns_cfg3_wide(n=100_000, seed=SEEDS["cfg3_pat"]):
+    base = patterns_cfg3(n, seed)
+    z = zstream(seed ^ 0x5A5A, np.arange(len(base), dtype=np.uint64))
+    out = []
+    for w, zi in zip(base, z.tolist()):
+        style = zi % 3
+        v = w if style == 0 else (w[:1].upper() + w[1:] if style == 1 else w.upper())
+        if (zi >> 8) % 4 == 0:
+            v += bytes([ord("0") + ((zi >> 16) % 8)])
+        out.append(v)
+    return out
+
+
 # cfg5: 50 000 distinct UTF-8 patterns of 2-8 scalars drawn with Zipf(1.0) ranks from a 6 000-symbol
 # alphabet (hiragana, katakana, then CJK unified ideographs from U+4E00; all 3 bytes in UTF-8), no empty pattern;
 # the haystack is i.i.d. scalars of the same distribution plus 10 % ASCII (1-byte) characters, cut at a character boundary.

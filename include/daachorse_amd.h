@@ -90,6 +90,7 @@ typedef struct {
     uint32_t gram2_k;
     uint32_t gram2_lds_count;    /* LDS bytes per workgroup, count only / with checksum */
     uint32_t gram2_lds_exact;
+    uint8_t gram_wide;           /* 31 .. 62 byte classes: the GRAM engine runs on 64-bit words with K = 2 (gram2w.hpp) */
 } daac_info;
 
 typedef struct daac_pma daac_pma;         /* an automaton (host copy + per-device re-pack) */

@@ -318,6 +318,34 @@ def test_gram2_tables_on_the_device():
     assert p.count(ScanMode.FindOverlapping, b"aaa") == 7
 
 
+def test_wide_alphabet_dictionary_stays_on_gram():
+    """a 60-class dictionary (the cfg3 words in mixed case, some with a digit): beyond the 32-bit tables, served by the wide
+    GRAM engine (gram2w.hpp) instead of falling to DARRAY; count alone, count + checksum, shards, tuples (segment scanners)"""
+    import torch
+    pats = synth.patterns_cfg3_wide(30000)
+    o, p = _pma(pats)
+    info = p.upload().info()
+    assert info.gram_available and info.gram_wide and not info.tiered_available and info.num_classes == 61
+    for hay in (synth.uniform_haystack((3 << 20) + 5, synth.SEEDS["cfg3_hay"], synth.ALPHA_WIDE_SPACE),
+                synth.wordsoup_haystack(3 << 20, 11, pats, 20, alphabet=synth.ALPHA_WIDE)):
+        dev = torch.from_numpy(np.concatenate([np.zeros(7, dtype=np.uint8), hay])).cuda()[7:]
+        want = o.overlapping_count(hay, threads=8)
+        assert p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want
+        assert p.scan_count(ScanMode.FindOverlapping, dev) == want and da.last_engine() == int(Engine.Gram)
+        assert p.count(ScanMode.FindOverlapping, dev) == want[0] and da.last_engine() == int(Engine.Gram)
+        assert p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.DArray) == want
+        cut = 1234567
+        assert p.count(ScanMode.FindOverlapping, dev[:cut]) + p.count(ScanMode.FindOverlapping, dev, begin=cut) == want[0]
+        small = hay[:200000]
+        assert _same(p.scan(ScanMode.FindOverlapping, small), o.find_overlapping_iter(small))
+    # 61 distinct pattern bytes, short patterns, text over a wider byte range
+    rng = np.random.default_rng(8)
+    some = list(dict.fromkeys(bytes(rng.integers(33, 94, size=int(rng.integers(1, 9))).astype(np.uint8)) for _ in range(3000)))
+    o, p = _pma(some)
+    hay = rng.integers(30, 97, size=2_000_000).astype(np.uint8)
+    assert p.scan_count(ScanMode.FindOverlapping, hay, engine=Engine.Gram) == o.overlapping_count(hay, threads=8)
+
+
 def test_gram_tuple_emitter():
     """daac_scan_device / daac_scan through the GRAM tuple emitter (gram2_emit_kernels.hip): bit-exact tuples in the
     reference's order on texts that stress its seams — matches that straddle tile (1024 B) and region boundaries, lazy

@@ -216,6 +216,30 @@ def test_gram2_tables_reproduce_the_match_stream(gram2_check, tmp_path):
     assert subprocess.check_output([gram2_check, str(blob), "160000", str(h)]).decode().startswith("OK")
 
 
+def test_gram2w_tables_reproduce_the_match_stream(tmp_path):
+    """the wide-alphabet GRAM tables (31 .. 62 byte classes, 64-bit words, K = 2) walked with the kernel's rules == literal
+    automaton walk; at most 61 pattern bytes"""
+    exe = str(tmp_path / "gram2w_check")
+    csrc = os.path.join(ROOT, "daachorse_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "gram2w_check.cpp"),
+                           os.path.join(csrc, "pma.cpp"), os.path.join(csrc, "repack.cpp"), os.path.join(csrc, "gram2w.cpp")])
+    blob, h = tmp_path / "a.blob", tmp_path / "h.bin"
+    wide = synth.patterns_cfg3_wide(20000)
+    assert len({b for w in wide for b in w}) == 60
+    rng = np.random.default_rng(8)
+    some = [bytes(rng.integers(33, 94, size=int(rng.integers(1, 9))).astype(np.uint8)) for _ in range(400)]  # 61 distinct bytes
+    for pats, hay in ((wide, synth.uniform_haystack(100000, 3, synth.ALPHA_WIDE_SPACE)),
+                      (wide, synth.wordsoup_haystack(100000, 5, wide, 20, alphabet=synth.ALPHA_WIDE)),
+                      (list(dict.fromkeys(some)), rng.integers(30, 97, size=60000).astype(np.uint8)),
+                      (synth.patterns_cfg1(), synth.uniform_haystack(5000, 1, synth.ALPHA_ABCD))):
+        blob.write_bytes(orc.OraclePma.build(pats).serialize())
+        np.asarray(hay, dtype=np.uint8).tofile(h)
+        out = subprocess.check_output([exe, str(blob), "147000", str(h)]).decode()
+        assert out.startswith("OK"), out
+    blob.write_bytes(orc.OraclePma.build([bytes([i]) for i in range(33, 33 + 62)]).serialize())  # 62 pattern bytes: one too many
+    assert subprocess.check_output([exe, str(blob), "147000", str(h)]).decode().startswith("UNAVAILABLE")
+
+
 def test_emit_tables_reproduce_the_tuple_stream(tmp_path):
     """the tuple-emission tables (flag bits + value tables for short patterns, ehit / erec for deep ones) walked with the
     emitter's rules give the literal automaton's (start, end, value) list, order included"""

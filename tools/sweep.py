@@ -25,17 +25,19 @@ def main():
     ap.add_argument("--grid", default="engine=tiered,darray")
     ap.add_argument("--mode", default="overlapping", choices=["overlapping", "find", "leftmost"])
     args = ap.parse_args()
-    pats = synth.patterns_cfg3() if args.workload == "cfg3" else synth.patterns_cfg2()
+    pats = synth.patterns_cfg3() if args.workload == "cfg3" else synth.patterns_cfg3_wide() if args.workload == "cfg3w" else synth.patterns_cfg2()
     kind = da.MatchKind.LeftmostLongest if args.mode == "leftmost" else da.MatchKind.Standard
     mode = {"overlapping": ScanMode.FindOverlapping, "find": ScanMode.Find, "leftmost": ScanMode.LeftmostFind}[args.mode]
     blob = da.DoubleArrayAhoCorasickBuilder().match_kind(kind).build(pats).serialize()
     n = args.mib << 20
     hay = torch.empty(n, dtype=torch.uint8, device="cuda")
+    wl = "cfg3" if args.workload == "cfg3w" else args.workload
     if args.haystack == "sparse":
-        synth.device_uniform(hay, synth.SEEDS[f"{args.workload}_hay"], synth.ALPHA_LOWER_SPACE if args.workload == "cfg3" else synth.ALPHA_PRINTABLE)
+        synth.device_uniform(hay, synth.SEEDS[f"{wl}_hay"], synth.ALPHA_WIDE_SPACE if args.workload == "cfg3w" else
+                             synth.ALPHA_LOWER_SPACE if wl == "cfg3" else synth.ALPHA_PRINTABLE)
     else:
-        synth.device_wordsoup(hay, synth.SEEDS[f"{args.workload}_dense"], pats, 20 if args.workload == "cfg3" else 13,
-                              noise_256=77 if args.workload == "cfg3" else 0)
+        synth.device_wordsoup(hay, synth.SEEDS[f"{wl}_dense"], pats, 20 if wl == "cfg3" else 13, noise_256=77 if wl == "cfg3" else 0,
+                              alphabet=synth.ALPHA_WIDE if args.workload == "cfg3w" else synth.ALPHA_LOWER)
     res = torch.zeros(3, dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     keys, vals = [], []
