@@ -43,6 +43,8 @@ struct Options {
     std::atomic<int64_t> gram2_dpp{1};
     std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
     std::atomic<int64_t> emit{1};               // materialising overlapping scans: GRAM tuple emission where it applies (0: segment scanners)
+    std::atomic<int64_t> emit_staged{0};        // 1: the write pass gathers the tuples of 64 positions in LDS and stores them contiguously
+                                                // (8 waves per workgroup; measured no faster than a pair of stores per tuple with 16: DESIGN.md 4.5)
     std::atomic<int64_t> emit_tiles{64};        // tiles of 1024 positions a wave takes at a time
     std::atomic<int64_t> emit_rec_cap{256};     // deep-match records per wave and tile before the scan falls back
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
@@ -439,6 +441,8 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 e.off_ring = e.off_v2 + e.v2_bytes;
                 e.off_wave = e.off_ring + ring_bytes;
                 e.lds_bytes = e.off_wave + 16u * (2048u + 256u + 256u + 16u);
+                e.off_wave2 = e.off_ring + 8u * 128u * 8u;
+                e.lds_bytes2 = e.off_wave2 + 8u * (4096u + 1040u + 64u * 24u + 16u);
                 e.K = g2.K; e.C = g2.C; e.s16 = g2.s16; e.unused_byte = g2.unused_byte;
                 t->emit_ok = e.lds_bytes <= 160u * 1024u;
             }
@@ -717,8 +721,11 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
     // one launch geometry for all windows
     uint64_t max_regions = 0;
     for (const Win &w : wins) max_regions = std::max<uint64_t>(max_regions, (w.ntiles + tpr - 1) / tpr);
+    const int em_write = (g_opt.emit_staged.load() != 0 && e.lds_bytes2 <= 160u * 1024u) ? 2 : 1;
+    const uint32_t wpb_write = em_write == 2 ? 8u : 16u;  // waves per workgroup of the write pass
     const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (max_regions + 15) / 16)));
-    const uint64_t nwaves = static_cast<uint64_t>(blocks) * 16;
+    const uint32_t blocks_write = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (max_regions + wpb_write - 1) / wpb_write)));
+    const uint64_t nwaves = std::max<uint64_t>(static_cast<uint64_t>(blocks) * 16, static_cast<uint64_t>(blocks_write) * wpb_write);
     unsigned long long *d_tiles = nullptr;
     void *d_scratch = nullptr;
     const size_t wq_bytes = nwaves * wq_slab * sizeof(uint2), rec_bytes = nwaves * 2ull * rec_cap * sizeof(uint4);
@@ -739,7 +746,7 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
         a.fail = d_fail;
         return a;
     };
-    for (const Win &w : wins) HIP_TRY(launch_gram2_emit(e, args_of(w), false, blocks, stream));
+    for (const Win &w : wins) HIP_TRY(launch_gram2_emit(e, args_of(w), 0, blocks, stream));
     HIP_TRY(launch_exclusive_scan(d_tiles, tiles_total, d_tiles + tiles_total, stream));
     unsigned long long total = 0;
     HIP_TRY(hipMemcpyAsync(&total, d_tiles + tiles_total, sizeof(total), hipMemcpyDeviceToHost, stream));
@@ -757,7 +764,7 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
     for (const Win &w : wins) {
         EmitArgs a = args_of(w);
         a.out = d_out;
-        HIP_TRY(launch_gram2_emit(e, a, true, blocks, stream));
+        HIP_TRY(launch_gram2_emit(e, a, em_write, blocks_write, stream));
     }
     unsigned int fail = 0;
     HIP_TRY(hipMemcpyAsync(&fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, stream));
@@ -1457,6 +1464,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles") g_opt.emit_tiles = value;
+    else if (n == "emit_staged") g_opt.emit_staged = value;
     else if (n == "emit_rec_cap") g_opt.emit_rec_cap = value;
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;

@@ -157,6 +157,7 @@ struct Gram2EmitDev {
     const uint32_t *cfirst;
     uint32_t m_bytes, s_bytes, v1_bytes, v2_bytes;
     uint32_t off_s, off_v1, off_v2, off_ring, off_wave, lds_bytes;
+    uint32_t off_wave2, lds_bytes2;   // staged writes: 8 waves per workgroup with larger per-wave areas
     uint32_t K, C, s16, unused_byte;
 };
 struct EmitArgs {
@@ -174,7 +175,7 @@ struct EmitArgs {
     uint32_t ntiles, tiles_per_region, nregions;
     unsigned int *fail;           // set when a record list overflowed (the caller falls back to the segment scanners)
 };
-hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, bool write, uint32_t blocks, hipStream_t stream);
+hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, int em, uint32_t blocks, hipStream_t stream);
 hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool exact, uint32_t blocks, uint32_t threads, hipStream_t stream);
 
 hipError_t launch_tier_scan(const TierDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,

@@ -27,7 +27,11 @@ namespace {
 typedef uint32_t ge_u32x4_t __attribute__((ext_vector_type(4)));
 constexpr uint32_t kERing = 128;        // entries of a wave's hit stack
 constexpr uint32_t kTile = 1024;        // end positions per wave-step
-constexpr uint32_t kWaveLds = 2048 + 256 + 256 + 16;  // per wave: dm[1024] u16, lanebase[64] u32, nsw[64] u32, counters
+constexpr uint32_t kWaveLds = 2048 + 256 + 256 + 16;  // per wave (EM 0/1): dm[1024] u16, lanebase[64] u32, nsw[64] u32, counters
+// per wave (EM 2, staged writes): per position {deep lengths | offset of its first tuple << 16} u32[1024], {class | flags << 5}
+// u8[16 + 1024] (16 bytes of left context), a staging buffer for the tuples of 64 consecutive positions, counters
+constexpr uint32_t kStageCap = 64;
+constexpr uint32_t kWaveLds2 = 4096 + 1040 + kStageCap * 24 + 16;
 typedef __attribute__((address_space(3))) const uint32_t ldse_cu32;
 typedef __attribute__((address_space(3))) const uint8_t ldse_cu8;
 
@@ -39,6 +43,27 @@ __device__ __forceinline__ void ge_copy(void *dst, const void *src, uint32_t byt
     const uint4 *s = reinterpret_cast<const uint4 *>(src);
     uint4 *d = reinterpret_cast<uint4 *>(dst);
     for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+// one 24-byte tuple: a 16-byte and an 8-byte store.  Plain stores on purpose: the lanes of one store instruction write to
+// different 128-byte lines, and it is the L2 that puts the lines together before they go to HBM — the same stores marked
+// non-temporal ran 4.4x slower (63 ms instead of 14.4 ms for 1 GiB of cfg3, profiles/r02_emit_experiments.txt)
+__device__ __forceinline__ void put_tuple(daac_match *dst, unsigned long long start, unsigned long long end, uint32_t value) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u64x2 se = {start, end};
+    const u32x2 vp = {value, 0u};
+    *reinterpret_cast<u64x2 *>(dst) = se;
+    *reinterpret_cast<u32x2 *>(reinterpret_cast<char *>(dst) + 16) = vp;
+}
+// inclusive scan over the 64 lanes on the VALU (DPP row shifts + row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x) {
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return x;
 }
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t &total) {
     uint32_t x = v;
@@ -53,10 +78,13 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
 
 }  // namespace
 
-// K = context length; WRITE = emit tuples (else count per tile); S16 = rank directory entries are u16
-template <int K, bool WRITE, bool S16>
-__global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, const EmitArgs a) {
+// K = context length; EM = 0 count per tile, 1 emit with one pair of stores per tuple (1024 threads), 2 emit through an LDS
+// staging buffer so that the tuples of 64 consecutive positions leave as contiguous 512-byte stores (512 threads: the
+// per-wave areas are larger); S16 = rank directory entries are u16
+template <int K, int EM, bool S16, int TPB>
+__global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, const EmitArgs a) {
     constexpr int P = 16;
+    constexpr bool WRITE = EM != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t offM = kGram2OffM, offS = g.off_s;
     ge_copy(smem, g.cls, 256);
@@ -80,11 +108,13 @@ __global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, 
     uint4 *__restrict__ rec_a = a.recs + wave_global * 2ull * a.rec_cap, *__restrict__ rec_b = rec_a + a.rec_cap;
 
     // per-wave LDS: deep-match lengths per end position of the tile, lane offsets, short counts, list counters
-    char *wl = smem + g.off_wave + wave_in_wg * kWaveLds;
-    uint32_t *dm32 = reinterpret_cast<uint32_t *>(wl);            // 512 dwords = 1024 x u16
-    uint32_t *lb = reinterpret_cast<uint32_t *>(wl + 2048);       // 64
-    uint32_t *nsw = reinterpret_cast<uint32_t *>(wl + 2048 + 256);
-    uint32_t *ctr = reinterpret_cast<uint32_t *>(wl + 2048 + 512);  // [0] records of this tile, [1] of the next
+    char *wl = smem + (EM == 2 ? g.off_wave2 + wave_in_wg * kWaveLds2 : g.off_wave + wave_in_wg * kWaveLds);
+    uint32_t *dm32 = reinterpret_cast<uint32_t *>(wl);            // EM 1: 512 dwords = 1024 x u16; EM 2: 1024 dwords
+    uint32_t *lb = reinterpret_cast<uint32_t *>(wl + 2048);       // 64      (EM 1)
+    uint32_t *nsw = reinterpret_cast<uint32_t *>(wl + 2048 + 256);  //       (EM 1)
+    uint8_t *cf = reinterpret_cast<uint8_t *>(wl + 4096);         // EM 2: 16 + 1024 bytes
+    unsigned long long *stage = reinterpret_cast<unsigned long long *>(wl + 4096 + 1040);  // EM 2
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(wl + (EM == 2 ? 4096 + 1040 + kStageCap * 24 : 2048 + 512));  // [0] records of this tile, [1] of the next
 
     auto load_chunk = [&](uint32_t v) -> uint4 {
         if (v >= a.vlen) return uint4{ub4, ub4, ub4, ub4};
@@ -116,7 +146,10 @@ __global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, 
             const uint32_t slot = atomicAdd(&ctr[here ? 0 : 1], 1u);
             if (slot >= a.rec_cap) { atomicOr(a.fail, 1u); return; }
             (here ? cur_list : next_list)[slot] = uint4{p, len, value, 0u};
-            if (here) atomicOr(&dm32[(p - sb) >> 1], 1u << ((len - (K + 1)) + 16u * ((p - sb) & 1u)));
+            if (here) {
+                if (EM == 2) atomicOr(&dm32[p - sb], 1u << (len - (K + 1)));
+                else atomicOr(&dm32[(p - sb) >> 1], 1u << ((len - (K + 1)) + 16u * ((p - sb) & 1u)));
+            }
         } else {
             atomicAdd(&ctr[here ? 0 : 1], 1u);
         }
@@ -127,7 +160,7 @@ __global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, 
     // what one lane stored to the wave's slab / record lists is read back by another lane: the stores have to be out first
     auto mem_settle = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     auto drain = [&]() {
-        mem_settle();
+        if (wq_n != 0) mem_settle();
         for (uint32_t i = lane; i < wq_n; i += 64) {
             const uint2 e = slab[i];
             uint32_t vnext = e.x + 2;   // the state consumed the byte before vnext
@@ -272,13 +305,14 @@ __global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, 
 
             // this tile's per-position deep lengths start empty; what the previous tile's walkers found for this one is replayed
             if (WRITE) {
-                reinterpret_cast<uint4 *>(dm32)[lane * 2] = uint4{0u, 0u, 0u, 0u};
-                reinterpret_cast<uint4 *>(dm32)[lane * 2 + 1] = uint4{0u, 0u, 0u, 0u};
-                mem_settle();
+#pragma unroll
+                for (int q = 0; q < (EM == 2 ? 4 : 2); ++q) reinterpret_cast<uint4 *>(dm32)[lane * (EM == 2 ? 4 : 2) + q] = uint4{0u, 0u, 0u, 0u};
                 const uint32_t ncur = min(*reinterpret_cast<volatile uint32_t *>(&ctr[0]), a.rec_cap);  // (a list that overflowed set a.fail: the scan is redone elsewhere)
+                if (ncur != 0) mem_settle();  // only then: the counter drains this wave's stores too, the previous tile's tuples among them
                 for (uint32_t i = lane; i < ncur; i += 64) {
                     const uint4 r = cur_list[i];
-                    atomicOr(&dm32[(r.x - sb) >> 1], 1u << ((r.y - (K + 1)) + 16u * ((r.x - sb) & 1u)));
+                    if (EM == 2) atomicOr(&dm32[r.x - sb], 1u << (r.y - (K + 1)));
+                    else atomicOr(&dm32[(r.x - sb) >> 1], 1u << ((r.y - (K + 1)) + 16u * ((r.x - sb) & 1u)));
                 }
             }
 
@@ -286,24 +320,40 @@ __global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, 
             uint32_t flags = 0;       // 2 bits per position: number of short patterns ending there
             uint32_t fl3[2] = {0, 0};  // 3 flag bits per position (10 positions per dword would do; two dwords of 8 keep it simple)
             uint32_t mprev = lds_u32(am[0]);
+            uint32_t am_prev = am[0];  // LDS address of the M word of the K-gram ending at j - 1
 #pragma unroll
             for (int j = 0; j < P; ++j) {
-                const uint32_t mw = lds_u32(am[j + 1]);
+                const uint32_t am_here = am[j + 1];
+                const uint32_t mw = lds_u32(am_here);
                 uint32_t f = mw >> 29;
                 if (prologue || v + j < a.emit_from) f = 0;  // (bytes at and beyond vlen are class 0: no flags there)
                 fl3[j >> 3] |= f << (4 * (j & 7));
                 flags |= static_cast<uint32_t>(__popc(f)) << (2 * j);
+                // the value of a 3-byte pattern comes from L2: asked for now, used when the tile's tuples are written (by then
+                // the hits and walkers of the tile have been through, and the answer is there); it takes the place of am[j + 1]
+                if (EM == 1 && K == 3) am[j + 1] = (f & 4u) ? g.v3[(am_here - offM) >> 2] : 0u;
                 const bool hit = __builtin_amdgcn_ubfe(mprev, kx[K + j], 1) != 0;
                 const unsigned long long m = __ballot(hit);
                 if (m != 0) {
                     const uint32_t q_s = q_n;
                     if (hit)
                         (ring + q_s)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] =
-                            uint2{(tri[j] << 17) | am[j], v + j};
+                            uint2{(tri[j] << 17) | am_prev, v + j};
                     q_n = q_s + static_cast<uint32_t>(__popcll(m));
                     if (q_n >= 64u) process_batch();
                 }
                 mprev = mw;
+                am_prev = am_here;
+            }
+            if (EM == 2) {  // {class | flags << 5} of this lane's 16 positions, and the K classes before the tile
+                uint32_t cw[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < P; ++j) cw[j >> 2] |= (kx[K + j] | (((fl3[j >> 3] >> (4 * (j & 7))) & 7u) << 5)) << (8 * (j & 3));
+                reinterpret_cast<uint4 *>(cf + 16)[lane] = uint4{cw[0], cw[1], cw[2], cw[3]};
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < K; ++i) cf[16 - K + i] = static_cast<uint8_t>(kx[i]);
+                }
             }
             // everything this tile's hits lead to has to be known before its tuples can be placed
             while (q_n != 0) process_batch();
@@ -319,6 +369,67 @@ __global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, 
                     uint32_t total;
                     (void)wave_excl_scan(nshort, lane, total);
                     if (lane == 0) a.tile_cnt[t] = static_cast<unsigned long long>(total) + *reinterpret_cast<volatile uint32_t *>(&ctr[0]);
+                } else if (EM == 2) {
+                    // ---- offsets: the tuples of position p = 64 k + lane start at dmo[p] >> 16 (relative to the tile) ----
+                    const uint32_t Cc = g.C;
+                    uint32_t cstart[17], v3v[16];
+                    cstart[0] = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const uint32_t p = 64u * k + lane;
+                        const uint32_t d = dm32[p] & 0xffffu;
+                        const uint32_t cfv = cf[16 + p], f = cfv >> 5;
+                        const uint32_t tc = __popc(d) + __popc(f);
+                        const uint32_t incl = wave_incl_scan_dpp(tc);
+                        dm32[p] = d | ((cstart[k] + incl - tc) << 16);
+                        cstart[k + 1] = cstart[k] + __builtin_amdgcn_readlane(incl, 63);
+                        v3v[k] = 0;
+                        if (K == 3 && (f & 4u)) v3v[k] = g.v3[((cf[16 + p - 2] & 31u) * Cc + (cf[16 + p - 1] & 31u)) * Cc + (cfv & 31u)];
+                    }
+                    daac_match *__restrict__ out = a.out + tile_base;
+                    mem_settle();
+                    const uint32_t ncur = min(*reinterpret_cast<volatile uint32_t *>(&ctr[0]), a.rec_cap);
+                    uint4 myrec = uint4{0xffffffffu, 0u, 0u, 0u};
+                    if (ncur <= 64u && lane < ncur) myrec = cur_list[lane];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const uint32_t c_lo = cstart[k], n_k = cstart[k + 1] - c_lo;  // wave-uniform
+                        if (n_k == 0) continue;
+                        const bool staged = n_k <= kStageCap;
+                        auto place = [&](uint32_t slot, unsigned long long start, unsigned long long end, uint32_t value) {
+                            if (staged) {
+                                unsigned long long *q = stage + 3u * (slot - c_lo);
+                                q[0] = start; q[1] = end; q[2] = value;
+                            } else {
+                                put_tuple(out + slot, start, end, value);
+                            }
+                        };
+                        auto place_deep = [&](const uint4 &r) {
+                            const uint32_t rel = r.x - sb;
+                            if (rel - 64u * k >= 64u) return;  // not in this chunk
+                            const uint32_t word = dm32[rel];
+                            const unsigned long long end = a.pos_base + r.x;
+                            place((word >> 16) + __popc((word & 0xffffu) >> (r.y - (K + 1) + 1)), end - r.y, end, r.z);
+                        };
+                        if (ncur <= 64u) {
+                            if (myrec.x != 0xffffffffu) place_deep(myrec);
+                        } else {
+                            for (uint32_t i = lane; i < ncur; i += 64) place_deep(cur_list[i]);
+                        }
+                        {
+                            const uint32_t p = 64u * k + lane, word = dm32[p];
+                            uint32_t slot = (word >> 16) + __popc(word & 0xffffu);
+                            const uint32_t cfv = cf[16 + p], f = cfv >> 5, c0 = cfv & 31u;
+                            const unsigned long long end = a.pos_base + sb + p;
+                            if (K == 3 && (f & 4u)) place(slot++, end - 3, end, v3v[k]);
+                            if (f & 2u) place(slot++, end - 2, end, lds_u32(g.off_v2 + 4u * ((cf[16 + p - 1] & 31u) * Cc + c0)));
+                            if (f & 1u) place(slot++, end - 1, end, lds_u32(g.off_v1 + 4u * c0));
+                        }
+                        if (staged) {  // 24 n_k contiguous bytes: 8 per lane and store
+                            unsigned long long *dst = reinterpret_cast<unsigned long long *>(out + c_lo);
+                            for (uint32_t q = lane; q < 3u * n_k; q += 64) dst[q] = stage[q];
+                        }
+                    }
                 } else {
                     uint32_t dmw[8];
                     {
@@ -352,9 +463,7 @@ __global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, 
                         const uint32_t here = (dw[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
                         const uint32_t longer = __popc(here >> (r.y - (K + 1) + 1));
                         const unsigned long long end = a.pos_base + r.x;
-                        daac_match mt;
-                        mt.start = end - r.y; mt.end = end; mt.value = r.z; mt._pad = 0;
-                        out[lb[L] + before + longer] = mt;
+                        put_tuple(out + (lb[L] + before + longer), end - r.y, end, r.z);
                     }
                     // short matches: each lane walks its 16 positions
                     uint32_t running = lanebase;
@@ -366,19 +475,13 @@ __global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, 
                         if (__ballot(f != 0) == 0) continue;
                         const unsigned long long end = end0 + j;
                         if (K == 3 && (f & 4u)) {
-                            daac_match mt;
-                            mt.start = end - 3; mt.end = end; mt.value = g.v3[(am[j + 1] - offM) >> 2]; mt._pad = 0;
-                            out[running++] = mt;
+                            put_tuple(out + running++, end - 3, end, am[j + 1]);  // (the value asked for during detection)
                         }
                         if (f & 2u) {
-                            daac_match mt;
-                            mt.start = end - 2; mt.end = end; mt.value = lds_u32(g.off_v2 + 4u * (kx[K + j - 1] * g.C + kx[K + j])); mt._pad = 0;
-                            out[running++] = mt;
+                            put_tuple(out + running++, end - 2, end, lds_u32(g.off_v2 + 4u * (kx[K + j - 1] * g.C + kx[K + j])));
                         }
                         if (f & 1u) {
-                            daac_match mt;
-                            mt.start = end - 1; mt.end = end; mt.value = lds_u32(g.off_v1 + 4u * kx[K + j]); mt._pad = 0;
-                            out[running++] = mt;
+                            put_tuple(out + running++, end - 1, end, lds_u32(g.off_v1 + 4u * kx[K + j]));
                         }
                     }
                 }
@@ -393,24 +496,26 @@ __global__ __launch_bounds__(1024) void gram2_emit_kernel(const Gram2EmitDev g, 
     }
 }
 
-template <int K, bool WRITE>
+template <int K, int EM, int TPB>
 static hipError_t launch_e(const Gram2EmitDev &dev, const EmitArgs &a, uint32_t blocks, hipStream_t stream) {
     hipError_t e;
+    const uint32_t lds = EM == 2 ? dev.lds_bytes2 : dev.lds_bytes;
     if (dev.s16) {
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_emit_kernel<K, WRITE, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(dev.lds_bytes))) != hipSuccess) return e;
-        hipLaunchKernelGGL((gram2_emit_kernel<K, WRITE, true>), dim3(blocks), dim3(1024), dev.lds_bytes, stream, dev, a);
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_emit_kernel<K, EM, true, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds))) != hipSuccess) return e;
+        hipLaunchKernelGGL((gram2_emit_kernel<K, EM, true, TPB>), dim3(blocks), dim3(TPB), lds, stream, dev, a);
     } else {
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_emit_kernel<K, WRITE, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(dev.lds_bytes))) != hipSuccess) return e;
-        hipLaunchKernelGGL((gram2_emit_kernel<K, WRITE, false>), dim3(blocks), dim3(1024), dev.lds_bytes, stream, dev, a);
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_emit_kernel<K, EM, false, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds))) != hipSuccess) return e;
+        hipLaunchKernelGGL((gram2_emit_kernel<K, EM, false, TPB>), dim3(blocks), dim3(TPB), lds, stream, dev, a);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, bool write, uint32_t blocks, hipStream_t stream) {
-    if (dev.K == 3) return write ? launch_e<3, true>(dev, a, blocks, stream) : launch_e<3, false>(dev, a, blocks, stream);
-    return write ? launch_e<2, true>(dev, a, blocks, stream) : launch_e<2, false>(dev, a, blocks, stream);
+// em: 0 count, 1 write (a pair of stores per tuple), 2 write (staged: contiguous stores); waves per workgroup: 16, 16, 8
+hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, int em, uint32_t blocks, hipStream_t stream) {
+    if (dev.K == 3) return em == 0 ? launch_e<3, 0, 1024>(dev, a, blocks, stream) : em == 1 ? launch_e<3, 1, 1024>(dev, a, blocks, stream) : launch_e<3, 2, 512>(dev, a, blocks, stream);
+    return em == 0 ? launch_e<2, 0, 1024>(dev, a, blocks, stream) : em == 1 ? launch_e<2, 1, 1024>(dev, a, blocks, stream) : launch_e<2, 2, 512>(dev, a, blocks, stream);
 }
 
 }  // namespace daac

@@ -233,6 +233,7 @@ void daac_stream_close(daac_stream *s);
  *   gram_ppl (0 = auto: 32 positions per lane and step for automata without short patterns, else 16)
  *   gram_version (0 = second table set where it applies, 1 = first only, 2 = second only), gram2_dpp (1: DPP wave shifts)
  *   emit (1)                    materialising overlapping scans through the GRAM tuple emitter where it applies (0: segment scanners);
+ *   emit_staged (0: one pair of stores per tuple; 1: the write pass gathers the tuples of 64 positions in LDS and stores them contiguously),
  *   emit_tiles (64), emit_rec_cap (256)   tiles of 1024 positions per wave region / deep-match records per wave and tile
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners

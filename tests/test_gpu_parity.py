@@ -365,7 +365,8 @@ def test_gram_tuple_emitter():
         for pats, hay in cases:
             o, _ = _pma(pats)
             want = o.find_overlapping_iter(hay)
-            for tiles, budget, shift in ((64, 158 * 1024, 0), (1, 158 * 1024, 3), (2, 24 * 1024, 9)):
+            for tiles, budget, shift, staged in ((64, 158 * 1024, 0, 1), (1, 158 * 1024, 3, 1), (2, 24 * 1024, 9, 1), (3, 158 * 1024, 5, 0)):
+                da.set_option("emit_staged", staged)  # 1: tuples gathered in LDS and stored contiguously; 0: a pair of stores per tuple
                 da.set_option("emit_tiles", tiles)
                 da.set_option("gram_lds_budget", budget)
                 p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
@@ -406,7 +407,7 @@ def test_gram_tuple_emitter():
             p.scan(ScanMode.FindOverlapping, b"xabcabab", engine=Engine.Gram)
         assert ei.value.code == 6
     finally:
-        for k, v in (("emit_tiles", 64), ("gram_lds_budget", 158 * 1024), ("iter_window", 64 << 20), ("emit_rec_cap", 256)):
+        for k, v in (("emit_tiles", 64), ("gram_lds_budget", 158 * 1024), ("iter_window", 64 << 20), ("emit_rec_cap", 256), ("emit_staged", 0)):
             da.set_option(k, v)
 
 

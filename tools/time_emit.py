@@ -21,8 +21,9 @@ if hk == "sparse":
     synth.device_uniform(hay, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
 else:
     synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
-for emit in (1, 0):
-    da.set_option("emit", emit)
+for emit in (2, 1, 0):  # 2: staged writes, 1: a pair of stores per tuple, 0: segment scanners
+    da.set_option("emit", 1 if emit else 0)
+    da.set_option("emit_staged", 1 if emit == 2 else 0)
     pma = da.DoubleArrayAhoCorasick.new(pats)
     pma.upload(0)
     n = hay.numel() if emit else min(hay.numel(), 256 << 20)  # the segment scanners are slow: a prefix is enough
