@@ -47,6 +47,8 @@ struct Options {
                                                 // (8 waves per workgroup; measured no faster than a pair of stores per tuple with 16: DESIGN.md 4.5)
     std::atomic<int64_t> emit_tiles{64};        // tiles of 1024 positions a wave takes at a time
     std::atomic<int64_t> emit_rec_cap{256};     // deep-match records per wave and tile before the scan falls back
+    std::atomic<int64_t> restart_tier{0};       // 1: find_iter of Standard bytewise automata chains over the TIERED tables (measured 7-9 % slower
+                                                // than over the double array on cfg3: half the waves per CU, and a match costs a gather more)
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
     std::atomic<int64_t> char_map_lds{0};       // charwise chain scans: stage the populated stretch of the code mapper in LDS
@@ -528,6 +530,7 @@ struct Plan {
     bool tier;
     bool charwise = false;  // the charwise engine (scan_kernel<CharEngine> / char_restart_kernel)
     bool restart = false;   // find_iter / leftmost_find_iter: the restart scanners (DARRAY tables)
+    bool tier_chain = false;  // ... find_iter of a Standard bytewise automaton: the chain passes run over the TIERED tables
     bool leftmost = false;
     uint32_t blocks, threads;
     ScanArgs a;
@@ -592,6 +595,8 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
     if (pl.restart) {
         pl.threads = 256;
         pl.blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 8, (nseg + 255) / 256)));
+        pl.tier_chain = !pl.charwise && !pl.leftmost && t->tier_ok && t->tier.root_flag == 0 && g_opt.restart_tier.load() != 0 &&
+                        t->tier.lds_bytes + 512u <= 160u * 1024u;
     }
     return DAAC_OK;
 }
@@ -599,6 +604,9 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
 hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, hipStream_t s, unsigned long long *next_begin = nullptr) {
     if (pl.restart && pl.chain.x_prev != nullptr) {  // totals and per-segment counts are sums of tallies; only writing re-scans
         const int pass = kmode == 2 ? 2 : 3;
+        if (pl.tier_chain)
+            return launch_tier_chain(t->tier, pl.a, pl.chain, pass, kmode, next_begin,
+                                     static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(t->num_cu, (pl.a.nseg + 1023) / 1024))), s);
         return pl.charwise ? launch_char_chain(t->chr, pl.a, pl.chain, pass, kmode, pl.leftmost, next_begin, pl.blocks, s)
                            : launch_chain(t->da, pl.a, pl.chain, pass, kmode, pl.leftmost, next_begin, pl.blocks, s);
     }
@@ -636,6 +644,9 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
     c.tally_delta = tallies + n;
     c.x_out = x_spec;
     auto run = [&](int pass) {
+        if (pl.tier_chain)
+            return launch_tier_chain(t->tier, pl.a, c, pass, 0, nullptr,
+                                     static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(t->num_cu, (pl.a.nseg + 1023) / 1024))), stream);
         return pl.charwise ? launch_char_chain(t->chr, pl.a, c, pass, 0, pl.leftmost, nullptr, pl.blocks, stream)
                            : launch_chain(t->da, pl.a, c, pass, 0, pl.leftmost, nullptr, pl.blocks, stream);
     };
@@ -1462,6 +1473,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_version") g_opt.gram_version = value;
     else if (n == "gram2_dpp") g_opt.gram2_dpp = value;
     else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
+    else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles") g_opt.emit_tiles = value;
     else if (n == "emit_staged") g_opt.emit_staged = value;

@@ -99,11 +99,68 @@ struct ChainWalker {
         }
     }
 
+    // The chain from `entry` until it leaves [.., hi): `r = entry; while (r < hi) r = link(r)`, written as ONE loop that
+    // takes one symbol per turn.  As nested loops (a loop over links around the loop over a link's symbols) the 64 lanes of a
+    // wave re-converge at the end of every link: a lane whose link ended after three symbols idles until the longest link of
+    // the wave is through, and with a match every few bytes most of the wave idles most of the time (the scan then runs at
+    // a quarter of the rate at which the memory system answers).  Here a lane that reports a match goes straight on to the
+    // first symbol of its next link in the same turn of the loop.
     template <class Emit>
     __device__ __forceinline__ uint64_t run(uint64_t entry, uint64_t hi, Emit &&emit) {
-        uint64_t r = entry;
-        while (r < hi && !overflow) r = link(r, hi, emit);
-        return r;
+        if (entry >= hi || overflow) return entry;
+        typename T::State st = t.root();
+        uint64_t pos = entry;
+        uint32_t clen;
+        if (!LEFTMOST) {
+            for (;;) {
+                if (pos >= len) return len;
+                const uint32_t sym = t.symbol_at(win, pos, clen);
+                pos += clen;
+                t.step_plain(st, sym);
+                const uint32_t op = t.opos(st);
+                if (op != 0) {
+                    emit(op, pos);
+                    if (pos >= hi) return pos;
+                    st = t.root();  // the next link
+                } else if (pos >= hi) {
+                    if (t.is_root(st)) return pos;
+                    if (pos - hi > cap) { overflow = true; return pos; }
+                }
+            }
+        } else {
+            uint32_t best = 0;          // last_output_pos
+            uint64_t best_end = entry;  // self.pos
+            for (;;) {
+                bool report = false;
+                if (pos >= len) {
+                    if (best == 0) return len;
+                    report = true;
+                } else {
+                    const uint32_t sym = t.symbol_at(win, pos, clen);
+                    t.step_leftmost(st, sym);
+                    if (t.is_root(st)) {
+                        if (best != 0) {
+                            report = true;
+                        } else {
+                            pos += clen;
+                            if (pos >= hi) return pos;
+                        }
+                    } else {
+                        pos += clen;
+                        const uint32_t op = t.opos(st);
+                        if (op != 0) { best = op; best_end = pos; }
+                        else if (best == 0 && pos >= hi && pos - hi > cap) { overflow = true; return pos; }
+                    }
+                }
+                if (report) {  // the link ends with its longest / first match; the next one starts where that match ended
+                    emit(best, best_end);
+                    if (best_end >= hi) return best_end;
+                    st = t.root();
+                    pos = best_end;
+                    best = 0;
+                }
+            }
+        }
     }
 };
 

@@ -236,6 +236,7 @@ void daac_stream_close(daac_stream *s);
  *   emit_staged (0: one pair of stores per tuple; 1: the write pass gathers the tuples of 64 positions in LDS and stores them contiguously),
  *   emit_tiles (64), emit_rec_cap (256)   tiles of 1024 positions per wave region / deep-match records per wave and tile
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
+ *   restart_tier (0)            1: find_iter of Standard bytewise automata runs its chains over the TIERED tables instead of the double array
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners
  *   char_map_lds (0)            charwise chain scans: code mapper staged in LDS when it fits
  *   iter_window (64 MiB)        haystack bytes per window of the lazy iterator

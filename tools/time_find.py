@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""find_iter / leftmost_find_iter count + checksum throughput on cfg3 (bytewise) — tools/time_find.py [mib] [sparse|dense]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import daachorse_amd as da
+from daachorse_amd import ScanMode, synth
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+hk = sys.argv[2] if len(sys.argv) > 2 else "sparse"
+pats = synth.patterns_cfg3()
+hay = torch.empty(mib << 20, dtype=torch.uint8, device="cuda")
+if hk == "sparse":
+    synth.device_uniform(hay, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+else:
+    synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
+res = {}
+for name, kind, mode, opts in (("find_iter (tier chains)", da.MatchKind.Standard, ScanMode.Find, {"restart_tier": 1}),
+                               ("find_iter (double array)", da.MatchKind.Standard, ScanMode.Find, {"restart_tier": 0}),
+                               ("leftmost_find_iter LL", da.MatchKind.LeftmostLongest, ScanMode.LeftmostFind, {})):
+    for k, v in opts.items():
+        da.set_option(k, v)
+    pma = da.DoubleArrayAhoCorasickBuilder().match_kind(kind).build(pats)
+    pma.upload(0)
+    r = pma.scan_count(mode, hay)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r2 = pma.scan_count(mode, hay)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    assert r2 == r
+    print(f"{name:28s} {hk} {mib} MiB: {best * 1e3:8.2f} ms  {hay.numel() / best / 1e9:7.1f} GB/s  count={r[0]} checksum={r[1]:016x}", flush=True)
+    res[(kind, name.split(' (')[0])] = r
+da.set_option("restart_tier", 0)
