@@ -188,6 +188,51 @@ public:
         return open(DAAC_LEFTMOST_FIND, std::move(haystack), "Error: match_kind must be leftmost.");
     }
 
+    // `pma.find_overlapping_iter(h).count()` and its three siblings without materialising a match (Iterator::count on the
+    // iterators of src/bytewise/iter.rs / src/charwise/iter.rs): one device pass, nothing but the number comes back.
+    size_t find_iter_count(std::string_view haystack) const { return count(DAAC_FIND, haystack, "Error: match_kind must be standard."); }
+    size_t find_overlapping_iter_count(std::string_view haystack) const {
+        return count(DAAC_FIND_OVERLAPPING, haystack, "Error: match_kind must be standard.");
+    }
+    size_t find_overlapping_no_suffix_iter_count(std::string_view haystack) const {
+        return count(DAAC_FIND_OVERLAPPING_NO_SUFFIX, haystack, "Error: match_kind must be standard.");
+    }
+    size_t leftmost_find_iter_count(std::string_view haystack) const {
+        return count(DAAC_LEFTMOST_FIND, haystack, "Error: match_kind must be leftmost.");
+    }
+
+    // The whole match list of find_overlapping_iter, in the iterator's order, left in device memory for a consumer that
+    // runs on the GPU (daac_scan_device); `haystack_dev` is a device pointer.  to_host() copies a slice back.
+    class DeviceMatches {
+    public:
+        DeviceMatches(DeviceMatches &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+        DeviceMatches(const DeviceMatches &) = delete;
+        ~DeviceMatches() { daac_device_free(p_); }
+        const daac_match *data() const { return p_; }  // device pointer
+        size_t size() const { return n_; }
+        std::vector<Match> to_host(size_t first, size_t n) const {
+            if (first > n_ || n > n_ - first) throw std::out_of_range("DeviceMatches::to_host");
+            std::vector<daac_match> raw(n);
+            if (n && daac_device_to_host(raw.data(), p_ + first, n * sizeof(daac_match)) != DAAC_OK) throw PanicError(daac_last_error());
+            std::vector<Match> out;
+            out.reserve(n);
+            for (const auto &m : raw) out.emplace_back(m.start, m.end, m.value);
+            return out;
+        }
+
+    private:
+        friend class BasicAhoCorasick;
+        DeviceMatches(daac_match *p, size_t n) : p_(p), n_(n) {}
+        daac_match *p_;
+        size_t n_;
+    };
+    DeviceMatches find_overlapping_device(const uint8_t *haystack_dev, size_t len, void *stream = nullptr) const {
+        return scan_device(haystack_dev, len, 1, stream);
+    }
+    DeviceMatches find_overlapping_device(std::string_view host_haystack) const {  // the haystack is copied over first
+        return scan_device(reinterpret_cast<const uint8_t *>(host_haystack.data()), host_haystack.size(), 0, nullptr);
+    }
+
     // bytewise.rs:238-251, 353-375 / charwise.rs: steppers for text that arrives in pieces
     Stepper find_stepper() const { return open_stepper(DAAC_FIND); }
     Stepper find_overlapping_stepper() const { return open_stepper(DAAC_FIND_OVERLAPPING); }
@@ -204,6 +249,22 @@ private:
         daac_info i;
         daac_pma_info(h_.get(), &i);
         return i;
+    }
+    size_t count(int mode, std::string_view hay, const char *panic_msg) const {
+        uint64_t n = 0;
+        const daac_status st = daac_scan_count_only_range(h_.get(), mode, DAAC_ENGINE_AUTO, reinterpret_cast<const uint8_t *>(hay.data()),
+                                                          hay.size(), 0, 0, nullptr, &n, nullptr);
+        if (st == DAAC_ERR_MATCH_KIND) throw PanicError(panic_msg);
+        if (st != DAAC_OK) throw PanicError(std::string("device scan failed: ") + daac_last_error());
+        return n;
+    }
+    DeviceMatches scan_device(const uint8_t *hay, size_t len, int on_device, void *stream) const {
+        daac_match *p = nullptr;
+        uint64_t n = 0;
+        const daac_status st = daac_scan_device(h_.get(), DAAC_FIND_OVERLAPPING, DAAC_ENGINE_AUTO, hay, len, on_device, stream, &p, &n);
+        if (st == DAAC_ERR_MATCH_KIND) throw PanicError("Error: match_kind must be standard.");
+        if (st != DAAC_OK) throw PanicError(std::string("device scan failed: ") + daac_last_error());
+        return DeviceMatches(p, n);
     }
     Stepper open_stepper(int mode) const {
         daac_stream *st = nullptr;

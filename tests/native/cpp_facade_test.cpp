@@ -67,6 +67,17 @@ int main(int argc, char **argv) {
     CHECK(!cit.next());
     auto cll = CharwiseDoubleArrayAhoCorasickBuilder().match_kind(MatchKind::LeftmostLongest).build({"世界", "全世界", "世"}).unwrap();
     CHECK(same(cll.leftmost_find_iter("全世界中に世").collect(), {Match(0, 9, 1), Match(15, 18, 2)}));
+    // Iterator::count() on the four iterators without materialising, and the list left in device memory
+    CHECK(pma.find_overlapping_iter_count("abcd") == 3 && pma.find_iter_count("abcd") == 2);
+    CHECK(pma.find_overlapping_no_suffix_iter_count("abcd") == 2 && ll.leftmost_find_iter_count("abcd") == 1);
+    CHECK(cw.find_overlapping_iter_count("全世界中に") == 3);
+    panicked = false;
+    try { ll.find_overlapping_iter_count("abcd"); } catch (const PanicError &) { panicked = true; }
+    CHECK(panicked);
+    auto dm = pma.find_overlapping_device("abcdabcd");
+    CHECK(dm.size() == 6 && same(dm.to_host(0, 3), {Match(0, 1, 2), Match(0, 2, 1), Match(1, 4, 0)}));
+    CHECK(same(dm.to_host(3, 3), {Match(4, 5, 2), Match(4, 6, 1), Match(5, 8, 0)}));
+    CHECK(pma.find_overlapping_device("zzz").size() == 0);
     auto stepper = pma.find_overlapping_stepper();  // the text in three pieces, a pattern across each cut
     std::vector<Match> fed;
     for (const char *piece : {"a", "bc", "d"})
