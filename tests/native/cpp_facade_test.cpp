@@ -69,7 +69,7 @@ int main(int argc, char **argv) {
     CHECK(same(cll.leftmost_find_iter("全世界中に世").collect(), {Match(0, 9, 1), Match(15, 18, 2)}));
     // Iterator::count() on the four iterators without materialising, and the list left in device memory
     CHECK(pma.find_overlapping_iter_count("abcd") == 3 && pma.find_iter_count("abcd") == 2);
-    CHECK(pma.find_overlapping_no_suffix_iter_count("abcd") == 2 && ll.leftmost_find_iter_count("abcd") == 1);
+    CHECK(pma.find_overlapping_no_suffix_iter_count("abcd") == 3 && ll.leftmost_find_iter_count("abcd") == 1);
     CHECK(cw.find_overlapping_iter_count("全世界中に") == 3);
     panicked = false;
     try { ll.find_overlapping_iter_count("abcd"); } catch (const PanicError &) { panicked = true; }

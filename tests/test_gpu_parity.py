@@ -531,7 +531,8 @@ def test_cpp_facade_on_gpu(tmp_path):
     libdir = os.path.join(ROOT, "daachorse_amd", "lib")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "cpp_facade_test.cpp"),
                            "-L" + libdir, "-ldaachorse_amd", "-Wl,-rpath," + libdir])
-    assert subprocess.check_output([exe, "gpu"]).decode().strip() == "OK gpu"
+    r = subprocess.run([exe, "gpu"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0 and r.stdout.decode().strip().endswith("OK gpu"), r.stdout.decode()
 
 
 def test_concurrent_scans_share_one_handle():

@@ -48,5 +48,17 @@ done
 rm -rf /tmp/prof_$TAG/emit
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/emit -o e -- python $R/tools/time_emit.py 1024 sparse 3 > $OUT/${TAG}_emit.txt 2>&1
 find /tmp/prof_$TAG/emit -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_emit_kernel_stats.csv \;
+# 6. the restart iterators: cfg3 find_iter / leftmost_find_iter and cfg5 (charwise, true SURVEY 8d workload), timing + kernel stats
+for w in sparse dense; do
+  rm -rf /tmp/prof_$TAG/find_$w
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/find_$w -o k -- python $R/tools/time_find.py 1024 $w > $OUT/${TAG}_find_$w.txt 2>&1
+  find /tmp/prof_$TAG/find_$w -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_find_${w}_kernel_stats.csv \;
+done
+for m in leftmost find overlapping; do
+  python $R/tools/bench_cfg5.py --mode $m > $OUT/${TAG}_bench_cfg5_$m.json 2>> $OUT/${TAG}_bench.err
+done
+rm -rf /tmp/prof_$TAG/cfg5
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/cfg5 -o k -- python $R/tools/bench_cfg5.py --mode leftmost --cpu-mib 0 > /tmp/prof_$TAG/cfg5.log 2>&1
+find /tmp/prof_$TAG/cfg5 -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_cfg5_leftmost_kernel_stats.csv \;
 cat $OUT/${TAG}_bench.json
 head -8 $OUT/${TAG}_kernel_stats.csv
