@@ -51,7 +51,7 @@ struct Options {
                                                 // than over the double array on cfg3: half the waves per CU, and a match costs a gather more)
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
-    std::atomic<int64_t> char_map_lds{0};       // charwise chain scans: stage the populated stretch of the code mapper in LDS
+    std::atomic<int64_t> char_map_lds{1};       // charwise chain scans: stage the populated stretch of the code mapper in LDS
                                                 // (off: measured slower on cfg5, 88 vs 104 GB/s — the stretch is L1-resident anyway)
 };
 static Options g_opt;
@@ -209,7 +209,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     const HostPma &h = pma->host;
     daac_status st;
     // outputs, shared by all engines
-    const uint32_t *d_outputs = nullptr;
+    const uint32_t *d_outputs = nullptr, *d_ohash = nullptr;
     {
         const std::vector<OutputRec> &outs = pma->charwise ? pma->chost.outputs : h.outputs;
         std::vector<uint32_t> flat(outs.size() * 3);
@@ -217,6 +217,9 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             flat[3 * i] = outs[i].value; flat[3 * i + 1] = outs[i].length; flat[3 * i + 2] = outs[i].parent;
         }
         if ((st = t->put(flat, d_outputs)) != DAAC_OK) return st;
+        std::vector<uint32_t> oh(outs.size());
+        for (size_t i = 0; i < outs.size(); ++i) oh[i] = match_hash32(outs[i].value, outs[i].length);
+        if ((st = t->put(oh, d_ohash)) != DAAC_OK) return st;
     }
     if (pma->charwise) {
         CharTables ct;
@@ -231,6 +234,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         c.states = reinterpret_cast<const uint4 *>(states);
         c.osum = reinterpret_cast<const uint2 *>(osum);
         c.outputs = d_outputs;
+        c.ohash = d_ohash;
         c.table_len = static_cast<uint32_t>(ct.table.size());
         c.n = static_cast<uint32_t>(ct.states.size());
         c.root_flag = ct.root_flag;
@@ -239,7 +243,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         // it fits 32 KB, moved up to the first mapped code point at or above it (CJK text: the table is dense from the
         // kana up, ASCII below stays in L2).
         {
-            const uint32_t cap = 16u * 1024u;  // u16 entries
+            const uint32_t cap = 16u * 1024u - 128u;  // u16 entries (128 more hold ASCII)
             uint32_t lo = c.table_len > cap ? c.table_len - cap : 0u;
             while (lo < c.table_len && ct.table[lo] == kInvalidCode) ++lo;
             c.map_lo = lo;
@@ -271,6 +275,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         t->da.root = reinterpret_cast<const uint4 *>(root);
         t->da.osum = reinterpret_cast<const uint2 *>(osum);
         t->da.outputs = d_outputs;
+        t->da.ohash = d_ohash;
         t->da.n = static_cast<uint32_t>(h.states_len());
         t->da.root_flag = output_pos_of(h.opos_ch(kRoot)) != 0;
     }
@@ -296,6 +301,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             d.ssum = reinterpret_cast<const uint2 *>(ssum);
             d.grec = reinterpret_cast<const uint4 *>(grec);
             d.outputs = d_outputs;
+            d.ohash = d_ohash;
             d.C = tt.C; d.NA = tt.NA; d.NB = tt.NB; d.N = tt.N;
             auto pad16 = [](uint32_t x) { return (x + 15u) & ~15u; };
             d.off_bcmap = pad16(tt.NA * tt.C * (tt.row32 ? 4u : 2u));

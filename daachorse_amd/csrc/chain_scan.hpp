@@ -30,6 +30,16 @@
 
 #include "device_tables.hpp"
 
+#ifndef DAAC_WIN_AHEAD
+#define DAAC_WIN_AHEAD 1
+#endif
+#ifndef DAAC_TALLY_DEFER
+#define DAAC_TALLY_DEFER 1
+#endif
+#ifndef DAAC_CW_MICRO
+#define DAAC_CW_MICRO 1
+#endif
+
 namespace daac {
 
 // A lane's window on the haystack: the aligned 16-byte granule around the last byte it asked for.  A chain
@@ -37,14 +47,72 @@ namespace daac {
 // are served from registers instead of the memory pipeline, where 64 lanes asking for 64 different lines cost
 // 64 cycles each time.  A granule never crosses a page, so reading all of it is safe at either end of a buffer.
 struct HayWindow {
+    typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
     uintptr_t base = ~static_cast<uintptr_t>(0);
-    uint4 w;
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     __device__ __forceinline__ uint32_t byte_at(const uint8_t *p) {
         const uintptr_t addr = reinterpret_cast<uintptr_t>(p), b = addr & ~static_cast<uintptr_t>(15);
-        if (b != base) { base = b; w = *reinterpret_cast<const uint4 *>(b); }
+        if (b != base) {
+            const U32x4 v = *reinterpret_cast<const U32x4 __attribute__((address_space(1))) *>(b);
+            w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w;
+            base = b;
+        }
         const uint32_t k = static_cast<uint32_t>(addr) & 15u;
-        const uint32_t word = (k & 8u) ? ((k & 4u) ? w.w : w.z) : ((k & 4u) ? w.y : w.x);
+        uint32_t a0 = w0, a1 = w1, a2 = w2, a3 = w3;  // (as values, not as four adjacent fields the optimiser may index in memory)
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        const uint32_t word = (k & 8u) ? ((k & 4u) ? a3 : a2) : ((k & 4u) ? a1 : a0);
         return (word >> ((k & 3u) * 8u)) & 0xffu;
+    }
+};
+
+// The window of the walkers that take one memory round trip per turn (run_micro): 32 resident bytes [base, base + 32) and
+// the 16 after them in flight.  word_at() slides the window when the four bytes asked for reach beyond it: the granule in
+// flight was asked for a slide (16 bytes of text, several turns) ago and every turn ends with a full wait for the turn's
+// own transition, so it has arrived — the optimiser's bookkeeping of outstanding loads sees that too and puts no wait of
+// its own behind the new request.  A step back of up to 12 bytes after a leftmost match stays inside the window.
+struct HayStream {
+    typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+    uintptr_t base = ~static_cast<uintptr_t>(0) - 64;  // far from any address: the first request takes the cold path
+    uintptr_t limit = 0;                               // granules beginning at or beyond this address are never read
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+
+    __device__ __forceinline__ void ask_ahead() {
+        const uintptr_t g = base + 32;
+        U32x4 v = U32x4{0u, 0u, 0u, 0u};
+        if (g < limit) v = *reinterpret_cast<const U32x4 __attribute__((address_space(1))) *>(g);
+        f0 = v.x; f1 = v.y; f2 = v.z; f3 = v.w;
+    }
+    // the four bytes from p on, first byte lowest; bytes at or beyond `limit`'s granule read as zero
+    __device__ __forceinline__ uint32_t word_at(const uint8_t *p) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+        uint32_t off = static_cast<uint32_t>(addr - base);
+        if (addr - base > 28u) {
+            if (addr - base < 44u) {  // the usual step: slide by one granule
+                w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+                n0 = f0; n1 = f1; n2 = f2; n3 = f3;
+                base += 16;
+            } else {  // a segment's first request, or a step back beyond the window: two granules fetched and waited for
+                const uintptr_t b = addr & ~static_cast<uintptr_t>(15);
+                const bool two = b + 16 < limit;
+                const uintptr_t b2 = two ? b + 16 : b;
+                U32x4 v0, v1;
+                asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(v0), "=&v"(v1) : "v"(b), "v"(b2) : "memory");
+                w0 = v0.x; w1 = v0.y; w2 = v0.z; w3 = v0.w;
+                n0 = two ? v1.x : 0u; n1 = two ? v1.y : 0u; n2 = two ? v1.z : 0u; n3 = two ? v1.w : 0u;
+                base = b;
+            }
+            ask_ahead();
+            off = static_cast<uint32_t>(addr - base);
+        }
+        uint32_t a0 = w0, a1 = w1, a2 = w2, a3 = w3, a4 = n0, a5 = n1, a6 = n2, a7 = n3;
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        const bool up = (off & 16u) != 0;  // dwords q .. q + 1 of the eight, q = off / 4 (off <= 28: the last word is only ever `lo`)
+        const uint32_t b0 = up ? a4 : a0, b1 = up ? a5 : a1, b2 = up ? a6 : a2, b3 = up ? a7 : a3, b4 = up ? a7 : a4;
+        const bool mid = (off & 8u) != 0;
+        const uint32_t c0 = mid ? b2 : b0, c1 = mid ? b3 : b1, c2 = mid ? b4 : b2;
+        const bool odd = (off & 4u) != 0;
+        return __builtin_amdgcn_alignbyte(odd ? c2 : c1, odd ? c1 : c0, off & 3u);
     }
 };
 
@@ -56,6 +124,7 @@ struct ChainWalker {
     uint64_t cap;
     bool overflow = false;
     HayWindow win;
+    HayStream str;  // run_micro's window
 
     // One link of the chain from position r (reference bytewise/iter.rs:87-112 / 272-340, charwise/iter.rs:
     // 133-156 / 325-399, one call of next()); returns the next chain position, > r.
@@ -106,8 +175,15 @@ struct ChainWalker {
     // a quarter of the rate at which the memory system answers).  Here a lane that reports a match goes straight on to the
     // first symbol of its next link in the same turn of the loop.
     template <class Emit>
+    __device__ __forceinline__ uint64_t run_micro(uint64_t entry, uint64_t hi, Emit &&emit);
+
+    template <class Emit>
     __device__ __forceinline__ uint64_t run(uint64_t entry, uint64_t hi, Emit &&emit) {
         if (entry >= hi || overflow) return entry;
+        if constexpr (T::kMicro) {
+            if (hi - entry >= 0x40000000ull) { overflow = true; return entry; }  // (segments are KBs; the driver falls back)
+            return run_micro(entry, hi, emit);
+        }
         typename T::State st = t.root();
         uint64_t pos = entry;
         uint32_t clen;
@@ -164,24 +240,105 @@ struct ChainWalker {
     }
 };
 
+// The same chain with the TRANSITION taken apart as well: a turn of the loop is exactly one memory round trip of the
+// automaton (T::micro: the probe of a child slot, or the record a failure link leads to), for every lane.  With whole
+// transitions per turn a wave waits for its slowest lane's failure walk — on a CJK dictionary 1.6 round trips per symbol
+// on average but 4.5 for the slowest of 64 lanes — while here a lane that is through takes its next symbol at once.
+// The turn is written as straight-line selects (the lanes of a wave are in every phase at once: nested branches would be
+// executed all the same, plus the bookkeeping of their masks); positions are 32-bit offsets from `entry`.
+template <class T, bool LEFTMOST>
+template <class Emit>
+__device__ __forceinline__ uint64_t ChainWalker<T, LEFTMOST>::run_micro(uint64_t entry, uint64_t hi, Emit &&emit) {
+    const uint8_t *const p0 = t.hay + entry;
+    const uint64_t room = len - entry;
+    const uint32_t end32 = room > 0xffffff00ull ? 0xffffff00u : static_cast<uint32_t>(room);  // the haystack's end
+    const uint32_t hi32 = static_cast<uint32_t>(hi - entry);
+    const uint32_t cap32 = cap > 0x3fffffffull ? 0x3fffffffu : static_cast<uint32_t>(cap);
+    str.limit = reinterpret_cast<uintptr_t>(t.hay) + len;
+    typename T::State st = t.root();
+    uint32_t pos = 0, clen = 0, code = 0, phase = 0;
+    bool pending = false;   // a symbol has been read and its transition is under way
+    uint32_t best = 0;      // leftmost: last_output_pos
+    uint32_t best_end = 0;  // leftmost: self.pos
+    uint32_t ret = 0;
+    for (;;) {
+        bool fin = false, report = false;
+        if (!pending) {
+            if (pos >= end32) {  // out of text
+                if (LEFTMOST && best != 0) report = true;
+                else { ret = end32; fin = true; }
+            } else {
+                code = t.symbol_code(str, p0 + pos, end32 - pos, clen);
+                phase = 0;
+                pending = true;
+            }
+        }
+        const bool done = t.template micro<LEFTMOST>(st, code, phase, pending);  // (nothing happens for a lane that is not pending)
+        pending = pending && !done;
+        const bool at_root = t.is_root(st);
+        const uint32_t op = t.opos(st);
+        if (!LEFTMOST) {
+            const uint32_t npos = pos + clen;
+            pos = done ? npos : pos;
+            const bool match = done && op != 0;
+            if (match) emit(op, entry + pos);
+            const bool out = done && pos >= hi32;
+            const bool lost = out && !match && !at_root && pos - hi32 > cap32;
+            if (lost) overflow = true;
+            if (out && (match || at_root || lost)) { ret = pos; fin = true; }
+            if (match) st = t.root();  // the next link
+        } else {
+            const bool ends = done && at_root && best != 0;  // the walk died with a match in hand: the symbol is not taken
+            report = report || ends;
+            const bool adv = done && !ends;
+            pos = adv ? pos + clen : pos;
+            const bool better = adv && !at_root && op != 0;
+            best_end = better ? pos : best_end;
+            best = better ? op : best;
+            const bool out = adv && pos >= hi32;
+            const bool lost = out && !at_root && op == 0 && best == 0 && pos - hi32 > cap32;
+            if (lost) overflow = true;
+            if (out && (at_root || lost)) { ret = pos; fin = true; }
+            if (report) {  // the link ends with its longest / first match; the next one starts where that match ended
+                emit(best, entry + best_end);
+                if (best_end >= hi32) { ret = best_end; fin = true; }
+                st = t.root();
+                pos = best_end;
+                best = 0;
+            }
+        }
+        if (fin) break;
+    }
+    return ret == end32 ? len : entry + ret;
+}
+
 struct ChainNoEmit {
     __device__ __forceinline__ void operator()(uint32_t, uint64_t) const {}
 };
 
-// {count, S1, S2} of the matches a chain reports (the checksum of include/daachorse_amd.h, daac_scan_count)
+// {count, S1, S2} of the matches a chain reports (the checksum of include/daachorse_amd.h, daac_scan_count).  h of a match
+// is a function of its output record alone and comes precomputed (`ohash`, one u32 per record); the value asked for at one
+// report is folded in at the next one (or by packed()), so that the walker never waits for it: the answer arrives behind
+// the transition's own memory round trip.
 struct ChainTally {
-    const uint32_t *outputs;
+    const uint32_t *ohash;
     unsigned long long cnt = 0;
     uint32_t s1 = 0, s2 = 0;
+    uint32_t h_wait = 0, end_wait = 0;
     __device__ __forceinline__ void operator()(uint32_t opos, uint64_t end) {
-        const uint32_t *r = outputs + 3u * (opos - 1u);
-        uint64_t z = (static_cast<uint64_t>(r[0]) << 32) | r[1];
-        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-        const uint32_t h = static_cast<uint32_t>(z ^ (z >> 31));
-        cnt += 1; s1 += h; s2 += h * static_cast<uint32_t>(end);
+#if DAAC_TALLY_DEFER
+        s1 += h_wait; s2 += h_wait * end_wait;
+        h_wait = ohash[opos - 1u];
+        end_wait = static_cast<uint32_t>(end);
+#else
+        const uint32_t h = ohash[opos - 1u];
+        s1 += h; s2 += h * static_cast<uint32_t>(end);
+#endif
+        cnt += 1;
     }
-    __device__ __forceinline__ uint4 packed() const { return uint4{static_cast<uint32_t>(cnt), static_cast<uint32_t>(cnt >> 32), s1, s2}; }
+    __device__ __forceinline__ uint4 packed() const {
+        return uint4{static_cast<uint32_t>(cnt), static_cast<uint32_t>(cnt >> 32), s1 + h_wait, s2 + h_wait * end_wait};
+    }
 };
 __device__ __forceinline__ uint4 tally_sub(const uint4 &a, const uint4 &b) {  // a - b, field by field
     const unsigned long long ca = (static_cast<unsigned long long>(a.y) << 32) | a.x, cb = (static_cast<unsigned long long>(b.y) << 32) | b.x;
@@ -191,13 +348,13 @@ __device__ __forceinline__ uint4 tally_sub(const uint4 &a, const uint4 &b) {  //
 
 // pass 1: exits of the speculative chains
 template <class T, bool LEFTMOST>
-__device__ __forceinline__ void chain_spec_body(const T &t, const ScanArgs &a, const ChainArgs &c, const uint32_t *outputs) {
+__device__ __forceinline__ void chain_spec_body(const T &t, const ScanArgs &a, const ChainArgs &c, const uint32_t *ohash) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     ChainWalker<T, LEFTMOST> w{t, a.total_len, c.cap};
     for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
         const uint64_t lo = a.begin + seg * a.seg_bytes;
         const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
-        ChainTally tally{outputs};
+        ChainTally tally{ohash};
         c.x_out[seg] = w.run(seg == 0 ? lo : t.boundary_at_or_after(lo), hi, tally);
         c.tally_spec[seg] = tally.packed();
     }
@@ -206,7 +363,7 @@ __device__ __forceinline__ void chain_spec_body(const T &t, const ScanArgs &a, c
 
 // pass 2 (repeated until nothing changes): exits given the previous round's exits as entries
 template <class T, bool LEFTMOST>
-__device__ __forceinline__ void chain_fix_body(const T &t, const ScanArgs &a, const ChainArgs &c, const uint32_t *outputs) {
+__device__ __forceinline__ void chain_fix_body(const T &t, const ScanArgs &a, const ChainArgs &c, const uint32_t *ohash) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     ChainWalker<T, LEFTMOST> w{t, a.total_len, c.cap};
     bool changed = false;
@@ -224,7 +381,7 @@ __device__ __forceinline__ void chain_fix_body(const T &t, const ScanArgs &a, co
                 delta = tally_sub(delta, c.tally_spec[seg]);
             } else if (entry != s) {
                 uint64_t x = entry;         // the true chain; s follows the speculative one
-                ChainTally of_true{outputs}, of_spec{outputs};
+                ChainTally of_true{ohash}, of_spec{ohash};
                 bool merged = false;
                 while (x < hi && !w.overflow) {
                     while (s < x && s < hi && !w.overflow) s = w.link(s, hi, of_spec);

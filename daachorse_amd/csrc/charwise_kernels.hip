@@ -24,11 +24,12 @@ __device__ __forceinline__ uint64_t cw_mix64(uint64_t z) {
 
 struct CwState { uint32_t idx, base, fail, opos; };
 
-// MAPLDS: the populated stretch [map_lo, table_len) of the code mapper is staged in LDS as u16 (0xffff = unmapped):
-// one L2 round trip less per character; code points below map_lo (ASCII in CJK text) still go to the L2 copy
+// MAPLDS: ASCII and the populated stretch [map_lo, table_len) of the code mapper are staged in LDS as u16 (0xffff =
+// unmapped): one L2 round trip less per character; the code points in between (rare in CJK text) go to the L2 copy
 template <bool MAPLDS>
 struct CwTablesT {
     using State = CwState;
+    static constexpr bool kMicro = DAAC_CW_MICRO != 0;  // chain_scan.hpp: the walker takes the transition one memory round trip at a time
     const CharDev &d;
     uint4 root_rec;
     const uint8_t *__restrict__ hay;
@@ -66,13 +67,64 @@ struct CwTablesT {
         return cp;
     }
     __device__ __forceinline__ uint32_t code_of(uint32_t cp) const {
-        if (MAPLDS) {
-            if (cp >= d.table_len) return 0xffffffffu;
-            if (cp < d.map_lo) return d.table[cp];
-            const uint32_t c = l_map[cp - d.map_lo];
-            return c == 0xffffu ? 0xffffffffu : c;
+        if (MAPLDS) {  // l_map: 128 entries for ASCII, then the stretch [map_lo, table_len)
+            const uint32_t rel = cp - d.map_lo;
+            const bool low = cp < 128u, high = rel < d.table_len - d.map_lo;
+            if (low || high) {
+                const uint32_t c = l_map[low ? cp : rel + 128u];
+                return c == 0xffffu ? 0xffffffffu : c;
+            }
+            // between ASCII and the stretch: rare, from L2 — asked and waited for in one piece, so that the optimiser does
+            // not, on the common path, wait for a load it would otherwise believe might be outstanding
+            uint32_t c = 0xffffffffu;
+            if (cp < d.table_len) asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(c) : "v"(d.table + cp) : "memory");
+            return c;
         }
         return cp < d.table_len ? d.table[cp] : 0xffffffffu;
+    }
+    // The code of the scalar that begins at p (a character boundary of well-formed UTF-8; charwise/iter.rs:64-98) and its
+    // length in bytes; `avail` bytes are left in the haystack: a sequence cut by its end is completed with zero payload bits.
+    __device__ __forceinline__ uint32_t symbol_code(HayStream &win, const uint8_t *p, uint32_t avail, uint32_t &clen) const {
+        uint32_t x = win.word_at(p);
+        if (avail < 4u) x &= (1u << (8u * avail)) - 1u;
+        const uint32_t b0 = x & 0xffu;
+        const uint32_t c1 = (x >> 8) & 0x3fu, c2 = (x >> 16) & 0x3fu, c3 = (x >> 24) & 0x3fu;
+        const uint32_t cp2 = ((b0 & 0x1fu) << 6) | c1, cp3 = ((b0 & 0x0fu) << 12) | (c1 << 6) | c2,
+                       cp4 = ((b0 & 0x07u) << 18) | (c1 << 12) | (c2 << 6) | c3;
+        const uint32_t n = b0 < 0x80u ? 1u : b0 < 0xe0u ? 2u : b0 < 0xf0u ? 3u : 4u;
+        clen = n;
+        return code_of(n == 1u ? b0 : n == 2u ? cp2 : n == 3u ? cp3 : cp4);
+    }
+    // One memory round trip of the transition on `code` (charwise.rs:1022-1050 / 1056-1092 taken apart): phase 0 probes the
+    // child slot, phase 1 fetches the record a failure link leads to; a link to ROOT needs no memory (that record is at hand),
+    // the symbol is tried again from there in the next turn.  True once the transition is complete.  Every lane loads, every
+    // turn (an idle lane asks for slot 0), and the outcome is a handful of selects.
+    template <bool LM>
+    __device__ __forceinline__ bool micro(CwState &st, uint32_t code, uint32_t &phase, bool act) const {
+        const bool known = code != 0xffffffffu;  // charwise.rs:1031-1035
+        const bool probe = phase == 0;
+        const bool ask = act && known && (!probe || st.base != 0);
+        const uint32_t slot = ask ? (probe ? (st.base ^ code) : st.fail) : 0u;
+        // the turn's one memory round trip: all four words in one request, and the turn's one full wait with it
+        typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+        U32x4 rv;
+        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(rv) : "v"(d.states + slot) : "memory");
+        const uint4 r = uint4{rv.x, rv.y, rv.z, rv.w};
+        uint32_t f = r.z;
+        if (!LM && d.fail_plain) f = d.fail_plain[slot];
+        const bool hit = ask && probe && r.y == st.idx;
+        const bool take = hit || (ask && !probe);                 // the record read becomes the state
+        const bool miss = act && known && probe && !hit;          // no such child
+        const bool dead = miss && st.idx != 0 && LM && st.fail == 1u;
+        const bool to_root = (act && !known) || dead || (miss && st.idx != 0 && st.fail == 0);
+        const bool done = (act && !known) || hit || dead || (miss && st.idx == 0);
+        phase = (miss && !done && !to_root) ? 1u : 0u;
+        const CwState rt = root();
+        st.idx = take ? slot : to_root ? rt.idx : st.idx;
+        st.base = take ? r.x : to_root ? rt.base : st.base;
+        st.fail = take ? f : to_root ? rt.fail : st.fail;
+        st.opos = take ? r.w : to_root ? rt.opos : st.opos;
+        return done;
     }
     __device__ __forceinline__ void load(CwState &st, uint32_t slot, bool plain) const {
         const uint4 r = d.states[slot];
@@ -280,15 +332,16 @@ __global__ __launch_bounds__(MAPLDS ? 512 : 256) void char_chain_kernel(const Ch
     extern __shared__ __attribute__((aligned(16))) uint16_t l_map[];
     __shared__ unsigned long long scratch[3 * 8];
     if (MAPLDS && PASS != 3) {
-        for (uint32_t i = dev.map_lo + threadIdx.x; i < dev.table_len; i += blockDim.x) {
-            const uint32_t code = dev.table[i];
-            l_map[i - dev.map_lo] = code == 0xffffffffu ? 0xffffu : static_cast<uint16_t>(code);
+        for (uint32_t i = threadIdx.x; i < 128u + (dev.table_len - dev.map_lo); i += blockDim.x) {
+            const uint32_t cp = i < 128u ? i : i - 128u + dev.map_lo;
+            const uint32_t code = cp < dev.table_len ? dev.table[cp] : 0xffffffffu;
+            l_map[i] = code == 0xffffffffu ? 0xffffu : static_cast<uint16_t>(code);
         }
         __syncthreads();
     }
     const CwTablesT<MAPLDS> T{dev, dev.states[0], a.hay, a.total_len, l_map};
-    if (PASS == 0) chain_spec_body<CwTablesT<MAPLDS>, LEFTMOST>(T, a, c, dev.outputs);
-    else if (PASS == 1) chain_fix_body<CwTablesT<MAPLDS>, LEFTMOST>(T, a, c, dev.outputs);
+    if (PASS == 0) chain_spec_body<CwTablesT<MAPLDS>, LEFTMOST>(T, a, c, dev.ohash);
+    else if (PASS == 1) chain_fix_body<CwTablesT<MAPLDS>, LEFTMOST>(T, a, c, dev.ohash);
     else if (PASS == 3) chain_sum_body<KMODE>(a, c, next_begin, scratch);
     else chain_emit_body<CwTablesT<MAPLDS>, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
 }
@@ -298,7 +351,7 @@ static hipError_t launch_char_chain_ml(const CharDev &dev, const ScanArgs &a, co
                                        unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
     // with the mapper in LDS (<= 32 KB) four 512-thread workgroups share a CU: the same 2048 lanes as without
     const dim3 g(MAPLDS ? (blocks + 1u) / 2u : blocks), b(MAPLDS ? 512 : 256);
-    const uint32_t lds = MAPLDS && pass != 3 ? (((dev.table_len - dev.map_lo) * 2u + 15u) & ~15u) : 0u;
+    const uint32_t lds = MAPLDS && pass != 3 ? (((128u + dev.table_len - dev.map_lo) * 2u + 15u) & ~15u) : 0u;
 #define DAAC_CC(L, P, M) hipLaunchKernelGGL((char_chain_kernel<L, P, M, MAPLDS>), g, b, lds, stream, dev, a, c, next_begin)
     if (pass == 0) { if (leftmost) DAAC_CC(true, 0, 0); else DAAC_CC(false, 0, 0); }
     else if (pass == 1) { if (leftmost) DAAC_CC(true, 1, 0); else DAAC_CC(false, 1, 0); }

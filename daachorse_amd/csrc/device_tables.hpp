@@ -20,6 +20,7 @@ struct TierDev {
     const uint4 *grec;       // N x {cmap, omap, first_child, fail}
     const uint32_t *sopos;   // N output_pos per state (1-based, 0 = none)
     const uint32_t *outputs; // n_outputs x {value, length, parent}
+    const uint32_t *ohash;   // n_outputs x h32 of the record's own match (checksum definition)
     uint32_t C, NA, NB, N;
     uint32_t off_bcmap, off_bfail, off_ssum, off_cls, lds_bytes;  // rows are at offset 0
     uint32_t row32, root_flag;
@@ -33,6 +34,7 @@ struct DArrayDev {
     const uint4 *root;       // 256 x {child, child.base, child.opos_ch, 0}, staged into LDS
     const uint2 *osum;       // per output record {chain count, chain sum of h32}
     const uint32_t *outputs; // n_outputs x {value, length, parent}
+    const uint32_t *ohash;   // n_outputs x h32 of the record's own match
     uint32_t n, root_flag, leftmost;
 };
 
@@ -43,6 +45,7 @@ struct CharDev {
     const uint32_t *table;       // code point -> code, 0xffffffff = not in any pattern (mapper.rs:36-42)
     const uint2 *osum;           // per output record {chain count, chain sum of h32}
     const uint32_t *outputs;     // n_outputs x {value, length, parent}
+    const uint32_t *ohash;       // n_outputs x h32 of the record's own match
     uint32_t table_len, n, root_flag, leftmost;
     uint32_t map_in_lds;         // the populated stretch of the mapper fits LDS as u16 codes ((table_len - map_lo) * 2 <= 32 KB)
     uint32_t map_lo;             // first code point worth staging (the dense tail of the table starts here)

@@ -40,6 +40,7 @@ struct RsState { uint32_t idx, base, opos_ch; };
 
 struct RestartTables {
     using State = RsState;
+    static constexpr bool kMicro = false;
     const DArrayDev &d;
     const uint4 *l_root;  // 256 x {child, child.base, child.opos_ch, 0} in LDS
     const uint8_t *__restrict__ hay = nullptr;
@@ -253,8 +254,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const DArrayDev dev, const S
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root[i];
     __syncthreads();
     const RestartTables T{dev, l_root, a.hay};
-    if (PASS == 0) chain_spec_body<RestartTables, LEFTMOST>(T, a, c, dev.outputs);
-    else if (PASS == 1) chain_fix_body<RestartTables, LEFTMOST>(T, a, c, dev.outputs);
+    if (PASS == 0) chain_spec_body<RestartTables, LEFTMOST>(T, a, c, dev.ohash);
+    else if (PASS == 1) chain_fix_body<RestartTables, LEFTMOST>(T, a, c, dev.ohash);
     else if (PASS == 3) chain_sum_body<KMODE>(a, c, next_begin, scratch);
     else chain_emit_body<RestartTables, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
 }

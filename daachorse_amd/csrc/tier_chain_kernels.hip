@@ -22,6 +22,7 @@ namespace {
 template <bool ROW32>
 struct TierChainTables {
     using Row = typename std::conditional<ROW32, uint32_t, uint16_t>::type;
+    static constexpr bool kMicro = false;
     struct State { uint32_t id, out; };  // out: the state carries an output list (known from the row entry / the parent's omap)
 
     const TierDev &d;
@@ -89,8 +90,8 @@ __global__ __launch_bounds__(1024) void tier_chain_kernel(const TierDev dev, con
         __syncthreads();
     }
     const TierChainTables<ROW32> T(dev, smem, a.hay);
-    if (PASS == 0) chain_spec_body<TierChainTables<ROW32>, false>(T, a, c, dev.outputs);
-    else if (PASS == 1) chain_fix_body<TierChainTables<ROW32>, false>(T, a, c, dev.outputs);
+    if (PASS == 0) chain_spec_body<TierChainTables<ROW32>, false>(T, a, c, dev.ohash);
+    else if (PASS == 1) chain_fix_body<TierChainTables<ROW32>, false>(T, a, c, dev.ohash);
     else if (PASS == 3) chain_sum_body<KMODE>(a, c, next_begin, scratch);
     else chain_emit_body<TierChainTables<ROW32>, false, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
 }
