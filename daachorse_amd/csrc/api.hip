@@ -51,7 +51,8 @@ struct Options {
                                                 // than over the double array on cfg3: half the waves per CU, and a match costs a gather more)
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
-    std::atomic<int64_t> char_map_lds{1};       // charwise chain scans: stage the populated stretch of the code mapper in LDS
+    std::atomic<int64_t> char_map_lds{1};
+    std::atomic<int64_t> char_row_lds{1};       // ... and ROOT's row of children beside it       // charwise chain scans: stage the populated stretch of the code mapper in LDS
                                                 // (off: measured slower on cfg5, 88 vs 104 GB/s — the stretch is L1-resident anyway)
 };
 static Options g_opt;
@@ -252,6 +253,33 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             // worth it only if most of the alphabet lives in the stretch
             c.map_in_lds = g_opt.char_map_lds.load() != 0 && lo < c.table_len && pma->chost.alphabet_size < 0xffffu &&
                            staged * 4u >= pma->chost.alphabet_size * 3u;
+        }
+        // ROOT's row of children for the chain walkers: a lane at ROOT (where failed walks end) then needs no memory at all.
+        // Staged beside the mapper when both fit 80 KB (two 1024-lane workgroups per CU) and every child packs into 8 bytes.
+        {
+            const uint32_t A = pma->chost.alphabet_size;
+            std::vector<U32x2> row(A, U32x2{0u, 2u});
+            bool ok = c.map_in_lds != 0 && g_opt.char_row_lds.load() != 0 && A != 0;
+            const CStateRec &rt = ct.states[0];
+            for (uint32_t code = 0; ok && code < A; ++code) {
+                if (rt.base == 0) break;
+                const uint32_t child = rt.base ^ code;
+                if (child >= ct.states.size() || ct.states[child].check != 0) continue;
+                const CStateRec &ch = ct.states[child];
+                const uint32_t fl = (c.leftmost || ct.fail_plain.empty()) ? ch.fail : ct.fail_plain[child];
+                if (fl > 1u || (fl == 1u && !c.leftmost) || ch.output_pos >= (1u << 30)) ok = false;
+                row[code] = U32x2{ch.base, (ch.output_pos << 2) | fl};
+            }
+            const uint32_t map_bytes = ((128u + c.table_len - c.map_lo) * 2u + 15u) & ~15u;
+            ok = ok && map_bytes + A * 8u <= 80u * 1024u;
+            c.alphabet = A;
+            c.row_in_lds = ok;
+            c.root_row = nullptr;
+            if (ok) {
+                const U32x2 *drow;
+                if ((st = t->put(row, drow)) != DAAC_OK) return st;
+                c.root_row = reinterpret_cast<const uint2 *>(drow);
+            }
         }
         HIP_TRY(hipDeviceSynchronize());
         *out = t.get();
@@ -634,6 +662,17 @@ struct ChainBuffers {
     ~ChainBuffers() { if (buf) (void)hipFree(buf); }
 };
 
+// a few page-locked words per host thread for flags read back between passes
+static unsigned int *pinned_words() {
+    struct Holder {
+        unsigned int *p = nullptr;
+        Holder() { if (hipHostMalloc(reinterpret_cast<void **>(&p), 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; } }
+        ~Holder() { if (p) (void)hipHostFree(p); }
+    };
+    static thread_local Holder h;
+    return h.p;
+}
+
 daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, hipStream_t stream, ChainBuffers &cb) {
     pl.chain = ChainArgs{};
     if (!pl.restart || pma->root_has_output() || g_opt.restart_chain.load() == 0 || pl.a.nseg == 0) return DAAC_OK;
@@ -664,8 +703,10 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
         c.x_spec = x_spec; c.x_prev = prev; c.x_out = out;
         HIP_TRY(hipMemsetAsync(flags, 0, sizeof(unsigned int), stream));
         HIP_TRY(run(1));
-        unsigned int f[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(f, flags, sizeof(f), hipMemcpyDeviceToHost, stream));
+        unsigned int *f = pinned_words();  // page-locked: the copy is a plain DMA, not a staged one
+        unsigned int f_local[2] = {0, 0};
+        if (!f) f = f_local;
+        HIP_TRY(hipMemcpyAsync(f, flags, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (f[1] != 0) return DAAC_OK;  // a link ran away: not this method's text
         prev = out;
@@ -1488,6 +1529,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "restart_chain") g_opt.restart_chain = value;
     else if (n == "chain_rounds") g_opt.chain_rounds = value;
     else if (n == "char_map_lds") g_opt.char_map_lds = value;
+    else if (n == "char_row_lds") g_opt.char_row_lds = value;
     else { set_error("unknown option: " + n); return DAAC_ERR_INVALID_ARGUMENT; }
     return DAAC_OK;
 }

@@ -72,27 +72,24 @@ struct HayWindow {
 // its own behind the new request.  A step back of up to 12 bytes after a leftmost match stays inside the window.
 struct HayStream {
     typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
-    uintptr_t base = ~static_cast<uintptr_t>(0) - 64;  // far from any address: the first request takes the cold path
-    uintptr_t limit = 0;                               // granules beginning at or beyond this address are never read
+    const uint8_t *org = nullptr;  // positions are 32-bit offsets from here
+    uintptr_t limit = 0;           // granules beginning at or beyond this address are never read
+    uint32_t boff = 0x80000000u;   // offset of the window's first byte (far from any position: the first request is cold)
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0;
 
-    __device__ __forceinline__ void ask_ahead() {
-        const uintptr_t g = base + 32;
-        U32x4 v = U32x4{0u, 0u, 0u, 0u};
-        if (g < limit) v = *reinterpret_cast<const U32x4 __attribute__((address_space(1))) *>(g);
-        f0 = v.x; f1 = v.y; f2 = v.z; f3 = v.w;
+    __device__ __forceinline__ uintptr_t addr_of(uint32_t off) const {
+        return reinterpret_cast<uintptr_t>(org) + static_cast<uintptr_t>(static_cast<intptr_t>(static_cast<int32_t>(off)));
     }
-    // the four bytes from p on, first byte lowest; bytes at or beyond `limit`'s granule read as zero
-    __device__ __forceinline__ uint32_t word_at(const uint8_t *p) {
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
-        uint32_t off = static_cast<uint32_t>(addr - base);
-        if (addr - base > 28u) {
-            if (addr - base < 44u) {  // the usual step: slide by one granule
+    // the four bytes from position `pos` on, first byte lowest; bytes at or beyond `limit`'s granule read as zero
+    __device__ __forceinline__ uint32_t word_at(uint32_t pos) {
+        uint32_t off = pos - boff;
+        if (off > 28u) {
+            if (off < 44u) {  // the usual step: slide by one granule
                 w0 = n0; w1 = n1; w2 = n2; w3 = n3;
                 n0 = f0; n1 = f1; n2 = f2; n3 = f3;
-                base += 16;
+                boff += 16;
             } else {  // a segment's first request, or a step back beyond the window: two granules fetched and waited for
-                const uintptr_t b = addr & ~static_cast<uintptr_t>(15);
+                const uintptr_t addr = addr_of(pos), b = addr & ~static_cast<uintptr_t>(15);
                 const bool two = b + 16 < limit;
                 const uintptr_t b2 = two ? b + 16 : b;
                 U32x4 v0, v1;
@@ -100,15 +97,17 @@ struct HayStream {
                              : "=&v"(v0), "=&v"(v1) : "v"(b), "v"(b2) : "memory");
                 w0 = v0.x; w1 = v0.y; w2 = v0.z; w3 = v0.w;
                 n0 = two ? v1.x : 0u; n1 = two ? v1.y : 0u; n2 = two ? v1.z : 0u; n3 = two ? v1.w : 0u;
-                base = b;
+                boff = pos - (static_cast<uint32_t>(addr) & 15u);
             }
-            ask_ahead();
-            off = static_cast<uint32_t>(addr - base);
+            const uintptr_t g = addr_of(boff + 32u);
+            U32x4 v = U32x4{0u, 0u, 0u, 0u};
+            if (g < limit) v = *reinterpret_cast<const U32x4 __attribute__((address_space(1))) *>(g);
+            f0 = v.x; f1 = v.y; f2 = v.z; f3 = v.w;
+            off = pos - boff;
         }
-        uint32_t a0 = w0, a1 = w1, a2 = w2, a3 = w3, a4 = n0, a5 = n1, a6 = n2, a7 = n3;
-        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
-        const bool up = (off & 16u) != 0;  // dwords q .. q + 1 of the eight, q = off / 4 (off <= 28: the last word is only ever `lo`)
-        const uint32_t b0 = up ? a4 : a0, b1 = up ? a5 : a1, b2 = up ? a6 : a2, b3 = up ? a7 : a3, b4 = up ? a7 : a4;
+        // dwords q and q + 1 of the eight resident ones, q = off / 4 (off <= 28: the last word is only ever the low one)
+        const bool up = (off & 16u) != 0;
+        const uint32_t b0 = up ? n0 : w0, b1 = up ? n1 : w1, b2 = up ? n2 : w2, b3 = up ? n3 : w3, b4 = up ? n3 : n0;
         const bool mid = (off & 8u) != 0;
         const uint32_t c0 = mid ? b2 : b0, c1 = mid ? b3 : b1, c2 = mid ? b4 : b2;
         const bool odd = (off & 4u) != 0;
@@ -249,12 +248,13 @@ struct ChainWalker {
 template <class T, bool LEFTMOST>
 template <class Emit>
 __device__ __forceinline__ uint64_t ChainWalker<T, LEFTMOST>::run_micro(uint64_t entry, uint64_t hi, Emit &&emit) {
-    const uint8_t *const p0 = t.hay + entry;
     const uint64_t room = len - entry;
     const uint32_t end32 = room > 0xffffff00ull ? 0xffffff00u : static_cast<uint32_t>(room);  // the haystack's end
     const uint32_t hi32 = static_cast<uint32_t>(hi - entry);
     const uint32_t cap32 = cap > 0x3fffffffull ? 0x3fffffffu : static_cast<uint32_t>(cap);
     str.limit = reinterpret_cast<uintptr_t>(t.hay) + len;
+    str.org = t.hay + entry;
+    str.boff = 0x80000000u;
     typename T::State st = t.root();
     uint32_t pos = 0, clen = 0, code = 0, phase = 0;
     bool pending = false;   // a symbol has been read and its transition is under way
@@ -268,7 +268,7 @@ __device__ __forceinline__ uint64_t ChainWalker<T, LEFTMOST>::run_micro(uint64_t
                 if (LEFTMOST && best != 0) report = true;
                 else { ret = end32; fin = true; }
             } else {
-                code = t.symbol_code(str, p0 + pos, end32 - pos, clen);
+                code = t.symbol_code(str, pos, end32 - pos, clen);
                 phase = 0;
                 pending = true;
             }

@@ -26,8 +26,9 @@ struct CwState { uint32_t idx, base, fail, opos; };
 
 // MAPLDS: ASCII and the populated stretch [map_lo, table_len) of the code mapper are staged in LDS as u16 (0xffff =
 // unmapped): one L2 round trip less per character; the code points in between (rare in CJK text) go to the L2 copy
-template <bool MAPLDS>
+template <int LVL>  // what is staged in LDS: 0 nothing, 1 the code mapper, 2 the mapper and ROOT's row of children
 struct CwTablesT {
+    static constexpr bool MAPLDS = LVL >= 1, ROWLDS = LVL >= 2;
     using State = CwState;
     static constexpr bool kMicro = DAAC_CW_MICRO != 0;  // chain_scan.hpp: the walker takes the transition one memory round trip at a time
     const CharDev &d;
@@ -35,6 +36,7 @@ struct CwTablesT {
     const uint8_t *__restrict__ hay;
     uint64_t len;  // real end of the haystack: nothing at or beyond it is read
     const uint16_t *l_map = nullptr;
+    const uint2 *l_row = nullptr;  // per code: {child.base, child.output_pos << 2 | child.fail (0 ROOT, 1 DEAD)}, or {0, 2}: no such child
 
     __device__ __forceinline__ CwState root() const { return CwState{0, root_rec.x, root_rec.z, root_rec.w}; }
     // the automaton as chain_scan.hpp wants it
@@ -84,16 +86,19 @@ struct CwTablesT {
     }
     // The code of the scalar that begins at p (a character boundary of well-formed UTF-8; charwise/iter.rs:64-98) and its
     // length in bytes; `avail` bytes are left in the haystack: a sequence cut by its end is completed with zero payload bits.
-    __device__ __forceinline__ uint32_t symbol_code(HayStream &win, const uint8_t *p, uint32_t avail, uint32_t &clen) const {
-        uint32_t x = win.word_at(p);
-        if (avail < 4u) x &= (1u << (8u * avail)) - 1u;
+    __device__ __forceinline__ uint32_t symbol_code(HayStream &win, uint32_t pos, uint32_t avail, uint32_t &clen) const {
+        uint32_t x = win.word_at(pos);
+        if (__builtin_amdgcn_ballot_w64(avail < 4u) != 0) {  // (only at the very end of the haystack: skipped by the whole wave otherwise)
+            if (avail < 4u) x &= (1u << (8u * avail)) - 1u;
+        }
         const uint32_t b0 = x & 0xffu;
-        const uint32_t c1 = (x >> 8) & 0x3fu, c2 = (x >> 16) & 0x3fu, c3 = (x >> 24) & 0x3fu;
-        const uint32_t cp2 = ((b0 & 0x1fu) << 6) | c1, cp3 = ((b0 & 0x0fu) << 12) | (c1 << 6) | c2,
-                       cp4 = ((b0 & 0x07u) << 18) | (c1 << 12) | (c2 << 6) | c3;
-        const uint32_t n = b0 < 0x80u ? 1u : b0 < 0xe0u ? 2u : b0 < 0xf0u ? 3u : 4u;
+        // one formula for the four lengths: the lead byte's payload over three 6-bit groups, shifted down by the groups not there
+        const uint32_t m2 = b0 >= 0x80u, m3 = b0 >= 0xe0u, m4 = b0 >= 0xf0u;
+        const uint32_t n = 1u + m2 + m3 + m4;
+        const uint32_t lead = b0 & (0xffu >> (n + m2));  // 0x7f, 0x1f, 0x0f, 0x07
+        const uint32_t tail = (((x >> 8) & 0x3fu) << 12) | (((x >> 16) & 0x3fu) << 6) | ((x >> 24) & 0x3fu);
         clen = n;
-        return code_of(n == 1u ? b0 : n == 2u ? cp2 : n == 3u ? cp3 : cp4);
+        return code_of(((lead << 18) | tail) >> (24u - 6u * n));
     }
     // One memory round trip of the transition on `code` (charwise.rs:1022-1050 / 1056-1092 taken apart): phase 0 probes the
     // child slot, phase 1 fetches the record a failure link leads to; a link to ROOT needs no memory (that record is at hand),
@@ -103,8 +108,13 @@ struct CwTablesT {
     __device__ __forceinline__ bool micro(CwState &st, uint32_t code, uint32_t &phase, bool act) const {
         const bool known = code != 0xffffffffu;  // charwise.rs:1031-1035
         const bool probe = phase == 0;
-        const bool ask = act && known && (!probe || st.base != 0);
+        const bool at_root = st.idx == 0;
+        // with ROOT's row at hand a lane standing at ROOT asks memory nothing, and a failed probe whose failure link leads to
+        // ROOT is settled in the same turn
+        const bool ask = act && known && (probe ? (st.base != 0 && !(ROWLDS && at_root)) : true);
         const uint32_t slot = ask ? (probe ? (st.base ^ code) : st.fail) : 0u;
+        uint2 e = uint2{0u, 2u};
+        if (ROWLDS) e = l_row[known ? code : 0u];
         // the turn's one memory round trip: all four words in one request, and the turn's one full wait with it
         typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
         U32x4 rv;
@@ -113,17 +123,20 @@ struct CwTablesT {
         uint32_t f = r.z;
         if (!LM && d.fail_plain) f = d.fail_plain[slot];
         const bool hit = ask && probe && r.y == st.idx;
-        const bool take = hit || (ask && !probe);                 // the record read becomes the state
-        const bool miss = act && known && probe && !hit;          // no such child
-        const bool dead = miss && st.idx != 0 && LM && st.fail == 1u;
-        const bool to_root = (act && !known) || dead || (miss && st.idx != 0 && st.fail == 0);
-        const bool done = (act && !known) || hit || dead || (miss && st.idx == 0);
-        phase = (miss && !done && !to_root) ? 1u : 0u;
+        const bool take = hit || (ask && !probe);                  // the record read becomes the state
+        const bool miss = act && known && probe && !hit;           // no such child (at ROOT with the row: not asked)
+        const bool dead = miss && !at_root && LM && st.fail == 1u;
+        const bool rootward = miss && !dead && (at_root || st.fail == 0);  // the symbol is ROOT's to take
+        const bool by_row = ROWLDS && rootward;
+        const bool child = by_row && (e.y & 3u) != 2u;
+        const bool to_root = (act && !known) || dead || (rootward && !child);
+        const bool done = (act && !known) || hit || dead || by_row || (miss && at_root);
+        phase = (miss && !dead && !rootward) ? 1u : 0u;
         const CwState rt = root();
-        st.idx = take ? slot : to_root ? rt.idx : st.idx;
-        st.base = take ? r.x : to_root ? rt.base : st.base;
-        st.fail = take ? f : to_root ? rt.fail : st.fail;
-        st.opos = take ? r.w : to_root ? rt.opos : st.opos;
+        st.idx = take ? slot : child ? (rt.base ^ code) : to_root ? rt.idx : st.idx;
+        st.base = take ? r.x : child ? e.x : to_root ? rt.base : st.base;
+        st.fail = take ? f : child ? (e.y & 3u) : to_root ? rt.fail : st.fail;
+        st.opos = take ? r.w : child ? (e.y >> 2) : to_root ? rt.opos : st.opos;
         return done;
     }
     __device__ __forceinline__ void load(CwState &st, uint32_t slot, bool plain) const {
@@ -177,7 +190,7 @@ struct CwTablesT {
         return st.idx == 0 ? pos : len;
     }
 };
-using CwTables = CwTablesT<false>;
+using CwTables = CwTablesT<0>;
 
 // KMODE 0: totals {count, S1, S2}; 1: per-segment counts; 2: write matches at out + seg_counts[seg]
 template <bool LEFTMOST, int KMODE>
@@ -326,33 +339,53 @@ __global__ __launch_bounds__(256) void char_restart_kernel(const CharDev dev, co
 }
 
 // ---- speculate / reconcile / emit (chain_scan.hpp) over the charwise double array -------------------------
-template <bool LEFTMOST, int PASS, int KMODE, bool MAPLDS>
-__global__ __launch_bounds__(MAPLDS ? 512 : 256) void char_chain_kernel(const CharDev dev, const ScanArgs a, const ChainArgs c,
-                                                                         unsigned long long *next_begin) {
+template <bool LEFTMOST, int PASS, int KMODE, int LVL>
+__global__ __launch_bounds__(LVL == 2 ? 1024 : LVL == 1 ? 512 : 256) void char_chain_kernel(const CharDev dev, const ScanArgs a, const ChainArgs c,
+                                                                                           unsigned long long *next_begin) {
     extern __shared__ __attribute__((aligned(16))) uint16_t l_map[];
-    __shared__ unsigned long long scratch[3 * 8];
-    if (MAPLDS && PASS != 3) {
-        for (uint32_t i = threadIdx.x; i < 128u + (dev.table_len - dev.map_lo); i += blockDim.x) {
+    __shared__ unsigned long long scratch[3 * 16];
+    const uint32_t n_map = 128u + (dev.table_len - dev.map_lo);
+    uint2 *l_row = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(l_map) + ((n_map * 2u + 15u) & ~15u));
+    if (LVL >= 1 && PASS != 3) {
+        for (uint32_t i = threadIdx.x; i < n_map; i += blockDim.x) {
             const uint32_t cp = i < 128u ? i : i - 128u + dev.map_lo;
             const uint32_t code = cp < dev.table_len ? dev.table[cp] : 0xffffffffu;
             l_map[i] = code == 0xffffffffu ? 0xffffu : static_cast<uint16_t>(code);
         }
+        if (LVL >= 2)
+            for (uint32_t i = threadIdx.x; i < dev.alphabet; i += blockDim.x) l_row[i] = dev.root_row[i];
         __syncthreads();
     }
-    const CwTablesT<MAPLDS> T{dev, dev.states[0], a.hay, a.total_len, l_map};
-    if (PASS == 0) chain_spec_body<CwTablesT<MAPLDS>, LEFTMOST>(T, a, c, dev.ohash);
-    else if (PASS == 1) chain_fix_body<CwTablesT<MAPLDS>, LEFTMOST>(T, a, c, dev.ohash);
+    const CwTablesT<LVL> T{dev, dev.states[0], a.hay, a.total_len, l_map, l_row};
+    if (PASS == 0) chain_spec_body<CwTablesT<LVL>, LEFTMOST>(T, a, c, dev.ohash);
+    else if (PASS == 1) chain_fix_body<CwTablesT<LVL>, LEFTMOST>(T, a, c, dev.ohash);
     else if (PASS == 3) chain_sum_body<KMODE>(a, c, next_begin, scratch);
-    else chain_emit_body<CwTablesT<MAPLDS>, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
+    else chain_emit_body<CwTablesT<LVL>, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
 }
 
-template <bool MAPLDS>
+template <int LVL>
 static hipError_t launch_char_chain_ml(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
                                        unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
-    // with the mapper in LDS (<= 32 KB) four 512-thread workgroups share a CU: the same 2048 lanes as without
-    const dim3 g(MAPLDS ? (blocks + 1u) / 2u : blocks), b(MAPLDS ? 512 : 256);
-    const uint32_t lds = MAPLDS && pass != 3 ? (((128u + dev.table_len - dev.map_lo) * 2u + 15u) & ~15u) : 0u;
-#define DAAC_CC(L, P, M) hipLaunchKernelGGL((char_chain_kernel<L, P, M, MAPLDS>), g, b, lds, stream, dev, a, c, next_begin)
+    // `blocks` counts 256-lane workgroups (8 per CU).  With the mapper in LDS (<= 32 KB) four 512-lane workgroups share a
+    // CU, with ROOT's row as well (<= 80 KB together) two 1024-lane ones: the same 2048 lanes per CU every time.
+    constexpr uint32_t per = LVL == 2 ? 4u : LVL == 1 ? 2u : 1u;
+    const dim3 g((blocks + per - 1u) / per), b(256u * per);
+    const uint32_t map_bytes = ((128u + dev.table_len - dev.map_lo) * 2u + 15u) & ~15u;
+    const uint32_t lds = pass == 3 ? 0u : LVL == 2 ? map_bytes + dev.alphabet * 8u : LVL == 1 ? map_bytes : 0u;
+    if (LVL == 2 && lds > 48u * 1024u) {
+        hipError_t e;
+#define DAAC_ATTR(L, P, M)                                                                                                      \
+    do {                                                                                                                        \
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(char_chain_kernel<L, P, M, LVL>),                           \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))) != hipSuccess) return e; \
+    } while (0)
+        if (pass == 0) { if (leftmost) DAAC_ATTR(true, 0, 0); else DAAC_ATTR(false, 0, 0); }
+        else if (pass == 1) { if (leftmost) DAAC_ATTR(true, 1, 0); else DAAC_ATTR(false, 1, 0); }
+        else if (pass == 2 && leftmost) { if (kmode == 0) DAAC_ATTR(true, 2, 0); else if (kmode == 1) DAAC_ATTR(true, 2, 1); else DAAC_ATTR(true, 2, 2); }
+        else if (pass == 2) { if (kmode == 0) DAAC_ATTR(false, 2, 0); else if (kmode == 1) DAAC_ATTR(false, 2, 1); else DAAC_ATTR(false, 2, 2); }
+#undef DAAC_ATTR
+    }
+#define DAAC_CC(L, P, M) hipLaunchKernelGGL((char_chain_kernel<L, P, M, LVL>), g, b, lds, stream, dev, a, c, next_begin)
     if (pass == 0) { if (leftmost) DAAC_CC(true, 0, 0); else DAAC_CC(false, 0, 0); }
     else if (pass == 1) { if (leftmost) DAAC_CC(true, 1, 0); else DAAC_CC(false, 1, 0); }
     else if (pass == 3) { if (kmode == 0) DAAC_CC(false, 3, 0); else DAAC_CC(false, 3, 1); }
@@ -364,10 +397,9 @@ static hipError_t launch_char_chain_ml(const CharDev &dev, const ScanArgs &a, co
 
 hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
                              unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
-    // u16 codes of the populated stretch, at most 32 KB of LDS: otherwise the mapper stays in L2
-    const bool map_lds = dev.map_in_lds != 0;
-    return map_lds ? launch_char_chain_ml<true>(dev, a, c, pass, kmode, leftmost, next_begin, blocks, stream)
-                   : launch_char_chain_ml<false>(dev, a, c, pass, kmode, leftmost, next_begin, blocks, stream);
+    if (dev.map_in_lds != 0 && dev.row_in_lds != 0) return launch_char_chain_ml<2>(dev, a, c, pass, kmode, leftmost, next_begin, blocks, stream);
+    if (dev.map_in_lds != 0) return launch_char_chain_ml<1>(dev, a, c, pass, kmode, leftmost, next_begin, blocks, stream);
+    return launch_char_chain_ml<0>(dev, a, c, pass, kmode, leftmost, next_begin, blocks, stream);
 }
 
 hipError_t launch_char_restart_scan(const CharDev &dev, const ScanArgs &a, int kmode, bool leftmost, unsigned long long *next_begin,

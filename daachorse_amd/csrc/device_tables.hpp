@@ -49,6 +49,9 @@ struct CharDev {
     uint32_t table_len, n, root_flag, leftmost;
     uint32_t map_in_lds;         // the populated stretch of the mapper fits LDS as u16 codes ((table_len - map_lo) * 2 <= 32 KB)
     uint32_t map_lo;             // first code point worth staging (the dense tail of the table starts here)
+    const uint2 *root_row;       // per code: {child.base, child.output_pos << 2 | child.fail}, {0, 2} = ROOT has no such child
+    uint32_t alphabet;           // number of codes
+    uint32_t row_in_lds;         // ROOT's row fits LDS beside the mapper (and every entry can be packed)
 };
 
 struct ScanArgs {
