@@ -298,6 +298,11 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         t->da.leftmost = !h.is_standard();
         if ((st = t->put(da.root, root)) != DAAC_OK) return st;
         if ((st = t->put(da.osum, osum)) != DAAC_OK) return st;
+        {
+            std::vector<uint32_t> rec(da.hot.size() * 3);
+            for (size_t i = 0; i < da.hot.size(); ++i) { rec[3 * i] = da.hot[i].x; rec[3 * i + 1] = da.hot[i].y; rec[3 * i + 2] = da.fail[i]; }
+            if ((st = t->put(rec, t->da.rec)) != DAAC_OK) return st;
+        }
         t->da.hot = reinterpret_cast<const uint2 *>(hot);
         t->da.fail = fail;
         t->da.root = reinterpret_cast<const uint4 *>(root);

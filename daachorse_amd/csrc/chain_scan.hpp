@@ -80,6 +80,13 @@ struct HayStream {
     __device__ __forceinline__ uintptr_t addr_of(uint32_t off) const {
         return reinterpret_cast<uintptr_t>(org) + static_cast<uintptr_t>(static_cast<intptr_t>(static_cast<int32_t>(off)));
     }
+    uint32_t cword = 0, cpos = 0x80000000u;  // byte_at: the last word fetched and where it begins
+    // one byte; three of four requests are answered by the word the previous one fetched
+    __device__ __forceinline__ uint32_t byte_at(uint32_t pos) {
+        uint32_t dlt = pos - cpos;
+        if (dlt > 3u) { cword = word_at(pos); cpos = pos; dlt = 0; }
+        return (cword >> (8u * dlt)) & 0xffu;
+    }
     // the four bytes from position `pos` on, first byte lowest; bytes at or beyond `limit`'s granule read as zero
     __device__ __forceinline__ uint32_t word_at(uint32_t pos) {
         uint32_t off = pos - boff;
@@ -255,6 +262,7 @@ __device__ __forceinline__ uint64_t ChainWalker<T, LEFTMOST>::run_micro(uint64_t
     str.limit = reinterpret_cast<uintptr_t>(t.hay) + len;
     str.org = t.hay + entry;
     str.boff = 0x80000000u;
+    str.cpos = 0x80000000u;
     typename T::State st = t.root();
     uint32_t pos = 0, clen = 0, code = 0, phase = 0;
     bool pending = false;   // a symbol has been read and its transition is under way

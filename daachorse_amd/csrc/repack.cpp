@@ -48,7 +48,7 @@ void build_darray_tables(const HostPma &p, DArrayTables &out) {
             const uint32_t t = rbase ^ c;
             if (t < n && check_of(p.opos_ch(t)) == c) child = t;
         }
-        out.root[c] = U32x4{child, n ? p.base(child) : 0, n ? p.opos_ch(child) : 0, 0};
+        out.root[c] = U32x4{child, n ? p.base(child) : 0, n ? p.opos_ch(child) : 0, (n && child) ? p.fail(child) : 0};
     }
     build_chain_sums(p, out.osum);
 

@@ -45,7 +45,7 @@ struct DArrayTables {
     std::vector<uint32_t> fail;    // per slot: the automaton's own failure links (leftmost kinds: DEAD = 1 marks "stop")
     std::vector<uint32_t> fail_plain;  // leftmost kinds only: classic Aho-Corasick failure links of the same trie,
                                        // used to find positions no occurrence spans (restart-scan sync points)
-    std::vector<U32x4> root;       // 256 x {child idx, child base, child opos_ch, 0}; Standard only
+    std::vector<U32x4> root;       // 256 x {child idx, child base, child opos_ch, child fail}; no child: the ROOT record
     std::vector<OutSum> osum;      // per output record
 };
 

@@ -25,6 +25,9 @@
 
 #include <cstdint>
 
+#ifndef DAAC_RS_MICRO
+#define DAAC_RS_MICRO 1
+#endif
 #include "chain_scan.hpp"
 #include "device_tables.hpp"
 
@@ -36,11 +39,11 @@ __device__ __forceinline__ uint64_t rs_mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-struct RsState { uint32_t idx, base, opos_ch; };
+struct RsState { uint32_t idx, base, opos_ch, fail; };  // fail: only kept by the micro-step walker (chain_scan.hpp, run_micro)
 
 struct RestartTables {
     using State = RsState;
-    static constexpr bool kMicro = false;
+    static constexpr bool kMicro = DAAC_RS_MICRO != 0;  // chain_scan.hpp: the walker takes the transition one memory round trip at a time
     const DArrayDev &d;
     const uint4 *l_root;  // 256 x {child, child.base, child.opos_ch, 0} in LDS
     const uint8_t *__restrict__ hay = nullptr;
@@ -51,6 +54,38 @@ struct RestartTables {
     __device__ __forceinline__ uint32_t opos(const RsState &st) const { return st.opos_ch >> 8; }
     __device__ __forceinline__ bool is_root(const RsState &st) const { return st.idx == 0; }
     __device__ __forceinline__ uint64_t boundary_at_or_after(uint64_t x) const { return x; }
+
+    // ---- the micro-step walker's view (chain_scan.hpp, run_micro) ----
+    __device__ __forceinline__ uint32_t symbol_code(HayStream &win, uint32_t pos, uint32_t, uint32_t &clen) const {
+        clen = 1;
+        return win.byte_at(pos);
+    }
+    // One memory round trip of the transition on byte c (bytewise.rs:1063-1088 / 1094-1128 taken apart) over the 12-byte
+    // records {base, opos_ch, fail}: phase 0 probes the child slot, phase 1 fetches the record a failure link leads to.
+    // ROOT's row is in LDS: a lane at ROOT, or one whose failed probe leaves it with a link to ROOT, is through without
+    // asking memory.  Every lane loads, every turn (an idle lane asks for slot 0); the outcome is a handful of selects.
+    template <bool LM>
+    __device__ __forceinline__ bool micro(RsState &st, uint32_t c, uint32_t &phase, bool act) const {
+        const bool probe = phase == 0;
+        const bool at_root = st.idx == 0;
+        const bool ask = act && (probe ? (!at_root && st.base != 0) : true);
+        const uint32_t slot = ask ? (probe ? (st.base ^ c) : st.fail) : 0u;
+        const uint4 rr = l_root[c];
+        typedef uint32_t U32x3 __attribute__((ext_vector_type(3)));
+        U32x3 r;
+        asm volatile("global_load_dwordx3 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(d.rec + 3ull * slot) : "memory");
+        const bool hit = ask && probe && (r.y & 0xffu) == c;
+        const bool take = hit || (ask && !probe);
+        const bool miss = act && probe && !hit;
+        const bool dead = miss && !at_root && LM && st.fail == 1u;
+        const bool rootward = miss && !dead && (at_root || st.fail == 0);
+        phase = (miss && !dead && !rootward) ? 1u : 0u;
+        st.idx = take ? slot : rootward ? rr.x : dead ? 0u : st.idx;
+        st.base = take ? r.x : rootward ? rr.y : dead ? 0u : st.base;
+        st.opos_ch = take ? r.y : rootward ? rr.z : dead ? 0u : st.opos_ch;
+        st.fail = take ? r.z : rootward ? rr.w : dead ? 0u : st.fail;
+        return hit || dead || rootward;
+    }
 
     // classic delta (failure links never stop): reference src/bytewise.rs:1063-1088 over fail_plain
     __device__ __forceinline__ void step_plain(RsState &st, uint32_t c) const {
