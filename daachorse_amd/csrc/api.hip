@@ -51,6 +51,8 @@ struct Options {
                                                 // than over the double array on cfg3: half the waves per CU, and a match costs a gather more)
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
+    std::atomic<int64_t> pool{1};               // scratch / result buffers from the stream-ordered pool
+    std::atomic<int64_t> pool_keep{0};          // bytes the pool keeps between calls (0 = auto)
     std::atomic<int64_t> char_map_lds{1};
     std::atomic<int64_t> char_row_lds{1};       // ... and ROOT's row of children beside it       // charwise chain scans: stage the populated stretch of the code mapper in LDS
                                                 // (off: measured slower on cfg5, 88 vs 104 GB/s — the stretch is L1-resident anyway)
@@ -67,6 +69,46 @@ static daac_status hip_fail(hipError_t e, const char *what) {
         hipError_t _e = (expr);                                            \
         if (_e != hipSuccess) return hip_fail(_e, #expr);                  \
     } while (0)
+
+// Scratch and result buffers of the scans come from the device's stream-ordered pool (hipMallocAsync): a scan that needs
+// tens of MB of scratch, or hands back GBs of tuples, does not pay the driver's map / unmap each time — the pool keeps up
+// to `pool_keep` bytes (default 1/8 of the device memory, at most 32 GiB) for the next call.  Option pool = 0: plain hipMalloc.
+static std::atomic<int> g_pool_mode{-1};  // -1 undecided, 0 hipMalloc / hipFree, 1 stream-ordered pool
+static hipError_t dev_malloc(void **p, size_t bytes, hipStream_t s) {
+    int mode = g_pool_mode.load();
+    if (mode < 0) {
+        mode = 0;
+        if (g_opt.pool.load() != 0) {
+            int dev = 0, supported = 0;
+            hipMemPool_t pool;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) == hipSuccess &&
+                supported && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                size_t fr = 0, tot = 0;
+                (void)hipMemGetInfo(&fr, &tot);
+                uint64_t keep = static_cast<uint64_t>(g_opt.pool_keep.load());
+                if (keep == 0) keep = std::min<uint64_t>(32ull << 30, tot / 8);
+                if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) mode = 1;
+            }
+            (void)hipGetLastError();
+        }
+        g_pool_mode.store(mode);
+    }
+    if (bytes == 0) bytes = 16;
+    return mode == 1 ? hipMallocAsync(p, bytes, s) : hipMalloc(p, bytes);
+}
+static void dev_free(void *p, hipStream_t s) {
+    if (!p) return;
+    if (g_pool_mode.load() == 1) (void)hipFreeAsync(p, s); else (void)hipFree(p);
+}
+struct DevBuf {  // scratch that lives as long as the call
+    void *p = nullptr;
+    hipStream_t s = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { dev_free(p, s); }
+    hipError_t alloc(size_t bytes, hipStream_t stream) { s = stream; return dev_malloc(&p, bytes, stream); }
+};
 
 // ----------------------------------------------------------------------------- device tables
 struct DeviceTables {
@@ -664,7 +706,8 @@ hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, 
 // stays empty and the sync-point scanners of restart_kernels.hip / charwise_kernels.hip do the scan.
 struct ChainBuffers {
     void *buf = nullptr;
-    ~ChainBuffers() { if (buf) (void)hipFree(buf); }
+    hipStream_t s = nullptr;
+    ~ChainBuffers() { dev_free(buf, s); }
 };
 
 // a few page-locked words per host thread for flags read back between passes
@@ -682,7 +725,8 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
     pl.chain = ChainArgs{};
     if (!pl.restart || pma->root_has_output() || g_opt.restart_chain.load() == 0 || pl.a.nseg == 0) return DAAC_OK;
     const uint64_t n = pl.a.nseg;
-    HIP_TRY(hipMalloc(&cb.buf, (3 * n + 2) * sizeof(unsigned long long) + 2 * n * sizeof(uint4)));
+    cb.s = stream;
+    HIP_TRY(dev_malloc(&cb.buf, (3 * n + 2) * sizeof(unsigned long long) + 2 * n * sizeof(uint4), stream));
     uint4 *tallies = static_cast<uint4 *>(cb.buf);  // 16-byte records first (alignment), then the exits
     unsigned long long *x_spec = reinterpret_cast<unsigned long long *>(tallies + 2 * n), *xa = x_spec + n, *xb = xa + n;
     unsigned int *flags = reinterpret_cast<unsigned int *>(xb + n);
@@ -746,7 +790,8 @@ struct DevMatches {
     DevMatches() = default;
     DevMatches(const DevMatches &) = delete;
     DevMatches &operator=(const DevMatches &) = delete;
-    ~DevMatches() { if (p) (void)hipFree(p); }
+    hipStream_t s = nullptr;
+    ~DevMatches() { dev_free(p, s); }
     daac_match *release() { daac_match *q = p; p = nullptr; n = 0; return q; }
 };
 
@@ -792,10 +837,11 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
     unsigned long long *d_tiles = nullptr;
     void *d_scratch = nullptr;
     const size_t wq_bytes = nwaves * wq_slab * sizeof(uint2), rec_bytes = nwaves * 2ull * rec_cap * sizeof(uint4);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_tiles), (tiles_total + 2) * sizeof(unsigned long long)));
-    std::unique_ptr<void, void (*)(void *)> g1(d_tiles, [](void *p) { (void)hipFree(p); });
-    HIP_TRY(hipMalloc(&d_scratch, wq_bytes + rec_bytes + 16));
-    std::unique_ptr<void, void (*)(void *)> g2(d_scratch, [](void *p) { (void)hipFree(p); });
+    DevBuf g1, g2;
+    HIP_TRY(g1.alloc((tiles_total + 2) * sizeof(unsigned long long), stream));
+    d_tiles = static_cast<unsigned long long *>(g1.p);
+    HIP_TRY(g2.alloc(wq_bytes + rec_bytes + 16, stream));
+    d_scratch = g2.p;
     unsigned int *d_fail = reinterpret_cast<unsigned int *>(static_cast<char *>(d_scratch) + wq_bytes + rec_bytes);
     HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(unsigned int), stream));
     auto args_of = [&](const Win &w) {
@@ -812,8 +858,12 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
     for (const Win &w : wins) HIP_TRY(launch_gram2_emit(e, args_of(w), 0, blocks, stream));
     HIP_TRY(launch_exclusive_scan(d_tiles, tiles_total, d_tiles + tiles_total, stream));
     unsigned long long total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, d_tiles + tiles_total, sizeof(total), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    {
+        unsigned long long *pin = reinterpret_cast<unsigned long long *>(pinned_words());
+        HIP_TRY(hipMemcpyAsync(pin ? pin : &total, d_tiles + tiles_total, sizeof(total), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (pin) total = *pin;
+    }
     g_last_engine = DAAC_ENGINE_GRAM;
     if (total == 0) { *served = true; return DAAC_OK; }
     if (total * sizeof(daac_match) > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
@@ -821,8 +871,9 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
         return DAAC_ERR_AUTOMATON_SCALE;
     }
     daac_match *d_out = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), total * sizeof(daac_match)));
+    HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_out), total * sizeof(daac_match), stream));
     out.p = d_out;
+    out.s = stream;
     out.n = total;
     for (const Win &w : wins) {
         EmitArgs a = args_of(w);
@@ -830,10 +881,14 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
         HIP_TRY(launch_gram2_emit(e, a, em_write, blocks_write, stream));
     }
     unsigned int fail = 0;
-    HIP_TRY(hipMemcpyAsync(&fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    {
+        unsigned int *pin = pinned_words();
+        HIP_TRY(hipMemcpyAsync(pin ? pin : &fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (pin) fail = *pin;
+    }
     if (fail != 0) {  // a wave met more deep matches in one tile than it has record space for: leave it to the segment scanners
-        (void)hipFree(out.release());
+        dev_free(out.release(), stream);
         return DAAC_OK;
     }
     *served = true;
@@ -868,9 +923,9 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
     if (pl.a.nseg == 0) { if (begin != 0) return DAAC_OK; pl.a.nseg = 1; }
     pl.a.hay = dev_hay;
     pl.a.total_len = total_len;
-    unsigned long long *d_counts = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_counts), (pl.a.nseg + 3) * sizeof(unsigned long long)));
-    std::unique_ptr<void, void (*)(void *)> g1(d_counts, [](void *p) { (void)hipFree(p); });
+    DevBuf g1;
+    HIP_TRY(g1.alloc((pl.a.nseg + 3) * sizeof(unsigned long long), stream));
+    unsigned long long *d_counts = static_cast<unsigned long long *>(g1.p);
     pl.a.seg_counts = d_counts;
     pl.a.result = d_counts + pl.a.nseg;
     unsigned long long *d_next = d_counts + pl.a.nseg + 1;
@@ -895,8 +950,9 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
         return DAAC_ERR_AUTOMATON_SCALE;
     }
     daac_match *d_out = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_out), total * sizeof(daac_match)));
+    HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_out), total * sizeof(daac_match), stream));
     out.p = d_out;
+    out.s = stream;
     out.n = total;
     pl.a.out = d_out;
     HIP_TRY(launch(t, pl, 2, heads, stream, nullptr));
@@ -1283,7 +1339,7 @@ daac_status daac_scan_device(daac_pma *pma, int mode, int engine, const uint8_t 
     return DAAC_OK;
 }
 
-void daac_device_free(void *p) { if (p) (void)hipFree(p); }
+void daac_device_free(void *p) { dev_free(p, nullptr); }
 
 daac_status daac_device_to_host(void *dst, const void *dev_src, size_t bytes) {
     if (bytes && (!dst || !dev_src)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
@@ -1533,6 +1589,8 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;
     else if (n == "chain_rounds") g_opt.chain_rounds = value;
+    else if (n == "pool") g_opt.pool = value;
+    else if (n == "pool_keep") g_opt.pool_keep = value;
     else if (n == "char_map_lds") g_opt.char_map_lds = value;
     else if (n == "char_row_lds") g_opt.char_row_lds = value;
     else { set_error("unknown option: " + n); return DAAC_ERR_INVALID_ARGUMENT; }

@@ -47,9 +47,16 @@ __device__ __forceinline__ void ge_copy(void *dst, const void *src, uint32_t byt
 // one 24-byte tuple: a 16-byte and an 8-byte store.  Plain stores on purpose: the lanes of one store instruction write to
 // different 128-byte lines, and it is the L2 that puts the lines together before they go to HBM — the same stores marked
 // non-temporal ran 4.4x slower (63 ms instead of 14.4 ms for 1 GiB of cfg3, profiles/r02_emit_experiments.txt)
+#ifndef DAAC_EMX
+#define DAAC_EMX 0  // timing experiments (profiles/r02_emit_experiments.txt): 1 = no tuple stores (wrong output)
+#endif
 __device__ __forceinline__ void put_tuple(daac_match *dst, unsigned long long start, unsigned long long end, uint32_t value) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#if DAAC_EMX == 1
+    asm volatile("" :: "v"(dst), "v"(start), "v"(end), "v"(value));
+    return;
+#endif
     const u64x2 se = {start, end};
     const u32x2 vp = {value, 0u};
     *reinterpret_cast<u64x2 *>(dst) = se;
