@@ -124,6 +124,7 @@ struct Gram2Dev {
     const uint16_t *cid4;     // C^K: LDS address of the context's H entry (kGram2OffH + 4 * id)
     const uint32_t *hsum;     // per id: sum of h32
     const uint4 *drec;        // N x {cmap, first_child, own_cnt, own_hsum}  (HBM / L2)
+    const uint4 *drec_c;      // the same for `.count()`, single paths folded into tail records (gram2.hpp)
     const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}
     const uint32_t *cfirst;   // depth-(K+1) states by rank: id of the first child
     uint32_t m_bytes, s_bytes, cid_bytes, h_bytes;  // multiples of 16

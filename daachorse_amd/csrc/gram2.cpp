@@ -173,6 +173,33 @@ bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out)
     out.unused_byte = rep[0];
     out.drec.resize(N);
     for (uint32_t s = 0; s < N; ++s) out.drec[s] = U32x4{cmap[s], first_child[s], own_cnt[s], own_hs[s]};
+    {   // tail records: children carry larger numbers than their parents, so one pass from the back knows every subtree
+        out.drec_c = out.drec;
+        std::vector<uint8_t> path_len(N, 0xff);  // edges of the single path below s; 0xff: the subtree branches (or is too long)
+        for (uint32_t s = N; s-- > 0;) {
+            const uint32_t kids = static_cast<uint32_t>(__builtin_popcount(cmap[s] & kGram2MaskBits));
+            if (own_cnt[s] > 1) continue;
+            if (kids == 0) { path_len[s] = 0; continue; }
+            if (kids != 1) continue;
+            const uint32_t c = first_child[s];
+            if (path_len[c] == 0xff || path_len[c] >= 8) continue;
+            path_len[s] = static_cast<uint8_t>(path_len[c] + 1);
+        }
+        for (uint32_t s = 0; s < N; ++s) {
+            // (not at depth K + 2, where the walkers start: most of them end there, and that record stays as cheap as it was)
+            if (depth[s] < out.K + 3 || path_len[s] == 0xff || path_len[s] == 0) continue;
+            uint64_t bytes = 0;
+            uint32_t ends = own_cnt[s] ? 1u : 0u, cur = s;
+            const uint32_t first_class = static_cast<uint32_t>(__builtin_ctz(cmap[s] & kGram2MaskBits));
+            for (uint32_t i = 0; i < path_len[s]; ++i) {
+                const uint32_t d = static_cast<uint32_t>(__builtin_ctz(cmap[cur] & kGram2MaskBits));
+                bytes |= static_cast<uint64_t>(rep[d]) << (8 * i);
+                cur = first_child[cur];
+                if (own_cnt[cur]) ends |= 2u << i;
+            }
+            out.drec_c[s] = U32x4{0x80000000u | path_len[s] | (ends << 4) | (first_class << 13), 0u, static_cast<uint32_t>(bytes), static_cast<uint32_t>(bytes >> 32)};
+        }
+    }
     out.available = true;
 
     // ---- tuple emission tables ----

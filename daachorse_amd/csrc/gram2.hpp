@@ -43,6 +43,11 @@ struct Gram2Tables {
     std::vector<uint16_t> cid4;     // C^K: 4 * id of the context's {sum of h32} (0 = nothing ends here)
     std::vector<uint32_t> hsum;     // per id
     std::vector<U32x4> drec;        // N: {cmap, first_child, own_cnt, own_hsum}
+    // The same for `.count()`, with every state below which the trie is a single path of 1 .. 8 edges (and no duplicate
+    // patterns on it) replaced by a TAIL record {1 << 31 | edges | word_ends << 4 | class of the first path byte << 13, 0, path bytes 0-3, path bytes 4-7}: the
+    // walker compares the path with the next eight haystack bytes in one step instead of fetching a record per edge.
+    // word_ends bit i: the state i edges down the path is the end of a pattern (bit 0: the state itself).
+    std::vector<U32x4> drec_c;
     std::vector<U32x2> dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}; own_cnt == (own_hsum != 0)
     std::vector<uint32_t> cfirst;   // same order: first child id
     uint32_t lds_count = 0, lds_exact = 0;  // table bytes in LDS per mode (without the hit rings)

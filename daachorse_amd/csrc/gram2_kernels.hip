@@ -25,6 +25,9 @@ namespace {
 
 typedef uint32_t g2_u32x4_t __attribute__((ext_vector_type(4)));
 // build-time knobs for A/B runs of library variants (tools/mkvar2.sh); the defaults are the measured best
+#ifndef DAAC_G2_TAILS
+#define DAAC_G2_TAILS 1
+#endif
 #ifndef G2_GROUP
 #define G2_GROUP 8
 #endif
@@ -139,14 +142,31 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
     };
     auto class_at = [&](uint64_t p) -> uint32_t { return (p >= a.lead && p < a.vlen) ? cls_of(hay[p]) : 0u; };
 
-    // Finishes the queued branches, 64 per round (gram_kernels.hip: drain)
+    // Finishes the queued branches, 64 per round (gram_kernels.hip: drain).  (A version in which a lane whose branch has ended
+    // takes the next entry at once, one record per lane and turn, was no faster on word-soup text and 11 % slower on uniform
+    // text: the drain is not where the time goes, profiles/r02_emit_experiments.txt.)
     auto drain = [&]() {
+        const uint4 *__restrict__ recs = (EXACT || !DAAC_G2_TAILS) ? g.drec : g.drec_c;
         for (uint32_t i = lane; i < wq_n; i += 64) {
             const uint2 e = slab[i];
             uint64_t vnext = ((static_cast<uint64_t>(slab_hi) << 32) | e.x) + 2;  // the state consumed the byte before vnext
-            uint4 r = g.drec[e.y & 0x07ffffffu];  // {cmap, first_child, own_cnt, own_hsum}
+            uint4 r = recs[e.y & 0x07ffffffu];  // {cmap, first_child, own_cnt, own_hsum}, or a tail record (count only)
             uint32_t kn = e.y >> 27;
-            uint32_t ahead = 0, n_ahead = 0;
+            // the eight bytes from vnext on are only asked for once the walk is known to need them: on text that is not made of
+            // the dictionary's words most branches end at their first record, and the bytes come from HBM (the scan's own reads
+            // of the text are non-temporal)
+            unsigned long long ahead = 0;
+            uint32_t n_ahead = 0;
+            auto read_ahead = [&]() {
+                if (vnext >= a.lead && vnext + 8 <= a.vlen) {
+                    __builtin_memcpy(&ahead, hay + vnext, 8);
+                } else {
+                    ahead = 0;
+                    for (int b = 7; b >= 0; --b) ahead = (ahead << 8) | ((vnext + b >= a.lead && vnext + b < a.vlen) ? hay[vnext + b] : g.unused_byte);
+                }
+                n_ahead = 8;
+            };
+            // the walker stands on a state reached by the byte before vnext; `kn` is the class of the byte AT vnext
             for (;;) {
                 cnt32 += r.z;
                 if (EXACT) {
@@ -154,20 +174,21 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
                     tot_s2 += r.w * static_cast<uint32_t>(vnext - a.lead);
                 }
                 if (((r.x >> kn) & 1u) == 0) break;
-                r = g.drec[r.y + __popc(r.x & ((1u << kn) - 1u))];
+                r = recs[r.y + __popc(r.x & ((1u << kn) - 1u))];
                 ++vnext;
-                if (n_ahead == 0) {
-                    if (vnext >= a.lead && vnext + 4 <= a.vlen) {
-                        __builtin_memcpy(&ahead, hay + vnext, 4);
-                    } else {
-                        ahead = 0;
-                        for (int b = 3; b >= 0; --b) ahead = (ahead << 8) | ((vnext + b >= a.lead && vnext + b < a.vlen) ? hay[vnext + b] : g.unused_byte);
-                    }
-                    n_ahead = 4;
+                if (n_ahead <= 1u) read_ahead();
+                else { ahead >>= 8; --n_ahead; }
+                if (!EXACT && DAAC_G2_TAILS && (r.x >> 31)) {  // the rest of the subtree is one path: compare it with the text in one go
+                    const uint32_t edges = r.x & 15u;
+                    if (n_ahead < edges) read_ahead();
+                    const unsigned long long path = (static_cast<unsigned long long>(r.w) << 32) | r.z;
+                    const unsigned long long diff = path ^ ahead;
+                    uint32_t same = diff ? static_cast<uint32_t>(__builtin_ctzll(diff)) >> 3 : 8u;
+                    same = same < edges ? same : edges;
+                    cnt32 += __popc((r.x >> 4) & ((2u << same) - 1u) & 0x1ffu);
+                    break;
                 }
-                kn = cls_of(ahead & 0xffu);
-                ahead >>= 8;
-                --n_ahead;
+                kn = cls_of(static_cast<uint32_t>(ahead) & 0xffu);
             }
         }
         wq_n = 0;

@@ -46,7 +46,8 @@ int main(int argc, char **argv) {
         for (uint32_t t = 0; t < K; ++t) w = w * C + cls(pos - (K - 1) + t);
         return w;
     };
-    uint64_t gc = 0;
+    auto byte_at = [&](long long pos) -> int { return (pos >= 0 && pos < n) ? hay[pos] : -1; };  // -1: nothing there
+    uint64_t gc = 0, gc_walk = 0, gc_tail = 0;
     uint32_t g1 = 0, g2 = 0;
     for (long long pz = 0; pz < n; ++pz) {
         const uint32_t end = static_cast<uint32_t>(pz + 1);
@@ -72,9 +73,30 @@ int main(int argc, char **argv) {
                 id = g.cfirst[rank] + __builtin_popcount(hrec.x & ((1u << k1) - 1u));
                 long long nx = pz + 2;  // the state consumed the byte before nx
                 uint32_t kn = k2;
+                {   // the `.count()` walk over drec_c: tail records compare the path with the text in one step
+                    uint32_t id_c = id;
+                    long long nc = nx;
+                    uint32_t kc = kn;
+                    for (;;) {
+                        const U32x4 r = g.drec_c[id_c];
+                        if (r.x >> 31) {
+                            const uint32_t edges = r.x & 15u;
+                            uint32_t same = 0;
+                            while (same < edges && byte_at(nc + same) == static_cast<int>(((same < 4 ? r.z >> (8 * same) : r.w >> (8 * (same - 4))) & 0xffu))) ++same;
+                            gc_tail += __builtin_popcount((r.x >> 4) & ((2u << same) - 1u) & 0x1ffu);
+                            break;
+                        }
+                        gc_tail += r.z;
+                        if (((r.x >> kc) & 1u) == 0) break;
+                        id_c = r.y + __builtin_popcount(r.x & ((1u << kc) - 1u));
+                        ++nc;
+                        kc = cls(nc);
+                    }
+                }
                 for (;;) {
                     const U32x4 r = g.drec[id];
                     gc += r.z; g1 += r.w; g2 += r.w * static_cast<uint32_t>(nx);
+                    gc_walk += r.z;
                     if (((r.x >> kn) & 1u) == 0) break;
                     id = r.y + __builtin_popcount(r.x & ((1u << kn) - 1u));
                     ++nx;
@@ -83,6 +105,7 @@ int main(int argc, char **argv) {
             }
         }
     }
+    if (gc_tail != gc_walk) { std::printf("MISMATCH tail records %llu vs %llu\n", (unsigned long long)gc_tail, (unsigned long long)gc_walk); return 1; }
     if (!g.exact_available) {  // count only: the short patterns' share of the checksum is not in the tables that would be staged
         if (gc != rc) { std::printf("MISMATCH count %llu vs %llu\n", (unsigned long long)gc, (unsigned long long)rc); return 1; }
         std::printf("OK-COUNT %lld K=%u C=%u count=%llu lds=%u\n", n, K, C, (unsigned long long)gc, g.lds_count);
