@@ -469,6 +469,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             if ((st = t->put(g2.drec, drec)) != DAAC_OK) return st;
             { const U32x4 *dc; if ((st = t->put(g2.drec_c, dc)) != DAAC_OK) return st; d.drec_c = reinterpret_cast<const uint4 *>(dc); }
             if ((st = t->put(g2.dhit, dhit)) != DAAC_OK) return st;
+            { const U32x2 *hc; if ((st = t->put(g2.dhit_c, hc)) != DAAC_OK) return st; d.dhit_c = reinterpret_cast<const uint2 *>(hc); }
             if ((st = t->put(g2.cfirst, d.cfirst)) != DAAC_OK) return st;
             d.drec = reinterpret_cast<const uint4 *>(drec);
             d.dhit = reinterpret_cast<const uint2 *>(dhit);

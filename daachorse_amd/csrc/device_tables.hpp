@@ -126,6 +126,7 @@ struct Gram2Dev {
     const uint4 *drec;        // N x {cmap, first_child, own_cnt, own_hsum}  (HBM / L2)
     const uint4 *drec_c;      // the same for `.count()`, single paths folded into tail records (gram2.hpp)
     const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}
+    const uint2 *dhit_c;      // the same for `.count()`: {cmap | ends-a-pattern, first_child}
     const uint32_t *cfirst;   // depth-(K+1) states by rank: id of the first child
     uint32_t m_bytes, s_bytes, cid_bytes, h_bytes;  // multiples of 16
     uint32_t off_m_count, off_s_count, off_ring_count, lds_count;

@@ -160,9 +160,11 @@ bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out)
         out.lds_exact = static_cast<uint32_t>(lds_exact);
         out.exact_available = exact_ok && lds_exact <= lds_budget;
         out.dhit.clear();
+        out.dhit_c.clear();
         out.cfirst.clear();
         for (uint32_t s = level_start; s < level_start + n_deep; ++s) {
             out.dhit.push_back(U32x2{cmap[s], own_hs[s]});
+            out.dhit_c.push_back(U32x2{cmap[s] | (own_cnt[s] ? 1u : 0u), first_child[s]});  // (class 0 labels no edge: bit 0 is free)
             out.cfirst.push_back(first_child[s]);
         }
         break;

@@ -49,6 +49,7 @@ struct Gram2Tables {
     // word_ends bit i: the state i edges down the path is the end of a pattern (bit 0: the state itself).
     std::vector<U32x4> drec_c;
     std::vector<U32x2> dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}; own_cnt == (own_hsum != 0)
+    std::vector<U32x2> dhit_c;      // the same for `.count()`: {cmap | 1 if the state ends a pattern, first_child} (no second look-up)
     std::vector<uint32_t> cfirst;   // same order: first child id
     uint32_t lds_count = 0, lds_exact = 0;  // table bytes in LDS per mode (without the hit rings)
 

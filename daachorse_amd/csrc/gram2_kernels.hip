@@ -204,19 +204,21 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
     auto consume_pending = [&]() {
         if (!pend_valid) return;
         pend_valid = false;
-        const uint2 r = pend;     // {cmap, own h32 sum}; zero for idle lanes
-        cnt32 += r.y != 0;
+        const uint2 r = pend;     // EXACT: {cmap, own h32 sum}, else {cmap | ends-a-pattern, first_child}; zero for idle lanes
         if (EXACT) {
+            cnt32 += r.y != 0;
             tot_s1 += r.y;
             tot_s2 += r.y * (pend_pos - a.lead + 1u);  // end = position - lead + 1 (mod 2^32)
+        } else {
+            cnt32 += r.x & 1u;
         }
-        const uint32_t k1 = (pend_item >> 22) & 31u;
-        const bool go = (r.x >> k1) & 1u;
+        const uint32_t k1 = (pend_item >> 22) & 31u;  // (a class >= 1 where there is an edge to follow; class 0: bit 0 is not an edge)
+        const bool go = k1 != 0 && ((r.x >> k1) & 1u);
         const unsigned long long m = __ballot(go);
         if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker
             if (go)
                 (slab + wq_n)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
-                    uint2{pend_pos, (g.cfirst[pend_rank] + __popc(r.x & ((1u << k1) - 1u))) | ((pend_item >> 27) << 27)};
+                    uint2{pend_pos, ((EXACT ? g.cfirst[pend_rank] : r.y) + __popc(r.x & ((1u << k1) - 2u))) | ((pend_item >> 27) << 27)};
             wq_n += __popcll(m);
         }
     };
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
             pend_item = it.x;
             pend_pos = it.y;
             pend_rank = deep_rank(it.x & 0x1ffffu, (it.x >> 17) & 31u);
-            pend = g.dhit[pend_rank];
+            pend = EXACT ? g.dhit[pend_rank] : g.dhit_c[pend_rank];
         }
         pend_valid = true;
     };

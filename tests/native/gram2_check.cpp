@@ -66,6 +66,7 @@ int main(int argc, char **argv) {
             uint32_t id = g.level_start + rank;
             const U32x2 hrec = g.dhit[rank];
             if (hrec.x != g.drec[id].x || hrec.y != g.drec[id].w || g.drec[id].z != (hrec.y != 0 ? 1u : 0u)) { std::printf("MISMATCH dhit\n"); return 1; }
+            if (g.dhit_c[rank].x != (hrec.x | (hrec.y != 0 ? 1u : 0u)) || g.dhit_c[rank].y != g.cfirst[rank]) { std::printf("MISMATCH dhit_c\n"); return 1; }
             gc += hrec.y != 0; g1 += hrec.y; g2 += hrec.y * end;
             const uint32_t k1 = cls(pz + 1), k2 = cls(pz + 2);
             if ((hrec.x >> k1) & 1u) {
