@@ -110,6 +110,13 @@ struct DevBuf {  // scratch that lives as long as the call
     hipError_t alloc(size_t bytes, hipStream_t stream) { s = stream; return dev_malloc(&p, bytes, stream); }
 };
 
+// hit records with the first child beside them: one request instead of a dependent second one
+static std::vector<U32x4> zip_first_child(const std::vector<U32x2> &hit, const std::vector<uint32_t> &first) {
+    std::vector<U32x4> out(hit.size());
+    for (size_t i = 0; i < hit.size(); ++i) out[i] = U32x4{hit[i].x, hit[i].y, first[i], 0u};
+    return out;
+}
+
 // ----------------------------------------------------------------------------- device tables
 struct DeviceTables {
     int device = -1;
@@ -401,6 +408,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 if ((st = t->put(gt.bsuper, g.bsuper)) != DAAC_OK) return st;
                 if ((st = t->put(gt.drec, drec)) != DAAC_OK) return st;
                 if ((st = t->put(gt.dhit, dhit)) != DAAC_OK) return st;
+                { const U32x4 *h4; if ((st = t->put(zip_first_child(gt.dhit, gt.cfirst), h4)) != DAAC_OK) return st; g.dhit4 = reinterpret_cast<const uint4 *>(h4); }
                 if ((st = t->put(gt.cfirst, g.cfirst)) != DAAC_OK) return st;
                 g.combo = reinterpret_cast<const uint2 *>(combo);
                 g.drec = reinterpret_cast<const uint4 *>(drec);
@@ -470,6 +478,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             { const U32x4 *dc; if ((st = t->put(g2.drec_c, dc)) != DAAC_OK) return st; d.drec_c = reinterpret_cast<const uint4 *>(dc); }
             if ((st = t->put(g2.dhit, dhit)) != DAAC_OK) return st;
             { const U32x2 *hc; if ((st = t->put(g2.dhit_c, hc)) != DAAC_OK) return st; d.dhit_c = reinterpret_cast<const uint2 *>(hc); }
+            { const U32x4 *h4; if ((st = t->put(zip_first_child(g2.dhit, g2.cfirst), h4)) != DAAC_OK) return st; d.dhit4 = reinterpret_cast<const uint4 *>(h4); }
             if ((st = t->put(g2.cfirst, d.cfirst)) != DAAC_OK) return st;
             d.drec = reinterpret_cast<const uint4 *>(drec);
             d.dhit = reinterpret_cast<const uint2 *>(dhit);
@@ -516,6 +525,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 if ((st = t->put(g2.v3, e.v3)) != DAAC_OK) return st;
                 if ((st = t->put(g2.erec, erec)) != DAAC_OK) return st;
                 if ((st = t->put(g2.ehit, ehit)) != DAAC_OK) return st;
+                { const U32x4 *h4; if ((st = t->put(zip_first_child(g2.ehit, g2.cfirst), h4)) != DAAC_OK) return st; e.ehit4 = reinterpret_cast<const uint4 *>(h4); }
                 e.erec = reinterpret_cast<const uint4 *>(erec);
                 e.ehit = reinterpret_cast<const uint2 *>(ehit);
                 e.m_bytes = d.m_bytes; e.s_bytes = d.s_bytes;

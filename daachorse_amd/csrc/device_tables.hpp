@@ -90,6 +90,7 @@ struct GramDev {
     const uint32_t *bsuper;   // per 8 words: set bits before the superblock
     const uint4 *drec;        // N x {cmap, first_child, own_cnt, own_hsum}  (HBM / L2)
     const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}          (HBM / L2)
+    const uint4 *dhit4;       // the same with the first child: {cmap, own_hsum, first_child, 0} (what the kernel reads)
     const uint32_t *cfirst;   // depth-(K+1) states by rank: id of the first child     (HBM / L2)
     uint32_t off_cid, off_combo, off_bbits, off_brank, off_bsuper, off_scratch, lds_bytes;  // cls32 at 0, bbits at 1024
     uint32_t K, C, CC, CCC;
@@ -127,6 +128,7 @@ struct Gram2Dev {
     const uint4 *drec_c;      // the same for `.count()`, single paths folded into tail records (gram2.hpp)
     const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}
     const uint2 *dhit_c;      // the same for `.count()`: {cmap | ends-a-pattern, first_child}
+    const uint4 *dhit4;       // for count + checksum: {cmap, own_hsum, first_child, 0}
     const uint32_t *cfirst;   // depth-(K+1) states by rank: id of the first child
     uint32_t m_bytes, s_bytes, cid_bytes, h_bytes;  // multiples of 16
     uint32_t off_m_count, off_s_count, off_ring_count, lds_count;
@@ -163,6 +165,7 @@ struct Gram2EmitDev {
     const uint32_t *v3;       // values of the 3-gram patterns (L2)
     const uint4 *erec;        // N x {cmap | own (bit 0), first_child, own_value, depth}
     const uint2 *ehit;        // depth-(K+1) states by rank: {cmap | own, own_value}
+    const uint4 *ehit4;       // the same with the first child: {cmap | own, own_value, first_child, 0} (what the kernel reads)
     const uint32_t *cfirst;
     uint32_t m_bytes, s_bytes, v1_bytes, v2_bytes;
     uint32_t off_s, off_v1, off_v2, off_ring, off_wave, lds_bytes;

@@ -194,13 +194,13 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
 
     uint2 *ring = reinterpret_cast<uint2 *>(smem + g.off_ring) + wave_in_wg * kERing;
     uint32_t q_n = 0;
-    uint2 pend = uint2{0u, 0u};
+    uint4 pend = uint4{0u, 0u, 0u, 0u};
     uint32_t pend_item = 0, pend_pos = 0, pend_rank = 0;
     bool pend_valid = false;
     auto consume_pending = [&]() {
         if (!pend_valid) return;
         pend_valid = false;
-        const uint2 r = pend;  // {cmap | own, own_value}; zero for idle lanes
+        const uint4 r = pend;  // {cmap | own, own_value, first_child, -}; zero for idle lanes
         if (r.x & 1u) log_deep(pend_pos, K + 1, r.y);
         const uint32_t k1 = (pend_item >> 22) & 31u;
         const bool go = k1 != 0 && ((r.x >> k1) & 1u);
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
         if (m != 0) {
             if (go)
                 (slab + wq_n)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
-                    uint2{pend_pos, (g.cfirst[pend_rank] + __popc(r.x & ((1u << k1) - 1u) & ~1u)) | ((pend_item >> 27) << 27)};
+                    uint2{pend_pos, (r.z + __popc(r.x & ((1u << k1) - 1u) & ~1u)) | ((pend_item >> 27) << 27)};
             wq_n += __popcll(m);
         }
     };
@@ -230,14 +230,14 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
         consume_pending();
         const uint32_t n = q_n < 64u ? q_n : 64u;
         q_n -= n;
-        pend = uint2{0u, 0u};
+        pend = uint4{0u, 0u, 0u, 0u};
         pend_item = 0;
         if (lane < n) {
             const uint2 it = ring[q_n + lane];
             pend_item = it.x;
             pend_pos = it.y;
             pend_rank = deep_rank(it.x & 0x1ffffu, (it.x >> 17) & 31u);
-            pend = g.ehit[pend_rank];
+            pend = g.ehit4[pend_rank];
         }
         pend_valid = true;
     };

@@ -198,13 +198,13 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
     // << 17 | classes of the next two bytes << 22 / << 27, low 32 bits of the position of the hit byte}
     uint2 *ring = reinterpret_cast<uint2 *>(smem + offRing) + wave_in_wg * kRing2;
     uint32_t q_n = 0;             // wave-uniform
-    uint2 pend = uint2{0u, 0u};   // record read for the previous batch, not yet consumed
+    uint4 pend = uint4{0u, 0u, 0u, 0u};  // record read for the previous batch, not yet consumed
     uint32_t pend_item = 0, pend_pos = 0, pend_rank = 0;
     bool pend_valid = false;      // wave-uniform
     auto consume_pending = [&]() {
         if (!pend_valid) return;
         pend_valid = false;
-        const uint2 r = pend;     // EXACT: {cmap, own h32 sum}, else {cmap | ends-a-pattern, first_child}; zero for idle lanes
+        const uint4 r = pend;     // EXACT: {cmap, own h32 sum, first_child, -}, else {cmap | ends-a-pattern, first_child, -, -}; zero for idle lanes
         if (EXACT) {
             cnt32 += r.y != 0;
             tot_s1 += r.y;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
         if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker
             if (go)
                 (slab + wq_n)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
-                    uint2{pend_pos, ((EXACT ? g.cfirst[pend_rank] : r.y) + __popc(r.x & ((1u << k1) - 2u))) | ((pend_item >> 27) << 27)};
+                    uint2{pend_pos, ((EXACT ? r.z : r.y) + __popc(r.x & ((1u << k1) - 2u))) | ((pend_item >> 27) << 27)};
             wq_n += __popcll(m);
         }
     };
@@ -248,14 +248,19 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
         consume_pending();
         const uint32_t n = q_n < 64u ? q_n : 64u;
         q_n -= n;
-        pend = uint2{0u, 0u};
+        pend = uint4{0u, 0u, 0u, 0u};
         pend_item = 0;
         if (lane < n) {
             const uint2 it = ring[q_n + lane];
             pend_item = it.x;
             pend_pos = it.y;
             pend_rank = deep_rank(it.x & 0x1ffffu, (it.x >> 17) & 31u);
-            pend = EXACT ? g.dhit[pend_rank] : g.dhit_c[pend_rank];
+            if (EXACT) {
+                pend = g.dhit4[pend_rank];
+            } else {
+                const uint2 h = g.dhit_c[pend_rank];
+                pend = uint4{h.x, h.y, 0u, 0u};
+            }
         }
         pend_valid = true;
     };

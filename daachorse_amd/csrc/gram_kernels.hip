@@ -196,13 +196,13 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
     // (a stack: batches are taken from the top, so no wrap-around arithmetic; order does not matter)
     uint2 *ring = reinterpret_cast<uint2 *>(smem + g.off_scratch) + wave_in_wg * kRing;
     uint32_t q_n = 0;                           // wave-uniform
-    uint2 pend = uint2{0u, 0u};                 // record read for the previous batch, not yet consumed
+    uint4 pend = uint4{0u, 0u, 0u, 0u};         // record read for the previous batch, not yet consumed
     uint32_t pend_item = 0, pend_pos = 0, pend_rank = 0;
     bool pend_valid = false;                    // wave-uniform
     auto consume_pending = [&]() {
         if (!pend_valid) return;
         pend_valid = false;
-        const uint2 r = pend;                   // {cmap, own h32 sum}; zero for idle lanes
+        const uint4 r = pend;                   // {cmap, own h32 sum, first child, -}; zero for idle lanes
         tot_cnt += r.y != 0;
         tot_s1 += r.y;
         tot_s2 += r.y * (pend_pos - a.lead + 1u);  // end = position - lead + 1 (mod 2^32)
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker (same slab epoch: see the step loop)
             if (go)
                 (slab + wq_n)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
-                    uint2{pend_pos, (g.cfirst[pend_rank] + __popc(r.x & ((1u << k1) - 1u))) | ((pend_item >> 25) << 27)};
+                    uint2{pend_pos, (r.z + __popc(r.x & ((1u << k1) - 1u))) | ((pend_item >> 25) << 27)};
             wq_n += __popcll(m);
         }
     };
@@ -225,14 +225,14 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
         consume_pending();
         const uint32_t n = q_n < 64u ? q_n : 64u;
         q_n -= n;
-        pend = uint2{0u, 0u};
+        pend = uint4{0u, 0u, 0u, 0u};
         pend_item = 0;
         if (lane < n) {
             const uint2 it = ring[q_n + lane];
             pend_item = it.x;
             pend_pos = it.y;
             pend_rank = deep_rank(it.x & 0xfffffu);
-            pend = g.dhit[pend_rank];
+            pend = g.dhit4[pend_rank];
         }
         pend_valid = true;
     };
