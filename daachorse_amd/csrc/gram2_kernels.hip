@@ -28,6 +28,9 @@ typedef uint32_t g2_u32x4_t __attribute__((ext_vector_type(4)));
 #ifndef DAAC_G2_TAILS
 #define DAAC_G2_TAILS 1
 #endif
+#ifndef DAAC_G2_DRAIN_W
+#define DAAC_G2_DRAIN_W 2
+#endif
 #ifndef G2_GROUP
 #define G2_GROUP 8
 #endif
@@ -147,48 +150,85 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
     // text: the drain is not where the time goes, profiles/r02_emit_experiments.txt.)
     auto drain = [&]() {
         const uint4 *__restrict__ recs = (EXACT || !DAAC_G2_TAILS) ? g.drec : g.drec_c;
-        for (uint32_t i = lane; i < wq_n; i += 64) {
-            const uint2 e = slab[i];
-            uint64_t vnext = ((static_cast<uint64_t>(slab_hi) << 32) | e.x) + 2;  // the state consumed the byte before vnext
-            uint4 r = recs[e.y & 0x07ffffffu];  // {cmap, first_child, own_cnt, own_hsum}, or a tail record (count only)
-            uint32_t kn = e.y >> 27;
-            // the eight bytes from vnext on are only asked for once the walk is known to need them: on text that is not made of
-            // the dictionary's words most branches end at their first record, and the bytes come from HBM (the scan's own reads
-            // of the text are non-temporal)
-            unsigned long long ahead = 0;
-            uint32_t n_ahead = 0;
-            auto read_ahead = [&]() {
-                if (vnext >= a.lead && vnext + 8 <= a.vlen) {
-                    __builtin_memcpy(&ahead, hay + vnext, 8);
+        // W branches per lane at a time, each taken through its first record and first step (where, with the single paths folded
+        // into tail records, nearly every branch ends); what is left of a branch walks on by itself.  (W = 1, 2, 4, 6 measured
+        // the same: the drain is not bound by the latency of a round.)
+        constexpr int W = DAAC_G2_DRAIN_W;
+        for (uint32_t base = 0; base < wq_n; base += 64u * W) {
+            uint4 r[W];
+            uint64_t vnext[W];
+            uint32_t kn[W];
+            unsigned long long ahead[W];
+            bool go[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t i = base + 64u * w + lane;
+                uint2 e = uint2{0u, 0u};
+                if (i < wq_n) e = slab[i];
+                vnext[w] = ((static_cast<uint64_t>(slab_hi) << 32) | e.x) + 2;  // the state consumed the byte before vnext
+                kn[w] = e.y >> 27;
+                r[w] = uint4{0u, 0u, 0u, 0u};  // (an idle slot: counts nothing, leads nowhere)
+                if (i < wq_n) r[w] = recs[e.y & 0x07ffffffu];  // {cmap, first_child, own_cnt, own_hsum}
+            }
+            auto read_ahead = [&](uint64_t v) -> unsigned long long {
+                unsigned long long x;
+                if (v >= a.lead && v + 8 <= a.vlen) {
+                    __builtin_memcpy(&x, hay + v, 8);
                 } else {
-                    ahead = 0;
-                    for (int b = 7; b >= 0; --b) ahead = (ahead << 8) | ((vnext + b >= a.lead && vnext + b < a.vlen) ? hay[vnext + b] : g.unused_byte);
+                    x = 0;
+                    for (int b = 7; b >= 0; --b) x = (x << 8) | ((v + b >= a.lead && v + b < a.vlen) ? hay[v + b] : g.unused_byte);
                 }
-                n_ahead = 8;
+                return x;
             };
-            // the walker stands on a state reached by the byte before vnext; `kn` is the class of the byte AT vnext
-            for (;;) {
-                cnt32 += r.z;
+            // the first step of each: the walker stands on a state reached by the byte before vnext, `kn` is the class of the byte AT
+            // vnext.  Only a branch that goes on asks for more — its next record and, with it, the eight bytes from vnext on (from
+            // HBM: the scan's own reads of the text are non-temporal); asking for all of them regardless cost 9 % on uniform text.
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                cnt32 += r[w].z;
                 if (EXACT) {
-                    tot_s1 += r.w;
-                    tot_s2 += r.w * static_cast<uint32_t>(vnext - a.lead);
+                    tot_s1 += r[w].w;
+                    tot_s2 += r[w].w * static_cast<uint32_t>(vnext[w] - a.lead);
                 }
-                if (((r.x >> kn) & 1u) == 0) break;
-                r = recs[r.y + __popc(r.x & ((1u << kn) - 1u))];
-                ++vnext;
-                if (n_ahead <= 1u) read_ahead();
-                else { ahead >>= 8; --n_ahead; }
-                if (!EXACT && DAAC_G2_TAILS && (r.x >> 31)) {  // the rest of the subtree is one path: compare it with the text in one go
-                    const uint32_t edges = r.x & 15u;
-                    if (n_ahead < edges) read_ahead();
-                    const unsigned long long path = (static_cast<unsigned long long>(r.w) << 32) | r.z;
-                    const unsigned long long diff = path ^ ahead;
-                    uint32_t same = diff ? static_cast<uint32_t>(__builtin_ctzll(diff)) >> 3 : 8u;
-                    same = same < edges ? same : edges;
-                    cnt32 += __popc((r.x >> 4) & ((2u << same) - 1u) & 0x1ffu);
-                    break;
+                go[w] = ((r[w].x >> kn[w]) & 1u) != 0;
+                ahead[w] = 0;
+                if (go[w]) {
+                    r[w] = recs[r[w].y + __popc(r[w].x & ((1u << kn[w]) - 1u))];
+                    ++vnext[w];
+                    ahead[w] = read_ahead(vnext[w]);
                 }
-                kn = cls_of(static_cast<uint32_t>(ahead) & 0xffu);
+            }
+            // ... and whatever is left of each
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                if (!go[w]) continue;
+                uint4 rr = r[w];
+                uint64_t vn = vnext[w];
+                unsigned long long ah = ahead[w];
+                uint32_t n_ahead = 8, k = 0;
+                for (;;) {
+                    if (!EXACT && DAAC_G2_TAILS && (rr.x >> 31)) {  // the rest of the subtree is one path: compare it with the text in one go
+                        const uint32_t edges = rr.x & 15u;
+                        if (n_ahead < edges) { ah = read_ahead(vn); n_ahead = 8; }
+                        const unsigned long long path = (static_cast<unsigned long long>(rr.w) << 32) | rr.z;
+                        const unsigned long long diff = path ^ ah;
+                        uint32_t same = diff ? static_cast<uint32_t>(__builtin_ctzll(diff)) >> 3 : 8u;
+                        same = same < edges ? same : edges;
+                        cnt32 += __popc((rr.x >> 4) & ((2u << same) - 1u) & 0x1ffu);
+                        break;
+                    }
+                    k = cls_of(static_cast<uint32_t>(ah) & 0xffu);
+                    cnt32 += rr.z;
+                    if (EXACT) {
+                        tot_s1 += rr.w;
+                        tot_s2 += rr.w * static_cast<uint32_t>(vn - a.lead);
+                    }
+                    if (((rr.x >> k) & 1u) == 0) break;
+                    rr = recs[rr.y + __popc(rr.x & ((1u << k) - 1u))];
+                    ++vn;
+                    if (n_ahead <= 1u) { ah = read_ahead(vn); n_ahead = 8; }
+                    else { ah >>= 8; --n_ahead; }
+                }
             }
         }
         wq_n = 0;
@@ -214,7 +254,11 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
         }
         const uint32_t k1 = (pend_item >> 22) & 31u;  // (a class >= 1 where there is an edge to follow; class 0: bit 0 is not an edge)
         const bool go = k1 != 0 && ((r.x >> k1) & 1u);
+#ifdef DAAC_G2_NOSLAB
+        const unsigned long long m = 0; (void)go;
+#else
         const unsigned long long m = __ballot(go);
+#endif
         if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker
             if (go)
                 (slab + wq_n)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
