@@ -254,11 +254,7 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
         }
         const uint32_t k1 = (pend_item >> 22) & 31u;  // (a class >= 1 where there is an edge to follow; class 0: bit 0 is not an edge)
         const bool go = k1 != 0 && ((r.x >> k1) & 1u);
-#ifdef DAAC_G2_NOSLAB
-        const unsigned long long m = 0; (void)go;
-#else
         const unsigned long long m = __ballot(go);
-#endif
         if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker
             if (go)
                 (slab + wq_n)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =

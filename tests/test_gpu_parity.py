@@ -632,3 +632,75 @@ def test_gram_text_made_of_patterns_overflows_nothing():
         da.set_option("gram_lds_budget", 158 * 1024)
         da.set_option("gram_ppl", 0)
         da.set_option("gram_slab", 4096)
+
+
+def test_chain_walkers_step_back_and_window_edges():
+    """The micro-step chain walkers keep 32 resident bytes of text and slide forward; a leftmost match that ends far
+    behind the walker (a long pattern that fails at its last byte) steps back beyond the window, short texts end inside the
+    first granule, and multi-byte characters straddle granules.  Against the oracle's literal iterators, several segment sizes."""
+    long_a = b"a" * 45 + b"b"
+    cases = [
+        ([b"a", long_a], (b"a" * 45 + b"c") * 40 + b"a" * 45 + b"b" + b"a" * 7),
+        ([b"ab", b"abababababababababababababababababababababc"], b"ab" * 300),
+        ([b"xyz", b"x" * 30 + b"y"], b"x" * 29 + b"z" + b"xyz" * 50 + b"x" * 31),
+        ([b"a", b"ab"], b"a"), ([b"a", b"ab"], b""), ([b"a", b"ab"], b"ab"), ([b"abcdefgh" * 3], b"abcdefgh" * 3),
+    ]
+    for pats, text in cases:
+        hay = np.frombuffer(text, dtype=np.uint8)
+        for kind, api, mode in (("LeftmostLongest", "leftmost_find_iter", ScanMode.LeftmostFind), ("LeftmostFirst", "leftmost_find_iter", ScanMode.LeftmostFind),
+                                ("Standard", "find_iter", ScanMode.Find)):
+            o, p = _pma(pats, kind=kind)
+            want = getattr(o, api)(hay)
+            for seg in (0, 16, 48, 256):
+                da.set_option("seg_bytes", seg)
+                assert _same(p.scan(mode, hay), want), (pats, kind, seg)
+                assert p.scan_count(mode, hay) == (len(want), orc.matches_checksum(want)), (pats, kind, seg)
+                assert p.count(mode, hay) == len(want), (pats, kind, seg)
+    # charwise: three-byte characters (a granule boundary falls inside every other one), ASCII in between, a long pattern
+    cpats = ["世界", "全世界", "世", "にほんごのながいぱたーんです", "abc", "b"]
+    text = ("全世界中に世界の世abcにほんごのながいぱたーんでx" * 60 + "にほんごのながいぱたーんです" + "世") * 3
+    for kind, api, mode in ((1, "leftmost_find_iter", ScanMode.LeftmostFind), (2, "leftmost_find_iter", ScanMode.LeftmostFind), (0, "find_iter", ScanMode.Find)):
+        co = orc.OracleCharwisePma.build(cpats, kind=kind)
+        cp, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(co.serialize())
+        want = getattr(co, api)(text)
+        for seg in (0, 16, 64, 1024):
+            da.set_option("seg_bytes", seg)
+            for rows in (1, 0):
+                da.set_option("char_row_lds", rows)
+                cp2, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(co.serialize())
+                assert _same(cp2.scan(mode, text), want), (kind, seg, rows)
+                assert cp2.scan_count(mode, text) == (len(want), orc.matches_checksum(want)), (kind, seg, rows)
+    da.set_option("char_row_lds", 1)
+
+
+def test_gram_tail_records():
+    """`.count()` folds single trie paths into tail records compared with the text eight bytes at a time: words that are
+    prefixes of longer words on one path, paths longer than eight bytes (a tail below ordinary records), the byte 0x00 as
+    a pattern byte (the bytes shifted into a spent look-ahead are zeros too), paths running into the end of the text."""
+    rng = np.random.default_rng(77)
+    stems = [bytes(rng.integers(97, 101, size=5).astype(np.uint8)) for _ in range(40)]
+    pats = set()
+    for s in stems:
+        tail = bytes(rng.integers(97, 123, size=16).astype(np.uint8))
+        for cut in (0, 1, 3, 7, 8, 9, 12, 16):
+            pats.add(s + tail[:cut])
+    pats = sorted(pats)
+    o, p = _pma(pats)
+    text = bytearray()
+    for i in range(3000):
+        w = pats[int(rng.integers(0, len(pats)))]
+        text += w[:int(rng.integers(4, len(w) + 1))] if i % 3 == 0 else w
+        text += bytes(rng.integers(97, 123, size=int(rng.integers(0, 3))).astype(np.uint8))
+    text += pats[-1][:-1]  # a path that runs into the end of the text
+    hay = np.frombuffer(bytes(text), dtype=np.uint8)
+    want = o.find_overlapping_iter(hay)
+    assert _check_counts(p, ScanMode.FindOverlapping, hay, want)
+    for cut in (1, 5, 9, 13):  # ... and at every distance from the end
+        h2 = hay[:len(hay) - cut]
+        assert p.count(ScanMode.FindOverlapping, h2) == len(o.find_overlapping_iter(h2)), cut
+    # 0x00 .. 0x03 as the alphabet
+    zpats = sorted({bytes(rng.integers(0, 4, size=int(rng.integers(1, 14))).astype(np.uint8)) for _ in range(300)})
+    zo, zp = _pma(zpats)
+    zhay = np.concatenate([np.frombuffer(zpats[int(rng.integers(0, len(zpats)))], dtype=np.uint8) for _ in range(4000)] + [np.zeros(9, dtype=np.uint8)])
+    zwant = zo.find_overlapping_iter(zhay)
+    _check_counts(zp, ScanMode.FindOverlapping, zhay, zwant)
