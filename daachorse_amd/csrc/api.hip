@@ -51,6 +51,7 @@ struct Options {
                                                 // than over the double array on cfg3: half the waves per CU, and a match costs a gather more)
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
+    std::atomic<int64_t> overlap_micro{1};      // counts of overlapping scans outside GRAM: 1 micro-step walker (charwise, DARRAY), 2 also instead of TIERED, 0 off
     std::atomic<int64_t> pool{1};               // scratch / result buffers from the stream-ordered pool
     std::atomic<int64_t> pool_keep{0};          // bytes the pool keeps between calls (0 = auto)
     std::atomic<int64_t> char_map_lds{1};
@@ -702,6 +703,13 @@ hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, 
                                      static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(t->num_cu, (pl.a.nseg + 1023) / 1024))), s);
         return pl.charwise ? launch_char_chain(t->chr, pl.a, pl.chain, pass, kmode, pl.leftmost, next_begin, pl.blocks, s)
                            : launch_chain(t->da, pl.a, pl.chain, pass, kmode, pl.leftmost, next_begin, pl.blocks, s);
+    }
+    // count (+ checksum) of an overlapping scan the GRAM tables do not serve: the micro-step walker over segments (2048 lanes
+    // per CU, a segment each) instead of the byte-at-a-time segment scanners
+    if (kmode == 0 && !heads && !pl.restart && g_opt.overlap_micro.load() != 0 && (pl.charwise || !pl.tier || g_opt.overlap_micro.load() == 2)) {
+        const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 8, (pl.a.nseg + 255) / 256)));
+        if (pl.charwise && t->chr.root_flag == 0) return launch_char_overlap_count(t->chr, pl.a, blocks, s);
+        if (!pl.charwise && t->da.root_flag == 0) return launch_overlap_count(t->da, pl.a, blocks, s);
     }
     if (pl.charwise) {
         return pl.restart ? launch_char_restart_scan(t->chr, pl.a, kmode, pl.leftmost, next_begin, pl.blocks, pl.threads, s)
@@ -1601,6 +1609,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;
     else if (n == "chain_rounds") g_opt.chain_rounds = value;
+    else if (n == "overlap_micro") g_opt.overlap_micro = value;
     else if (n == "pool") g_opt.pool = value;
     else if (n == "pool_keep") g_opt.pool_keep = value;
     else if (n == "char_map_lds") g_opt.char_map_lds = value;

@@ -320,6 +320,69 @@ __device__ __forceinline__ uint64_t ChainWalker<T, LEFTMOST>::run_micro(uint64_t
     return ret == end32 ? len : entry + ret;
 }
 
+// find_overlapping_iter().count() (+ checksum) by segment with the same one-round-trip-per-turn walker: a lane enters its
+// segment `halo` bytes early at ROOT (classic Aho-Corasick transitions, nothing reported before lo) and tallies the output
+// list of every state it passes with an end in (lo, hi] — the list's {count, sum of h32} come precomputed (osum), asked for
+// when the state is entered and folded in at the next report.  T as for ChainWalker (T::micro<false> = the classic delta).
+template <class T>
+__device__ __forceinline__ void overlap_count_body(const T &t, const ScanArgs &a, const uint2 *__restrict__ osum, unsigned long long *scratch) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long tot_cnt = 0;
+    uint32_t tot_s1 = 0, tot_s2 = 0;
+    HayStream str;
+    str.limit = reinterpret_cast<uintptr_t>(t.hay) + a.total_len;
+    for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
+        const uint64_t lo = a.begin + seg * a.seg_bytes;
+        const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
+        const uint64_t p0 = t.boundary_at_or_after(lo > a.halo ? lo - a.halo : 0);
+        if (p0 >= hi) continue;
+        const uint32_t warm = lo > p0 ? static_cast<uint32_t>(lo - p0) : 0u;  // ends <= warm belong to the segment before
+        const uint32_t end32 = static_cast<uint32_t>(hi - p0);
+        const uint64_t room = a.total_len - p0;
+        const uint32_t text32 = room > 0xffffff00ull ? 0xffffff00u : static_cast<uint32_t>(room);
+        str.org = t.hay + p0;
+        str.boff = 0x80000000u;
+        str.cpos = 0x80000000u;
+        typename T::State st = t.root();
+        uint32_t pos = 0, clen = 0, code = 0, phase = 0;
+        bool pending = false;
+        unsigned long long cnt = 0;
+        uint32_t s1 = 0, s2 = 0;
+        uint2 q_wait = uint2{0u, 0u};
+        uint32_t end_wait = 0;
+        for (;;) {
+            if (!pending && pos < end32) {
+                code = t.symbol_code(str, pos, text32 - pos, clen);
+                phase = 0;
+                pending = true;
+            }
+            const bool done = t.template micro<false>(st, code, phase, pending);
+            pending = pending && !done;
+            pos = done ? pos + clen : pos;
+            const uint32_t op = t.opos(st);
+            if (done && op != 0 && pos > warm && pos <= end32) {  // (a character cut by hi ends in the next segment)
+                cnt += q_wait.x; s1 += q_wait.y; s2 += q_wait.y * end_wait;
+                q_wait = osum[op - 1u];
+                end_wait = static_cast<uint32_t>(p0) + pos;
+            }
+            if (!pending && pos >= end32) break;
+        }
+        cnt += q_wait.x; s1 += q_wait.y; s2 += q_wait.y * end_wait;
+        tot_cnt += cnt; tot_s1 += s1; tot_s2 += s2;
+    }
+    unsigned long long cc = tot_cnt, x1 = tot_s1, x2 = tot_s2;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { cc += __shfl_down(cc, off, 64); x1 += __shfl_down(x1, off, 64); x2 += __shfl_down(x2, off, 64); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { scratch[wave * 3] = cc; scratch[wave * 3 + 1] = x1; scratch[wave * 3 + 2] = x2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long r0 = 0, r1 = 0, r2 = 0;
+        for (int v = 0; v < static_cast<int>((blockDim.x + 63) >> 6); ++v) { r0 += scratch[v * 3]; r1 += scratch[v * 3 + 1]; r2 += scratch[v * 3 + 2]; }
+        if (r0 | r1 | r2) { atomicAdd(a.result, r0); atomicAdd(a.result + 1, r1); atomicAdd(a.result + 2, r2); }
+    }
+}
+
 struct ChainNoEmit {
     __device__ __forceinline__ void operator()(uint32_t, uint64_t) const {}
 };

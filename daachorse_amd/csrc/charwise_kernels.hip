@@ -395,6 +395,49 @@ static hipError_t launch_char_chain_ml(const CharDev &dev, const ScanArgs &a, co
     return hipGetLastError();
 }
 
+// find_overlapping_iter().count() (+ checksum) of a charwise automaton with the micro-step walker (overlap_count_body)
+template <int LVL>
+__global__ __launch_bounds__(LVL == 2 ? 1024 : LVL == 1 ? 512 : 256) void char_overlap_count_kernel(const CharDev dev, const ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t l_map[];
+    __shared__ unsigned long long scratch[3 * 16];
+    const uint32_t n_map = 128u + (dev.table_len - dev.map_lo);
+    uint2 *l_row = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(l_map) + ((n_map * 2u + 15u) & ~15u));
+    if (LVL >= 1) {
+        for (uint32_t i = threadIdx.x; i < n_map; i += blockDim.x) {
+            const uint32_t cp = i < 128u ? i : i - 128u + dev.map_lo;
+            const uint32_t code = cp < dev.table_len ? dev.table[cp] : 0xffffffffu;
+            l_map[i] = code == 0xffffffffu ? 0xffffu : static_cast<uint16_t>(code);
+        }
+        if (LVL >= 2)
+            for (uint32_t i = threadIdx.x; i < dev.alphabet; i += blockDim.x) l_row[i] = dev.root_row[i];
+        __syncthreads();
+    }
+    const CwTablesT<LVL> T{dev, dev.states[0], a.hay, a.total_len, l_map, l_row};
+    overlap_count_body<CwTablesT<LVL>>(T, a, dev.osum, scratch);
+}
+
+template <int LVL>
+static hipError_t launch_char_overlap_ml(const CharDev &dev, const ScanArgs &a, uint32_t blocks, hipStream_t stream) {
+    constexpr uint32_t per = LVL == 2 ? 4u : LVL == 1 ? 2u : 1u;
+    const dim3 g((blocks + per - 1u) / per), b(256u * per);
+    const uint32_t map_bytes = ((128u + dev.table_len - dev.map_lo) * 2u + 15u) & ~15u;
+    const uint32_t lds = LVL == 2 ? map_bytes + dev.alphabet * 8u : LVL == 1 ? map_bytes : 0u;
+    if (lds > 48u * 1024u) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(char_overlap_count_kernel<LVL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((char_overlap_count_kernel<LVL>), g, b, lds, stream, dev, a);
+    return hipGetLastError();
+}
+
+// `blocks` counts 256-lane workgroups
+hipError_t launch_char_overlap_count(const CharDev &dev, const ScanArgs &a, uint32_t blocks, hipStream_t stream) {
+    if (dev.map_in_lds != 0 && dev.row_in_lds != 0) return launch_char_overlap_ml<2>(dev, a, blocks, stream);
+    if (dev.map_in_lds != 0) return launch_char_overlap_ml<1>(dev, a, blocks, stream);
+    return launch_char_overlap_ml<0>(dev, a, blocks, stream);
+}
+
 hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
                              unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
     if (dev.map_in_lds != 0 && dev.row_in_lds != 0) return launch_char_chain_ml<2>(dev, a, c, pass, kmode, leftmost, next_begin, blocks, stream);

@@ -295,6 +295,22 @@ __global__ __launch_bounds__(256) void chain_kernel(const DArrayDev dev, const S
     else chain_emit_body<RestartTables, LEFTMOST, KMODE>(T, a, c, dev.outputs, next_begin, scratch);
 }
 
+// find_overlapping_iter().count() (+ checksum) over the double array with the micro-step walker (chain_scan.hpp,
+// overlap_count_body): the engine for automata the GRAM tables do not fit (more than 62 byte classes)
+__global__ __launch_bounds__(256) void overlap_count_kernel(const DArrayDev dev, const ScanArgs a) {
+    __shared__ uint4 l_root[256];
+    __shared__ unsigned long long scratch[3 * 4];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root[i];
+    __syncthreads();
+    const RestartTables T{dev, l_root, a.hay};
+    overlap_count_body<RestartTables>(T, a, dev.osum, scratch);
+}
+
+hipError_t launch_overlap_count(const DArrayDev &dev, const ScanArgs &a, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(overlap_count_kernel, dim3(blocks), dim3(256), 0, stream, dev, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_chain(const DArrayDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
                         unsigned long long *next_begin, uint32_t blocks, hipStream_t stream) {
     const dim3 g(blocks), b(256);

@@ -46,7 +46,7 @@ def main():
         keys.append(k)
         vals.append(v.split(","))
     ref = None
-    defaults = {"gram_version": 0, "gram2_dpp": 1, "gram_rank_in_lds": -1, "gram_dense": -1, "gram_ppl": 0, "gram_region": 0, "gram_lds_budget": 161792, "gram_slab": 4096, "restart_chain": 1, "seg_bytes": 0, "lds_budget": 96 * 1024, "dense_depth": -1, "rows_share_pct": 45, "blocks_per_cu": 0, "threads": 1024}
+    defaults = {"overlap_micro": 1, "gram_version": 0, "gram2_dpp": 1, "gram_rank_in_lds": -1, "gram_dense": -1, "gram_ppl": 0, "gram_region": 0, "gram_lds_budget": 161792, "gram_slab": 4096, "restart_chain": 1, "seg_bytes": 0, "lds_budget": 96 * 1024, "dense_depth": -1, "rows_share_pct": 45, "blocks_per_cu": 0, "threads": 1024}
     for combo in itertools.product(*vals):
         cfg = dict(zip(keys, combo))
         for k, v in defaults.items():
