@@ -238,7 +238,12 @@ void daac_stream_close(daac_stream *s);
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
  *   restart_tier (0)            1: find_iter of Standard bytewise automata runs its chains over the TIERED tables instead of the double array
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners
- *   char_map_lds (0)            charwise chain scans: code mapper staged in LDS when it fits
+ *   char_map_lds (1)            charwise walkers: ASCII and the populated stretch of the code mapper staged in LDS when they fit 32 KB
+ *   char_row_lds (1)            ... and ROOT's row of children beside it when both fit 80 KB (read at upload)
+ *   overlap_micro (1)           count (+ checksum) of overlapping scans the GRAM tables do not serve: 1 = the micro-step walker for
+ *                               charwise automata and the double array, 2 = also in place of the TIERED engine, 0 = the segment scanners
+ *   pool (1), pool_keep (0)     scratch and result buffers from the device's stream-ordered pool, which keeps up to pool_keep bytes
+ *                               between calls (0 = 1/8 of the device memory, at most 32 GiB); read at the first scan of the process
  *   iter_window (64 MiB)        haystack bytes per window of the lazy iterator
  *   max_result_bytes (8 GiB)    largest match list daac_scan may materialise */
 daac_status daac_set_option(const char *name, int64_t value);

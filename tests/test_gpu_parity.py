@@ -704,3 +704,46 @@ def test_gram_tail_records():
     zhay = np.concatenate([np.frombuffer(zpats[int(rng.integers(0, len(zpats)))], dtype=np.uint8) for _ in range(4000)] + [np.zeros(9, dtype=np.uint8)])
     zwant = zo.find_overlapping_iter(zhay)
     _check_counts(zp, ScanMode.FindOverlapping, zhay, zwant)
+
+
+def test_engine_options_do_not_change_answers():
+    """The knobs that pick between implementations of the same scan (stream-ordered pool or hipMalloc, the micro-step walker
+    or the byte-at-a-time segment scanners for counts, mapper / ROOT's row in LDS or in L2, sync-point scanners or chains)
+    must not change a single number."""
+    rng = np.random.default_rng(5)
+    pats = synth.patterns_cfg3(3000)
+    hay = synth.wordsoup_haystack(300_000, synth.SEEDS["cfg3_dense"], pats, 20)
+    o, _ = _pma(pats)
+    ol, _ = _pma(pats, kind="LeftmostLongest")
+    want = {"ov": o.find_overlapping_iter(hay), "find": o.find_iter(hay), "lm": ol.leftmost_find_iter(hay)}
+    cpats = ["".join(chr(0x4E00 + int(c)) for c in rng.integers(0, 300, size=int(rng.integers(1, 5)))) for _ in range(2000)] + ["ab", "b", "全世界"]
+    ctext = "".join(chr(0x4E00 + int(c)) if c < 300 else "ab "[int(c) % 3] for c in rng.integers(0, 340, size=60_000))
+    co = orc.OracleCharwisePma.build(cpats)
+    col = orc.OracleCharwisePma.build(cpats, kind=1)
+    cwant = {"ov": co.find_overlapping_iter(ctext), "find": co.find_iter(ctext), "lm": col.leftmost_find_iter(ctext)}
+    try:
+        for opts in ({}, {"pool": 0}, {"overlap_micro": 0}, {"overlap_micro": 2}, {"char_map_lds": 0}, {"char_row_lds": 0}, {"restart_chain": 0},
+                     {"restart_tier": 1}, {"seg_bytes": 4096, "overlap_micro": 2}):
+            for k, v in opts.items():
+                da.set_option(k, v)
+            _, p = _pma(pats)       # (tables are laid out at upload: a fresh handle per setting)
+            _, pl = _pma(pats, kind="LeftmostLongest")
+            cp, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(co.serialize())
+            cpl, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(col.serialize())
+            for eng in (Engine.Auto, Engine.DArray, Engine.Tiered):
+                assert p.scan_count(ScanMode.FindOverlapping, hay, engine=eng) == (len(want["ov"]), orc.matches_checksum(want["ov"])), (opts, eng)
+            assert p.scan_count(ScanMode.Find, hay) == (len(want["find"]), orc.matches_checksum(want["find"])), opts
+            assert pl.scan_count(ScanMode.LeftmostFind, hay) == (len(want["lm"]), orc.matches_checksum(want["lm"])), opts
+            assert _same(pl.scan(ScanMode.LeftmostFind, hay), want["lm"]), opts
+            dm = p.scan_device(ScanMode.FindOverlapping, hay)
+            assert _same(dm.to_numpy(), want["ov"]), opts
+            dm.free()
+            assert cp.scan_count(ScanMode.FindOverlapping, ctext) == (len(cwant["ov"]), orc.matches_checksum(cwant["ov"])), opts
+            assert cp.scan_count(ScanMode.Find, ctext) == (len(cwant["find"]), orc.matches_checksum(cwant["find"])), opts
+            assert cpl.scan_count(ScanMode.LeftmostFind, ctext) == (len(cwant["lm"]), orc.matches_checksum(cwant["lm"])), opts
+            assert _same(cp.scan(ScanMode.FindOverlapping, ctext), cwant["ov"]), opts
+            for k in opts:
+                da.set_option(k, {"pool": 1, "overlap_micro": 1, "char_map_lds": 1, "char_row_lds": 1, "restart_chain": 1, "restart_tier": 0, "seg_bytes": 0}[k])
+    finally:
+        for k, v in {"pool": 1, "overlap_micro": 1, "char_map_lds": 1, "char_row_lds": 1, "restart_chain": 1, "restart_tier": 0, "seg_bytes": 0}.items():
+            da.set_option(k, v)
