@@ -1249,7 +1249,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         const uint32_t blocks = static_cast<uint32_t>(
             std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (ga.nregions + wpb - 1) / wpb)));
         // room for what one step can queue at worst (64 * ppl + 128 walkers) on top of a useful fill level
-        ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(2 * (64 * ga.ppl + 128), g_opt.gram_slab.load()));
+        ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(64 * ga.ppl + 128 + 64, g_opt.gram_slab.load()));  // (a step can queue 64 * ppl walkers)
         // more than ~1 % of the (K+1)-grams are trie prefixes: some lane of the wave hits on nearly every position
         {
             const uint64_t n_deep = use_gw ? t->gramw.n_deep : use_g2 ? t->gram2.n_deep : t->gram.n_deep, C = use_gw ? t->gramw.C : use_g2 ? t->gram2.C : t->gram.C,
