@@ -706,11 +706,11 @@ hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, 
     }
     // count (+ checksum) of an overlapping scan the GRAM tables do not serve: the micro-step walker over segments (2048 lanes
     // per CU, a segment each) instead of the byte-at-a-time segment scanners
-    if (kmode == 0 && !heads && !pl.restart && g_opt.overlap_micro.load() != 0 && (pl.charwise || !pl.tier || g_opt.overlap_micro.load() == 2) &&
+    if (kmode == 0 && !pl.restart && g_opt.overlap_micro.load() != 0 && (pl.charwise || !pl.tier || g_opt.overlap_micro.load() == 2) &&
         pl.a.seg_bytes + pl.a.halo < (1ull << 30)) {  // (the walker counts in 32-bit offsets from where it enters its segment)
         const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 8, (pl.a.nseg + 255) / 256)));
-        if (pl.charwise && t->chr.root_flag == 0) return launch_char_overlap_count(t->chr, pl.a, blocks, s);
-        if (!pl.charwise && t->da.root_flag == 0) return launch_overlap_count(t->da, pl.a, blocks, s);
+        if (pl.charwise && t->chr.root_flag == 0) return launch_char_overlap_count(t->chr, pl.a, heads, blocks, s);
+        if (!pl.charwise && t->da.root_flag == 0) return launch_overlap_count(t->da, pl.a, heads, blocks, s);
     }
     if (pl.charwise) {
         return pl.restart ? launch_char_restart_scan(t->chr, pl.a, kmode, pl.leftmost, next_begin, pl.blocks, pl.threads, s)

@@ -324,8 +324,10 @@ __device__ __forceinline__ uint64_t ChainWalker<T, LEFTMOST>::run_micro(uint64_t
 // segment `halo` bytes early at ROOT (classic Aho-Corasick transitions, nothing reported before lo) and tallies the output
 // list of every state it passes with an end in (lo, hi] — the list's {count, sum of h32} come precomputed (osum), asked for
 // when the state is entered and folded in at the next report.  T as for ChainWalker (T::micro<false> = the classic delta).
-template <class T>
-__device__ __forceinline__ void overlap_count_body(const T &t, const ScanArgs &a, const uint2 *__restrict__ osum, unsigned long long *scratch) {
+// HEADS: FindOverlappingNoSuffixIterator — only the head of a state's list (`ohash`: h of the record alone).
+template <class T, bool HEADS>
+__device__ __forceinline__ void overlap_count_body(const T &t, const ScanArgs &a, const uint2 *__restrict__ osum, const uint32_t *__restrict__ ohash,
+                                                   unsigned long long *scratch) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     unsigned long long tot_cnt = 0;
     uint32_t tot_s1 = 0, tot_s2 = 0;
@@ -362,7 +364,8 @@ __device__ __forceinline__ void overlap_count_body(const T &t, const ScanArgs &a
             const uint32_t op = t.opos(st);
             if (done && op != 0 && pos > warm && pos <= end32) {  // (a character cut by hi ends in the next segment)
                 cnt += q_wait.x; s1 += q_wait.y; s2 += q_wait.y * end_wait;
-                q_wait = osum[op - 1u];
+                if (HEADS) q_wait = uint2{1u, ohash[op - 1u]};
+                else q_wait = osum[op - 1u];
                 end_wait = static_cast<uint32_t>(p0) + pos;
             }
             if (!pending && pos >= end32) break;

@@ -396,7 +396,7 @@ static hipError_t launch_char_chain_ml(const CharDev &dev, const ScanArgs &a, co
 }
 
 // find_overlapping_iter().count() (+ checksum) of a charwise automaton with the micro-step walker (overlap_count_body)
-template <int LVL>
+template <int LVL, bool HEADS>
 __global__ __launch_bounds__(LVL == 2 ? 1024 : LVL == 1 ? 512 : 256) void char_overlap_count_kernel(const CharDev dev, const ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint16_t l_map[];
     __shared__ unsigned long long scratch[3 * 16];
@@ -413,29 +413,31 @@ __global__ __launch_bounds__(LVL == 2 ? 1024 : LVL == 1 ? 512 : 256) void char_o
         __syncthreads();
     }
     const CwTablesT<LVL> T{dev, dev.states[0], a.hay, a.total_len, l_map, l_row};
-    overlap_count_body<CwTablesT<LVL>>(T, a, dev.osum, scratch);
+    overlap_count_body<CwTablesT<LVL>, HEADS>(T, a, dev.osum, dev.ohash, scratch);
 }
 
-template <int LVL>
+template <int LVL, bool HEADS>
 static hipError_t launch_char_overlap_ml(const CharDev &dev, const ScanArgs &a, uint32_t blocks, hipStream_t stream) {
     constexpr uint32_t per = LVL == 2 ? 4u : LVL == 1 ? 2u : 1u;
     const dim3 g((blocks + per - 1u) / per), b(256u * per);
     const uint32_t map_bytes = ((128u + dev.table_len - dev.map_lo) * 2u + 15u) & ~15u;
     const uint32_t lds = LVL == 2 ? map_bytes + dev.alphabet * 8u : LVL == 1 ? map_bytes : 0u;
     if (lds > 48u * 1024u) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(char_overlap_count_kernel<LVL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(char_overlap_count_kernel<LVL, HEADS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((char_overlap_count_kernel<LVL>), g, b, lds, stream, dev, a);
+    hipLaunchKernelGGL((char_overlap_count_kernel<LVL, HEADS>), g, b, lds, stream, dev, a);
     return hipGetLastError();
 }
 
 // `blocks` counts 256-lane workgroups
-hipError_t launch_char_overlap_count(const CharDev &dev, const ScanArgs &a, uint32_t blocks, hipStream_t stream) {
-    if (dev.map_in_lds != 0 && dev.row_in_lds != 0) return launch_char_overlap_ml<2>(dev, a, blocks, stream);
-    if (dev.map_in_lds != 0) return launch_char_overlap_ml<1>(dev, a, blocks, stream);
-    return launch_char_overlap_ml<0>(dev, a, blocks, stream);
+hipError_t launch_char_overlap_count(const CharDev &dev, const ScanArgs &a, bool heads, uint32_t blocks, hipStream_t stream) {
+    const int lvl = dev.map_in_lds != 0 ? (dev.row_in_lds != 0 ? 2 : 1) : 0;
+    if (heads) return lvl == 2 ? launch_char_overlap_ml<2, true>(dev, a, blocks, stream) : lvl == 1 ? launch_char_overlap_ml<1, true>(dev, a, blocks, stream)
+                                                                                                      : launch_char_overlap_ml<0, true>(dev, a, blocks, stream);
+    return lvl == 2 ? launch_char_overlap_ml<2, false>(dev, a, blocks, stream) : lvl == 1 ? launch_char_overlap_ml<1, false>(dev, a, blocks, stream)
+                                                                                           : launch_char_overlap_ml<0, false>(dev, a, blocks, stream);
 }
 
 hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,

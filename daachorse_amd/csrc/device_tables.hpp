@@ -190,8 +190,8 @@ struct EmitArgs {
 hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, int em, uint32_t blocks, hipStream_t stream);
 hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool exact, uint32_t blocks, uint32_t threads, hipStream_t stream);
 
-hipError_t launch_overlap_count(const DArrayDev &dev, const ScanArgs &a, uint32_t blocks, hipStream_t stream);
-hipError_t launch_char_overlap_count(const CharDev &dev, const ScanArgs &a, uint32_t blocks, hipStream_t stream);
+hipError_t launch_overlap_count(const DArrayDev &dev, const ScanArgs &a, bool heads, uint32_t blocks, hipStream_t stream);
+hipError_t launch_char_overlap_count(const CharDev &dev, const ScanArgs &a, bool heads, uint32_t blocks, hipStream_t stream);
 hipError_t launch_tier_scan(const TierDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,
                             hipStream_t stream);
 hipError_t launch_darray_scan(const DArrayDev &dev, const ScanArgs &a, int mode, bool heads, uint32_t blocks, uint32_t threads,

@@ -297,17 +297,19 @@ __global__ __launch_bounds__(256) void chain_kernel(const DArrayDev dev, const S
 
 // find_overlapping_iter().count() (+ checksum) over the double array with the micro-step walker (chain_scan.hpp,
 // overlap_count_body): the engine for automata the GRAM tables do not fit (more than 62 byte classes)
+template <bool HEADS>
 __global__ __launch_bounds__(256) void overlap_count_kernel(const DArrayDev dev, const ScanArgs a) {
     __shared__ uint4 l_root[256];
     __shared__ unsigned long long scratch[3 * 4];
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root[i];
     __syncthreads();
     const RestartTables T{dev, l_root, a.hay};
-    overlap_count_body<RestartTables>(T, a, dev.osum, scratch);
+    overlap_count_body<RestartTables, HEADS>(T, a, dev.osum, dev.ohash, scratch);
 }
 
-hipError_t launch_overlap_count(const DArrayDev &dev, const ScanArgs &a, uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(overlap_count_kernel, dim3(blocks), dim3(256), 0, stream, dev, a);
+hipError_t launch_overlap_count(const DArrayDev &dev, const ScanArgs &a, bool heads, uint32_t blocks, hipStream_t stream) {
+    if (heads) hipLaunchKernelGGL(overlap_count_kernel<true>, dim3(blocks), dim3(256), 0, stream, dev, a);
+    else hipLaunchKernelGGL(overlap_count_kernel<false>, dim3(blocks), dim3(256), 0, stream, dev, a);
     return hipGetLastError();
 }
 
