@@ -150,6 +150,20 @@ __global__ __launch_bounds__(1024) void k_lshladd64(uint32_t *out, uint32_t seed
     if (r == 0x12345u) out[0] = 1;
 }
 
+// v_mad_u64_u32: what the compiler picks for `a * b + c` on 32-bit values it cannot prove to be 24-bit (low half = the 32-bit result)
+__global__ __launch_bounds__(1024) void k_mad64(uint32_t *out, uint32_t seed, int iters) {
+    uint64_t a0 = threadIdx.x + seed, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    uint32_t s = seed | 1u;
+    for (int i = 0; i < iters; ++i) {
+        asm volatile("v_mad_u64_u32 %0, s[20:21], %8, %8, %0\nv_mad_u64_u32 %1, s[20:21], %8, %8, %1\nv_mad_u64_u32 %2, s[20:21], %8, %8, %2\n"
+                     "v_mad_u64_u32 %3, s[20:21], %8, %8, %3\nv_mad_u64_u32 %4, s[20:21], %8, %8, %4\nv_mad_u64_u32 %5, s[20:21], %8, %8, %5\n"
+                     "v_mad_u64_u32 %6, s[20:21], %8, %8, %6\nv_mad_u64_u32 %7, s[20:21], %8, %8, %7\n"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s) : "s20", "s21");
+    }
+    uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if (r == 0x12345u) out[0] = 1;
+}
+
 typedef void (*valu_fn)(uint32_t *, uint32_t, int);
 static int run_valu(const char *name, valu_fn fn, int ops_per_asm = 8) {
     uint32_t *out;
@@ -381,7 +395,7 @@ int main(int argc, char **argv) {
     RV(k_mov) RV(k_movsdwa) RV(k_addsdwa) RV(k_lshlsdwa) RV(k_movdpp) RV(k_movwshr) RV(k_adddpp) RV(k_fma) RV(k_fadd) RV(k_fmul) RV(k_fmac)
     RV(k_cvtub0) RV(k_cvtub2) RV(k_cvtu32) RV(k_cvtf32) RV(k_pkmad16) RV(k_pkadd16) RV(k_pklshl16) RV(k_lshladd) RV(k_cndmask) RV(k_cmp) RV(k_cmps)
     RV(k_mbcnt) RV(k_dot4) RV(k_sad) RV(k_mullo) RV(k_maxu) RV(k_xad) RV(k_andor) RV(k_or3) RV(k_bfi) RV(k_readlane) RV(k_madu16)
-    RV(k_pkfma) RV(k_lshladd64)
+    RV(k_pkfma) RV(k_lshladd64) RV(k_mad64)
 
     // LDS reads
     if (run_lds<0>("ds_read_u8  class table, 27 symbols (a-z, space)", 0, 1, 27, out)) return 1;
