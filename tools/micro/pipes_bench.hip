@@ -62,6 +62,9 @@ static double g_clk = 2.4e9;
 #define A_PKLSHL16(k) "v_pk_lshlrev_b16 %" #k ", 2, %" #k "\n"
 #define A_LSHLADD(k) "v_lshl_add_u32 %" #k ", %" #k ", 2, %8\n"
 #define A_CNDMASK(k) "v_cndmask_b32 %" #k ", %" #k ", %8, vcc\n"
+#define A_CNDMASKS(k) "v_cndmask_b32_e64 %" #k ", %" #k ", %8, s[20:21]\n"
+#define A_CMPCND(k) "v_cmp_ne_u32 vcc, %" #k ", %8\nv_cndmask_b32 %" #k ", %" #k ", %8, vcc\n"
+#define A_CMPSCND(k) "v_cmp_ne_u32 s[20:21], %" #k ", %8\nv_cndmask_b32_e64 %" #k ", %" #k ", %8, s[20:21]\n"
 #define A_CMP(k) "v_cmp_ne_u32 vcc, %" #k ", %8\n"
 #define A_CMPS(k) "v_cmp_ne_u32 s[20:21], %" #k ", %8\n"
 #define A_MBCNT(k) "v_mbcnt_lo_u32_b32 %" #k ", %8, %" #k "\n"
@@ -111,6 +114,9 @@ VALU_KERNEL(k_pkadd16, A_PKADD16, NOCLOB)
 VALU_KERNEL(k_pklshl16, A_PKLSHL16, NOCLOB)
 VALU_KERNEL(k_lshladd, A_LSHLADD, NOCLOB)
 VALU_KERNEL(k_cndmask, A_CNDMASK, CLOB_VCC)
+VALU_KERNEL(k_cndmask_s, A_CNDMASKS, CLOB_S)
+VALU_KERNEL(k_cmp_cnd, A_CMPCND, CLOB_VCC)
+VALU_KERNEL(k_cmps_cnd, A_CMPSCND, CLOB_S)
 VALU_KERNEL(k_cmp, A_CMP, CLOB_VCC)
 VALU_KERNEL(k_cmps, A_CMPS, CLOB_S)
 VALU_KERNEL(k_mbcnt, A_MBCNT, NOCLOB)
@@ -395,7 +401,9 @@ int main(int argc, char **argv) {
     RV(k_mov) RV(k_movsdwa) RV(k_addsdwa) RV(k_lshlsdwa) RV(k_movdpp) RV(k_movwshr) RV(k_adddpp) RV(k_fma) RV(k_fadd) RV(k_fmul) RV(k_fmac)
     RV(k_cvtub0) RV(k_cvtub2) RV(k_cvtu32) RV(k_cvtf32) RV(k_pkmad16) RV(k_pkadd16) RV(k_pklshl16) RV(k_lshladd) RV(k_cndmask) RV(k_cmp) RV(k_cmps)
     RV(k_mbcnt) RV(k_dot4) RV(k_sad) RV(k_mullo) RV(k_maxu) RV(k_xad) RV(k_andor) RV(k_or3) RV(k_bfi) RV(k_readlane) RV(k_madu16)
-    RV(k_pkfma) RV(k_lshladd64) RV(k_mad64)
+    RV(k_pkfma) RV(k_lshladd64) RV(k_mad64) RV(k_cndmask_s)
+    if (run_valu("k_cmp_cnd (2 instr)", k_cmp_cnd, 16)) return 1;
+    if (run_valu("k_cmps_cnd (2 instr)", k_cmps_cnd, 16)) return 1;
 
     // LDS reads
     if (run_lds<0>("ds_read_u8  class table, 27 symbols (a-z, space)", 0, 1, 27, out)) return 1;
