@@ -859,7 +859,7 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
     void *d_scratch = nullptr;
     const size_t wq_bytes = nwaves * wq_slab * sizeof(uint2), rec_bytes = nwaves * 2ull * rec_cap * sizeof(uint4);
     DevBuf g1, g2;
-    HIP_TRY(g1.alloc((tiles_total + 2) * sizeof(unsigned long long), stream));
+    HIP_TRY(g1.alloc((tiles_total + 2 + exclusive_scan_scratch(tiles_total)) * sizeof(unsigned long long), stream));
     d_tiles = static_cast<unsigned long long *>(g1.p);
     HIP_TRY(g2.alloc(wq_bytes + rec_bytes + 16, stream));
     d_scratch = g2.p;
@@ -877,7 +877,7 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
         return a;
     };
     for (const Win &w : wins) HIP_TRY(launch_gram2_emit(e, args_of(w), 0, blocks, stream));
-    HIP_TRY(launch_exclusive_scan(d_tiles, tiles_total, d_tiles + tiles_total, stream));
+    HIP_TRY(launch_exclusive_scan(d_tiles, tiles_total, d_tiles + tiles_total, d_tiles + tiles_total + 2, stream));
     unsigned long long total = 0;
     {
         unsigned long long *pin = reinterpret_cast<unsigned long long *>(pinned_words());
@@ -945,7 +945,7 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
     pl.a.hay = dev_hay;
     pl.a.total_len = total_len;
     DevBuf g1;
-    HIP_TRY(g1.alloc((pl.a.nseg + 3) * sizeof(unsigned long long), stream));
+    HIP_TRY(g1.alloc((pl.a.nseg + 3 + exclusive_scan_scratch(pl.a.nseg)) * sizeof(unsigned long long), stream));
     unsigned long long *d_counts = static_cast<unsigned long long *>(g1.p);
     pl.a.seg_counts = d_counts;
     pl.a.result = d_counts + pl.a.nseg;
@@ -955,7 +955,7 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
     ChainBuffers chain_buffers;
     if ((st = chain_resolve(pma, t, pl, stream, chain_buffers)) != DAAC_OK) return st;
     HIP_TRY(launch(t, pl, 1, heads, stream, d_next));
-    HIP_TRY(launch_exclusive_scan(d_counts, pl.a.nseg, d_counts + pl.a.nseg, stream));
+    HIP_TRY(launch_exclusive_scan(d_counts, pl.a.nseg, d_counts + pl.a.nseg, d_counts + pl.a.nseg + 3, stream));
     unsigned long long total = 0, nbf[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(&total, d_counts + pl.a.nseg, sizeof(total), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(nbf, d_next, sizeof(nbf), hipMemcpyDeviceToHost, stream));

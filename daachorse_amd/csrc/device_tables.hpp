@@ -215,6 +215,7 @@ hipError_t launch_tier_chain(const TierDev &dev, const ScanArgs &a, const ChainA
                              uint32_t blocks, hipStream_t stream);
 hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
                              unsigned long long *next_begin, uint32_t blocks, hipStream_t stream);
-hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned long long *total, hipStream_t stream);
+hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned long long *total, unsigned long long *scratch, hipStream_t stream);
+inline uint64_t exclusive_scan_scratch(uint64_t n) { return n / 2048 + 2; }  // values of scratch the scan of n counts wants
 
 }  // namespace daac

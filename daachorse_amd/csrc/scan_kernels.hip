@@ -407,8 +407,64 @@ hipError_t launch_char_scan(const CharDev &dev, const ScanArgs &a, int mode, boo
     return launch_mode<CharEngine>(dev, a, mode, heads, dim3(blocks), dim3(threads), 1024, stream);
 }
 
-hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned long long *total, hipStream_t stream) {
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, v, n, total);
+// The same for millions of counts (the tuple emitter: one per tile of 1 KiB of text), in three launches: sums of chunks of
+// kScanChunk elements, their exclusive scan by the one-workgroup kernel above, the scan inside every chunk on top of its sum.
+constexpr uint32_t kScanChunk = 2048;  // 256 threads x 8 consecutive elements
+__global__ __launch_bounds__(256) void scan_chunk_sums_kernel(const unsigned long long *__restrict__ v, uint64_t n, unsigned long long *__restrict__ sums) {
+    __shared__ unsigned long long part[4];
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanChunk;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint64_t i = base + static_cast<uint64_t>(k) * 256 + threadIdx.x;
+        if (i < n) s += v[i];
+    }
+    s = wave_sum_u64(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(256) void scan_chunks_kernel(unsigned long long *__restrict__ v, uint64_t n, const unsigned long long *__restrict__ sums_excl) {
+    __shared__ unsigned long long part[256];
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanChunk + static_cast<uint64_t>(threadIdx.x) * 8;
+    unsigned long long x[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { x[k] = base + k < n ? v[base + k] : 0ull; s += x[k]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {  // 256 thread sums: four per lane of the first wave
+        unsigned long long q[4], t = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { q[k] = part[threadIdx.x * 4 + k]; t += q[k]; }
+        unsigned long long incl = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long y = __shfl_up(incl, off, 64);
+            if (static_cast<int>(threadIdx.x) >= off) incl += y;
+        }
+        unsigned long long run = incl - t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { part[threadIdx.x * 4 + k] = run; run += q[k]; }
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x] + sums_excl[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (base + k < n) v[base + k] = run;
+        run += x[k];
+    }
+}
+
+// `scratch`: room for n / kScanChunk + 2 more values (may be null for short arrays)
+hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned long long *total, unsigned long long *scratch, hipStream_t stream) {
+    if (scratch == nullptr || n <= 4 * kScanChunk) {
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, v, n, total);
+        return hipGetLastError();
+    }
+    const uint32_t nb = static_cast<uint32_t>((n + kScanChunk - 1) / kScanChunk);
+    hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(nb), dim3(256), 0, stream, v, n, scratch);
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, scratch, static_cast<uint64_t>(nb), total);
+    hipLaunchKernelGGL(scan_chunks_kernel, dim3(nb), dim3(256), 0, stream, v, n, scratch);
     return hipGetLastError();
 }
 
