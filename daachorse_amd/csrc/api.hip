@@ -39,8 +39,10 @@ struct Options {
     std::atomic<int64_t> gram_ppl{0};           // 0 = auto (32 positions per lane for automata without short patterns), 16, 32
     std::atomic<int64_t> gram_dense{-1};        // -1 = decide per automaton
     std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
-    std::atomic<int64_t> gram_version{0};       // 0 = the second table set where it applies (else v1), 1 = v1 only, 2 = v2 only
+    std::atomic<int64_t> gram_version{0};       // 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram3 on the v2 tables), 1 = v1 only,
+                                                // 2 = v2 tables with gram2_kernels.hip, 3 = v2 tables with gram3_kernels.hip for `.count()`
     std::atomic<int64_t> gram2_dpp{1};
+    std::atomic<int64_t> gram3_tail{-1};        // gram3: tail records from the hit record on (-1 = decide per launch)
     std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
     std::atomic<int64_t> emit{1};               // materialising overlapping scans: GRAM tuple emission where it applies (0: segment scanners)
     std::atomic<int64_t> emit_staged{0};        // 1: the write pass gathers the tuples of 64 positions in LDS and stores them contiguously
@@ -74,32 +76,39 @@ static daac_status hip_fail(hipError_t e, const char *what) {
 // Scratch and result buffers of the scans come from the device's stream-ordered pool (hipMallocAsync): a scan that needs
 // tens of MB of scratch, or hands back GBs of tuples, does not pay the driver's map / unmap each time — the pool keeps up
 // to `pool_keep` bytes (default 1/8 of the device memory, at most 32 GiB) for the next call.  Option pool = 0: plain hipMalloc.
-static std::atomic<int> g_pool_mode{-1};  // -1 undecided, 0 hipMalloc / hipFree, 1 stream-ordered pool
-static hipError_t dev_malloc(void **p, size_t bytes, hipStream_t s) {
-    int mode = g_pool_mode.load();
-    if (mode < 0) {
-        mode = 0;
-        if (g_opt.pool.load() != 0) {
-            int dev = 0, supported = 0;
-            hipMemPool_t pool;
-            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) == hipSuccess &&
-                supported && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-                size_t fr = 0, tot = 0;
-                (void)hipMemGetInfo(&fr, &tot);
-                uint64_t keep = static_cast<uint64_t>(g_opt.pool_keep.load());
-                if (keep == 0) keep = std::min<uint64_t>(32ull << 30, tot / 8);
-                if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) mode = 1;
-            }
-            (void)hipGetLastError();
+// decided per device (a process may scan on several): -1 undecided, 0 hipMalloc / hipFree, 1 stream-ordered pool
+constexpr int kMaxDevices = 64;
+static std::atomic<int> g_pool_mode[kMaxDevices];
+static struct PoolModeInit { PoolModeInit() { for (auto &m : g_pool_mode) m.store(-1); } } g_pool_mode_init;
+static int pool_mode_of_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    int mode = g_pool_mode[dev].load();
+    if (mode >= 0) return mode;
+    mode = 0;
+    if (g_opt.pool.load() != 0) {
+        int supported = 0;
+        hipMemPool_t pool;
+        if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) == hipSuccess && supported &&
+            hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            uint64_t keep = static_cast<uint64_t>(g_opt.pool_keep.load());
+            if (keep == 0) keep = std::min<uint64_t>(32ull << 30, tot / 8);
+            if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) mode = 1;
         }
-        g_pool_mode.store(mode);
+        (void)hipGetLastError();
     }
+    g_pool_mode[dev].store(mode);
+    return mode;
+}
+static hipError_t dev_malloc(void **p, size_t bytes, hipStream_t s) {
     if (bytes == 0) bytes = 16;
-    return mode == 1 ? hipMallocAsync(p, bytes, s) : hipMalloc(p, bytes);
+    return pool_mode_of_current_device() == 1 ? hipMallocAsync(p, bytes, s) : hipMalloc(p, bytes);
 }
 static void dev_free(void *p, hipStream_t s) {
     if (!p) return;
-    if (g_pool_mode.load() == 1) (void)hipFreeAsync(p, s); else (void)hipFree(p);
+    if (pool_mode_of_current_device() == 1) (void)hipFreeAsync(p, s); else (void)hipFree(p);
 }
 struct DevBuf {  // scratch that lives as long as the call
     void *p = nullptr;
@@ -481,6 +490,8 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             { const U32x2 *hc; if ((st = t->put(g2.dhit_c, hc)) != DAAC_OK) return st; d.dhit_c = reinterpret_cast<const uint2 *>(hc); }
             { const U32x4 *h4; if ((st = t->put(zip_first_child(g2.dhit, g2.cfirst), h4)) != DAAC_OK) return st; d.dhit4 = reinterpret_cast<const uint4 *>(h4); }
             if ((st = t->put(g2.cfirst, d.cfirst)) != DAAC_OK) return st;
+            { const U32x4 *x; if ((st = t->put(g2.dhit_t, x)) != DAAC_OK) return st; d.dhit_t = reinterpret_cast<const uint4 *>(x); }
+            { const U32x4 *x; if ((st = t->put(g2.drec_t, x)) != DAAC_OK) return st; d.drec_t = reinterpret_cast<const uint4 *>(x); }
             d.drec = reinterpret_cast<const uint4 *>(drec);
             d.dhit = reinterpret_cast<const uint2 *>(dhit);
             d.m_bytes = p16(g2.m.size() * 4);
@@ -1184,7 +1195,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     // (measured on cfg3: with the checksum both table sets spend three LDS lookups per position and the first is a little
     // faster; `.count()` alone needs one lookup per position on the second and runs 20-25 % faster there)
     const bool g1_can = t->gram_ok && gv != 2;
-    const bool g2_can = t->gram2_ok && (!want_checksum || t->gram2.exact_ok) && gv != 1 && !(gv == 0 && want_checksum && g1_can);
+    const bool g2_can = t->gram2_ok && (!want_checksum || t->gram2.exact_ok) && gv != 1 && !(gv == 0 && want_checksum && g1_can) && !(gv == 3 && want_checksum && g1_can);
     const bool gw_can = t->gramw_ok && (!want_checksum || t->gramw.exact_ok);  // wide alphabets: built only where the others are not
     const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len - begin < (1ull << 35) &&
                           (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (g2_can || g1_can || gw_can)));
@@ -1193,6 +1204,21 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         return DAAC_ERR_UNSUPPORTED;
     }
     const bool use_g2 = use_gram && g2_can;
+    // `.count()` alone on the second table set: the lane-local-mask kernel (gram3_kernels.hip) when asked for (gram_version = 3)
+    Gram3Lds g3l{};
+    uint32_t g3_ppl = g_opt.gram_ppl.load() == 16 ? 16u : 32u;   // (32 positions per lane measured 3-10 % ahead of 16: profiles/r03_gram3_ab.txt)
+    bool use_g3 = use_g2 && !want_checksum && (gv == 3 || gv == 0);
+    if (use_g3) {
+        // 32 positions per lane: 16 waves per workgroup when the LDS takes their text slots (with the coarser directory), else 8
+        const bool want_rfull = g_opt.gram2_rfull.load() != 0;
+        const uint32_t want_threads = static_cast<uint32_t>(g_opt.threads.load());
+        if (g3_ppl == 32 && want_threads > 512 && gram3_plan(t->gram2, 32, 16, want_rfull, 160u * 1024u, g3l)) {
+        } else if (g3_ppl == 32 && want_threads <= 512 && gram3_plan(t->gram2, 32, 8, want_rfull, 160u * 1024u, g3l)) {
+        } else {
+            g3_ppl = 16;
+            use_g3 = gram3_plan(t->gram2, 16, 16, want_rfull, 160u * 1024u, g3l);
+        }
+    }
     const bool use_gw = use_gram && !g2_can && !g1_can && gw_can;
     Plan pl;
     bool heads = false;
@@ -1233,18 +1259,22 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         ga.vlen = ga.lead + static_cast<uint64_t>(len - begin);
         // a power of two >= 2 KiB: regions then never straddle a multiple of 4 GiB (the kernel keeps 32-bit positions per epoch)
         uint64_t region = 2048;
-        const int64_t region_opt = g_opt.gram_region.load() > 0 ? g_opt.gram_region.load() : (use_g2 ? 65536 : 16384);
+        // (second table set: 256 KiB regions once there are several per wave — a region's start costs a handful of dependent
+        // loads and the refill of the prefetch pipeline: 64 KiB regions measured 2-6 % slower on 4 GiB)
+        const int64_t region_opt = g_opt.gram_region.load() > 0 ? g_opt.gram_region.load()
+                                   : use_g2 ? ((len - begin) >= (1ull << 31) ? 262144 : 65536) : 16384;
         while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, region_opt)) && region < (1ull << 30)) region *= 2;
-        ga.ppl = (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
+        ga.ppl = use_g3 ? g3_ppl : (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;
         ga.result = d_res;
         uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
         threads = std::min(1024u, std::max(64u, threads & ~63u));
         if (use_gw) threads = 1024;  // the wide kernel has one launch shape
+        if (use_g3) threads = g3l.threads;
         const uint32_t wpb = threads / 64;
         uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
-        const uint32_t gram_lds = use_gw ? (want_checksum ? t->gramw.lds_exact : t->gramw.lds_count)
+        const uint32_t gram_lds = use_g3 ? g3l.lds_bytes : use_gw ? (want_checksum ? t->gramw.lds_exact : t->gramw.lds_count)
                                          : use_g2 ? gram2_lds_bytes(t->gram2, want_checksum) : t->gram.lds_bytes;
         if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / gram_lds));
         const uint32_t blocks = static_cast<uint32_t>(
@@ -1257,10 +1287,15 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
                            K = use_gw ? 2 : use_g2 ? t->gram2.K : t->gram.K;
             ga.dense = g_opt.gram_dense.load() >= 0 ? g_opt.gram_dense.load() != 0 : n_deep * 100 > C * C * C * (K == 3 ? C : 1);
         }
+        // gram3: tail records from the hit record on pay on text made of dictionary words (+20 %) and cost 3-4 % elsewhere; unless
+        // the option decides, every workgroup samples the haystack at its start and runs the variant the text calls for
+        const int64_t tail_opt = g_opt.gram3_tail.load();
         void *wq = nullptr;
-        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * sizeof(uint2), stream));
+        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * (use_g3 ? sizeof(uint4) : sizeof(uint2)), stream));
         ga.wq = static_cast<uint2 *>(wq);
-        const hipError_t le = use_gw ? launch_gram2w_scan(t->gramw, ga, want_checksum, blocks, stream)
+        ga.sel_want = tail_opt < 0 ? ((len - begin) >= (1ull << 20) ? 2u : 0u) : tail_opt > 0 ? 1u : 0u;
+        const hipError_t le = use_g3 ? launch_gram3_scan(t->gram2, ga, g3l, blocks, stream)
+                              : use_gw ? launch_gram2w_scan(t->gramw, ga, want_checksum, blocks, stream)
                               : use_g2 ? launch_gram2_scan(t->gram2, ga, want_checksum, blocks, threads, stream)
                                        : launch_gram_scan(t->gram, ga, blocks, threads, stream);
         HIP_TRY(hipFreeAsync(wq, stream));
@@ -1279,6 +1314,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
                     const uint32_t h = match_hash32(m.value, static_cast<uint32_t>(m.end - m.start));
                     add[0] += 1; add[1] += h; add[2] += static_cast<uint32_t>(h * static_cast<uint32_t>(m.end));
                 }
+                g_last_engine = DAAC_ENGINE_GRAM;  // (the sliver's few bytes went through the segment scanners)
             }
             // ends were relative to `begin`: S2 += low32(begin) * S1, then the sliver's tuples
             hipLaunchKernelGGL(shard_fixup_kernel, dim3(1), dim3(1), 0, stream, d_res, static_cast<unsigned long long>(begin & 0xffffffffull), add[0],
@@ -1360,7 +1396,11 @@ daac_status daac_scan_device(daac_pma *pma, int mode, int engine, const uint8_t 
     return DAAC_OK;
 }
 
-void daac_device_free(void *p) { dev_free(p, nullptr); }
+void daac_device_free(void *p) {
+    // hipFree is legal for stream-ordered allocations of any device and synchronises: the list may come from another device's
+    // pool than the current one, and its consumer ran on a stream this library never saw
+    if (p) (void)hipFree(p);
+}
 
 daac_status daac_device_to_host(void *dst, const void *dev_src, size_t bytes) {
     if (bytes && (!dst || !dev_src)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
@@ -1602,6 +1642,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_version") g_opt.gram_version = value;
     else if (n == "gram2_dpp") g_opt.gram2_dpp = value;
     else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
+    else if (n == "gram3_tail") g_opt.gram3_tail = value;
     else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles") g_opt.emit_tiles = value;

@@ -110,6 +110,8 @@ struct GramArgs {
     uint32_t wq_slab;            // entries per wave
     uint32_t ppl;                // positions per lane and step: 16 or 32 (region_bytes is a multiple of 64 * ppl)
     uint32_t dense;              // B hits are frequent: queue them position by position without testing the group first
+    const uint32_t *sel;         // (unused)
+    uint32_t sel_want;           // gram3: 0 = plain records, 1 = tail records from the hit record on, 2 = decided by the kernel's density probe
 };
 
 hipError_t launch_gram_scan(const GramDev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, hipStream_t stream);
@@ -128,6 +130,8 @@ struct Gram2Dev {
     const uint4 *drec_c;      // the same for `.count()`, single paths folded into tail records (gram2.hpp)
     const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}
     const uint2 *dhit_c;      // the same for `.count()`: {cmap | ends-a-pattern, first_child}
+    const uint4 *dhit_t;      // gram3 TAIL: the same as 16-byte records, single paths below a hit folded into a tail record
+    const uint4 *drec_t;      // gram3 TAIL: drec_c with tail records from depth K + 2 on
     const uint4 *dhit4;       // for count + checksum: {cmap, own_hsum, first_child, 0}
     const uint32_t *cfirst;   // depth-(K+1) states by rank: id of the first child
     uint32_t m_bytes, s_bytes, cid_bytes, h_bytes;  // multiples of 16
@@ -189,6 +193,16 @@ struct EmitArgs {
 };
 hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, int em, uint32_t blocks, hipStream_t stream);
 hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool exact, uint32_t blocks, uint32_t threads, hipStream_t stream);
+
+// `.count()` with lane-local hit masks and the step's text staged in LDS (gram3_kernels.hip); tables of Gram2Dev.
+struct Gram3Lds {
+    uint32_t off_s;        // rank directory (M sits at 256)
+    uint32_t off_wave;     // first wave's area: two text slots, then the hit queue
+    uint32_t wave_stride;
+    uint32_t lds_bytes, threads, rfull;
+};
+bool gram3_plan(const Gram2Dev &dev, uint32_t ppl, uint32_t waves, bool want_rfull, uint32_t lds_limit, Gram3Lds &L);
+hipError_t launch_gram3_scan(const Gram2Dev &dev, const GramArgs &a, const Gram3Lds &L, uint32_t blocks, hipStream_t stream);
 
 hipError_t launch_overlap_count(const DArrayDev &dev, const ScanArgs &a, bool heads, uint32_t blocks, hipStream_t stream);
 hipError_t launch_char_overlap_count(const CharDev &dev, const ScanArgs &a, bool heads, uint32_t blocks, hipStream_t stream);

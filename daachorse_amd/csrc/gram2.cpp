@@ -187,9 +187,11 @@ bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out)
             if (path_len[c] == 0xff || path_len[c] >= 8) continue;
             path_len[s] = static_cast<uint8_t>(path_len[c] + 1);
         }
+        out.drec_t = out.drec;
+        out.dhit_t.clear();
+        for (uint32_t s = out.level_start; s < out.level_start + out.dhit_c.size(); ++s) out.dhit_t.push_back(U32x4{out.dhit_c[s - out.level_start].x, out.dhit_c[s - out.level_start].y, 0u, 0u});
         for (uint32_t s = 0; s < N; ++s) {
-            // (not at depth K + 2, where the walkers start: most of them end there, and that record stays as cheap as it was)
-            if (depth[s] < out.K + 3 || path_len[s] == 0xff || path_len[s] == 0) continue;
+            if (depth[s] < out.K + 1 || path_len[s] == 0xff || path_len[s] == 0) continue;
             uint64_t bytes = 0;
             uint32_t ends = own_cnt[s] ? 1u : 0u, cur = s;
             const uint32_t first_class = static_cast<uint32_t>(__builtin_ctz(cmap[s] & kGram2MaskBits));
@@ -199,7 +201,12 @@ bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out)
                 cur = first_child[cur];
                 if (own_cnt[cur]) ends |= 2u << i;
             }
-            out.drec_c[s] = U32x4{0x80000000u | path_len[s] | (ends << 4) | (first_class << 13), 0u, static_cast<uint32_t>(bytes), static_cast<uint32_t>(bytes >> 32)};
+            const U32x4 tail{0x80000000u | path_len[s] | (ends << 4) | (first_class << 13), 0u, static_cast<uint32_t>(bytes), static_cast<uint32_t>(bytes >> 32)};
+            if (depth[s] == out.K + 1) out.dhit_t[s - out.level_start] = tail;
+            else out.drec_t[s] = tail;
+            // (`.count()` of gram2_kernels.hip: not at depth K + 2, where its walkers start — most of them end there, and that
+            // record stays as cheap as it was)
+            if (depth[s] >= out.K + 3) out.drec_c[s] = tail;
         }
     }
     out.available = true;

@@ -51,6 +51,9 @@ struct Gram2Tables {
     std::vector<U32x2> dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}; own_cnt == (own_hsum != 0)
     std::vector<U32x2> dhit_c;      // the same for `.count()`: {cmap | 1 if the state ends a pattern, first_child} (no second look-up)
     std::vector<uint32_t> cfirst;   // same order: first child id
+    // gram3_kernels.hip, TAIL: tail records wherever the trie below a state is one path — from the hit records on (16 bytes each:
+    // {cmap | ends-a-pattern, first_child, 0, 0} or a tail record) and in the walk records from depth K + 2 on
+    std::vector<U32x4> dhit_t, drec_t;
     uint32_t lds_count = 0, lds_exact = 0;  // table bytes in LDS per mode (without the hit rings)
 
     // ---- tuple emission (gram2_emit_kernels.hip): the same lookups, but every match has to come out as (start, end, value) ----

@@ -99,3 +99,81 @@ def test_cfg5_charwise_leftmost_longest():
         w = getattr(o0, api)(h2)
         assert _same(p0.scan(mode, two), w), api
         assert p0.scan_count(mode, two) == (len(w), orc.matches_checksum(w)), api
+
+
+def test_cfg2_full_256_mib():
+    """BASELINE configs[1] at its stated size: count + checksum and `.count()` of the whole 256 MiB random-ASCII haystack
+    (and of the dense pattern soup of the same size) against the oracle"""
+    import torch
+    pats = synth.patterns_cfg2()
+    o = orc.OraclePma.build(pats)
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    n = 256 << 20
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for kind in ("sparse", "dense"):
+        if kind == "sparse":
+            synth.device_uniform(dev, synth.SEEDS["cfg2_hay"], synth.ALPHA_PRINTABLE)
+        else:
+            synth.device_wordsoup(dev, synth.SEEDS["cfg2_dense"], pats, 13, noise_256=0)
+        want = o.overlapping_count(dev.cpu().numpy(), threads=16)
+        assert want[0] > 0
+        for eng in (Engine.Auto, Engine.Gram, Engine.Tiered):
+            assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want, (kind, eng)
+            assert p.count(ScanMode.FindOverlapping, dev, engine=eng) == want[0], (kind, eng)
+
+
+def test_cfg3_full_4_gib_count_and_checksum():
+    """SURVEY 8d, whole-haystack equality: (count, checksum) of ALL 4 GiB of the cfg3 haystack (BASELINE configs[2]) from the
+    count + checksum kernel and the count from the `.count()` kernel against the oracle (positions beyond 2^32 included)"""
+    import torch
+    pats = synth.patterns_cfg3()
+    o = orc.OraclePma.build(pats)
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    n = 4 << 30
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+    host = dev.cpu().numpy()
+    want = o.overlapping_count(host, threads=16)
+    del host
+    assert want[0] > 2_000_000_000
+    assert p.scan_count(ScanMode.FindOverlapping, dev) == want
+    assert da.last_engine() == int(Engine.Gram)
+    assert p.count(ScanMode.FindOverlapping, dev) == want[0]
+    for version, ppl in ((2, 0), (3, 16), (3, 32)):
+        da.set_option("gram_version", version)
+        da.set_option("gram_ppl", ppl)
+        try:
+            assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want[0], (version, ppl)
+        finally:
+            da.set_option("gram_version", 0)
+            da.set_option("gram_ppl", 0)
+
+
+def test_cfg3_count_kernel_on_a_vector_of_window_counts():
+    """The `.count()` kernel is observed through ONE integer per call; a missed match here and a double count there would cancel.
+    4 096 windows (begin, len) of random sizes and alignments over 64 MiB of the cfg3 haystack, each counted on its own
+    (`daac_scan_count_only_range`) and compared with the oracle's matches ending in (begin, len]."""
+    import torch
+    pats = synth.patterns_cfg3()
+    o = orc.OraclePma.build(pats)
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    n = 64 << 20
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+    ends = np.sort(o.find_overlapping_iter(dev.cpu().numpy())["end"].astype(np.int64))
+    rng = np.random.default_rng(4096)
+    los = rng.integers(0, n - (1 << 17), size=4096)
+    sizes = np.concatenate([rng.integers(1, 64, size=512), rng.integers(64, 4096, size=1536), rng.integers(4096, 1 << 17, size=2048)])
+    his = los + sizes
+    want = np.searchsorted(ends, his, side="right") - np.searchsorted(ends, los, side="right")
+    got = np.array([p.count(ScanMode.FindOverlapping, dev[:int(h)], begin=int(l)) for l, h in zip(los, his)])
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (bad[:8], got[bad[:8]], want[bad[:8]], los[bad[:8]], his[bad[:8]])
+    assert da.last_engine() == int(Engine.Gram)
+    # the lane-local-mask kernel on every eighth window
+    da.set_option("gram_version", 3)
+    try:
+        got3 = np.array([p.count(ScanMode.FindOverlapping, dev[:int(h)], begin=int(l), engine=Engine.Gram) for l, h in zip(los[::8], his[::8])])
+    finally:
+        da.set_option("gram_version", 0)
+    assert np.array_equal(got3, want[::8])
