@@ -38,6 +38,7 @@ class Engine(enum.IntEnum):
     Tiered = 1
     DArray = 2
     Gram = 3
+    Pfx = 4
 
 
 class Match:

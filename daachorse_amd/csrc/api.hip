@@ -17,6 +17,7 @@
 #include "gram.hpp"
 #include "gram2.hpp"
 #include "gram2w.hpp"
+#include "pfx.hpp"
 #include "pma.hpp"
 #include "repack.hpp"
 
@@ -42,6 +43,7 @@ struct Options {
     std::atomic<int64_t> gram_version{0};       // 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram3 on the v2 tables), 1 = v1 only,
                                                 // 2 = v2 tables with gram2_kernels.hip, 3 = v2 tables with gram3_kernels.hip for `.count()`
     std::atomic<int64_t> gram2_dpp{1};
+    std::atomic<int64_t> pfx{1};                // PFX engine: 1 = built for automata the GRAM tables do not serve, 2 = always, 0 = never (read at upload)
     std::atomic<int64_t> gram3_tail{-1};        // gram3: tail records from the hit record on (-1 = decide per launch)
     std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
     std::atomic<int64_t> emit{1};               // materialising overlapping scans: GRAM tuple emission where it applies (0: segment scanners)
@@ -141,6 +143,8 @@ struct DeviceTables {
     bool gram2_ok = false;     // second table set (gram2.hpp)
     Gram2Dev gram2{};
     bool gramw_ok = false;     // wide alphabets (gram2w.hpp)
+    bool pfx_ok = false;       // any byte alphabet, `.count()` (pfx.hpp)
+    PfxDev pfx{};
     Gram2WDev gramw{};
     bool emit_ok = false;      // tuple emission on the second table set (gram2_emit_kernels.hip)
     Gram2EmitDev emit{};
@@ -590,6 +594,28 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             d.C = gw.C; d.unused_byte = gw.unused_byte; d.n_deep = static_cast<uint32_t>(gw.dhit.size());
             d.exact_ok = gw.exact_available && kGram2OffH + gw.hsum.size() * 4 <= 65536 && d.lds_exact <= 160u * 1024u;
             t->gramw_ok = d.lds_count <= 160u * 1024u;
+        }
+    }
+    // PFX engine: `.count()` for every bytewise Standard automaton the GRAM tables do not serve (any alphabet); pfx = 2 builds it always
+    if (g_opt.pfx.load() == 2 || (g_opt.pfx.load() == 1 && !t->gram_ok && !t->gram2_ok && !t->gramw_ok)) {
+        PfxTables px;
+        if (build_pfx_tables(h, 160u * 1024u - 16u * (2u * 1040u + 512u), px)) {
+            PfxDev &d = t->pfx;
+            auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
+            px.disp.resize((px.disp.size() + 7) & ~size_t(7), 0);
+            const U32x4 *sl; const U32x2 *wr;
+            if ((st = t->put(px.bloom, d.bloom)) != DAAC_OK) return st;
+            if ((st = t->put(px.cnt1, d.cnt1)) != DAAC_OK) return st;
+            if ((st = t->put(px.disp, d.disp)) != DAAC_OK) return st;
+            if ((st = t->put(px.slots, sl)) != DAAC_OK) return st;
+            if ((st = t->put(px.wrec, wr)) != DAAC_OK) return st;
+            d.slots = reinterpret_cast<const uint4 *>(sl);
+            d.wrec = reinterpret_cast<const uint2 *>(wr);
+            d.G = px.G; d.has_len1 = px.has_len1; d.bloom_log2 = px.bloom_log2; d.buckets = px.buckets; d.slots_log2 = px.slots_log2;
+            d.seed = px.seed; d.n_keys = px.n_keys;
+            d.bloom_bytes = p16(px.bloom.size() * 4);
+            d.disp_bytes = p16(px.disp.size() * 2);
+            t->pfx_ok = pfx_plan(d, 160u * 1024u);
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -1199,6 +1225,13 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     const bool gw_can = t->gramw_ok && (!want_checksum || t->gramw.exact_ok);  // wide alphabets: built only where the others are not
     const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len - begin < (1ull << 35) &&
                           (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (g2_can || g1_can || gw_can)));
+    // PFX: `.count()` for automata over any byte alphabet — what AUTO takes where the GRAM tables do not apply
+    const bool use_pfx = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && !want_checksum && t->pfx_ok &&
+                         len - begin < (1ull << 35) && (engine == DAAC_ENGINE_PFX || (engine == DAAC_ENGINE_AUTO && !use_gram));
+    if (engine == DAAC_ENGINE_PFX && !use_pfx) {
+        set_error("PFX engine not available for this automaton / request (bytewise Standard automata without \"\", `.count()` of find_overlapping)");
+        return DAAC_ERR_UNSUPPORTED;
+    }
     if (engine == DAAC_ENGINE_GRAM && (!use_gram || !(g2_can || g1_can || gw_can))) {
         set_error("GRAM engine not available for this automaton / mode");
         return DAAC_ERR_UNSUPPORTED;
@@ -1222,7 +1255,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     const bool use_gw = use_gram && !g2_can && !g1_can && gw_can;
     Plan pl;
     bool heads = false;
-    if ((st = make_plan(pma, t, mode, use_gram ? DAAC_ENGINE_AUTO : engine, begin, len, pl, heads)) != DAAC_OK) return st;
+    if ((st = make_plan(pma, t, mode, (use_gram || use_pfx) ? DAAC_ENGINE_AUTO : engine, begin, len, pl, heads)) != DAAC_OK) return st;
     if (pl.a.nseg == 0 && begin == 0) pl.a.nseg = 1;  // ROOT's list at end = 0
     void *staged = nullptr;
     const uint8_t *dev_hay = hay;
@@ -1247,8 +1280,8 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         pl.a.flags = static_cast<unsigned long long *>(flagbuf);
     }
     std::unique_ptr<void, void (*)(void *)> g3(flagbuf, [](void *p) { if (p) (void)hipFree(p); });
-    g_last_engine = use_gram ? DAAC_ENGINE_GRAM : (pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY);
-    if (use_gram && len != begin) {
+    g_last_engine = use_pfx ? DAAC_ENGINE_PFX : use_gram ? DAAC_ENGINE_GRAM : (pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY);
+    if ((use_gram || use_pfx) && len != begin) {
         // A shard [begin, len) is scanned as a haystack of its own: that counts every occurrence lying inside it,
         // with ends relative to `begin`.  What is missing are the occurrences that start before `begin` and end
         // after it (at most Lmax - 1 bytes in); they are added below from a materialising scan of that sliver.
@@ -1262,9 +1295,9 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         // (second table set: 256 KiB regions once there are several per wave — a region's start costs a handful of dependent
         // loads and the refill of the prefetch pipeline: 64 KiB regions measured 2-6 % slower on 4 GiB)
         const int64_t region_opt = g_opt.gram_region.load() > 0 ? g_opt.gram_region.load()
-                                   : use_g2 ? ((len - begin) >= (1ull << 31) ? 262144 : 65536) : 16384;
+                                   : (use_g2 || use_pfx) ? ((len - begin) >= (1ull << 31) ? 262144 : 65536) : 16384;
         while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, region_opt)) && region < (1ull << 30)) region *= 2;
-        ga.ppl = use_g3 ? g3_ppl : (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
+        ga.ppl = use_pfx ? 16 : use_g3 ? g3_ppl : (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;
         ga.result = d_res;
@@ -1272,9 +1305,10 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         threads = std::min(1024u, std::max(64u, threads & ~63u));
         if (use_gw) threads = 1024;  // the wide kernel has one launch shape
         if (use_g3) threads = g3l.threads;
+        if (use_pfx) threads = t->pfx.threads;
         const uint32_t wpb = threads / 64;
         uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
-        const uint32_t gram_lds = use_g3 ? g3l.lds_bytes : use_gw ? (want_checksum ? t->gramw.lds_exact : t->gramw.lds_count)
+        const uint32_t gram_lds = use_pfx ? t->pfx.lds_bytes : use_g3 ? g3l.lds_bytes : use_gw ? (want_checksum ? t->gramw.lds_exact : t->gramw.lds_count)
                                          : use_g2 ? gram2_lds_bytes(t->gram2, want_checksum) : t->gram.lds_bytes;
         if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / gram_lds));
         const uint32_t blocks = static_cast<uint32_t>(
@@ -1291,10 +1325,11 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         // the option decides, every workgroup samples the haystack at its start and runs the variant the text calls for
         const int64_t tail_opt = g_opt.gram3_tail.load();
         void *wq = nullptr;
-        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * (use_g3 ? sizeof(uint4) : sizeof(uint2)), stream));
+        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * ((use_g3 || use_pfx) ? sizeof(uint4) : sizeof(uint2)), stream));
         ga.wq = static_cast<uint2 *>(wq);
         ga.sel_want = tail_opt < 0 ? ((len - begin) >= (1ull << 20) ? 2u : 0u) : tail_opt > 0 ? 1u : 0u;
-        const hipError_t le = use_g3 ? launch_gram3_scan(t->gram2, ga, g3l, blocks, stream)
+        const hipError_t le = use_pfx ? launch_pfx_scan(t->pfx, ga, blocks, stream)
+                              : use_g3 ? launch_gram3_scan(t->gram2, ga, g3l, blocks, stream)
                               : use_gw ? launch_gram2w_scan(t->gramw, ga, want_checksum, blocks, stream)
                               : use_g2 ? launch_gram2_scan(t->gram2, ga, want_checksum, blocks, threads, stream)
                                        : launch_gram_scan(t->gram, ga, blocks, threads, stream);
@@ -1314,7 +1349,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
                     const uint32_t h = match_hash32(m.value, static_cast<uint32_t>(m.end - m.start));
                     add[0] += 1; add[1] += h; add[2] += static_cast<uint32_t>(h * static_cast<uint32_t>(m.end));
                 }
-                g_last_engine = DAAC_ENGINE_GRAM;  // (the sliver's few bytes went through the segment scanners)
+                g_last_engine = use_pfx ? DAAC_ENGINE_PFX : DAAC_ENGINE_GRAM;  // (the sliver's few bytes went through the segment scanners)
             }
             // ends were relative to `begin`: S2 += low32(begin) * S1, then the sliver's tuples
             hipLaunchKernelGGL(shard_fixup_kernel, dim3(1), dim3(1), 0, stream, d_res, static_cast<unsigned long long>(begin & 0xffffffffull), add[0],
@@ -1643,6 +1678,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram2_dpp") g_opt.gram2_dpp = value;
     else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
     else if (n == "gram3_tail") g_opt.gram3_tail = value;
+    else if (n == "pfx") g_opt.pfx = value;
     else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles") g_opt.emit_tiles = value;

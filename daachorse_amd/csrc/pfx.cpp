@@ -1,0 +1,149 @@
+// PFX engine (host side) — see pfx.hpp.
+#include "pfx.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace daac {
+
+namespace {
+constexpr uint32_t kNone = 0xffffffffu;
+struct Key { uint32_t k0, k1, state; };
+}  // namespace
+
+bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
+    out = PfxTables{};
+    if (!p.is_standard()) return false;
+    const uint32_t n = static_cast<uint32_t>(p.states.size());
+    if (n == 0 || output_pos_of(p.states[kRoot].opos_ch) != 0) return false;  // "" is a pattern: left to the AC engines
+
+    // ---- breadth-first walk over the double array: depth and first bytes of every state ----
+    std::vector<uint32_t> depth(n, kNone), order{kRoot}, k0(n, 0), k1(n, 0);
+    depth[kRoot] = 0;
+    for (size_t qi = 0; qi < order.size(); ++qi) {
+        const uint32_t s = order[qi], base = p.states[s].base;
+        if (base == 0) continue;
+        for (uint32_t c = 0; c < 256; ++c) {
+            const uint32_t t = base ^ c;
+            if (t >= n || t == kRoot || check_of(p.states[t].opos_ch) != c) continue;
+            if (depth[t] != kNone) return false;  // not a tree
+            depth[t] = depth[s] + 1;
+            k0[t] = k0[s]; k1[t] = k1[s];
+            if (depth[s] < 4) k0[t] |= c << (8 * depth[s]); else if (depth[s] < 8) k1[t] |= c << (8 * (depth[s] - 4));
+            order.push_back(t);
+        }
+    }
+    // ---- patterns that END in a state (its own, not those of its suffixes): list entries as long as the state is deep ----
+    std::vector<uint32_t> own(n, 0);
+    uint32_t min_len2 = kNone;
+    bool has_len1 = false;
+    for (const uint32_t s : order) {
+        uint32_t op = output_pos_of(p.states[s].opos_ch);
+        while (op != 0 && p.outputs[op - 1].length == depth[s]) {
+            ++own[s];
+            op = p.outputs[op - 1].parent;
+        }
+        if (own[s] >= (1u << 24)) return false;
+        if (own[s] != 0) {
+            if (depth[s] == 1) has_len1 = true; else min_len2 = std::min(min_len2, depth[s]);
+        }
+    }
+    if (min_len2 == kNone) return false;  // one-byte patterns only: nothing for a prefix filter to do
+    const uint32_t G = std::min<uint32_t>(min_len2, 6);
+    out.G = G;
+    out.has_len1 = has_len1;
+
+    std::vector<Key> keys;
+    for (const uint32_t s : order)
+        if (depth[s] == G) keys.push_back(Key{k0[s], k1[s], s});
+    if (keys.empty()) return false;
+    const uint32_t nk = static_cast<uint32_t>(keys.size());
+    out.n_keys = nk;
+
+    // ---- sizes ----
+    out.buckets = std::max<uint32_t>(16, (nk + 4) / 5);
+    uint32_t slots_log2 = 4;
+    while ((1ull << slots_log2) < 3ull * nk) ++slots_log2;  // load <= 1/3
+    out.slots_log2 = slots_log2;
+    const uint32_t disp_bytes = (out.buckets * 2 + 15) & ~15u;
+    uint32_t bloom_log2 = 14;  // 64 KB
+    while (bloom_log2 > 8 && (4u << bloom_log2) + disp_bytes + 512 > lds_budget) --bloom_log2;
+    while (bloom_log2 > 8 && (32ull << (bloom_log2 - 1)) >= 64ull * nk) --bloom_log2;  // (no point in more than 64 bits per key)
+    if ((4u << bloom_log2) + disp_bytes + 512 > lds_budget) return false;
+    out.bloom_log2 = bloom_log2;
+    out.lds_tables = (4u << bloom_log2) + disp_bytes + 512;
+
+    // ---- BLOOM: word = top bits of m, bit = the five bits below ----
+    out.bloom.assign(1u << bloom_log2, 0);
+    for (const Key &k : keys) {
+        const uint32_t m = k.k0 * kPfxMulBloom0 + k.k1 * kPfxMulBloom1;
+        out.bloom[m >> (32 - bloom_log2)] |= 1u << ((m >> (27 - bloom_log2)) & 31u);
+    }
+    // ---- CNT1 ----
+    out.cnt1.assign(256, 0);
+    for (const uint32_t s : order)
+        if (depth[s] == 1) {
+            if (own[s] > 0xffff) return false;
+            out.cnt1[k0[s] & 0xffu] = static_cast<uint16_t>(own[s]);
+        }
+
+    // ---- hash and displace ----
+    const uint32_t M = 1u << slots_log2;
+    bool placed = false;
+    for (uint32_t seed = 0; seed < 16 && !placed; ++seed) {
+        std::vector<std::vector<uint32_t>> bucket(out.buckets);
+        for (uint32_t i = 0; i < nk; ++i) {
+            const uint32_t mb = keys[i].k0 * kPfxMulBucket0 + (keys[i].k1 ^ seed) * kPfxMulBucket1;
+            bucket[static_cast<uint32_t>((static_cast<uint64_t>(mb) * out.buckets) >> 32)].push_back(i);
+        }
+        std::vector<uint32_t> by_size(out.buckets);
+        std::iota(by_size.begin(), by_size.end(), 0u);
+        std::stable_sort(by_size.begin(), by_size.end(), [&](uint32_t a, uint32_t b) { return bucket[a].size() > bucket[b].size(); });
+        std::vector<uint8_t> used(M, 0);
+        std::vector<uint16_t> disp(out.buckets, 0);
+        std::vector<uint32_t> slot_of(nk, 0);
+        bool ok = true;
+        for (const uint32_t b : by_size) {
+            const auto &ks = bucket[b];
+            if (ks.empty()) break;
+            std::vector<uint32_t> home(ks.size());
+            for (size_t j = 0; j < ks.size(); ++j) {
+                const uint32_t ms = keys[ks[j]].k0 * kPfxMulSlot0 + (keys[ks[j]].k1 ^ seed) * kPfxMulSlot1;
+                home[j] = ms >> (32 - slots_log2);
+            }
+            bool found = false;
+            for (uint32_t d = 0; d < 65536 && !found; ++d) {
+                bool fits = true;
+                for (size_t j = 0; j < ks.size() && fits; ++j) {
+                    const uint32_t sl = (home[j] + d) & (M - 1);
+                    if (used[sl]) fits = false;
+                    for (size_t j2 = 0; j2 < j && fits; ++j2) fits = ((home[j2] + d) & (M - 1)) != sl;
+                }
+                if (!fits) continue;
+                for (size_t j = 0; j < ks.size(); ++j) { const uint32_t sl = (home[j] + d) & (M - 1); used[sl] = 1; slot_of[ks[j]] = sl; }
+                disp[b] = static_cast<uint16_t>(d);
+                found = true;
+            }
+            if (!found) { ok = false; break; }
+        }
+        if (!ok) continue;
+        out.seed = seed;
+        out.disp = std::move(disp);
+        out.slots.assign(M, U32x4{0u, 0x80000000u, 0u, 0u});
+        for (uint32_t i = 0; i < nk; ++i) out.slots[slot_of[i]] = U32x4{keys[i].k0, keys[i].k1, p.states[keys[i].state].base, own[keys[i].state]};
+        placed = true;
+    }
+    if (!placed) return false;
+
+    // ---- WREC ----
+    out.wrec.resize(n);
+    for (uint32_t s = 0; s < n; ++s) {
+        // vacant slots keep a CHECK no transition can produce (builder.rs:391-400): they are copied as they are, with nothing ending there
+        const uint32_t o = depth[s] != kNone ? own[s] : 0u;
+        out.wrec[s] = U32x2{p.states[s].base, static_cast<uint32_t>(check_of(p.states[s].opos_ch)) | (o << 8)};
+    }
+    out.available = true;
+    return true;
+}
+
+}  // namespace daac

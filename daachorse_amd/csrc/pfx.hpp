@@ -1,0 +1,57 @@
+// PFX engine (host side): `.count()` of find_overlapping_iter for bytewise Standard automata over ANY byte alphabet.
+//
+// The GRAM engines enumerate every K-gram of byte CLASSES in LDS, which ties them to dictionaries of at most 62 distinct
+// bytes.  The transition function they replace has no such limit (reference src/bytewise.rs:1063-1088), and two of the four
+// dictionaries the crate publishes numbers for are wide (UTF-8 Japanese, o200k_base: figures/overlapping.txt).  PFX looks at
+// occurrences from their START instead (SURVEY §8a note C: a start-parallel formulation is exact for the overlapping stream):
+//
+//   G            = min(length of the shortest pattern of two or more bytes, 6): every such pattern begins with a depth-G trie path
+//   BLOOM        one bit per hashed G-gram that is a depth-G trie path (64 KB of LDS, one lookup per haystack byte): a position
+//                whose next G bytes fail it starts no pattern of two or more bytes;
+//   CNT1[256]    patterns of ONE byte, counted per haystack byte straight from LDS (only when the dictionary has any);
+//   DISP / SLOTS a hash-and-displace perfect hash of the depth-G paths: DISP (u16 per bucket, LDS) + ONE 16-byte record from L2
+//                {bytes 0-3, bytes 4-5, BASE of the depth-G state, patterns that ARE this path}: a survivor of the filter is
+//                settled by that one gather — a false positive shows as a key mismatch;
+//   WREC         the double array itself as 8-byte records {BASE, CHECK | patterns that end in this state << 8}: the branches
+//                that go on below depth G walk it goto-only (child = BASE ^ byte, CHECK == byte, bytewise.rs:1070-1077),
+//                no failure links: an occurrence is a root path, and every state met on it adds the patterns that end there.
+//
+// The count is exact: every occurrence starts at exactly one position, is found from there, and is counted once with its
+// multiplicity (duplicate patterns: `own` > 1).  Needs: Standard kind, no "" pattern, at least one pattern of two or more bytes.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "repack.hpp"
+
+namespace daac {
+
+constexpr uint32_t kPfxMulBloom0 = 0x9E3779B1u, kPfxMulBloom1 = 0x85EBCA77u;   // Bloom word / bit:      m = k0 * A0 + k1 * A1
+constexpr uint32_t kPfxMulBucket0 = 0xC2B2AE3Du, kPfxMulBucket1 = 0x27D4EB2Fu; // bucket of DISP:         (uint64(mb) * buckets) >> 32
+constexpr uint32_t kPfxMulSlot0 = 0x165667B1u, kPfxMulSlot1 = 0xD3A2646Du;     // home slot:              ms >> (32 - slots_log2)
+
+struct PfxTables {
+    bool available = false;
+    uint32_t G = 0;                  // bytes of a key
+    bool has_len1 = false;           // the dictionary has one-byte patterns (CNT1 is looked at)
+    uint32_t bloom_log2 = 0;         // words of BLOOM = 1 << bloom_log2
+    uint32_t buckets = 0;            // entries of DISP
+    uint32_t slots_log2 = 0;         // entries of SLOTS = 1 << slots_log2
+    uint32_t seed = 0;               // xor-ed into the second operand of the bucket / slot hashes (changed until the displacement search succeeds)
+    uint32_t n_keys = 0;
+    std::vector<uint32_t> bloom;
+    std::vector<uint16_t> cnt1;      // 256
+    std::vector<uint16_t> disp;
+    std::vector<U32x4> slots;        // {k0, k1 (an empty slot: 1 << 31), base, own}
+    std::vector<U32x2> wrec;         // per double-array slot {base, check | own << 8}
+    uint32_t lds_tables = 0;         // BLOOM + CNT1 + DISP bytes
+};
+
+inline uint32_t pfx_mask0(uint32_t G) { return G >= 4 ? 0xffffffffu : ((1u << (8 * G)) - 1u); }
+inline uint32_t pfx_mask1(uint32_t G) { return G <= 4 ? 0u : ((1u << (8 * (G - 4))) - 1u); }
+
+// `lds_budget`: bytes the three LDS tables may take.  Returns false if the automaton does not qualify.
+bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out);
+
+}  // namespace daac

@@ -1,0 +1,322 @@
+// PFX engine kernels (gfx950): `.count()` of the find_overlapping stream for bytewise automata over ANY byte alphabet.
+// Tables and method: pfx.hpp.  Occurrences are found from their START (SURVEY §8a note C): every position hashes its next
+// G bytes into a Bloom bitmap in LDS (one lookup per haystack byte, no byte classes); the survivors are queued, looked up in a
+// perfect hash of the depth-G trie paths (one displacement from LDS, one 16-byte record from L2) and, where the trie goes on
+// below depth G, walked goto-only over the double array (child = BASE ^ byte, CHECK == byte: reference src/bytewise.rs:1070-1077)
+// adding the patterns that end in every state on the way.  One-byte patterns are a 256-entry table in LDS.
+//
+// The skeleton is gram3_kernels.hip's: 16 positions per lane and step, coalesced 16-byte non-temporal haystack loads two steps
+// ahead, the step's kilobyte of text written to an LDS slot (plus the sixteen bytes behind it) so that the consumer — 64
+// survivors wide — takes keys and follow-up text from LDS, lane-local hit masks queued one set bit per lane and turn, one batch
+// of records in flight, walkers in per-wave slabs.
+//
+// Roofline: HBM bytes of haystack (1 B read per byte); integer work only, no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_tables.hpp"
+#include "pfx.hpp"
+
+namespace daac {
+
+namespace {
+
+typedef uint32_t px_u32x4_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t kRingP = 128;     // entries of a wave's survivor queue (FIFO; at most 63 left over + 64 new)
+typedef __attribute__((address_space(3))) const uint32_t ldsp_cu32;
+typedef __attribute__((address_space(3))) uint32_t ldsp_u32;
+typedef __attribute__((address_space(3))) const uint16_t ldsp_cu16;
+typedef __attribute__((address_space(3))) px_u32x4_t ldsp_u32x4;
+
+// lane i <- lane i + 1 of `v`; lane 63 keeps `lane63`
+__device__ __forceinline__ uint32_t wave_shl1_p(uint32_t v, uint32_t lane63) {
+    uint32_t d = lane63;
+    asm volatile("s_nop 1\nv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(v));
+    return d;
+}
+__device__ __forceinline__ unsigned long long px_wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ void px_copy(void *dst, const void *src, uint32_t bytes) {
+    const uint4 *s = reinterpret_cast<const uint4 *>(src);
+    uint4 *d = reinterpret_cast<uint4 *>(dst);
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+
+}  // namespace
+
+// G = key bytes (2 .. 6); LEN1 = the dictionary has one-byte patterns
+template <int G, bool LEN1, int TPB>
+__global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs a) {
+    constexpr int P = 16;
+    constexpr uint32_t SB = 64u * P;          // bytes a wave takes per step
+    constexpr uint32_t SLOT = SB + 16u;       // the step | 16 bytes of the next
+    constexpr uint32_t KMASK0 = G >= 4 ? 0xffffffffu : ((1u << (8 * (G & 3))) - 1u);
+    constexpr uint32_t KMASK1 = G <= 4 ? 0u : ((1u << (8 * ((G - 4) & 3))) - 1u);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    px_copy(smem, g.bloom, g.bloom_bytes);
+    px_copy(smem + g.off_disp, g.disp, g.disp_bytes);
+    px_copy(smem + g.off_cnt1, g.cnt1, 512);
+    __syncthreads();
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // tables are read through absolute LDS addresses
+    auto lds_u32 = [&](uint32_t addr) -> uint32_t { return *reinterpret_cast<ldsp_cu32 *>(static_cast<uintptr_t>(addr)); };
+    auto lds_u16 = [&](uint32_t addr) -> uint32_t { return *reinterpret_cast<ldsp_cu16 *>(static_cast<uintptr_t>(addr)); };
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint8_t *__restrict__ hay = a.hay_al;
+    const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
+    const uint32_t sh_word = 30u - g.bloom_log2, sh_bit = 27u - g.bloom_log2, sh_slot = 32u - g.slots_log2, slot_mask = (1u << g.slots_log2) - 1u;
+    const uint32_t tb = g.off_wave + wave_in_wg * g.wave_stride;   // this wave's LDS: two text slots, then the survivor queue
+    const uint32_t ringb = tb + 2u * SLOT;
+    // this wave's slab of pending walkers: {low 32 bits of the virtual position of the key's first byte, BASE of the depth-G state,
+    // the six text bytes behind the key}
+    uint4 *__restrict__ slab = reinterpret_cast<uint4 *>(a.wq) + (static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg) * a.wq_slab;
+    uint32_t wq_n = 0, slab_hi = 0;  // wave-uniform
+
+    unsigned long long tot_cnt = 0;
+    uint32_t cnt32 = 0;
+
+    auto load_chunk = [&](uint64_t v) -> uint4 {
+        if (v >= a.vlen) return uint4{0u, 0u, 0u, 0u};
+        const px_u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const px_u32x4_t *>(hay + v));
+        return uint4{q.x, q.y, q.z, q.w};  // (bytes outside [lead, vlen) are whatever memory holds: starts there are masked out)
+    };
+    auto read_ahead = [&](uint64_t v) -> unsigned long long {
+        unsigned long long x;
+        if (v + 8 <= a.vlen) {
+            __builtin_memcpy(&x, hay + v, 8);
+        } else {
+            x = 0;
+            for (int b = 7; b >= 0; --b) x = (x << 8) | ((v + b < a.vlen) ? hay[v + b] : 0u);
+        }
+        return x;
+    };
+
+    // Finishes the queued branches, 64 at a time: goto-only over the double array, every state met adds the patterns that end in it
+    auto drain = [&]() {
+        for (uint32_t base_i = 0; base_i < wq_n; base_i += 64u) {
+            const uint32_t i = base_i + lane;
+            uint4 e = uint4{0u, 0u, 0u, 0u};
+            if (i < wq_n) e = slab[i];
+            uint64_t vn = ((static_cast<uint64_t>(slab_hi) << 32) | e.x) + G;  // the next byte to take
+            uint32_t b = e.y, n_ahead = 6;
+            unsigned long long ah = (static_cast<unsigned long long>(e.w) << 32) | e.z;
+            while (b != 0 && vn < a.vlen) {
+                if (n_ahead == 0) { ah = read_ahead(vn); n_ahead = 8; }
+                const uint32_t c = static_cast<uint32_t>(ah) & 0xffu;
+                const uint2 r = g.wrec[b ^ c];
+                if ((r.y & 0xffu) != c) break;
+                cnt32 += r.y >> 8;
+                b = r.x;
+                ++vn;
+                ah >>= 8;
+                --n_ahead;
+            }
+        }
+        wq_n = 0;
+    };
+
+    // ---- the survivor queue: entry = LDS address of the key's first byte in one of the wave's two text slots
+    uint32_t q_head = 0, q_tail = 0;   // wave-uniform, free running
+    uint32_t posbias0 = 0, posbias1 = 0;  // per slot: (low 32 bits of the virtual position of a byte) - (its LDS address)
+    uint4 pend = uint4{0u, 0x80000000u, 0u, 0u};  // the record read for the previous batch {key bytes 0-3, 4-5, BASE, patterns that are the key}
+    uint32_t pend_pos = 0, pend_k0 = 0, pend_k1 = 0, pend_t0 = 0, pend_t1 = 0;
+    bool pend_valid = false;           // wave-uniform
+    auto consume_pending = [&]() {
+        if (!pend_valid) return;
+        pend_valid = false;
+        const uint4 r = pend;
+        const bool match = r.x == pend_k0 && r.y == pend_k1;  // (an empty slot and an idle lane carry 1 << 31 in r.y)
+        cnt32 += match ? r.w : 0u;
+        const bool go = match && r.z != 0;
+        const unsigned long long m = __ballot(go);
+        if (m != 0) {
+            if (go) {
+                const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+                slab[at] = uint4{pend_pos, r.z, pend_t0, pend_t1};
+            }
+            wq_n += __popcll(m);
+        }
+    };
+    auto process_batch = [&](uint32_t n) {  // n <= 64 entries from the head of the queue
+        __builtin_amdgcn_s_setprio(2);
+        consume_pending();
+        pend = uint4{0u, 0x80000000u, 0u, 0u};
+        if (lane < n) {
+            const uint32_t e = lds_u32(ringb + (((q_head + lane) & (kRingP - 1u)) << 2));
+            pend_pos = e + ((e - tb) >= SLOT ? posbias1 : posbias0);
+            const uint32_t a0 = e & ~3u, sh = e & 3u;
+            // (slots are self-contained: the key and the six bytes behind it never reach past slot + SLOT)
+            const uint32_t d0 = lds_u32(a0), d1 = lds_u32(a0 + 4u), d2 = lds_u32(a0 + 8u), d3 = lds_u32(a0 + 12u);
+            const uint32_t x0 = __builtin_amdgcn_alignbyte(d1, d0, sh), x1 = __builtin_amdgcn_alignbyte(d2, d1, sh), x2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            const uint32_t key0 = x0 & KMASK0, key1 = x1 & KMASK1;
+            pend_k0 = key0;
+            pend_k1 = key1;
+            // the six bytes from s + G on
+            if (G == 4) { pend_t0 = x1; pend_t1 = x2; }
+            else if (G < 4) { pend_t0 = __builtin_amdgcn_alignbyte(x1, x0, G & 3); pend_t1 = __builtin_amdgcn_alignbyte(x2, x1, G & 3); }
+            else { pend_t0 = __builtin_amdgcn_alignbyte(x2, x1, G & 3); pend_t1 = x2 >> (8 * (G & 3)); }
+            const uint32_t mb = key0 * kPfxMulBucket0 + (key1 ^ g.seed) * kPfxMulBucket1;
+            const uint32_t ms = key0 * kPfxMulSlot0 + (key1 ^ g.seed) * kPfxMulSlot1;
+            const uint32_t bucket = __umulhi(mb, g.buckets);
+            const uint32_t d = lds_u16(g.off_disp + (bucket << 1));
+            pend = g.slots[((ms >> sh_slot) + d) & slot_mask];
+        }
+        q_head += n;
+        pend_valid = true;
+    };
+
+    uint32_t sl = 0;          // slot of the current step (wave-uniform)
+    uint32_t carry_in = 0;    // queued entries that belong to the step before the current one
+    uint64_t region = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg;
+    // starts are valid in [lead, vlen - G]
+    const uint64_t start_end = a.vlen >= static_cast<uint64_t>(G) ? a.vlen - G + 1 : 0;
+    while (region < a.nregions) {
+      slab_hi = static_cast<uint32_t>((region * a.region_bytes) >> 32);
+      for (; region < a.nregions && static_cast<uint32_t>((region * a.region_bytes) >> 32) == slab_hi; region += nwaves) {
+        const uint64_t rbase = region * a.region_bytes;
+        const uint64_t rend = rbase + a.region_bytes < a.vlen ? rbase + a.region_bytes : a.vlen;
+        // the chunk of the step at s0; past the region's end only lane 0's (it feeds the last step's trailer and lane 63's keys)
+        auto fetch = [&](uint64_t s0) -> uint4 {
+            if (s0 < rend) return load_chunk(s0 + lane * P);
+            if (lane == 0 && s0 < rend + SB) return load_chunk(s0);
+            return uint4{0u, 0u, 0u, 0u};
+        };
+        uint4 pf0 = fetch(rbase), pf1 = fetch(rbase + SB);
+
+        for (uint64_t sb = rbase; sb < rend; sb += SB) {
+            if (wq_n + 64u * P + 128u > a.wq_slab) drain();
+            const uint64_t v = sb + lane * P;
+            const uint4 cur = pf0;
+            pf0 = pf1;
+            consume_pending();  // before the next chunk is requested: loads retire in order
+            __builtin_amdgcn_s_setprio(0);
+            pf1 = fetch(sb + 2ull * SB);
+
+            // ---- this step's text into its slot ----
+            const uint32_t slot = tb + sl * SLOT;                 // wave-uniform
+            const uint32_t my_text = slot + lane * P;             // LDS address of this lane's first byte
+            {
+                const uint32_t bias = static_cast<uint32_t>(sb) - slot;
+                if (sl) posbias1 = bias; else posbias0 = bias;
+            }
+            *reinterpret_cast<ldsp_u32x4 *>(static_cast<uintptr_t>(my_text)) = px_u32x4_t{cur.x, cur.y, cur.z, cur.w};
+            if (lane == 0) *reinterpret_cast<ldsp_u32x4 *>(static_cast<uintptr_t>(slot + SB)) = px_u32x4_t{pf0.x, pf0.y, pf0.z, pf0.w};
+
+            // ---- keys: the G bytes from each of this lane's 16 positions on (the last ones reach into the next lane's chunk) ----
+            uint32_t W[6] = {cur.x, cur.y, cur.z, cur.w, 0u, 0u};
+            W[4] = wave_shl1_p(cur.x, __builtin_amdgcn_readfirstlane(pf0.x));
+            W[5] = wave_shl1_p(cur.y, __builtin_amdgcn_readfirstlane(pf0.y));
+            uint32_t H = 0, c1 = 0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int q = j >> 2, r = j & 3;
+                uint32_t k0 = r == 0 ? W[q] : __builtin_amdgcn_alignbyte(W[q + 1], W[q], static_cast<uint32_t>(r));
+                if (G < 4) k0 &= KMASK0;
+                uint32_t m = k0 * kPfxMulBloom0;
+                if (G > 4) {
+                    uint32_t k1 = r == 0 ? W[q + 1] : __builtin_amdgcn_alignbyte(W[q + 2], W[q + 1], static_cast<uint32_t>(r));
+                    k1 &= KMASK1;
+                    m += k1 * kPfxMulBloom1;
+                }
+                const uint32_t word = lds_u32((m >> sh_word) & ~3u);   // BLOOM sits at LDS offset 0
+                H |= __builtin_amdgcn_ubfe(word, m >> sh_bit, 1) << j;
+                if (LEN1) c1 += lds_u16(g.off_cnt1 + (((W[q] >> (8 * r)) & 0xffu) << 1));
+            }
+            // starts before the haystack's first byte or too close to its end do not count (first / last step only)
+            if (v < a.lead || sb + SB + G > a.vlen + 1 || (LEN1 && sb + SB > a.vlen)) {
+                const uint64_t lo = a.lead > v ? a.lead - v : 0, hi = start_end > v ? start_end - v : 0;
+                uint32_t keep = hi >= 16 ? 0xffffu : ((1u << hi) - 1u);
+                keep &= lo >= 16 ? 0u : ~((1u << lo) - 1u);
+                H &= keep;
+                if (LEN1) {
+                    c1 = 0;
+                    for (int j = 0; j < P; ++j)
+                        if (v + j >= a.lead && v + j < a.vlen) c1 += lds_u16(g.off_cnt1 + (((W[j >> 2] >> (8 * (j & 3))) & 0xffu) << 1));
+                }
+            }
+            cnt32 += c1;
+
+            // ---- queue the survivors, one per lane and turn ----
+            bool did_batch = false;
+            for (;;) {
+                const bool has = H != 0;
+                const unsigned long long m = __ballot(has);
+                if (m == 0) break;
+                if (has) {
+                    const uint32_t b = static_cast<uint32_t>(__builtin_ctz(H));
+                    H &= H - 1u;
+                    const uint32_t at = q_tail + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+                    *reinterpret_cast<ldsp_u32 *>(static_cast<uintptr_t>(ringb + ((at & (kRingP - 1u)) << 2))) = my_text + b;
+                }
+                q_tail += static_cast<uint32_t>(__popcll(m));
+                if (q_tail - q_head >= 64u) { process_batch(64u); did_batch = true; }
+            }
+            // whatever was queued a step ago must be gone before its slot is written again
+            if (carry_in != 0 && !did_batch) process_batch(q_tail - q_head);
+            carry_in = q_tail - q_head;
+            sl ^= 1u;
+        }
+        tot_cnt += cnt32;  // per region: 32 bits cannot overflow within one
+        cnt32 = 0;
+      }
+      if (q_tail != q_head) process_batch(q_tail - q_head);
+      carry_in = 0;
+      consume_pending();
+      drain();
+      tot_cnt += cnt32;
+      cnt32 = 0;
+    }
+    {
+        const unsigned long long c = px_wave_sum(tot_cnt);
+        __syncthreads();
+        unsigned long long *scratch = reinterpret_cast<unsigned long long *>(smem);
+        if (lane == 0) scratch[wave_in_wg] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long r0 = 0;
+            for (int w = 0; w < static_cast<int>((blockDim.x + 63) >> 6); ++w) r0 += scratch[w];
+            if (r0) atomicAdd(a.result, r0);
+        }
+    }
+}
+
+template <int G, bool LEN1>
+static hipError_t launch_pfx_inst(const PfxDev &dev, const GramArgs &a, uint32_t blocks, hipStream_t stream) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfx_kernel<G, LEN1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(dev.lds_bytes));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((pfx_kernel<G, LEN1, 1024>), dim3(blocks), dim3(1024), dev.lds_bytes, stream, dev, a);
+    return hipGetLastError();
+}
+template <int G>
+static hipError_t launch_pfx_g(const PfxDev &dev, const GramArgs &a, uint32_t blocks, hipStream_t stream) {
+    return dev.has_len1 ? launch_pfx_inst<G, true>(dev, a, blocks, stream) : launch_pfx_inst<G, false>(dev, a, blocks, stream);
+}
+
+// LDS plan: BLOOM at 0, DISP, CNT1, then 16 waves x (two text slots + the survivor queue)
+bool pfx_plan(PfxDev &d, uint32_t lds_limit) {
+    d.off_disp = d.bloom_bytes;
+    d.off_cnt1 = d.off_disp + d.disp_bytes;
+    d.off_wave = d.off_cnt1 + 512u;
+    d.wave_stride = 2u * (1024u + 16u) + kRingP * 4u;
+    d.lds_bytes = d.off_wave + 16u * d.wave_stride;
+    d.threads = 1024;
+    return d.lds_bytes <= lds_limit;
+}
+
+hipError_t launch_pfx_scan(const PfxDev &dev, const GramArgs &a, uint32_t blocks, hipStream_t stream) {
+    switch (dev.G) {
+        case 2: return launch_pfx_g<2>(dev, a, blocks, stream);
+        case 3: return launch_pfx_g<3>(dev, a, blocks, stream);
+        case 4: return launch_pfx_g<4>(dev, a, blocks, stream);
+        case 5: return launch_pfx_g<5>(dev, a, blocks, stream);
+        default: return launch_pfx_g<6>(dev, a, blocks, stream);
+    }
+}
+
+}  // namespace daac

@@ -139,6 +139,32 @@ def patterns_cfg3(n=100_000, seed=SEEDS["cfg3_pat"]):
 
 # A 60-class variant of the cfg3 dictionary (dictionaries beyond 31 byte classes): the same words in lower,
 # Capitalised or UPPER case (by a hash of the index), a quarter of them followed by a digit 0-7.  26 + 26 + 8 = 60 pattern bytes.
+ALPHA_BYTES = bytes(range(256))                       # binary256: every byte value
+SEEDS["bin_pat"], SEEDS["bin_hay"] = 0xDAAC0006, 0xDAAC0016
+
+
+def patterns_binary256(n=100_000, seed=SEEDS["bin_pat"]):
+    """n distinct binary patterns: length uniform 3..12, bytes uniform over all 256 values (a dictionary no byte-class engine serves)"""
+    seen, out, j = set(), [], 0
+    batch = 1 << 15
+    while len(out) < n:
+        idx = np.arange(j, j + batch, dtype=np.uint64)
+        j += batch
+        z0 = zstream(seed, idx * np.uint64(3))
+        lengths = (3 + (z0 % np.uint64(10))).astype(np.int64)
+        sh = (np.arange(8, dtype=np.uint64) * np.uint64(8))[None, :]
+        raw = np.concatenate([(zstream(seed, idx * np.uint64(3) + np.uint64(t))[:, None] >> sh) & np.uint64(0xFF) for t in (1, 2)],
+                             axis=1).astype(np.uint8)
+        for row, length in zip(raw, lengths):
+            w = row[:length].tobytes()
+            if w not in seen:
+                seen.add(w)
+                out.append(w)
+                if len(out) == n:
+                    break
+    return out
+
+
 ALPHA_WIDE = ALPHA_LOWER + bytes(range(ord("A"), ord("Z") + 1)) + b"01234567"
 ALPHA_WIDE_SPACE = ALPHA_WIDE + b" "
 

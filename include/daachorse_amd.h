@@ -56,7 +56,9 @@ typedef enum {
     DAAC_ENGINE_AUTO = 0,
     DAAC_ENGINE_TIERED = 1, /* re-packed bitmap-rank trie, top levels dense in LDS */
     DAAC_ENGINE_DARRAY = 2, /* the reference's own double array, hot/cold split   */
-    DAAC_ENGINE_GRAM = 3    /* k-gram context tables in LDS, no state chain: count / checksum, and tuples of FIND_OVERLAPPING */
+    DAAC_ENGINE_GRAM = 3,   /* k-gram context tables in LDS, no state chain: count / checksum, and tuples of FIND_OVERLAPPING */
+    DAAC_ENGINE_PFX = 4     /* hashed prefix filter in LDS + goto-only walks from the start of an occurrence: `.count()` of
+                             * FIND_OVERLAPPING for dictionaries over any byte alphabet (what AUTO takes where GRAM's byte classes run out) */
 } daac_engine;
 
 /* Match<u32> (src/lib.rs:286-320): start() = end - length, end(), value() */

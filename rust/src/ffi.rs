@@ -1,0 +1,134 @@
+//! `extern "C"` mirror of include/daachorse_amd.h (ABI version 3).  Plain pointers and sizes only.
+#![allow(non_camel_case_types)]
+use core::ffi::{c_char, c_void};
+
+pub const DAAC_ABI_VERSION: u32 = 3;
+
+/// daac_status
+pub const DAAC_OK: i32 = 0;
+pub const DAAC_ERR_MATCH_KIND: i32 = 5; // the crate's assert! panics (bytewise.rs:194-197, 299-302, 415-418, 551-554)
+pub const DAAC_ERR_UNSUPPORTED: i32 = 6;
+/// daac_scan_mode
+pub const DAAC_FIND_OVERLAPPING: i32 = 0; // FindOverlappingIterator          bytewise/iter.rs:117-177
+pub const DAAC_FIND: i32 = 1; //              FindIterator                     bytewise/iter.rs:44-114
+pub const DAAC_LEFTMOST_FIND: i32 = 2; //     LeftmostFindIterator             bytewise/iter.rs:247-341
+pub const DAAC_FIND_OVERLAPPING_NO_SUFFIX: i32 = 3; // FindOverlappingNoSuffixIterator bytewise/iter.rs:180-244
+pub const DAAC_ENGINE_AUTO: i32 = 0;
+
+/// Match<u32> as the library reports it (src/lib.rs:286-320: start() = end - length)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct daac_match {
+    pub start: u64,
+    pub end: u64,
+    pub value: u32,
+    pub _pad: u32,
+}
+/// the 16-byte device tuple of daac_scan_device16: the crate's own `Match` fields (src/lib.rs:287-291)
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct daac_match16 {
+    pub end: u64,
+    pub length: u32,
+    pub value: u32,
+}
+#[repr(C)]
+pub struct daac_pma {
+    _p: [u8; 0],
+}
+#[repr(C)]
+pub struct daac_iter {
+    _p: [u8; 0],
+}
+
+#[link(name = "daachorse_amd")]
+extern "C" {
+    pub fn daac_abi_version() -> u32;
+    pub fn daac_last_error() -> *const c_char;
+    pub fn daac_bytewise_from_serialized(blob: *const u8, len: usize, out: *mut *mut daac_pma, consumed: *mut usize) -> i32;
+    pub fn daac_bytewise_from_parts(states: *const u32, n_states: usize, lstates: *const u32, fails: *const u32, n_lstates: usize,
+                                    outputs: *const u32, n_outputs: usize, match_kind: u8, num_states: u32, out: *mut *mut daac_pma) -> i32;
+    pub fn daac_charwise_from_serialized(blob: *const u8, len: usize, out: *mut *mut daac_pma, consumed: *mut usize) -> i32;
+    pub fn daac_pma_upload(pma: *mut daac_pma, device: i32) -> i32;
+    pub fn daac_pma_free(pma: *mut daac_pma);
+    pub fn daac_iter_open(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,
+                          stream: *mut c_void, out: *mut *mut daac_iter) -> i32;
+    pub fn daac_iter_next(it: *mut daac_iter, m: *mut daac_match) -> i32; // 1 = Some, 0 = None, < 0 = -daac_status
+    pub fn daac_iter_close(it: *mut daac_iter);
+    pub fn daac_scan_count_only_range(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, begin: usize,
+                                      hay_is_device: i32, stream: *mut c_void, count: *mut u64, result_dev: *mut u64) -> i32;
+    pub fn daac_scan_count(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,
+                           stream: *mut c_void, count: *mut u64, checksum: *mut u64, result_dev: *mut u64) -> i32;
+    pub fn daac_scan_device(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,
+                            stream: *mut c_void, dev_out: *mut *mut daac_match, count: *mut u64) -> i32;
+    pub fn daac_scan_device16(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,
+                              stream: *mut c_void, dev_out: *mut *mut daac_match16, count: *mut u64) -> i32;
+    pub fn daac_device_free(p: *mut c_void);
+}
+
+/// Owner of a `daac_pma*`: the device twin of one automaton, immutable after upload.
+pub struct HipPma(pub(crate) *mut daac_pma);
+unsafe impl Send for HipPma {}
+unsafe impl Sync for HipPma {}
+impl Drop for HipPma {
+    fn drop(&mut self) {
+        unsafe { daac_pma_free(self.0) }
+    }
+}
+
+/// What every iterator of the crate holds under the `hip` feature instead of (state_id, pos, output_pos):
+/// the open `daac_iter` plus what `count()` needs to run as one device pass.
+pub struct HipCursor<'a> {
+    pub(crate) it: *mut daac_iter,
+    pub(crate) pma: &'a HipPma,
+    pub(crate) mode: i32,
+    pub(crate) hay_ptr: *const u8,
+    pub(crate) hay_len: usize,
+    pub(crate) consumed: bool, // next() has been called: count() must not restart
+}
+impl<'a> HipCursor<'a> {
+    /// Opens the lazy façade.  Panics exactly where the crate panics (wrong MatchKind), with the crate's messages.
+    pub(crate) fn open(pma: &'a HipPma, mode: i32, hay: &[u8]) -> Self {
+        let mut it = core::ptr::null_mut();
+        let st = unsafe { daac_iter_open(pma.0, mode, DAAC_ENGINE_AUTO, hay.as_ptr(), hay.len(), 0, core::ptr::null_mut(), &mut it) };
+        assert!(!(st == DAAC_ERR_MATCH_KIND && mode != DAAC_LEFTMOST_FIND), "Error: match_kind must be standard.");
+        assert!(!(st == DAAC_ERR_MATCH_KIND && mode == DAAC_LEFTMOST_FIND), "Error: match_kind must be leftmost.");
+        assert!(st == DAAC_OK, "daachorse_amd: device scan failed (status {st})");
+        Self { it, pma, mode, hay_ptr: hay.as_ptr(), hay_len: hay.len(), consumed: false }
+    }
+    #[inline]
+    pub(crate) fn next(&mut self) -> Option<crate::Match<u32>> {
+        self.consumed = true;
+        let mut m = core::mem::MaybeUninit::<daac_match>::uninit();
+        match unsafe { daac_iter_next(self.it, m.as_mut_ptr()) } {
+            1 => {
+                let m = unsafe { m.assume_init() };
+                Some(crate::Match { length: (m.end - m.start) as usize, end: m.end as usize, value: m.value })
+            }
+            0 => None,
+            e => panic!("daachorse_amd: device scan failed (status {})", -e),
+        }
+    }
+    /// `Iterator::count()` as ONE device pass (`daac_scan_count_only_range`) when nothing has been pulled yet.
+    pub(crate) fn count(mut self) -> usize {
+        if self.consumed {
+            let mut n = 0;
+            while self.next().is_some() {
+                n += 1;
+            }
+            return n;
+        }
+        let mut n = 0u64;
+        let st = unsafe {
+            daac_scan_count_only_range(self.pma.0, self.mode, DAAC_ENGINE_AUTO, self.hay_ptr, self.hay_len, 0, 0,
+                                       core::ptr::null_mut(), &mut n, core::ptr::null_mut())
+        };
+        assert!(st == DAAC_OK, "daachorse_amd: device scan failed (status {st})");
+        n as usize
+    }
+}
+impl Drop for HipCursor<'_> {
+    fn drop(&mut self) {
+        unsafe { daac_iter_close(self.it) }
+    }
+}

@@ -1,0 +1,72 @@
+// Host-logic test for the PFX tables, pfx.hpp (no GPU needed): counts the find_overlapping stream from the tables, position by
+// position with the rules of pfx_kernels.hip (Bloom bit, displacement, slot record, goto-only walk over WREC, CNT1), and
+// compares with the literal automaton walk on the original double array.
+//   usage: pfx_check <blob> <lds_budget> <haystack-file>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
+#include <vector>
+
+#include "../../daachorse_amd/csrc/pfx.hpp"
+#include "../../daachorse_amd/csrc/pma.hpp"
+
+using namespace daac;
+
+static std::vector<uint8_t> slurp(const char *path) {
+    std::ifstream f(path, std::ios::binary);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char **argv) {
+    if (argc < 4) return 2;
+    const std::vector<uint8_t> blob = slurp(argv[1]);
+    HostPma p;
+    if (HostPma::deserialize(blob.data(), blob.size(), p, nullptr) != DAAC_OK) { std::printf("BADBLOB\n"); return 1; }
+    PfxTables g;
+    if (!build_pfx_tables(p, static_cast<uint32_t>(std::atoi(argv[2])), g)) { std::printf("UNAVAILABLE pfx\n"); return 0; }
+    const std::vector<uint8_t> hay = slurp(argv[3]);
+    const long long n = static_cast<long long>(hay.size());
+
+    uint64_t rc = 0;
+    uint32_t st = 0;
+    for (long long i = 0; i < n; ++i) {
+        st = p.next_state(st, hay[i]);
+        for (uint32_t op = output_pos_of(p.states[st].opos_ch); op != 0; op = p.outputs[op - 1].parent) rc++;
+    }
+
+    const uint32_t G = g.G, M = 1u << g.slots_log2;
+    uint64_t gc = 0, survivors = 0, false_pos = 0, walkers = 0;
+    for (long long s = 0; s < n; ++s) {
+        if (g.has_len1) gc += g.cnt1[hay[s]];
+        if (s + G > n) continue;
+        uint32_t k0 = 0, k1 = 0;
+        for (uint32_t i = 0; i < G; ++i) {
+            if (i < 4) k0 |= static_cast<uint32_t>(hay[s + i]) << (8 * i); else k1 |= static_cast<uint32_t>(hay[s + i]) << (8 * (i - 4));
+        }
+        const uint32_t m = k0 * kPfxMulBloom0 + k1 * kPfxMulBloom1;
+        if (!((g.bloom[m >> (32 - g.bloom_log2)] >> ((m >> (27 - g.bloom_log2)) & 31u)) & 1u)) continue;
+        ++survivors;
+        const uint32_t mb = k0 * kPfxMulBucket0 + (k1 ^ g.seed) * kPfxMulBucket1, ms = k0 * kPfxMulSlot0 + (k1 ^ g.seed) * kPfxMulSlot1;
+        const uint32_t bucket = static_cast<uint32_t>((static_cast<uint64_t>(mb) * g.buckets) >> 32);
+        const U32x4 r = g.slots[((ms >> (32 - g.slots_log2)) + g.disp[bucket]) & (M - 1)];
+        if (r.x != k0 || r.y != k1) { ++false_pos; continue; }
+        gc += r.w;
+        uint32_t b = r.z;
+        long long vn = s + G;
+        if (b != 0) ++walkers;
+        while (b != 0 && vn < n) {
+            const uint32_t c = hay[vn];
+            const U32x2 w = g.wrec[b ^ c];
+            if ((w.y & 0xffu) != c) break;
+            gc += w.y >> 8;
+            b = w.x;
+            ++vn;
+        }
+    }
+    if (gc != rc) { std::printf("MISMATCH count %llu != %llu\n", (unsigned long long)gc, (unsigned long long)rc); return 1; }
+    std::printf("OK G=%u len1=%d keys=%u bloom_log2=%u buckets=%u slots_log2=%u seed=%u lds=%u count=%llu survivors/byte=%.4f false_pos/byte=%.4f walkers/byte=%.4f\n",
+                G, (int)g.has_len1, g.n_keys, g.bloom_log2, g.buckets, g.slots_log2, g.seed, g.lds_tables, (unsigned long long)gc,
+                n ? double(survivors) / n : 0.0, n ? double(false_pos) / n : 0.0, n ? double(walkers) / n : 0.0);
+    return 0;
+}

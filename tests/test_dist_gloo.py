@@ -124,3 +124,23 @@ def test_bench_two_ranks_on_one_gpu_weak_and_strong():
     # the default op (.count() alone) under strong scaling: same count, no checksum in the line
     cnt = _run_bench(["--gpus", "2", "--scaling", "strong", "--bytes", str(96 << 20)] + common[:-2], env)
     assert cnt["match_count"] == one["match_count"] and cnt["match_checksum"] is None and cnt["op"].endswith(".count()")
+
+
+@pytest.mark.gpu
+def test_bench_takes_the_rccl_branch_on_one_gpu():
+    """RCCL on hardware: bench.py's distributed branch with the `nccl` backend at world size 1 — init_process_group("nccl"),
+    a device-tensor all-reduce per step, barriers, teardown — so that the first time that code runs is not on the 8-GPU node.
+    The line must equal the plain single-process one."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu", "--no-dense", "--materialize-mib", "0", "--workload", "cfg2", "--op", "checksum",
+              "--bytes", str(64 << 20)]
+    plain = _run_bench(["--gpus", "1"] + common)
+    env = {"DAAC_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+           "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    rccl = _run_bench(["--gpus", "1"] + common, env)
+    assert rccl["distributed"] == {"backend": "nccl", "world_size": 1, "all_reduces": 4}
+    assert plain["distributed"] is None
+    assert rccl["match_count"] == plain["match_count"] and rccl["match_checksum"] == plain["match_checksum"] and rccl["value"] > 0

@@ -1,0 +1,104 @@
+"""PFX engine (pfx_kernels.hip: hashed prefix filter + start-anchored goto-only walks; `.count()` of find_overlapping for
+dictionaries over ANY byte alphabet) against the oracle: a 256-byte-alphabet dictionary, a UTF-8 Japanese-like one scanned
+bytewise, one-byte patterns, duplicates, every key length G = 2 .. 6, unaligned and ragged haystacks, shards."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+import daachorse_amd as da
+from daachorse_amd import Engine, ScanMode, synth
+
+
+@pytest.fixture(autouse=True)
+def _opts():
+    da.set_option("pfx", 2)  # build the PFX tables for every automaton they can serve (default: only where GRAM does not apply)
+    yield
+    da.set_option("pfx", 1)
+    da.set_option("gram_region", 0)
+
+
+def _pma(patterns):
+    o = orc.OraclePma.build(patterns)
+    p, rest = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    assert rest == b""
+    return o, p
+
+
+def _count(p, hay, **kw):
+    got = p.count(ScanMode.FindOverlapping, hay, engine=Engine.Pfx, **kw)
+    assert da.last_engine() == int(Engine.Pfx)
+    return got
+
+
+def test_pfx_against_the_oracle():
+    import torch
+    rng = np.random.default_rng(2024)
+    binp = synth.patterns_binary256(20000)
+    jp = synth.patterns_cfg5(5000)
+    mixed = list(dict.fromkeys([bytes(rng.integers(0, 256, size=int(rng.integers(1, 9))).astype(np.uint8)) for _ in range(3000)]))
+    by_len = {g: [bytes(rng.integers(0, 256, size=int(rng.integers(g, g + 6))).astype(np.uint8)) for _ in range(4000)] for g in (2, 3, 4, 5, 6, 9)}
+    cases = [(binp, rng.integers(0, 256, size=3 << 20).astype(np.uint8)),
+             (binp, np.frombuffer(b"".join(binp[i] for i in rng.integers(0, len(binp), size=200000).tolist()), dtype=np.uint8)),
+             (jp, synth.zipf_text(48 * 40000)),
+             (mixed, rng.integers(0, 256, size=1 << 20).astype(np.uint8)),
+             ([b"ab", b"ab", b"b", b"abab", b"bababab", b"\xff\x00", b"\xff\x00"], np.frombuffer(b"abababbab\xff\x00" * 30000, dtype=np.uint8)),
+             (synth.patterns_cfg3(20000), synth.wordsoup_haystack(1 << 20, 5, synth.patterns_cfg3(20000), 20))]
+    for g, pats in by_len.items():
+        pats = list(dict.fromkeys(pats))
+        soup = b"".join(pats[i] if rng.integers(0, 3) else bytes(rng.integers(0, 256, size=5).astype(np.uint8)) for i in rng.integers(0, len(pats), size=60000).tolist())
+        cases.append((pats, np.frombuffer(soup, dtype=np.uint8)))
+    for pats, hay in cases:
+        o, p = _pma(pats)
+        p.upload()
+        want = o.overlapping_count(hay, threads=8)[0]
+        dev = torch.from_numpy(np.concatenate([np.zeros(7, dtype=np.uint8), hay])).cuda()[7:]  # not 16-byte aligned
+        assert _count(p, dev) == want, (len(pats), len(hay))
+        cut = int(rng.integers(1, len(hay)))
+        assert _count(p, dev[:cut]) + _count(p, dev, begin=cut) == want, cut
+        da.set_option("gram_region", 2048)
+        assert _count(p, dev) == want
+        da.set_option("gram_region", 0)
+
+
+def test_pfx_short_and_ragged_haystacks():
+    import torch
+    rng = np.random.default_rng(77)
+    pats = list(dict.fromkeys([bytes(rng.integers(0, 8, size=int(rng.integers(1, 7))).astype(np.uint8)) for _ in range(300)]))  # dense: 8 byte values, one-byte patterns too
+    o, p = _pma(pats)
+    p.upload()
+    base = rng.integers(0, 8, size=1 << 18).astype(np.uint8)
+    buf = torch.from_numpy(base).cuda()
+    da.set_option("gram_region", 2048)
+    lengths = [0, 1, 2, 3, 4, 5, 6, 7, 15, 16, 17, 63, 64, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4100, 65535, 65536, 65537]
+    lengths += [int(x) for x in rng.integers(1, 1 << 17, size=12)]
+    for n in lengths:
+        off = int(rng.integers(0, 32))
+        want = o.overlapping_count(base[off:off + n], threads=1)[0] if n else 0
+        assert _count(p, buf[off:off + n]) == want, (n, off)
+
+
+def test_pfx_is_what_auto_takes_for_wide_alphabets():
+    """256 pattern bytes: no GRAM table set applies; `.count()` runs on PFX (count + checksum stays on the double array)"""
+    import torch
+    da.set_option("pfx", 1)
+    pats = synth.patterns_binary256(30000)
+    o, p = _pma(pats)
+    info = p.upload().info()
+    assert not info.gram_available and not info.gram2_available
+    dev = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+    synth.device_uniform(dev, synth.SEEDS["bin_hay"], synth.ALPHA_BYTES)
+    want = o.overlapping_count(dev.cpu().numpy(), threads=16)
+    assert p.count(ScanMode.FindOverlapping, dev) == want[0] and da.last_engine() == int(Engine.Pfx)
+    assert p.scan_count(ScanMode.FindOverlapping, dev) == want and da.last_engine() in (int(Engine.DArray), int(Engine.Tiered))
+    # the UTF-8 dictionary of cfg5 scanned bytewise
+    jp = synth.patterns_cfg5(20000)
+    o, p = _pma(jp)
+    p.upload()
+    n = (32 << 20) - (32 << 20) % synth.CFG5_SLOT
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    synth.device_zipf_text(dev)
+    want = o.overlapping_count(dev.cpu().numpy(), threads=16)
+    assert p.count(ScanMode.FindOverlapping, dev) == want[0] and da.last_engine() == int(Engine.Pfx)

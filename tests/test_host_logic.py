@@ -240,6 +240,36 @@ def test_gram2w_tables_reproduce_the_match_stream(tmp_path):
     assert subprocess.check_output([exe, str(blob), "147000", str(h)]).decode().startswith("UNAVAILABLE")
 
 
+def test_pfx_tables_reproduce_the_match_count(tmp_path):
+    """the PFX tables (Bloom bitmap over hashed G-byte prefixes, hash-and-displace slots, goto-only walk records, one-byte
+    counts) walked with the kernel's rules == literal automaton walk, for dictionaries over any byte alphabet"""
+    exe = str(tmp_path / "pfx_check")
+    csrc = os.path.join(ROOT, "daachorse_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "pfx_check.cpp"),
+                           os.path.join(csrc, "pma.cpp"), os.path.join(csrc, "repack.cpp"), os.path.join(csrc, "pfx.cpp")])
+    blob, h = tmp_path / "a.blob", tmp_path / "h.bin"
+    rng = np.random.default_rng(12)
+    binp = synth.patterns_binary256(20000)
+    assert len({b for w in binp for b in w}) == 256
+    jp = synth.patterns_cfg5(5000)
+    mixed = list(dict.fromkeys([bytes(rng.integers(0, 256, size=int(rng.integers(1, 9))).astype(np.uint8)) for _ in range(3000)]))  # incl. one-byte patterns
+    dup = [b"ab", b"ab", b"b", b"abab", b"bababab", b"\xff\x00", b"\xff\x00"]
+    cases = ((binp, rng.integers(0, 256, size=200000).astype(np.uint8), "G=3"),
+             (binp, np.frombuffer(b"".join(binp[i] for i in rng.integers(0, len(binp), size=20000).tolist()), dtype=np.uint8), "G=3"),
+             (jp, synth.zipf_text(48 * 4000), "G=6"),
+             (mixed, rng.integers(0, 256, size=100000).astype(np.uint8), "len1=1"),
+             (dup, np.frombuffer(b"abababbab\xff\x00" * 3000, dtype=np.uint8), "G=2"),
+             (synth.patterns_cfg3(20000), synth.wordsoup_haystack(100000, 5, synth.patterns_cfg3(20000), 20), "G=2"))
+    for pats, hay, expect in cases:
+        blob.write_bytes(orc.OraclePma.build(pats).serialize())
+        np.asarray(hay, dtype=np.uint8).tofile(h)
+        out = subprocess.check_output([exe, str(blob), "120000", str(h)]).decode()
+        assert out.startswith("OK") and expect in out, out
+    for pats in (["", "a"], ["a", "b"]):  # "" in the set; one-byte patterns only
+        blob.write_bytes(orc.OraclePma.build(pats).serialize())
+        assert subprocess.check_output([exe, str(blob), "120000", str(h)]).decode().startswith("UNAVAILABLE"), pats
+
+
 def test_emit_tables_reproduce_the_tuple_stream(tmp_path):
     """the tuple-emission tables (flag bits + value tables for short patterns, ehit / erec for deep ones) walked with the
     emitter's rules give the literal automaton's (start, end, value) list, order included"""
