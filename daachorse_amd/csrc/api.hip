@@ -599,7 +599,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     // PFX engine: `.count()` for every bytewise Standard automaton the GRAM tables do not serve (any alphabet); pfx = 2 builds it always
     if (g_opt.pfx.load() == 2 || (g_opt.pfx.load() == 1 && !t->gram_ok && !t->gram2_ok && !t->gramw_ok)) {
         PfxTables px;
-        if (build_pfx_tables(h, 160u * 1024u - 16u * (2u * 1040u + 512u), px)) {
+        if (build_pfx_tables(h, 160u * 1024u - 16u * (2u * 1056u + 512u) - 64u, px)) {
             PfxDev &d = t->pfx;
             auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
             px.disp.resize((px.disp.size() + 7) & ~size_t(7), 0);
@@ -611,7 +611,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             if ((st = t->put(px.wrec, wr)) != DAAC_OK) return st;
             d.slots = reinterpret_cast<const uint4 *>(sl);
             d.wrec = reinterpret_cast<const uint2 *>(wr);
-            d.G = px.G; d.has_len1 = px.has_len1; d.bloom_log2 = px.bloom_log2; d.buckets = px.buckets; d.slots_log2 = px.slots_log2;
+            d.G = px.G; d.has_len1 = px.has_len1; d.bloom_words = px.bloom_words; d.buckets = px.buckets; d.n_slots = px.n_slots;
             d.seed = px.seed; d.n_keys = px.n_keys;
             d.bloom_bytes = p16(px.bloom.size() * 4);
             d.disp_bytes = p16(px.disp.size() * 2);

@@ -206,12 +206,12 @@ hipError_t launch_gram3_scan(const Gram2Dev &dev, const GramArgs &a, const Gram3
 
 // PFX engine (pfx.hpp): `.count()` for bytewise automata over any byte alphabet.  LDS: BLOOM at 0 | DISP | CNT1 | per-wave areas
 struct PfxDev {
-    const uint32_t *bloom;   // 1 << bloom_log2 words
+    const uint32_t *bloom;   // bloom_words words
     const uint16_t *cnt1;    // 256: patterns that are this one byte
     const uint16_t *disp;    // one displacement per bucket of the perfect hash
-    const uint4 *slots;      // 1 << slots_log2 x {key bytes 0-3, key bytes 4-5 (empty: 1 << 31), BASE of the depth-G state, patterns that are the key}
+    const uint4 *slots;      // n_slots x {key bytes 0-3, key bytes 4-5 | flags, BASE of the depth-G state, patterns that are the key} or a tail record (pfx.hpp)
     const uint2 *wrec;       // per double-array slot {BASE, CHECK | patterns that end in this state << 8}
-    uint32_t G, has_len1, bloom_log2, buckets, slots_log2, seed;
+    uint32_t G, has_len1, bloom_words, buckets, n_slots, seed;
     uint32_t bloom_bytes, disp_bytes;                       // multiples of 16
     uint32_t off_disp, off_cnt1, off_wave, wave_stride, lds_bytes, threads;   // pfx_plan
     uint32_t n_keys;

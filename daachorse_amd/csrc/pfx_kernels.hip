@@ -53,7 +53,7 @@ template <int G, bool LEN1, int TPB>
 __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs a) {
     constexpr int P = 16;
     constexpr uint32_t SB = 64u * P;          // bytes a wave takes per step
-    constexpr uint32_t SLOT = SB + 16u;       // the step | 16 bytes of the next
+    constexpr uint32_t SLOT = SB + 32u;       // the step | the first 16 bytes of the next (read up to 20 bytes past a key's first byte)
     constexpr uint32_t KMASK0 = G >= 4 ? 0xffffffffu : ((1u << (8 * (G & 3))) - 1u);
     constexpr uint32_t KMASK1 = G <= 4 ? 0u : ((1u << (8 * ((G - 4) & 3))) - 1u);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,11 +69,10 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
     const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint8_t *__restrict__ hay = a.hay_al;
     const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
-    const uint32_t sh_word = 30u - g.bloom_log2, sh_bit = 27u - g.bloom_log2, sh_slot = 32u - g.slots_log2, slot_mask = (1u << g.slots_log2) - 1u;
     const uint32_t tb = g.off_wave + wave_in_wg * g.wave_stride;   // this wave's LDS: two text slots, then the survivor queue
     const uint32_t ringb = tb + 2u * SLOT;
     // this wave's slab of pending walkers: {low 32 bits of the virtual position of the key's first byte, BASE of the depth-G state,
-    // the six text bytes behind the key}
+    // the eight text bytes behind the key}
     uint4 *__restrict__ slab = reinterpret_cast<uint4 *>(a.wq) + (static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg) * a.wq_slab;
     uint32_t wq_n = 0, slab_hi = 0;  // wave-uniform
 
@@ -96,25 +95,51 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
         return x;
     };
 
-    // Finishes the queued branches, 64 at a time: goto-only over the double array, every state met adds the patterns that end in it
+    // Finishes the queued branches: goto-only over the double array, every state met adds the patterns that end in it.  A step is one
+    // dependent 8-byte gather from L2, so every lane walks W branches side by side (one at a time the drain was half of the kernel's
+    // time on text that keeps the walkers busy: profiles/r03_pfx_decomposition.txt).
     auto drain = [&]() {
-        for (uint32_t base_i = 0; base_i < wq_n; base_i += 64u) {
-            const uint32_t i = base_i + lane;
-            uint4 e = uint4{0u, 0u, 0u, 0u};
-            if (i < wq_n) e = slab[i];
-            uint64_t vn = ((static_cast<uint64_t>(slab_hi) << 32) | e.x) + G;  // the next byte to take
-            uint32_t b = e.y, n_ahead = 6;
-            unsigned long long ah = (static_cast<unsigned long long>(e.w) << 32) | e.z;
-            while (b != 0 && vn < a.vlen) {
-                if (n_ahead == 0) { ah = read_ahead(vn); n_ahead = 8; }
-                const uint32_t c = static_cast<uint32_t>(ah) & 0xffu;
-                const uint2 r = g.wrec[b ^ c];
-                if ((r.y & 0xffu) != c) break;
-                cnt32 += r.y >> 8;
-                b = r.x;
-                ++vn;
-                ah >>= 8;
-                --n_ahead;
+        constexpr int W = 4;
+        for (uint32_t base_i = 0; base_i < wq_n; base_i += 64u * W) {
+            uint64_t vn[W];
+            uint32_t b[W], n_ahead[W];
+            unsigned long long ah[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t i = base_i + 64u * w + lane;
+                uint4 e = uint4{0u, 0u, 0u, 0u};
+                if (i < wq_n) e = slab[i];
+                vn[w] = ((static_cast<uint64_t>(slab_hi) << 32) | e.x) + G;  // the next byte to take
+                b[w] = e.y;
+                n_ahead[w] = 8;
+                ah[w] = (static_cast<unsigned long long>(e.w) << 32) | e.z;
+                if (vn[w] >= a.vlen) b[w] = 0;
+            }
+            for (;;) {
+                uint2 r[W];
+                bool any = false;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    r[w] = uint2{0u, 0u};
+                    if (b[w] != 0) {
+                        if (n_ahead[w] == 0) { ah[w] = read_ahead(vn[w]); n_ahead[w] = 8; }
+                        r[w] = g.wrec[b[w] ^ (static_cast<uint32_t>(ah[w]) & 0xffu)];
+                        any = true;
+                    }
+                }
+                if (!__any(any)) break;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    if (b[w] == 0) continue;
+                    const uint32_t c = static_cast<uint32_t>(ah[w]) & 0xffu;
+                    if ((r[w].y & 0xffu) != c) { b[w] = 0; continue; }
+                    cnt32 += r[w].y >> 8;
+                    b[w] = r[w].x;
+                    ++vn[w];
+                    ah[w] >>= 8;
+                    --n_ahead[w];
+                    if (vn[w] >= a.vlen) b[w] = 0;
+                }
             }
         }
         wq_n = 0;
@@ -123,16 +148,39 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
     // ---- the survivor queue: entry = LDS address of the key's first byte in one of the wave's two text slots
     uint32_t q_head = 0, q_tail = 0;   // wave-uniform, free running
     uint32_t posbias0 = 0, posbias1 = 0;  // per slot: (low 32 bits of the virtual position of a byte) - (its LDS address)
-    uint4 pend = uint4{0u, 0x80000000u, 0u, 0u};  // the record read for the previous batch {key bytes 0-3, 4-5, BASE, patterns that are the key}
+    uint4 pend = uint4{0u, kPfxEmpty, 0u, 0u};  // the record read for the previous batch (pfx.hpp: SLOTS)
     uint32_t pend_pos = 0, pend_k0 = 0, pend_k1 = 0, pend_t0 = 0, pend_t1 = 0;
     bool pend_valid = false;           // wave-uniform
     auto consume_pending = [&]() {
         if (!pend_valid) return;
         pend_valid = false;
         const uint4 r = pend;
-        const bool match = r.x == pend_k0 && r.y == pend_k1;  // (an empty slot and an idle lane carry 1 << 31 in r.y)
-        cnt32 += match ? r.w : 0u;
-        const bool go = match && r.z != 0;
+        // (an empty slot and an idle lane carry kPfxEmpty in r.y: 0x8000 in the upper half never equals a key)
+        const bool match = r.x == pend_k0 && (r.y & 0x8000ffffu) == pend_k1;
+        bool go = false;
+        if (match) {
+            if (r.y & kPfxTail) {  // one path below the key: compared with the text behind it, no walk
+                const uint32_t edges = (r.y >> 16) & 15u;
+                const unsigned long long path = (static_cast<unsigned long long>(r.w) << 32) | r.z;
+                const unsigned long long text = (static_cast<unsigned long long>(pend_t1) << 32) | pend_t0;
+                const unsigned long long diff = path ^ text;
+                uint32_t same = diff ? static_cast<uint32_t>(__builtin_ctzll(diff)) >> 3 : 8u;
+                same = same < edges ? same : edges;
+                // ... no further than the haystack goes
+                const uint64_t after = ((static_cast<uint64_t>(slab_hi) << 32) | pend_pos) + G;
+                const uint64_t left = a.vlen > after ? a.vlen - after : 0;
+                same = left < same ? static_cast<uint32_t>(left) : same;
+                cnt32 += __popc((r.y >> 20) & ((2u << same) - 1u) & 0x1ffu);
+            } else {
+                cnt32 += (r.y >> 16) & 0x3fffu;
+                // the two bytes behind the key against the record's filter of two-byte paths (with fewer than two bytes left: walk)
+                const uint64_t after = ((static_cast<uint64_t>(slab_hi) << 32) | pend_pos) + G;
+                go = r.z != 0 && (((r.w >> pfx_pair_bit(pend_t0)) & 1u) || after + 2 > a.vlen);
+            }
+        }
+#ifdef PFX_NO_WALKERS
+        go = false;
+#endif
         const unsigned long long m = __ballot(go);
         if (m != 0) {
             if (go) {
@@ -143,9 +191,12 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
         }
     };
     auto process_batch = [&](uint32_t n) {  // n <= 64 entries from the head of the queue
+#ifdef PFX_NO_CONSUMER
+        q_head += n; return;
+#endif
         __builtin_amdgcn_s_setprio(2);
         consume_pending();
-        pend = uint4{0u, 0x80000000u, 0u, 0u};
+        pend = uint4{0u, kPfxEmpty, 0u, 0u};
         if (lane < n) {
             const uint32_t e = lds_u32(ringb + (((q_head + lane) & (kRingP - 1u)) << 2));
             pend_pos = e + ((e - tb) >= SLOT ? posbias1 : posbias0);
@@ -156,15 +207,20 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
             const uint32_t key0 = x0 & KMASK0, key1 = x1 & KMASK1;
             pend_k0 = key0;
             pend_k1 = key1;
-            // the six bytes from s + G on
+            // the eight bytes from s + G on (s + G + 7 <= s + 13: a fifth dword for the longer keys)
             if (G == 4) { pend_t0 = x1; pend_t1 = x2; }
             else if (G < 4) { pend_t0 = __builtin_amdgcn_alignbyte(x1, x0, G & 3); pend_t1 = __builtin_amdgcn_alignbyte(x2, x1, G & 3); }
-            else { pend_t0 = __builtin_amdgcn_alignbyte(x2, x1, G & 3); pend_t1 = x2 >> (8 * (G & 3)); }
+            else {
+                const uint32_t d4 = lds_u32(a0 + 16u);
+                const uint32_t x3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+                pend_t0 = __builtin_amdgcn_alignbyte(x2, x1, G & 3);
+                pend_t1 = __builtin_amdgcn_alignbyte(x3, x2, G & 3);
+            }
             const uint32_t mb = key0 * kPfxMulBucket0 + (key1 ^ g.seed) * kPfxMulBucket1;
             const uint32_t ms = key0 * kPfxMulSlot0 + (key1 ^ g.seed) * kPfxMulSlot1;
             const uint32_t bucket = __umulhi(mb, g.buckets);
             const uint32_t d = lds_u16(g.off_disp + (bucket << 1));
-            pend = g.slots[((ms >> sh_slot) + d) & slot_mask];
+            pend = g.slots[pfx_slot(ms, d, g.n_slots)];
         }
         q_head += n;
         pend_valid = true;
@@ -223,8 +279,9 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
                     k1 &= KMASK1;
                     m += k1 * kPfxMulBloom1;
                 }
-                const uint32_t word = lds_u32((m >> sh_word) & ~3u);   // BLOOM sits at LDS offset 0
-                H |= __builtin_amdgcn_ubfe(word, m >> sh_bit, 1) << j;
+                const uint32_t word = lds_u32(__umulhi(m, g.bloom_words) << 2);   // BLOOM sits at LDS offset 0
+                const uint32_t m2 = m * kPfxMulBits;
+                H |= (__builtin_amdgcn_ubfe(word, m2 >> kPfxBit1, 1) & __builtin_amdgcn_ubfe(word, m2 >> kPfxBit2, 1)) << j;
                 if (LEN1) c1 += lds_u16(g.off_cnt1 + (((W[q] >> (8 * r)) & 0xffu) << 1));
             }
             // starts before the haystack's first byte or too close to its end do not count (first / last step only)
@@ -241,6 +298,9 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
             }
             cnt32 += c1;
 
+#ifdef PFX_NO_PRODUCER
+            H = 0;
+#endif
             // ---- queue the survivors, one per lane and turn ----
             bool did_batch = false;
             for (;;) {
@@ -303,7 +363,7 @@ bool pfx_plan(PfxDev &d, uint32_t lds_limit) {
     d.off_disp = d.bloom_bytes;
     d.off_cnt1 = d.off_disp + d.disp_bytes;
     d.off_wave = d.off_cnt1 + 512u;
-    d.wave_stride = 2u * (1024u + 16u) + kRingP * 4u;
+    d.wave_stride = 2u * (1024u + 32u) + kRingP * 4u;
     d.lds_bytes = d.off_wave + 16u * d.wave_stride;
     d.threads = 1024;
     return d.lds_bytes <= lds_limit;

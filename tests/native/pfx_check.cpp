@@ -35,7 +35,7 @@ int main(int argc, char **argv) {
         for (uint32_t op = output_pos_of(p.states[st].opos_ch); op != 0; op = p.outputs[op - 1].parent) rc++;
     }
 
-    const uint32_t G = g.G, M = 1u << g.slots_log2;
+    const uint32_t G = g.G, M = g.n_slots;
     uint64_t gc = 0, survivors = 0, false_pos = 0, walkers = 0;
     for (long long s = 0; s < n; ++s) {
         if (g.has_len1) gc += g.cnt1[hay[s]];
@@ -45,15 +45,25 @@ int main(int argc, char **argv) {
             if (i < 4) k0 |= static_cast<uint32_t>(hay[s + i]) << (8 * i); else k1 |= static_cast<uint32_t>(hay[s + i]) << (8 * (i - 4));
         }
         const uint32_t m = k0 * kPfxMulBloom0 + k1 * kPfxMulBloom1;
-        if (!((g.bloom[m >> (32 - g.bloom_log2)] >> ((m >> (27 - g.bloom_log2)) & 31u)) & 1u)) continue;
+        const uint32_t word = g.bloom[static_cast<uint32_t>((static_cast<uint64_t>(m) * g.bloom_words) >> 32)];
+        const uint32_t m2 = m * kPfxMulBits;
+        if (!((word >> ((m2 >> kPfxBit1) & 31u)) & (word >> ((m2 >> kPfxBit2) & 31u)) & 1u)) continue;
         ++survivors;
         const uint32_t mb = k0 * kPfxMulBucket0 + (k1 ^ g.seed) * kPfxMulBucket1, ms = k0 * kPfxMulSlot0 + (k1 ^ g.seed) * kPfxMulSlot1;
         const uint32_t bucket = static_cast<uint32_t>((static_cast<uint64_t>(mb) * g.buckets) >> 32);
-        const U32x4 r = g.slots[((ms >> (32 - g.slots_log2)) + g.disp[bucket]) & (M - 1)];
-        if (r.x != k0 || r.y != k1) { ++false_pos; continue; }
-        gc += r.w;
-        uint32_t b = r.z;
+        const U32x4 r = g.slots[pfx_slot(ms, g.disp[bucket], M)];
+        if (r.x != k0 || (r.y & 0xffffu) != k1 || (r.y & kPfxEmpty)) { ++false_pos; continue; }
         long long vn = s + G;
+        if (r.y & kPfxTail) {
+            const uint32_t edges = (r.y >> 16) & 15u, ends = (r.y >> 20) & 0x1ffu;
+            uint32_t same = 0;
+            while (same < edges && vn + same < n && hay[vn + same] == ((same < 4 ? r.z >> (8 * same) : r.w >> (8 * (same - 4))) & 0xffu)) ++same;
+            gc += static_cast<uint32_t>(__builtin_popcount(ends & ((2u << same) - 1u)));
+            continue;
+        }
+        gc += (r.y >> 16) & 0x3fffu;
+        uint32_t b = r.z;
+        if (b != 0 && vn + 2 <= n && !((r.w >> pfx_pair_bit(hay[vn] | (static_cast<uint32_t>(hay[vn + 1]) << 8))) & 1u)) b = 0;  // the filter says: nothing below
         if (b != 0) ++walkers;
         while (b != 0 && vn < n) {
             const uint32_t c = hay[vn];
@@ -65,8 +75,8 @@ int main(int argc, char **argv) {
         }
     }
     if (gc != rc) { std::printf("MISMATCH count %llu != %llu\n", (unsigned long long)gc, (unsigned long long)rc); return 1; }
-    std::printf("OK G=%u len1=%d keys=%u bloom_log2=%u buckets=%u slots_log2=%u seed=%u lds=%u count=%llu survivors/byte=%.4f false_pos/byte=%.4f walkers/byte=%.4f\n",
-                G, (int)g.has_len1, g.n_keys, g.bloom_log2, g.buckets, g.slots_log2, g.seed, g.lds_tables, (unsigned long long)gc,
+    std::printf("OK G=%u len1=%d keys=%u tails=%u bloom_words=%u buckets=%u slots=%u seed=%u lds=%u count=%llu survivors/byte=%.4f false_pos/byte=%.4f walkers/byte=%.4f\n",
+                G, (int)g.has_len1, g.n_keys, g.n_tails, g.bloom_words, g.buckets, g.n_slots, g.seed, g.lds_tables, (unsigned long long)gc,
                 n ? double(survivors) / n : 0.0, n ? double(false_pos) / n : 0.0, n ? double(walkers) / n : 0.0);
     return 0;
 }

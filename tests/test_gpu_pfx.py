@@ -102,3 +102,32 @@ def test_pfx_is_what_auto_takes_for_wide_alphabets():
     synth.device_zipf_text(dev)
     want = o.overlapping_count(dev.cpu().numpy(), threads=16)
     assert p.count(ScanMode.FindOverlapping, dev) == want[0] and da.last_engine() == int(Engine.Pfx)
+
+
+def test_pfx_on_a_vector_of_window_counts():
+    """one integer per call hides compensating errors: 1 024 windows (begin, len) of random sizes and alignments over 16 MiB of each of
+    the two wide-alphabet workloads, each counted on its own and compared with the oracle's matches ending in (begin, len]"""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 16 << 20
+    for name in ("binary256", "utf8jp"):
+        if name == "binary256":
+            pats = synth.patterns_binary256(50000)
+            # a third of the text is made of patterns so that windows hold matches
+            soup = b"".join(pats[i] if k % 3 == 0 else bytes(rng.integers(0, 256, size=24).astype(np.uint8)) for k, i in enumerate(rng.integers(0, len(pats), size=n // 12).tolist()))
+            hay = np.frombuffer(soup[:n], dtype=np.uint8)
+        else:
+            pats = synth.patterns_cfg5(20000)
+            hay = synth.zipf_text(n - n % synth.CFG5_SLOT)
+        o, p = _pma(pats)
+        p.upload()
+        dev = torch.from_numpy(hay.copy()).cuda()
+        ends = np.sort(o.find_overlapping_iter(hay)["end"].astype(np.int64))
+        assert len(ends) > 100000
+        los = rng.integers(0, len(hay) - (1 << 16), size=1024)
+        sizes = np.concatenate([rng.integers(1, 64, size=256), rng.integers(64, 4096, size=384), rng.integers(4096, 1 << 16, size=384)])
+        his = los + sizes
+        want = np.searchsorted(ends, his, side="right") - np.searchsorted(ends, los, side="right")
+        got = np.array([_count(p, dev[:int(h)], begin=int(l)) for l, h in zip(los, his)])
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (name, bad[:8], got[bad[:8]], want[bad[:8]], los[bad[:8]], his[bad[:8]])
