@@ -79,6 +79,8 @@ def lib():
     L.daac_scan_count_only_range.restype = C.c_int
     L.daac_scan_device.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp), P(C.c_uint64)]
     L.daac_scan_device.restype = C.c_int
+    L.daac_scan_device16.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp), P(C.c_uint64)]
+    L.daac_scan_device16.restype = C.c_int
     L.daac_device_free.argtypes = [vp]
     L.daac_device_to_host.argtypes = [vp, vp, sz]
     L.daac_device_to_host.restype = C.c_int

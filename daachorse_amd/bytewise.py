@@ -112,17 +112,25 @@ class _MatchList:
             pass
 
 
-class DeviceMatches:
-    """`count` daac_match tuples (24 bytes each, MATCH_DTYPE) at device address `ptr`, in the reference's order"""
+MATCH16_DTYPE = np.dtype([("end", "<u8"), ("length", "<u4"), ("value", "<u4")])  # daac_match16 = the crate's own Match fields
 
-    def __init__(self, ptr, count):
-        self.ptr, self.count = ptr, count
+
+class DeviceMatches:
+    """`count` tuples at device address `ptr`, in the reference's order: daac_match (24 bytes, MATCH_DTYPE) or, from
+    scan_device(fmt16=True), daac_match16 (MATCH16_DTYPE)"""
+
+    def __init__(self, ptr, count, dtype=None):
+        self.ptr, self.count, self.dtype = ptr, count, (MATCH_DTYPE if dtype is None else dtype)
 
     def to_numpy(self, first=0, n=None):
+        if self.count and self.ptr is None:
+            raise DaachorseError(1, "the device match list has been freed")
         n = self.count - first if n is None else n
-        out = np.zeros(n, dtype=MATCH_DTYPE)
+        if not (0 <= first <= self.count and 0 <= n <= self.count - first):
+            raise DaachorseError(1, f"to_numpy({first}, {n}) outside a list of {self.count} tuples")
+        out = np.zeros(n, dtype=self.dtype)
         if n:
-            _ffi.check(_ffi.lib().daac_device_to_host(out.ctypes.data, self.ptr + first * MATCH_DTYPE.itemsize, n * MATCH_DTYPE.itemsize))
+            _ffi.check(_ffi.lib().daac_device_to_host(out.ctypes.data, self.ptr + first * self.dtype.itemsize, n * self.dtype.itemsize))
         return out
 
     def free(self):
@@ -309,12 +317,13 @@ class DoubleArrayAhoCorasick:
             return np.zeros(0, dtype=MATCH_DTYPE)
         return np.asarray(_MatchList(out, n))  # read-only view of the library's buffer, freed with the array
 
-    def scan_device(self, mode, haystack, engine=Engine.Auto, stream=None):
-        """-> DeviceMatches: the match list left in device memory (daac_scan_device)"""
+    def scan_device(self, mode, haystack, engine=Engine.Auto, stream=None, fmt16=False):
+        """-> DeviceMatches: the match list left in device memory (daac_scan_device; fmt16: daac_scan_device16, 16-byte tuples)"""
         h = _Haystack(haystack)
         ptr, n = C.c_void_p(), C.c_uint64()
-        _ffi.check(_ffi.lib().daac_scan_device(self._h, int(mode), int(engine), h.ptr, h.len, h.is_device, stream, C.byref(ptr), C.byref(n)))
-        return DeviceMatches(ptr.value, n.value)
+        fn = _ffi.lib().daac_scan_device16 if fmt16 else _ffi.lib().daac_scan_device
+        _ffi.check(fn(self._h, int(mode), int(engine), h.ptr, h.len, h.is_device, stream, C.byref(ptr), C.byref(n)))
+        return DeviceMatches(ptr.value, n.value, MATCH16_DTYPE if fmt16 else MATCH_DTYPE)
 
     def count(self, mode, haystack, engine=Engine.Auto, stream=None, result_dev=None, begin=0):
         """`.count()` of the iterator: the number of matches with end in (begin, len], no checksum; with `result_dev`

@@ -47,8 +47,6 @@ struct Options {
     std::atomic<int64_t> gram3_tail{-1};        // gram3: tail records from the hit record on (-1 = decide per launch)
     std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
     std::atomic<int64_t> emit{1};               // materialising overlapping scans: GRAM tuple emission where it applies (0: segment scanners)
-    std::atomic<int64_t> emit_staged{0};        // 1: the write pass gathers the tuples of 64 positions in LDS and stores them contiguously
-                                                // (8 waves per workgroup; measured no faster than a pair of stores per tuple with 16: DESIGN.md 4.5)
     std::atomic<int64_t> emit_tiles{64};        // tiles of 1024 positions a wave takes at a time
     std::atomic<int64_t> emit_rec_cap{256};     // deep-match records per wave and tile before the scan falls back
     std::atomic<int64_t> restart_tier{0};       // 1: find_iter of Standard bytewise automata chains over the TIERED tables (measured 7-9 % slower
@@ -541,7 +539,16 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 if ((st = t->put(g2.v3, e.v3)) != DAAC_OK) return st;
                 if ((st = t->put(g2.erec, erec)) != DAAC_OK) return st;
                 if ((st = t->put(g2.ehit, ehit)) != DAAC_OK) return st;
-                { const U32x4 *h4; if ((st = t->put(zip_first_child(g2.ehit, g2.cfirst), h4)) != DAAC_OK) return st; e.ehit4 = reinterpret_cast<const uint4 *>(h4); }
+                {
+                    std::vector<U32x4> h4v = zip_first_child(g2.ehit, g2.cfirst);
+                    for (size_t i = 0; i < h4v.size(); ++i) h4v[i].w = g2.ecopies[i] << 24;
+                    const U32x4 *h4;
+                    if ((st = t->put(h4v, h4)) != DAAC_OK) return st;
+                    e.ehit4 = reinterpret_cast<const uint4 *>(h4);
+                }
+                if ((st = t->put(g2.dupo, e.dupo)) != DAAC_OK) return st;
+                if ((st = t->put(g2.dupv, e.dupv)) != DAAC_OK) return st;
+                e.level_start = g2.level_start;
                 e.erec = reinterpret_cast<const uint4 *>(erec);
                 e.ehit = reinterpret_cast<const uint2 *>(ehit);
                 e.m_bytes = d.m_bytes; e.s_bytes = d.s_bytes;
@@ -551,9 +558,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 e.off_v2 = e.off_v1 + e.v1_bytes;
                 e.off_ring = e.off_v2 + e.v2_bytes;
                 e.off_wave = e.off_ring + ring_bytes;
-                e.lds_bytes = e.off_wave + 16u * (2048u + 256u + 256u + 16u);
-                e.off_wave2 = e.off_ring + 8u * 128u * 8u;
-                e.lds_bytes2 = e.off_wave2 + 8u * (4096u + 1040u + 64u * 24u + 16u);
+                e.lds_bytes = e.off_wave + 16u * (2048u + 256u + 256u + 64u * 8u + 32u);  // kWaveLds of gram2_emit_kernels.hip
                 e.K = g2.K; e.C = g2.C; e.s16 = g2.s16; e.unused_byte = g2.unused_byte;
                 t->emit_ok = e.lds_bytes <= 160u * 1024u;
             }
@@ -828,6 +833,14 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
 }
 
 // {count, S1, S2} of a shard scanned with shard-relative ends -> absolute ends, plus tuples counted on the host
+// daac_match {start, end, value} -> {end u64, length u32, value u32}
+__global__ void repack16_kernel(const daac_match *in, uint4 *out, unsigned long long n) {
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+        const daac_match m = in[i];
+        out[i] = uint4{static_cast<uint32_t>(m.end), static_cast<uint32_t>(m.end >> 32), static_cast<uint32_t>(m.end - m.start), m.value};
+    }
+}
+
 __global__ void shard_fixup_kernel(unsigned long long *r, unsigned long long begin32, unsigned long long c, unsigned long long s1,
                                    unsigned long long s2) {
     r[2] += (r[1] & 0xffffffffull) * begin32 + s2;
@@ -843,14 +856,17 @@ __global__ void shard_fixup_kernel(unsigned long long *r, unsigned long long beg
 // on to the first sync point >= end, which is returned in *next_begin.
 // a match list in device memory (daac_scan_device, and the first half of every materialising scan)
 struct DevMatches {
-    daac_match *p = nullptr;
+    daac_match *p = nullptr;   // (or 16-byte tuples when f16)
     uint64_t n = 0;
+    bool f16 = false;          // in: the caller wants {end u64, length u32, value u32} tuples; out: that is what p holds
     DevMatches() = default;
     DevMatches(const DevMatches &) = delete;
     DevMatches &operator=(const DevMatches &) = delete;
     hipStream_t s = nullptr;
+    bool f16_done = false;     // the emitter wrote 16-byte tuples itself
     ~DevMatches() { dev_free(p, s); }
     daac_match *release() { daac_match *q = p; p = nullptr; n = 0; return q; }
+    daac_match *release_keep_n() { daac_match *q = p; p = nullptr; return q; }
 };
 
 // FindOverlappingIterator of a bytewise Standard automaton through the GRAM tuple emitter (gram2_emit_kernels.hip):
@@ -887,11 +903,8 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
     // one launch geometry for all windows
     uint64_t max_regions = 0;
     for (const Win &w : wins) max_regions = std::max<uint64_t>(max_regions, (w.ntiles + tpr - 1) / tpr);
-    const int em_write = (g_opt.emit_staged.load() != 0 && e.lds_bytes2 <= 160u * 1024u) ? 2 : 1;
-    const uint32_t wpb_write = em_write == 2 ? 8u : 16u;  // waves per workgroup of the write pass
     const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (max_regions + 15) / 16)));
-    const uint32_t blocks_write = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (max_regions + wpb_write - 1) / wpb_write)));
-    const uint64_t nwaves = std::max<uint64_t>(static_cast<uint64_t>(blocks) * 16, static_cast<uint64_t>(blocks_write) * wpb_write);
+    const uint64_t nwaves = static_cast<uint64_t>(blocks) * 16;
     unsigned long long *d_tiles = nullptr;
     void *d_scratch = nullptr;
     const size_t wq_bytes = nwaves * wq_slab * sizeof(uint2), rec_bytes = nwaves * 2ull * rec_cap * sizeof(uint4);
@@ -913,42 +926,49 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
         a.fail = d_fail;
         return a;
     };
-    for (const Win &w : wins) HIP_TRY(launch_gram2_emit(e, args_of(w), 0, blocks, stream));
+    for (const Win &w : wins) HIP_TRY(launch_gram2_emit(e, args_of(w), 0, false, blocks, stream));
     HIP_TRY(launch_exclusive_scan(d_tiles, tiles_total, d_tiles + tiles_total, d_tiles + tiles_total + 2, stream));
     unsigned long long total = 0;
+    unsigned int fail = 0;
     {
+        // the total and the COUNT pass's verdict on the record lists (a wave that met more deep matches in one tile than it has room
+        // for): known before anything is allocated or written
         unsigned long long *pin = reinterpret_cast<unsigned long long *>(pinned_words());
         HIP_TRY(hipMemcpyAsync(pin ? pin : &total, d_tiles + tiles_total, sizeof(total), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(pin ? reinterpret_cast<unsigned int *>(pin + 1) : &fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (pin) total = *pin;
+        if (pin) { total = pin[0]; fail = *reinterpret_cast<unsigned int *>(pin + 1); }
     }
+    if (fail != 0) { set_error("GRAM emitter: record lists overflowed in the count pass (code " + std::to_string(fail) + ")"); return DAAC_OK; }  // left to the segment scanners
     g_last_engine = DAAC_ENGINE_GRAM;
+    const size_t tuple_bytes = out.f16 ? 16 : sizeof(daac_match);
     if (total == 0) { *served = true; return DAAC_OK; }
-    if (total * sizeof(daac_match) > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+    if (total * tuple_bytes > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
         set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
         return DAAC_ERR_AUTOMATON_SCALE;
     }
     daac_match *d_out = nullptr;
-    HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_out), total * sizeof(daac_match), stream));
+    HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_out), total * tuple_bytes, stream));
     out.p = d_out;
     out.s = stream;
     out.n = total;
     for (const Win &w : wins) {
         EmitArgs a = args_of(w);
         a.out = d_out;
-        HIP_TRY(launch_gram2_emit(e, a, em_write, blocks_write, stream));
+        HIP_TRY(launch_gram2_emit(e, a, 1, out.f16, blocks, stream));
     }
-    unsigned int fail = 0;
     {
         unsigned int *pin = pinned_words();
         HIP_TRY(hipMemcpyAsync(pin ? pin : &fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (pin) fail = *pin;
     }
-    if (fail != 0) {  // a wave met more deep matches in one tile than it has record space for: leave it to the segment scanners
+    if (fail != 0) {  // more extras in one tile than the write pass places (the COUNT pass cannot know): leave it to the segment scanners
+        set_error("GRAM emitter: the write pass gave up (code " + std::to_string(fail) + ")");
         dev_free(out.release(), stream);
         return DAAC_OK;
     }
+    out.f16_done = out.f16;
     *served = true;
     return DAAC_OK;
 }
@@ -973,7 +993,7 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
         if (served) return DAAC_OK;
     }
     if (want_gram) {
-        set_error("the GRAM engine cannot emit tuples for this automaton / request");
+        set_error(std::string("the GRAM engine cannot emit tuples for this automaton / request [") + last_error_cstr() + "]");
         return DAAC_ERR_UNSUPPORTED;
     }
     g_last_engine = pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY;
@@ -1409,8 +1429,20 @@ daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, s
     return DAAC_OK;
 }
 
+static daac_status scan_device_impl(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
+                                    void **dev_out, uint64_t *count, bool f16);
+
 daac_status daac_scan_device(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
                              daac_match **dev_out, uint64_t *count) {
+    return scan_device_impl(pma, mode, engine, hay, len, hay_is_device, stream_, reinterpret_cast<void **>(dev_out), count, false);
+}
+daac_status daac_scan_device16(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
+                               daac_match16 **dev_out, uint64_t *count) {
+    return scan_device_impl(pma, mode, engine, hay, len, hay_is_device, stream_, reinterpret_cast<void **>(dev_out), count, true);
+}
+
+static daac_status scan_device_impl(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
+                                    void **dev_out, uint64_t *count, bool f16) {
     if (!pma || !dev_out || !count || (len && !hay)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceTables *t = nullptr;
@@ -1424,7 +1456,17 @@ daac_status daac_scan_device(daac_pma *pma, int mode, int engine, const uint8_t 
     }
     std::unique_ptr<void, void (*)(void *)> g1(staged, [](void *p) { if (p) (void)hipFree(p); });
     DevMatches dm;
+    dm.f16 = f16;
     if ((st = scan_range_device(pma, t, mode, engine, dev_hay, 0, len, len, stream, dm, nullptr)) != DAAC_OK) return st;
+    if (f16 && !dm.f16_done && dm.n != 0) {  // an engine that writes daac_match: repacked on the device
+        void *d16 = nullptr;
+        HIP_TRY(dev_malloc(&d16, dm.n * 16, stream));
+        hipLaunchKernelGGL(repack16_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>(65535, (dm.n + 255) / 256))), dim3(256), 0, stream,
+                           dm.p, static_cast<uint4 *>(d16), static_cast<unsigned long long>(dm.n));
+        HIP_TRY(hipGetLastError());
+        dev_free(dm.release_keep_n(), stream);
+        dm.p = static_cast<daac_match *>(d16);
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     *count = dm.n;
     *dev_out = dm.release();
@@ -1682,7 +1724,6 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles") g_opt.emit_tiles = value;
-    else if (n == "emit_staged") g_opt.emit_staged = value;
     else if (n == "emit_rec_cap") g_opt.emit_rec_cap = value;
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;

@@ -167,13 +167,14 @@ struct Gram2EmitDev {
     const void *sdir;         // rank directory (as Gram2Dev::sdir)
     const uint32_t *v1, *v2;  // values of the 1- and 2-gram patterns (staged in LDS)
     const uint32_t *v3;       // values of the 3-gram patterns (L2)
-    const uint4 *erec;        // N x {cmap | own (bit 0), first_child, own_value, depth}
+    const uint4 *erec;        // N x {cmap | own (bit 0), first_child, own_value, depth | further copies << 24}
     const uint2 *ehit;        // depth-(K+1) states by rank: {cmap | own, own_value}
-    const uint4 *ehit4;       // the same with the first child: {cmap | own, own_value, first_child, 0} (what the kernel reads)
+    const uint4 *ehit4;       // the same with the first child: {cmap | own, own_value, first_child, further copies << 24} (what the kernel reads)
+    const uint32_t *dupo, *dupv;  // per state: where in dupv the values of the further copies of a duplicate pattern start
+    uint32_t level_start;     // id of the first depth-(K+1) state
     const uint32_t *cfirst;
     uint32_t m_bytes, s_bytes, v1_bytes, v2_bytes;
     uint32_t off_s, off_v1, off_v2, off_ring, off_wave, lds_bytes;
-    uint32_t off_wave2, lds_bytes2;   // staged writes: 8 waves per workgroup with larger per-wave areas
     uint32_t K, C, s16, unused_byte;
 };
 struct EmitArgs {
@@ -183,15 +184,15 @@ struct EmitArgs {
     uint32_t emit_from;           // matches whose last byte lies at a virtual position >= this are reported
     unsigned long long pos_base;  // end (in haystack coordinates) of a match whose last byte is at virtual position v = pos_base + v
     unsigned long long *tile_cnt; // per tile of 1024 positions: tuple count (COUNT pass out) / exclusive offset (WRITE pass in)
-    daac_match *out;
-    uint4 *recs;                  // per wave two lists of rec_cap deep-match records {byte, length, value, -}
+    void *out;                    // daac_match (24 bytes) or {end u64, length u32, value u32} (16 bytes) tuples
+    uint4 *recs;                  // per wave two lists of rec_cap deep-match records {byte, length, value, 1 << 31 | copy for an extra}
     uint32_t rec_cap;
     uint2 *wq;                    // per-wave walker slabs
     uint32_t wq_slab;
     uint32_t ntiles, tiles_per_region, nregions;
     unsigned int *fail;           // set when a record list overflowed (the caller falls back to the segment scanners)
 };
-hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, int em, uint32_t blocks, hipStream_t stream);
+hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, int em, bool f16, uint32_t blocks, hipStream_t stream);
 hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool exact, uint32_t blocks, uint32_t threads, hipStream_t stream);
 
 // `.count()` with lane-local hit masks and the step's text staged in LDS (gram3_kernels.hip); tables of Gram2Dev.

@@ -217,8 +217,8 @@ bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out)
         uint32_t max_len = 0;
         bool ok = C <= 29;
         for (const OutputRec &o : p.outputs) max_len = std::max(max_len, o.length);
-        for (uint32_t s = 0; s < N && ok; ++s) ok = own_cnt[s] <= 1;
-        if (max_len > K + 16) ok = false;
+        for (uint32_t s = 0; s < N && ok; ++s) ok = own_cnt[s] <= (depth[s] <= K ? 1u : 256u);  // short duplicates: two values per flag bit
+        if (max_len >= (1u << 24)) ok = false;
         out.max_len = max_len;
         if (ok) {
             const uint32_t ngram = static_cast<uint32_t>(ipow(C, K));
@@ -239,13 +239,28 @@ bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out)
                 out.me[g] = word;
             }
             out.erec.resize(N);
+            out.dupo.assign(N, 0);
+            out.dupv.clear();
             for (uint32_t s = 0; s < N; ++s) {
                 uint32_t val = 0;
-                if (own_cnt[s]) val = p.outputs[output_pos_of(p.states[old_of_new[s]].opos_ch) - 1].value;
-                out.erec[s] = U32x4{cmap[s] | (own_cnt[s] ? 1u : 0u), first_child[s], val, depth[s]};
+                uint32_t op = output_pos_of(p.states[old_of_new[s]].opos_ch);
+                if (own_cnt[s]) val = p.outputs[op - 1].value;
+                if (own_cnt[s] > 1) {  // the further copies, in the order the iterator reports them (nfa_builder.rs:203-222)
+                    out.dupo[s] = static_cast<uint32_t>(out.dupv.size());
+                    for (uint32_t k = 1; k < own_cnt[s]; ++k) {
+                        op = p.outputs[op - 1].parent;
+                        out.dupv.push_back(p.outputs[op - 1].value);
+                    }
+                }
+                out.erec[s] = U32x4{cmap[s] | (own_cnt[s] ? 1u : 0u), first_child[s], val, depth[s] | ((own_cnt[s] > 1 ? own_cnt[s] - 1 : 0u) << 24)};
             }
             out.ehit.clear();
-            for (uint32_t s = out.level_start; s < out.level_start + out.dhit.size(); ++s) out.ehit.push_back(U32x2{out.erec[s].x, out.erec[s].z});
+            out.ecopies.clear();
+            for (uint32_t s = out.level_start; s < out.level_start + out.dhit.size(); ++s) {
+                out.ehit.push_back(U32x2{out.erec[s].x, out.erec[s].z});
+                out.ecopies.push_back(out.erec[s].w >> 24);
+            }
+            if (out.dupv.empty()) out.dupv.push_back(0);
             out.emit_available = true;
         }
     }

@@ -57,14 +57,17 @@ struct Gram2Tables {
     uint32_t lds_count = 0, lds_exact = 0;  // table bytes in LDS per mode (without the hit rings)
 
     // ---- tuple emission (gram2_emit_kernels.hip): the same lookups, but every match has to come out as (start, end, value) ----
-    // Needs: no duplicate patterns (a context then holds at most one pattern per length), <= 29 classes (three flag bits
-    // in the word), patterns no longer than K + 16 bytes (one u16 of deep-match lengths per position).
+    // Needs: no duplicates among the patterns of at most K bytes (a context then holds at most one pattern per length) and <= 29
+    // classes (three flag bits in the word).  Patterns longer than K + 16 bytes and the further copies of longer duplicate patterns
+    // do not fit the u16 of deep-match lengths per position: the kernel places them as "extras" (a slower path, per tile).
     bool emit_available = false;
     uint32_t max_len = 0;
     std::vector<uint32_t> me;       // C^K: continuation bits 1..28 as in m; bit 28 + len: a pattern of length len (1..3) ends after the context
     std::vector<uint32_t> v1, v2, v3;  // value of the pattern that IS the 1-/2-/3-gram (C, C^2, C^3 entries; v3 only for K = 3)
-    std::vector<U32x4> erec;        // N: {cmap | own (bit 0), first_child, own_value, depth}
+    std::vector<U32x4> erec;        // N: {cmap | own (bit 0), first_child, own_value, depth | further copies << 24}
     std::vector<U32x2> ehit;        // depth-(K+1) states by rank: {cmap | own (bit 0), own_value}
+    std::vector<uint32_t> ecopies;  // the same order: further copies of a duplicate pattern (0 = none)
+    std::vector<uint32_t> dupo, dupv;  // per state: offset into dupv of the values of those copies, in registration order
 };
 
 constexpr uint32_t kGram2MaskBits = 0x3fffffffu;  // continuation bits of an M word

@@ -27,11 +27,9 @@ namespace {
 typedef uint32_t ge_u32x4_t __attribute__((ext_vector_type(4)));
 constexpr uint32_t kERing = 128;        // entries of a wave's hit stack
 constexpr uint32_t kTile = 1024;        // end positions per wave-step
-constexpr uint32_t kWaveLds = 2048 + 256 + 256 + 16;  // per wave (EM 0/1): dm[1024] u16, lanebase[64] u32, nsw[64] u32, counters
-// per wave (EM 2, staged writes): per position {deep lengths | offset of its first tuple << 16} u32[1024], {class | flags << 5}
-// u8[16 + 1024] (16 bytes of left context), a staging buffer for the tuples of 64 consecutive positions, counters
-constexpr uint32_t kStageCap = 64;
-constexpr uint32_t kWaveLds2 = 4096 + 1040 + kStageCap * 24 + 16;
+constexpr uint32_t kMaxExtras = 64;     // matches per tile the per-position length bits cannot carry (longer than K + 16 bytes, further copies of a duplicate pattern)
+// per wave: dm[1024] u16, lanebase[64] u32, nsw[64] u32, extras[kMaxExtras] x {position, length | copy << 24}, counters
+constexpr uint32_t kWaveLds = 2048 + 256 + 256 + kMaxExtras * 8 + 32;
 typedef __attribute__((address_space(3))) const uint32_t ldse_cu32;
 typedef __attribute__((address_space(3))) const uint8_t ldse_cu8;
 
@@ -44,23 +42,25 @@ __device__ __forceinline__ void ge_copy(void *dst, const void *src, uint32_t byt
     uint4 *d = reinterpret_cast<uint4 *>(dst);
     for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
 }
-// one 24-byte tuple: a 16-byte and an 8-byte store.  Plain stores on purpose: the lanes of one store instruction write to
-// different 128-byte lines, and it is the L2 that puts the lines together before they go to HBM — the same stores marked
-// non-temporal ran 4.4x slower (63 ms instead of 14.4 ms for 1 GiB of cfg3, profiles/r02_emit_experiments.txt)
-#ifndef DAAC_EMX
-#define DAAC_EMX 0  // timing experiments (profiles/r02_emit_experiments.txt): 1 = no tuple stores (wrong output)
-#endif
-__device__ __forceinline__ void put_tuple(daac_match *dst, unsigned long long start, unsigned long long end, uint32_t value) {
+// One tuple.  daac_match (24 bytes: start, end, value) takes a 16-byte and an 8-byte store; daac_match16 (the crate's own Match
+// fields, src/lib.rs:287-291: end, length, value) ONE 16-byte store and a third less write traffic.  Plain stores on purpose: the
+// lanes of one store instruction write to different 128-byte lines, and it is the L2 that puts the lines together before they go
+// to HBM — the same stores marked non-temporal ran 4.4x slower (profiles/r02_emit_experiments.txt)
+template <bool F16>
+__device__ __forceinline__ void put_tuple(void *out, unsigned long long slot, unsigned long long start, unsigned long long end, uint32_t value) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-#if DAAC_EMX == 1
-    asm volatile("" :: "v"(dst), "v"(start), "v"(end), "v"(value));
-    return;
-#endif
-    const u64x2 se = {start, end};
-    const u32x2 vp = {value, 0u};
-    *reinterpret_cast<u64x2 *>(dst) = se;
-    *reinterpret_cast<u32x2 *>(reinterpret_cast<char *>(dst) + 16) = vp;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (F16) {
+        const u32x4 t = {static_cast<uint32_t>(end), static_cast<uint32_t>(end >> 32), static_cast<uint32_t>(end - start), value};
+        *reinterpret_cast<u32x4 *>(static_cast<char *>(out) + slot * 16ull) = t;
+    } else {
+        char *dst = static_cast<char *>(out) + slot * 24ull;
+        const u64x2 se = {start, end};
+        const u32x2 vp = {value, 0u};
+        *reinterpret_cast<u64x2 *>(dst) = se;
+        *reinterpret_cast<u32x2 *>(dst + 16) = vp;
+    }
 }
 // inclusive scan over the 64 lanes on the VALU (DPP row shifts + row broadcasts)
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x) {
@@ -85,10 +85,9 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
 
 }  // namespace
 
-// K = context length; EM = 0 count per tile, 1 emit with one pair of stores per tuple (1024 threads), 2 emit through an LDS
-// staging buffer so that the tuples of 64 consecutive positions leave as contiguous 512-byte stores (512 threads: the
-// per-wave areas are larger); S16 = rank directory entries are u16
-template <int K, int EM, bool S16, int TPB>
+// K = context length; EM = 0 count per tile, 1 emit; F16 = 16-byte tuples {end, length, value} instead of daac_match; S16 = rank
+// directory entries are u16
+template <int K, int EM, bool F16, bool S16, int TPB>
 __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, const EmitArgs a) {
     constexpr int P = 16;
     constexpr bool WRITE = EM != 0;
@@ -115,13 +114,12 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
     uint4 *__restrict__ rec_a = a.recs + wave_global * 2ull * a.rec_cap, *__restrict__ rec_b = rec_a + a.rec_cap;
 
     // per-wave LDS: deep-match lengths per end position of the tile, lane offsets, short counts, list counters
-    char *wl = smem + (EM == 2 ? g.off_wave2 + wave_in_wg * kWaveLds2 : g.off_wave + wave_in_wg * kWaveLds);
-    uint32_t *dm32 = reinterpret_cast<uint32_t *>(wl);            // EM 1: 512 dwords = 1024 x u16; EM 2: 1024 dwords
-    uint32_t *lb = reinterpret_cast<uint32_t *>(wl + 2048);       // 64      (EM 1)
-    uint32_t *nsw = reinterpret_cast<uint32_t *>(wl + 2048 + 256);  //       (EM 1)
-    uint8_t *cf = reinterpret_cast<uint8_t *>(wl + 4096);         // EM 2: 16 + 1024 bytes
-    unsigned long long *stage = reinterpret_cast<unsigned long long *>(wl + 4096 + 1040);  // EM 2
-    uint32_t *ctr = reinterpret_cast<uint32_t *>(wl + (EM == 2 ? 4096 + 1040 + kStageCap * 24 : 2048 + 512));  // [0] records of this tile, [1] of the next
+    char *wl = smem + g.off_wave + wave_in_wg * kWaveLds;
+    uint32_t *dm32 = reinterpret_cast<uint32_t *>(wl);            // 512 dwords = 1024 x u16
+    uint32_t *lb = reinterpret_cast<uint32_t *>(wl + 2048);       // 64
+    uint32_t *nsw = reinterpret_cast<uint32_t *>(wl + 2048 + 256);
+    uint2 *xs = reinterpret_cast<uint2 *>(wl + 2048 + 512);       // the tile's extras
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(wl + 2048 + 512 + kMaxExtras * 8);  // [0] records of this tile, [1] of the next, [2] / [3] extras among them, [4] scratch
 
     auto load_chunk = [&](uint32_t v) -> uint4 {
         if (v >= a.vlen) return uint4{ub4, ub4, ub4, ub4};
@@ -144,21 +142,28 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
     bool prologue = false;              // wave-uniform
     uint4 *cur_list = rec_a, *next_list = rec_b;
 
-    // a deep match: `p` = its last byte, `len` its length, found while the wave works on tile [sb, sb + 1024)
-    auto log_deep = [&](uint32_t p, uint32_t len, uint32_t value) {
+    // a deep match: `p` = its last byte, `len` its length, found while the wave works on tile [sb, sb + 1024); `copy` > 0: a further copy of
+    // a pattern registered more than once (its value comes from the duplicate list).  Matches the per-position length bits cannot carry —
+    // longer than K + 16 bytes, or copies — are EXTRAS: logged like the others, placed by the slower path at the end of the tile.
+    auto log_deep = [&](uint32_t p, uint32_t len, uint32_t value, uint32_t copy) {
         if (p < a.emit_from) return;
         const bool here = p < sb + kTile;
         if (here && prologue) return;   // belongs to the tile before this wave's region
+        const bool extra = len - (K + 1) >= 16u || copy != 0;
+        const uint32_t slot = atomicAdd(&ctr[here ? 0 : 1], 1u);
+        if (slot >= a.rec_cap) { atomicOr(a.fail, 1u); return; }   // (also in the COUNT pass: the caller falls back before it allocates)
+        if (extra) atomicAdd(&ctr[here ? 2 : 3], 1u);
         if (WRITE) {
-            const uint32_t slot = atomicAdd(&ctr[here ? 0 : 1], 1u);
-            if (slot >= a.rec_cap) { atomicOr(a.fail, 1u); return; }
-            (here ? cur_list : next_list)[slot] = uint4{p, len, value, 0u};
-            if (here) {
-                if (EM == 2) atomicOr(&dm32[p - sb], 1u << (len - (K + 1)));
-                else atomicOr(&dm32[(p - sb) >> 1], 1u << ((len - (K + 1)) + 16u * ((p - sb) & 1u)));
-            }
-        } else {
-            atomicAdd(&ctr[here ? 0 : 1], 1u);
+            (here ? cur_list : next_list)[slot] = uint4{p, len, value, extra ? (0x80000000u | copy) : 0u};
+            if (here && !extra) atomicOr(&dm32[(p - sb) >> 1], 1u << ((len - (K + 1)) + 16u * ((p - sb) & 1u)));
+        }
+    };
+    // a state that ends a pattern: its own match, then the further copies of a duplicate (erec.w / ehit4.w: count << 24)
+    auto log_state = [&](uint32_t p, uint32_t len, uint32_t value, uint32_t ncopies, uint32_t state) {
+        log_deep(p, len, value, 0u);
+        if (ncopies != 0) {
+            const uint32_t off = g.dupo[state];
+            for (uint32_t k = 0; k < ncopies; ++k) log_deep(p, len, g.dupv[off + k], k + 1u);
         }
     };
 
@@ -171,13 +176,15 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
         for (uint32_t i = lane; i < wq_n; i += 64) {
             const uint2 e = slab[i];
             uint32_t vnext = e.x + 2;   // the state consumed the byte before vnext
-            uint4 r = g.erec[e.y & 0x07ffffffu];  // {cmap | own, first_child, own_value, depth}
+            uint32_t state = e.y & 0x07ffffffu;
+            uint4 r = g.erec[state];  // {cmap | own, first_child, own_value, depth | further copies << 24}
             uint32_t kn = e.y >> 27;
             uint32_t ahead = 0, n_ahead = 0;
             for (;;) {
-                if (r.x & 1u) log_deep(vnext - 1, r.w, r.z);
+                if (r.x & 1u) log_state(vnext - 1, r.w & 0xffffffu, r.z, r.w >> 24, state);
                 if (((r.x >> kn) & 1u) == 0 || kn == 0) break;
-                r = g.erec[r.y + __popc(r.x & ((1u << kn) - 1u) & ~1u)];
+                state = r.y + __popc(r.x & ((1u << kn) - 1u) & ~1u);
+                r = g.erec[state];
                 ++vnext;
                 if (n_ahead == 0) {
                     ahead = 0;
@@ -200,8 +207,8 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
     auto consume_pending = [&]() {
         if (!pend_valid) return;
         pend_valid = false;
-        const uint4 r = pend;  // {cmap | own, own_value, first_child, -}; zero for idle lanes
-        if (r.x & 1u) log_deep(pend_pos, K + 1, r.y);
+        const uint4 r = pend;  // {cmap | own, own_value, first_child, further copies << 24}; zero for idle lanes
+        if (r.x & 1u) log_state(pend_pos, K + 1, r.y, r.w >> 24, g.level_start + pend_rank);
         const uint32_t k1 = (pend_item >> 22) & 31u;
         const bool go = k1 != 0 && ((r.x >> k1) & 1u);
         const unsigned long long m = __ballot(go);
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
         const uint32_t t_begin = static_cast<uint32_t>(region) * a.tiles_per_region;
         const uint32_t t_end = t_begin + a.tiles_per_region < a.ntiles ? t_begin + a.tiles_per_region : a.ntiles;
         uint32_t t = t_begin > 0 ? t_begin - 1 : t_begin;
-        if (lane < 2) ctr[lane] = 0;
+        if (lane < 5) ctr[lane] = 0;
         cur_list = rec_a;
         next_list = rec_b;
         q_n = 0;
@@ -313,13 +320,12 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
             // this tile's per-position deep lengths start empty; what the previous tile's walkers found for this one is replayed
             if (WRITE) {
 #pragma unroll
-                for (int q = 0; q < (EM == 2 ? 4 : 2); ++q) reinterpret_cast<uint4 *>(dm32)[lane * (EM == 2 ? 4 : 2) + q] = uint4{0u, 0u, 0u, 0u};
+                for (int q = 0; q < 2; ++q) reinterpret_cast<uint4 *>(dm32)[lane * 2 + q] = uint4{0u, 0u, 0u, 0u};
                 const uint32_t ncur = min(*reinterpret_cast<volatile uint32_t *>(&ctr[0]), a.rec_cap);  // (a list that overflowed set a.fail: the scan is redone elsewhere)
                 if (ncur != 0) mem_settle();  // only then: the counter drains this wave's stores too, the previous tile's tuples among them
                 for (uint32_t i = lane; i < ncur; i += 64) {
                     const uint4 r = cur_list[i];
-                    if (EM == 2) atomicOr(&dm32[r.x - sb], 1u << (r.y - (K + 1)));
-                    else atomicOr(&dm32[(r.x - sb) >> 1], 1u << ((r.y - (K + 1)) + 16u * ((r.x - sb) & 1u)));
+                    if (!(r.w >> 31)) atomicOr(&dm32[(r.x - sb) >> 1], 1u << ((r.y - (K + 1)) + 16u * ((r.x - sb) & 1u)));
                 }
             }
 
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
                 flags |= static_cast<uint32_t>(__popc(f)) << (2 * j);
                 // the value of a 3-byte pattern comes from L2: asked for now, used when the tile's tuples are written (by then
                 // the hits and walkers of the tile have been through, and the answer is there); it takes the place of am[j + 1]
-                if (EM == 1 && K == 3) am[j + 1] = (f & 4u) ? g.v3[(am_here - offM) >> 2] : 0u;
+                if (WRITE && K == 3) am[j + 1] = (f & 4u) ? g.v3[(am_here - offM) >> 2] : 0u;
                 const bool hit = __builtin_amdgcn_ubfe(mprev, kx[K + j], 1) != 0;
                 const unsigned long long m = __ballot(hit);
                 if (m != 0) {
@@ -351,16 +357,6 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
                 }
                 mprev = mw;
                 am_prev = am_here;
-            }
-            if (EM == 2) {  // {class | flags << 5} of this lane's 16 positions, and the K classes before the tile
-                uint32_t cw[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int j = 0; j < P; ++j) cw[j >> 2] |= (kx[K + j] | (((fl3[j >> 3] >> (4 * (j & 7))) & 7u) << 5)) << (8 * (j & 3));
-                reinterpret_cast<uint4 *>(cf + 16)[lane] = uint4{cw[0], cw[1], cw[2], cw[3]};
-                if (lane == 0) {
-#pragma unroll
-                    for (int i = 0; i < K; ++i) cf[16 - K + i] = static_cast<uint8_t>(kx[i]);
-                }
             }
             // everything this tile's hits lead to has to be known before its tuples can be placed
             while (q_n != 0) process_batch();
@@ -376,67 +372,6 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
                     uint32_t total;
                     (void)wave_excl_scan(nshort, lane, total);
                     if (lane == 0) a.tile_cnt[t] = static_cast<unsigned long long>(total) + *reinterpret_cast<volatile uint32_t *>(&ctr[0]);
-                } else if (EM == 2) {
-                    // ---- offsets: the tuples of position p = 64 k + lane start at dmo[p] >> 16 (relative to the tile) ----
-                    const uint32_t Cc = g.C;
-                    uint32_t cstart[17], v3v[16];
-                    cstart[0] = 0;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const uint32_t p = 64u * k + lane;
-                        const uint32_t d = dm32[p] & 0xffffu;
-                        const uint32_t cfv = cf[16 + p], f = cfv >> 5;
-                        const uint32_t tc = __popc(d) + __popc(f);
-                        const uint32_t incl = wave_incl_scan_dpp(tc);
-                        dm32[p] = d | ((cstart[k] + incl - tc) << 16);
-                        cstart[k + 1] = cstart[k] + __builtin_amdgcn_readlane(incl, 63);
-                        v3v[k] = 0;
-                        if (K == 3 && (f & 4u)) v3v[k] = g.v3[((cf[16 + p - 2] & 31u) * Cc + (cf[16 + p - 1] & 31u)) * Cc + (cfv & 31u)];
-                    }
-                    daac_match *__restrict__ out = a.out + tile_base;
-                    mem_settle();
-                    const uint32_t ncur = min(*reinterpret_cast<volatile uint32_t *>(&ctr[0]), a.rec_cap);
-                    uint4 myrec = uint4{0xffffffffu, 0u, 0u, 0u};
-                    if (ncur <= 64u && lane < ncur) myrec = cur_list[lane];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const uint32_t c_lo = cstart[k], n_k = cstart[k + 1] - c_lo;  // wave-uniform
-                        if (n_k == 0) continue;
-                        const bool staged = n_k <= kStageCap;
-                        auto place = [&](uint32_t slot, unsigned long long start, unsigned long long end, uint32_t value) {
-                            if (staged) {
-                                unsigned long long *q = stage + 3u * (slot - c_lo);
-                                q[0] = start; q[1] = end; q[2] = value;
-                            } else {
-                                put_tuple(out + slot, start, end, value);
-                            }
-                        };
-                        auto place_deep = [&](const uint4 &r) {
-                            const uint32_t rel = r.x - sb;
-                            if (rel - 64u * k >= 64u) return;  // not in this chunk
-                            const uint32_t word = dm32[rel];
-                            const unsigned long long end = a.pos_base + r.x;
-                            place((word >> 16) + __popc((word & 0xffffu) >> (r.y - (K + 1) + 1)), end - r.y, end, r.z);
-                        };
-                        if (ncur <= 64u) {
-                            if (myrec.x != 0xffffffffu) place_deep(myrec);
-                        } else {
-                            for (uint32_t i = lane; i < ncur; i += 64) place_deep(cur_list[i]);
-                        }
-                        {
-                            const uint32_t p = 64u * k + lane, word = dm32[p];
-                            uint32_t slot = (word >> 16) + __popc(word & 0xffffu);
-                            const uint32_t cfv = cf[16 + p], f = cfv >> 5, c0 = cfv & 31u;
-                            const unsigned long long end = a.pos_base + sb + p;
-                            if (K == 3 && (f & 4u)) place(slot++, end - 3, end, v3v[k]);
-                            if (f & 2u) place(slot++, end - 2, end, lds_u32(g.off_v2 + 4u * ((cf[16 + p - 1] & 31u) * Cc + c0)));
-                            if (f & 1u) place(slot++, end - 1, end, lds_u32(g.off_v1 + 4u * c0));
-                        }
-                        if (staged) {  // 24 n_k contiguous bytes: 8 per lane and store
-                            unsigned long long *dst = reinterpret_cast<unsigned long long *>(out + c_lo);
-                            for (uint32_t q = lane; q < 3u * n_k; q += 64) dst[q] = stage[q];
-                        }
-                    }
                 } else {
                     uint32_t dmw[8];
                     {
@@ -446,17 +381,40 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
                     uint32_t ndeep = 0;
 #pragma unroll
                     for (int w = 0; w < 8; ++w) ndeep += __popc(dmw[w]);
-                    uint32_t total;
-                    const uint32_t lanebase = wave_excl_scan(nshort + ndeep, lane, total);
-                    lb[lane] = lanebase;
-                    nsw[lane] = flags;
-                    daac_match *__restrict__ out = a.out + tile_base;
-                    // deep matches: replay the records of this tile into their slots
                     mem_settle();
                     const uint32_t ncur = min(*reinterpret_cast<volatile uint32_t *>(&ctr[0]), a.rec_cap);  // (a list that overflowed set a.fail: the scan is redone elsewhere)
-                    for (uint32_t i = lane; i < ncur; i += 64) {
-                        const uint4 r = cur_list[i];
-                        const uint32_t rel = r.x - sb, L = rel >> 4, j = rel & 15u;
+                    // ---- the tile's extras (rare): gathered into LDS, one per lane; every lane learns how many fall on each of its positions ----
+                    uint32_t xn = *reinterpret_cast<volatile uint32_t *>(&ctr[2]);   // wave-uniform
+                    uint2 ex = uint2{0xffffffffu, 0u};   // this lane's extra: {position, length | copy << 24}
+                    unsigned long long xin = 0;          // extras on this lane's 16 positions, four bits each
+                    uint32_t nex = 0;
+                    if (xn != 0) {
+                        if (xn > kMaxExtras) { if (lane == 0) atomicOr(a.fail, 2u); xn = kMaxExtras; }
+                        if (lane == 0) ctr[4] = 0;
+                        for (uint32_t i = lane; i < ncur; i += 64) {
+                            const uint4 r = cur_list[i];
+                            if (r.w >> 31) {
+                                const uint32_t idx = atomicAdd(&ctr[4], 1u);
+                                if (idx < kMaxExtras) xs[idx] = uint2{r.x, r.y | ((r.w & 0xffu) << 24)};
+                            }
+                        }
+                        if (lane < xn) ex = xs[lane];
+                        for (uint32_t i = 0; i < xn; ++i) {
+                            const uint32_t ep = __builtin_amdgcn_readlane(ex.x, i);
+                            if (ep - v < 16u) {
+                                if (((xin >> (4u * (ep - v))) & 15u) == 15u) atomicOr(a.fail, 4u);
+                                xin += 1ull << (4u * (ep - v));
+                                ++nex;
+                            }
+                        }
+                    }
+                    uint32_t total;
+                    const uint32_t lanebase = wave_excl_scan(nshort + ndeep + nex, lane, total);
+                    lb[lane] = lanebase;
+                    nsw[lane] = flags;
+                    void *__restrict__ out = reinterpret_cast<char *>(a.out) + tile_base * (F16 ? 16ull : 24ull);
+                    // tuples of lane L that lie before its position j, extras left aside: deep ones (length bits) and short ones (flags)
+                    auto before_of = [&](uint32_t L, uint32_t j, uint32_t &here16) -> uint32_t {
                         const uint4 d0 = reinterpret_cast<const uint4 *>(dm32)[L * 2], d1 = reinterpret_cast<const uint4 *>(dm32)[L * 2 + 1];
                         const uint32_t dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
                         uint32_t before = 0;
@@ -467,28 +425,77 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
                         }
                         const uint32_t x = nsw[L] & ((1u << (2 * j)) - 1u);
                         before += __popc(x & 0x55555555u) + 2u * __popc(x & 0xaaaaaaaau);
-                        const uint32_t here = (dw[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
-                        const uint32_t longer = __popc(here >> (r.y - (K + 1) + 1));
-                        const unsigned long long end = a.pos_base + r.x;
-                        put_tuple(out + (lb[L] + before + longer), end - r.y, end, r.z);
+                        here16 = (dw[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+                        return before;
+                    };
+                    // extras of the same lane-group of 16 positions that come before the key (position, length desc, copy asc)
+                    auto extras_before = [&](uint32_t p, uint32_t len, uint32_t copy) -> uint32_t {
+                        uint32_t n = 0;
+                        for (uint32_t i = 0; i < xn; ++i) {
+                            const uint32_t ep = __builtin_amdgcn_readlane(ex.x, i), ey = __builtin_amdgcn_readlane(ex.y, i);
+                            const uint32_t el = ey & 0xffffffu, ec = ey >> 24;
+                            if (((ep - sb) >> 4) != ((p - sb) >> 4)) continue;
+                            n += (ep < p || (ep == p && (el > len || (el == len && ec < copy)))) ? 1u : 0u;
+                        }
+                        return n;
+                    };
+                    // deep matches: replay the records of this tile into their slots
+                    for (uint32_t i0 = 0; i0 < ncur; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        uint4 r = uint4{0u, 0u, 0u, 0x80000000u};
+                        if (i < ncur) r = cur_list[i];
+                        const bool normal = !(r.w >> 31);
+                        uint32_t slot = 0;
+                        if (normal) {
+                            const uint32_t rel = r.x - sb;
+                            uint32_t here16;
+                            slot = lb[rel >> 4] + before_of(rel >> 4, rel & 15u, here16) + __popc(here16 >> (r.y - (K + 1) + 1));
+                        }
+                        if (xn != 0) slot += extras_before(normal ? r.x : sb, normal ? r.y : 0u, 0u);  // (all lanes walk the list together)
+                        if (normal) {
+                            const unsigned long long end = a.pos_base + r.x;
+                            put_tuple<F16>(out, slot, end - r.y, end, r.z);
+                        }
+                    }
+                    if (xn != 0) {  // the extras themselves, one per lane: after the deep matches of their position that are longer (and their own original)
+                        const uint32_t ep = ex.x, el = ex.y & 0xffffffu, ec = ex.y >> 24;
+                        const bool mine = lane < xn;
+                        uint32_t slot = 0;
+                        if (mine) {
+                            const uint32_t rel = ep - sb;
+                            uint32_t here16;
+                            slot = lb[rel >> 4] + before_of(rel >> 4, rel & 15u, here16);
+                            if (el - (K + 1) < 16u) slot += __popc(here16 >> (el - (K + 1) + 1)) + (ec != 0 ? 1u : 0u);
+                        }
+                        slot += extras_before(mine ? ep : sb, mine ? el : 0u, mine ? ec : 0u);
+                        if (mine) {
+                            // the value of an extra is in its record: find it again (the list is short and this is the slow path)
+                            uint32_t val = 0;
+                            for (uint32_t i = 0; i < ncur; ++i) {
+                                const uint4 r = cur_list[i];
+                                if ((r.w >> 31) && r.x == ep && r.y == el && (r.w & 0xffu) == ec) { val = r.z; break; }
+                            }
+                            const unsigned long long end = a.pos_base + ep;
+                            put_tuple<F16>(out, slot, end - el, end, val);
+                        }
                     }
                     // short matches: each lane walks its 16 positions
                     uint32_t running = lanebase;
                     const unsigned long long end0 = a.pos_base + v;
 #pragma unroll
                     for (int j = 0; j < P; ++j) {
-                        running += __popc((dmw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                        running += __popc((dmw[j >> 1] >> (16 * (j & 1))) & 0xffffu) + static_cast<uint32_t>((xin >> (4 * j)) & 15u);
                         const uint32_t f = (fl3[j >> 3] >> (4 * (j & 7))) & 7u;
                         if (__ballot(f != 0) == 0) continue;
                         const unsigned long long end = end0 + j;
                         if (K == 3 && (f & 4u)) {
-                            put_tuple(out + running++, end - 3, end, am[j + 1]);  // (the value asked for during detection)
+                            put_tuple<F16>(out, running++, end - 3, end, am[j + 1]);  // (the value asked for during detection)
                         }
                         if (f & 2u) {
-                            put_tuple(out + running++, end - 2, end, lds_u32(g.off_v2 + 4u * (kx[K + j - 1] * g.C + kx[K + j])));
+                            put_tuple<F16>(out, running++, end - 2, end, lds_u32(g.off_v2 + 4u * (kx[K + j - 1] * g.C + kx[K + j])));
                         }
                         if (f & 1u) {
-                            put_tuple(out + running++, end - 1, end, lds_u32(g.off_v1 + 4u * kx[K + j]));
+                            put_tuple<F16>(out, running++, end - 1, end, lds_u32(g.off_v1 + 4u * kx[K + j]));
                         }
                     }
                 }
@@ -496,33 +503,33 @@ __global__ __launch_bounds__(TPB) void gram2_emit_kernel(const Gram2EmitDev g, c
             // the next tile's list becomes the current one
             {
                 uint4 *tmp = cur_list; cur_list = next_list; next_list = tmp;
-                const uint32_t nn = *reinterpret_cast<volatile uint32_t *>(&ctr[1]);
-                if (lane == 0) { ctr[0] = nn; ctr[1] = 0; }
+                const uint32_t nn = *reinterpret_cast<volatile uint32_t *>(&ctr[1]), nx = *reinterpret_cast<volatile uint32_t *>(&ctr[3]);
+                if (lane == 0) { ctr[0] = nn; ctr[1] = 0; ctr[2] = nx; ctr[3] = 0; }
             }
         }
     }
 }
 
-template <int K, int EM, int TPB>
+template <int K, int EM, bool F16>
 static hipError_t launch_e(const Gram2EmitDev &dev, const EmitArgs &a, uint32_t blocks, hipStream_t stream) {
     hipError_t e;
-    const uint32_t lds = EM == 2 ? dev.lds_bytes2 : dev.lds_bytes;
+    const uint32_t lds = dev.lds_bytes;
     if (dev.s16) {
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_emit_kernel<K, EM, true, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_emit_kernel<K, EM, F16, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds))) != hipSuccess) return e;
-        hipLaunchKernelGGL((gram2_emit_kernel<K, EM, true, TPB>), dim3(blocks), dim3(TPB), lds, stream, dev, a);
+        hipLaunchKernelGGL((gram2_emit_kernel<K, EM, F16, true, 1024>), dim3(blocks), dim3(1024), lds, stream, dev, a);
     } else {
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_emit_kernel<K, EM, false, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_emit_kernel<K, EM, F16, false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      static_cast<int>(lds))) != hipSuccess) return e;
-        hipLaunchKernelGGL((gram2_emit_kernel<K, EM, false, TPB>), dim3(blocks), dim3(TPB), lds, stream, dev, a);
+        hipLaunchKernelGGL((gram2_emit_kernel<K, EM, F16, false, 1024>), dim3(blocks), dim3(1024), lds, stream, dev, a);
     }
     return hipGetLastError();
 }
 
-// em: 0 count, 1 write (a pair of stores per tuple), 2 write (staged: contiguous stores); waves per workgroup: 16, 16, 8
-hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, int em, uint32_t blocks, hipStream_t stream) {
-    if (dev.K == 3) return em == 0 ? launch_e<3, 0, 1024>(dev, a, blocks, stream) : em == 1 ? launch_e<3, 1, 1024>(dev, a, blocks, stream) : launch_e<3, 2, 512>(dev, a, blocks, stream);
-    return em == 0 ? launch_e<2, 0, 1024>(dev, a, blocks, stream) : em == 1 ? launch_e<2, 1, 1024>(dev, a, blocks, stream) : launch_e<2, 2, 512>(dev, a, blocks, stream);
+// em: 0 count, 1 write; f16: 16-byte tuples {end, length, value} instead of daac_match
+hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, int em, bool f16, uint32_t blocks, hipStream_t stream) {
+    if (dev.K == 3) return em == 0 ? launch_e<3, 0, false>(dev, a, blocks, stream) : f16 ? launch_e<3, 1, true>(dev, a, blocks, stream) : launch_e<3, 1, false>(dev, a, blocks, stream);
+    return em == 0 ? launch_e<2, 0, false>(dev, a, blocks, stream) : f16 ? launch_e<2, 1, true>(dev, a, blocks, stream) : launch_e<2, 1, false>(dev, a, blocks, stream);
 }
 
 }  // namespace daac

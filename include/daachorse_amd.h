@@ -69,6 +69,14 @@ typedef struct {
     uint32_t _pad;
 } daac_match;
 
+/* The same match as the crate keeps it (Match<u32>, src/lib.rs:287-291: length, end, value; start() = end - length): 16 bytes, what
+ * daac_scan_device16 leaves in device memory — one 16-byte store per tuple and a third less write traffic than daac_match. */
+typedef struct {
+    uint64_t end;
+    uint32_t length;
+    uint32_t value;
+} daac_match16;
+
 typedef struct {
     uint8_t match_kind;       /* DoubleArrayAhoCorasick::match_kind()  bytewise.rs:735-737 */
     uint32_t num_states;      /* ::num_states()                        bytewise.rs:785-787 */
@@ -168,6 +176,10 @@ daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, s
  * after the stream has finished.  daac_device_to_host copies (part of) such a list to host memory. */
 daac_status daac_scan_device(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len,
                              int hay_is_device, void *stream, daac_match **dev_out, uint64_t *count);
+/* The same list as 16-byte tuples {end, length, value} (daac_match16).  The GRAM emitter writes them directly; lists from the other
+ * engines are repacked on the device. */
+daac_status daac_scan_device16(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len,
+                               int hay_is_device, void *stream, daac_match16 **dev_out, uint64_t *count);
 void daac_device_free(void *p);
 daac_status daac_device_to_host(void *dst, const void *dev_src, size_t bytes);
 size_t daac_matches_count(const daac_matches *m);
@@ -235,7 +247,6 @@ void daac_stream_close(daac_stream *s);
  *   gram_ppl (0 = auto: 32 positions per lane and step for automata without short patterns, else 16)
  *   gram_version (0 = second table set where it applies, 1 = first only, 2 = second only), gram2_dpp (1: DPP wave shifts)
  *   emit (1)                    materialising overlapping scans through the GRAM tuple emitter where it applies (0: segment scanners);
- *   emit_staged (0: one pair of stores per tuple; 1: the write pass gathers the tuples of 64 positions in LDS and stores them contiguously),
  *   emit_tiles (64), emit_rec_cap (256)   tiles of 1024 positions per wave region / deep-match records per wave and tile
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
  *   restart_tier (0)            1: find_iter of Standard bytewise automata runs its chains over the TIERED tables instead of the double array

@@ -47,15 +47,20 @@ int main(int argc, char **argv) {
         for (uint32_t t = 0; t < K; ++t) w = w * C + cls(pos - (K - 1) + t);
         return w;
     };
-    // deep matches by the byte they end at: (length, value)
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> deep(static_cast<size_t>(n));
+    // deep matches by the byte they end at: (length, copy, value) — copy > 0: a further copy of a duplicate pattern
+    struct Deep { uint32_t len, copy, value; };
+    std::vector<std::vector<Deep>> deep(static_cast<size_t>(n));
+    auto add_state = [&](long long at, uint32_t len, uint32_t value, uint32_t copies, uint32_t state) {
+        deep[at].push_back(Deep{len, 0u, value});
+        for (uint32_t k = 0; k < copies; ++k) deep[at].push_back(Deep{len, k + 1, g.dupv[g.dupo[state] + k]});
+    };
     for (long long pz = 0; pz < n; ++pz) {
         const uint32_t gp = kgram_ending_at(pz - 1), wp = g.me[gp], d = cls(pz);
         if (d == 0 || ((wp >> d) & 1u) == 0) continue;
         uint32_t rank = g.sdir[gp >> 2] + __builtin_popcount(wp & 0x1ffffffeu & ((1u << d) - 1u));
         for (uint32_t i = gp & ~3u; i < gp; ++i) rank += __builtin_popcount(g.me[i] & 0x1ffffffeu);
         const U32x2 h = g.ehit[rank];
-        if (h.x & 1u) deep[pz].emplace_back(K + 1, h.y);
+        if (h.x & 1u) add_state(pz, K + 1, h.y, g.ecopies[rank], g.level_start + rank);
         uint32_t k1 = cls(pz + 1);
         if (k1 == 0 || ((h.x >> k1) & 1u) == 0) continue;
         uint32_t id = g.cfirst[rank] + __builtin_popcount(h.x & ((1u << k1) - 1u) & ~1u);
@@ -63,7 +68,7 @@ int main(int argc, char **argv) {
         uint32_t kn = cls(nx);
         for (;;) {
             const U32x4 r = g.erec[id];
-            if (r.x & 1u) { if (r.w != static_cast<uint32_t>(nx - 1 - (pz - K) + 1)) { std::printf("MISMATCH depth\n"); return 1; } deep[nx - 1].emplace_back(r.w, r.z); }
+            if (r.x & 1u) { if ((r.w & 0xffffffu) != static_cast<uint32_t>(nx - 1 - (pz - K) + 1)) { std::printf("MISMATCH depth\n"); return 1; } add_state(nx - 1, r.w & 0xffffffu, r.z, r.w >> 24, id); }
             if (kn == 0 || ((r.x >> kn) & 1u) == 0) break;
             id = r.y + __builtin_popcount(r.x & ((1u << kn) - 1u) & ~1u);
             ++nx;
@@ -72,11 +77,11 @@ int main(int argc, char **argv) {
     }
     std::vector<Tup> got;
     for (long long pz = 0; pz < n; ++pz) {
-        std::sort(deep[pz].begin(), deep[pz].end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first > b.first; });
+        std::sort(deep[pz].begin(), deep[pz].end(), [](const Deep &a, const Deep &b) { return a.len != b.len ? a.len > b.len : a.copy < b.copy; });
         for (size_t i = 0; i + 1 < deep[pz].size(); ++i)
-            if (deep[pz][i].first == deep[pz][i + 1].first) { std::printf("MISMATCH two deep matches of one length\n"); return 1; }
+            if (deep[pz][i].len == deep[pz][i + 1].len && deep[pz][i].copy == deep[pz][i + 1].copy) { std::printf("MISMATCH two deep matches of one length\n"); return 1; }
         const uint64_t end = static_cast<uint64_t>(pz + 1);
-        for (const auto &dv : deep[pz]) got.emplace_back(end - dv.first, end, dv.second);
+        for (const auto &dv : deep[pz]) got.emplace_back(end - dv.len, end, dv.value);
         const uint32_t gw = kgram_ending_at(pz), f = g.me[gw] >> 29;
         if (K == 3 && (f & 4u)) got.emplace_back(end - 3, end, g.v3[gw]);
         if (f & 2u) got.emplace_back(end - 2, end, g.v2[cls(pz - 1) * C + cls(pz)]);

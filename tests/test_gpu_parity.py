@@ -346,29 +346,43 @@ def test_wide_alphabet_dictionary_stays_on_gram():
     assert p.scan_count(ScanMode.FindOverlapping, hay, engine=Engine.Gram) == o.overlapping_count(hay, threads=8)
 
 
+def _same16(got16, want):
+    return len(got16) == len(want) and np.array_equal(got16["end"], want["end"]) and np.array_equal(got16["value"], want["value"]) and \
+        np.array_equal(got16["length"].astype(np.uint64), want["end"] - want["start"])
+
+
 def test_gram_tuple_emitter():
-    """daac_scan_device / daac_scan through the GRAM tuple emitter (gram2_emit_kernels.hip): bit-exact tuples in the
-    reference's order on texts that stress its seams — matches that straddle tile (1024 B) and region boundaries, lazy
-    windows that begin inside matches, unaligned device haystacks, both K, record-list overflow (falls back) — and the list
-    left in device memory equals the one copied to the host"""
+    """daac_scan_device / daac_scan_device16 / daac_scan through the GRAM tuple emitter (gram2_emit_kernels.hip): bit-exact tuples in
+    the reference's order, in both device formats, on texts that stress its seams — matches that straddle tile (1024 B) and region
+    boundaries, lazy windows that begin inside matches, unaligned device haystacks, both K, patterns longer than K + 16 bytes and
+    duplicate patterns (placed as extras), record-list overflow (falls back) — and the list left in device memory equals the one
+    copied to the host"""
     import torch
     rng = np.random.default_rng(123)
     pats3 = synth.patterns_cfg3(30000)
     long_pats = [b"abcdefghijklmnop", b"bcdefghijklmnopq", b"mnopqrs", b"ponmlkjihg", b"qrstuv", b"a", b"op", b"nop", b"lmnopqrstuvwxyzabc"]
+    # a word list with what round 2's emitter declined: five words of 25-40 bytes, a duplicate, nested long words, copies of a long word
+    extra_pats = pats3[:20000] + [pats3[i] + pats3[i + 1] + pats3[i + 2] + pats3[i + 3] for i in (3, 50, 700, 1200, 9000)] + \
+        [next(w for w in pats3 if len(w) >= 6), pats3[4000] * 3, pats3[4000] * 3, pats3[4000] * 3 + b"s", b"q" * 30, b"q" * 31]
+    assert max(len(w) for w in extra_pats) > 30 and len(set(extra_pats)) < len(extra_pats)
+    # (the special words spread over the text: a tile places at most 64 extras, denser texts fall back to the segment scanners — below)
+    extra_text = b" ".join(extra_pats[i] for i in rng.permutation(np.concatenate([rng.integers(0, len(extra_pats), size=40000), rng.integers(20000, 20009, size=1500),
+                                                                                   rng.integers(20009, len(extra_pats), size=150)])).tolist()) + b" " + b"q" * 40
     cases = [(synth.patterns_cfg1(), synth.uniform_haystack(9000, 3, synth.ALPHA_ABCD)),
              (long_pats, np.frombuffer((b"abcdefghijklmnopqrstuvwxyzabc" * 400)[:11000], dtype=np.uint8)),
              (long_pats, synth.uniform_haystack(20000, 4, b"abcdefghijklmnopqrstuvwxyz")),
              (synth.patterns_cfg2(500), synth.wordsoup_haystack(300000, 8, synth.patterns_cfg2(500), 13, noise_256=30)),
              (pats3, synth.uniform_haystack((1 << 20) + 777, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)),
-             (pats3, synth.wordsoup_haystack(1 << 20, synth.SEEDS["cfg3_dense"], pats3, 20))]
+             (pats3, synth.wordsoup_haystack(1 << 20, synth.SEEDS["cfg3_dense"], pats3, 20)),
+             (extra_pats, np.frombuffer(extra_text, dtype=np.uint8))]
     try:
         for pats, hay in cases:
             o, _ = _pma(pats)
             want = o.find_overlapping_iter(hay)
-            for tiles, budget, shift, staged in ((64, 158 * 1024, 0, 1), (1, 158 * 1024, 3, 1), (2, 24 * 1024, 9, 1), (3, 158 * 1024, 5, 0)):
-                da.set_option("emit_staged", staged)  # 1: tuples gathered in LDS and stored contiguously; 0: a pair of stores per tuple
+            for tiles, budget, shift in ((64, 158 * 1024, 0), (1, 158 * 1024, 3), (2, 24 * 1024, 9), (3, 158 * 1024, 5)):
                 da.set_option("emit_tiles", tiles)
                 da.set_option("gram_lds_budget", budget)
+                da.set_option("emit_rec_cap", 2048 if pats is extra_pats else 256)
                 p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
                 dev = torch.from_numpy(np.concatenate([np.zeros(shift, dtype=np.uint8), hay])).cuda()[shift:]
                 got = p.scan(ScanMode.FindOverlapping, dev, engine=Engine.Gram)  # Engine.Gram: no silent fallback
@@ -379,7 +393,12 @@ def test_gram_tuple_emitter():
                 if len(want) > 100:
                     mid = dm.to_numpy(first=len(want) // 2, n=50)
                     assert _same(mid, want[len(want) // 2:len(want) // 2 + 50])
+                with pytest.raises(da.DaachorseError):
+                    dm.to_numpy(first=len(want), n=1)
                 dm.free()
+                d16 = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
+                assert da.last_engine() == int(Engine.Gram) and d16.count == len(want) and _same16(d16.to_numpy(), want)
+                d16.free()
             da.set_option("emit_tiles", 64)
             da.set_option("gram_lds_budget", 158 * 1024)
             # lazy windows begin wherever the previous one ended: inside matches, off the tile grid
@@ -390,6 +409,7 @@ def test_gram_tuple_emitter():
             lazy = [(m.start(), m.end(), m.value()) for m in p.find_overlapping_iter(sub)]
             assert lazy == [(int(x["start"]), int(x["end"]), int(x["value"])) for x in wsub]
             da.set_option("iter_window", 64 << 20)
+        da.set_option("emit_rec_cap", 256)
         # more deep matches in one tile than a wave has record space for: the scan falls back and stays exact
         pats = [b"a" * k for k in range(1, 17)]
         hay = np.frombuffer(b"a" * 5000 + b"b" + b"a" * 3000, dtype=np.uint8)
@@ -397,17 +417,30 @@ def test_gram_tuple_emitter():
         want = o.find_overlapping_iter(hay)
         got = p.scan(ScanMode.FindOverlapping, hay)
         assert _same(got, want) and da.last_engine() != int(Engine.Gram)
+        d16 = p.scan_device(ScanMode.FindOverlapping, hay, fmt16=True)  # another engine's list, repacked on the device
+        assert da.last_engine() != int(Engine.Gram) and _same16(d16.to_numpy(), want)
+        d16.free()
         da.set_option("emit_rec_cap", 1 << 14)
         q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
         assert _same(q.scan(ScanMode.FindOverlapping, hay, engine=Engine.Gram), want)
-        # automata the emitter declines (duplicates): still served, by the segment scanners
+        # more extras in one tile than the write pass places (every prefix of a long run a pattern): falls back too
+        da.set_option("emit_rec_cap", 1 << 14)
+        o, p = _pma([b"z" * k for k in range(1, 60)])
+        hay = np.frombuffer(b"z" * 4000, dtype=np.uint8)
+        assert _same(p.scan(ScanMode.FindOverlapping, hay), o.find_overlapping_iter(hay))
+        # the other iterators in the 16-byte format (repacked)
+        o, p = _pma(pats3[:2000])
+        hay = synth.wordsoup_haystack(50000, 3, pats3[:2000], 20)
+        d16 = p.scan_device(ScanMode.Find, hay, fmt16=True)
+        assert _same16(d16.to_numpy(), o.find_iter(hay))
+        # automata the emitter declines (duplicates among the short patterns): still served, by the segment scanners
         o, p = _pma(["ab", "ab", "abc"])
         assert _same(p.scan(ScanMode.FindOverlapping, b"xabcabab"), o.find_overlapping_iter(b"xabcabab"))
         with pytest.raises(da.DaachorseError) as ei:
             p.scan(ScanMode.FindOverlapping, b"xabcabab", engine=Engine.Gram)
         assert ei.value.code == 6
     finally:
-        for k, v in (("emit_tiles", 64), ("gram_lds_budget", 158 * 1024), ("iter_window", 64 << 20), ("emit_rec_cap", 256), ("emit_staged", 0)):
+        for k, v in (("emit_tiles", 64), ("gram_lds_budget", 158 * 1024), ("iter_window", 64 << 20), ("emit_rec_cap", 256)):
             da.set_option(k, v)
 
 

@@ -291,8 +291,15 @@ def test_emit_tables_reproduce_the_tuple_stream(tmp_path):
         for budget in (147000, 9000):
             out = subprocess.check_output([exe, str(blob), str(budget), str(h)]).decode()
             assert out.startswith("OK"), out
-    # duplicate patterns, patterns longer than K + 16 bytes: no emission tables (the segment scanners serve)
-    for pats in (["ab", "ab", "abc"], ["a" * 25, "ab"]):
+    # patterns longer than K + 16 bytes and duplicates among the longer patterns: served (the kernel places them as "extras")
+    long_words = pats3[:3000] + [w + b"ological" * 3 for w in pats3[:40]] + [pats3[7] * 2] * 3 + [pats3[9] + b"xx"] * 2
+    soup = b" ".join(long_words[i] for i in rng.integers(0, len(long_words), size=9000).tolist())
+    blob.write_bytes(orc.OraclePma.build(long_words).serialize())
+    np.frombuffer(soup, dtype=np.uint8).tofile(h)
+    out = subprocess.check_output([exe, str(blob), "147000", str(h)]).decode()
+    assert out.startswith("OK") and "maxlen=" in out and int(out.split("maxlen=")[1]) > 19, out
+    # duplicates among the patterns of at most K bytes: no emission tables (the segment scanners serve)
+    for pats in (["ab", "ab", "abc"], ["a", "a", "abcd"]):
         blob.write_bytes(orc.OraclePma.build(pats).serialize())
         assert subprocess.check_output([exe, str(blob), "147000", str(h)]).decode().startswith("UNAVAILABLE"), pats
 

@@ -21,23 +21,23 @@ if hk == "sparse":
     synth.device_uniform(hay, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
 else:
     synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
-for emit in (2, 1, 0):  # 2: staged writes, 1: a pair of stores per tuple, 0: segment scanners
-    da.set_option("emit", 1 if emit else 0)
-    da.set_option("emit_staged", 1 if emit == 2 else 0)
+for emit, fmt16 in ((1, True), (1, False), (0, False)):  # the GRAM emitter in both device formats, then the segment scanners
+    da.set_option("emit", emit)
     pma = da.DoubleArrayAhoCorasick.new(pats)
     pma.upload(0)
     n = hay.numel() if emit else min(hay.numel(), 256 << 20)  # the segment scanners are slow: a prefix is enough
     h = hay[:n]
-    dm = pma.scan_device(ScanMode.FindOverlapping, h)
+    dm = pma.scan_device(ScanMode.FindOverlapping, h, fmt16=fmt16)
     cnt = dm.count
     dm.free()
     torch.cuda.synchronize()
     best = 1e9
     for _ in range(reps):
         t0 = time.perf_counter()
-        dm = pma.scan_device(ScanMode.FindOverlapping, h)
+        dm = pma.scan_device(ScanMode.FindOverlapping, h, fmt16=fmt16)
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
         dm.free()
-    print(f"emit={emit} engine_used={da.last_engine()} {hk} {n >> 20} MiB: {cnt} tuples, {best * 1e3:.2f} ms  ->  {n / best / 1e9:.1f} GB/s of haystack, "
-          f"{cnt * 24 / best / 1e9:.1f} GB/s of tuples written ({cnt / n:.3f} tuples/byte)", flush=True)
+    tb = 16 if fmt16 else 24
+    print(f"emit={emit} tuple_bytes={tb} engine_used={da.last_engine()} {hk} {n >> 20} MiB: {cnt} tuples, {best * 1e3:.2f} ms  ->  {n / best / 1e9:.1f} GB/s of haystack, "
+          f"{cnt * tb / best / 1e9:.1f} GB/s of tuples written ({cnt / n:.3f} tuples/byte)", flush=True)
