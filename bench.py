@@ -302,22 +302,24 @@ def main():
         except Exception:
             pass
 
-    # ---- tuples (reported, not the metric): device-resident list of a 1 GiB prefix, and a list copied to the host -----------
+    # ---- tuples (reported, not the metric): device-resident list of a 1 GiB prefix in both device formats, and a list copied to the host ----
     if args.materialize_mib > 0 and world == 1:
         da.set_option("max_result_bytes", 64 << 30)
         n = min(nbytes, 1 << 30)
-        dm = pma.scan_device(ScanMode.FindOverlapping, hay[:n], engine=mat_engine)
-        dm.free()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dm = pma.scan_device(ScanMode.FindOverlapping, hay[:n], engine=mat_engine)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out["tuples_device"] = {"bytes": n, "matches": int(dm.count), "seconds": round(dt, 4), "GB/s": round(n / dt / 1e9, 2),
-                                "tuple_GB/s": round(dm.count * 24 / dt / 1e9, 1), "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"),
-                                "note": "daac_scan_device: (start, end, value) tuples in reference order left in HBM; wall time of the call "
-                                        "(count pass, exclusive scan, allocation, write pass)"}
-        dm.free()
+        for key, fmt16, tb in (("tuples_device", True, 16), ("tuples_device_24", False, 24)):
+            dm = pma.scan_device(ScanMode.FindOverlapping, hay[:n], engine=mat_engine, fmt16=fmt16)
+            dm.free()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dm = pma.scan_device(ScanMode.FindOverlapping, hay[:n], engine=mat_engine, fmt16=fmt16)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[key] = {"bytes": n, "matches": int(dm.count), "tuple_bytes": tb, "seconds": round(dt, 4), "GB/s": round(n / dt / 1e9, 2),
+                        "tuple_GB/s": round(dm.count * tb / dt / 1e9, 1), "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"),
+                        "note": ("daac_scan_device16: {end u64, length u32, value u32} = the crate's Match fields" if fmt16 else
+                                 "daac_scan_device: daac_match {start, end, value, pad}") +
+                                ", reference order, left in HBM; wall time of the call (count pass, exclusive scan, allocation, write pass)"}
+            dm.free()
         n = min(nbytes, args.materialize_mib << 20)
         pma.scan(ScanMode.FindOverlapping, hay[:n], engine=mat_engine)
         torch.cuda.synchronize()
@@ -441,6 +443,48 @@ def main():
                           "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"), "match_count": int(result[0].item())}
         wide["byte_classes"] = wp.info().num_classes
         out["wide_alphabet"] = wide
+        del whay, wp
+        torch.cuda.empty_cache()
+        # ---- dictionaries no byte-class table serves: `.count()` on the PFX engine (any byte alphabet) ------------------
+        anyab = {}
+        for name in ("binary256", "utf8jp"):
+            pats_w = synth.patterns_binary256() if name == "binary256" else synth.patterns_cfg5()
+            ap = da.DoubleArrayAhoCorasick.new(pats_w)
+            ap.upload(local_rank)
+            an = 1 << 30
+            if name == "utf8jp":
+                an -= an % synth.CFG5_SLOT
+            ahay = torch.empty(an, dtype=torch.uint8, device="cuda")
+            if name == "binary256":
+                synth.device_uniform(ahay, synth.SEEDS["bin_hay"], synth.ALPHA_BYTES)
+            else:
+                synth.device_zipf_text(ahay)
+            fn = lambda: ap.count(ScanMode.FindOverlapping, ahay, stream=stream, result_dev=result.data_ptr())
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            gpu_cnt = int(result[0].item())
+            used = ENGINE_NAMES.get(da.last_engine(), "?")
+            # parity on a 64 MiB prefix against the oracle (the whole GiB would take the CPU a minute)
+            pn = (64 << 20) - ((64 << 20) % synth.CFG5_SLOT if name == "utf8jp" else 0)
+            ok = None
+            if not args.no_cpu:
+                from oracle import oracle as orc2
+                oo = orc2.OraclePma.deserialize(ap.serialize())
+                ok = bool(ap.count(ScanMode.FindOverlapping, ahay[:pn]) == oo.overlapping_count(ahay[:pn].cpu().numpy(), threads=16)[0])
+            anyab[name] = {"dictionary": ("100 000 random patterns of 3-12 bytes over all 256 byte values; haystack: uniform random bytes" if name == "binary256"
+                                          else "cfg5's 50 000 UTF-8 patterns (2-8 three-byte scalars, Zipf) scanned BYTEWISE; haystack: cfg5's Zipf text"),
+                            "bytes": an, "value": round(an / ms / 1e6, 2), "unit": "GB/s", "frac": round(an / ms / 1e6 / HBM_PEAK_GBS, 4),
+                            "kernel_ms": round(ms, 4), "engine_used": used, "match_count": gpu_cnt, "parity_64mib_prefix_vs_oracle": ok}
+            del ahay, ap
+            torch.cuda.empty_cache()
+        out["any_alphabet"] = anyab
     print(json.dumps(out))
 
 

@@ -24,14 +24,20 @@ class Match(C.Structure):
 
 
 class Info(C.Structure):
-    _fields_ = [("match_kind", C.c_uint8), ("num_states", C.c_uint32), ("states_len", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint32),
+                ("match_kind", C.c_uint8), ("num_states", C.c_uint32), ("states_len", C.c_uint64),
                 ("outputs_len", C.c_uint64), ("heap_bytes", C.c_uint64), ("max_pattern_len", C.c_uint32),
                 ("num_classes", C.c_uint32), ("tier_dense_states", C.c_uint32), ("tier_lds_states", C.c_uint32),
                 ("tier_lds_bytes", C.c_uint32), ("tiered_available", C.c_uint8), ("gram_available", C.c_uint8),
                 ("gram_k", C.c_uint32), ("gram_lds_bytes", C.c_uint32),
                 ("charwise", C.c_uint8), ("alphabet_size", C.c_uint32),
                 ("gram2_available", C.c_uint8), ("gram2_exact", C.c_uint8), ("gram2_k", C.c_uint32),
-                ("gram2_lds_count", C.c_uint32), ("gram2_lds_exact", C.c_uint32), ("gram_wide", C.c_uint8)]
+                ("gram2_lds_count", C.c_uint32), ("gram2_lds_exact", C.c_uint32), ("gram_wide", C.c_uint8),
+                ("pfx_available", C.c_uint8), ("pfx_key_bytes", C.c_uint32), ("pfx_lds_bytes", C.c_uint32),
+                ("plan_engine", C.c_uint8 * 8), ("plan_kernel", C.c_uint8 * 8), ("plan_reason", C.c_uint8 * 8)]
+
+
+ABI_VERSION = 3  # DAAC_ABI_VERSION of include/daachorse_amd.h this mirror was written against
 
 
 def lib():
@@ -48,6 +54,11 @@ def lib():
     # first and libdaachorse_amd.so binds to the same one.
     import torch  # noqa: F401
     L = C.CDLL(path)
+    if not hasattr(L, "daac_abi_version"):
+        raise ImportError(f"{path} predates ABI version {ABI_VERSION} (rebuild: __graft_entry__.build())")
+    L.daac_abi_version.restype = C.c_uint32
+    if L.daac_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {L.daac_abi_version()}, this package mirrors version {ABI_VERSION} (rebuild: __graft_entry__.build())")
     P, vp, sz, u8p = C.POINTER, C.c_void_p, C.c_size_t, C.c_void_p
     L.daac_last_error.restype = C.c_char_p
     L.daac_free.argtypes = [vp]
@@ -58,6 +69,8 @@ def lib():
     L.daac_charwise_build.argtypes = [vp, vp, vp, sz, C.c_uint8, C.c_uint32, P(vp)]
     L.daac_pma_serialize.argtypes = [vp, P(vp), P(sz)]
     L.daac_pma_info.argtypes = [vp, P(Info)]
+    L.daac_pma_explain.argtypes = [vp, C.c_char_p, sz]
+    L.daac_pma_explain.restype = sz
     L.daac_pma_free.argtypes = [vp]
     L.daac_pma_upload.argtypes = [vp, C.c_int]
     L.daac_scan.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp)]

@@ -266,8 +266,16 @@ class DoubleArrayAhoCorasick:
     # ---- introspection -----------------------------------------------------------------------------------
     def info(self):
         i = _ffi.Info()
+        i.struct_size = C.sizeof(_ffi.Info)
         _ffi.check(_ffi.lib().daac_pma_info(self._h, C.byref(i)))
         return i
+
+    def explain(self):
+        """the engine plan as text: which engine / kernel family serves each kind of request, and why not the fastest one"""
+        n = _ffi.lib().daac_pma_explain(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        _ffi.lib().daac_pma_explain(self._h, buf, n)
+        return buf.value.decode()
 
     def match_kind(self):
         return MatchKind(self.info().match_kind)

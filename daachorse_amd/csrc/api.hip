@@ -142,6 +142,7 @@ struct DeviceTables {
     Gram2Dev gram2{};
     bool gramw_ok = false;     // wide alphabets (gram2w.hpp)
     bool pfx_ok = false;       // any byte alphabet, `.count()` (pfx.hpp)
+    uint32_t n_distinct_bytes = 0;  // distinct pattern bytes (known when the PFX builder ran)
     PfxDev pfx{};
     Gram2WDev gramw{};
     bool emit_ok = false;      // tuple emission on the second table set (gram2_emit_kernels.hip)
@@ -604,7 +605,9 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     // PFX engine: `.count()` for every bytewise Standard automaton the GRAM tables do not serve (any alphabet); pfx = 2 builds it always
     if (g_opt.pfx.load() == 2 || (g_opt.pfx.load() == 1 && !t->gram_ok && !t->gram2_ok && !t->gramw_ok)) {
         PfxTables px;
-        if (build_pfx_tables(h, 160u * 1024u - 16u * (2u * 1056u + 512u) - 64u, px)) {
+        const bool px_ok = build_pfx_tables(h, 160u * 1024u - 16u * (2u * 1056u + 512u) - 64u, px);
+        t->n_distinct_bytes = px.n_distinct_bytes;
+        if (px_ok) {
             PfxDev &d = t->pfx;
             auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
             px.disp.resize((px.disp.size() + 7) & ~size_t(7), 0);
@@ -1165,54 +1168,151 @@ daac_status daac_pma_serialize(const daac_pma *pma, uint8_t **buf, size_t *len) 
     return DAAC_OK;
 }
 
-daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
-    if (!pma || !info) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
-    std::memset(info, 0, sizeof(*info));
+uint32_t daac_abi_version(void) { return DAAC_ABI_VERSION; }
+
+// the engine plan of a handle: what scan_count_impl / scan_range_device / make_plan decide for engine AUTO, said up front
+static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) {
+    auto set = [&](int req, int engine, int kernel, int why) {
+        f.plan_engine[req] = static_cast<uint8_t>(engine); f.plan_kernel[req] = static_cast<uint8_t>(kernel); f.plan_reason[req] = static_cast<uint8_t>(why);
+    };
+    for (int r = 0; r < DAAC_REQ_N; ++r) set(r, DAAC_ENGINE_AUTO, DAAC_KERNEL_NONE, t ? DAAC_WHY_FASTEST : DAAC_WHY_NOT_UPLOADED);
+    if (!t) return;
     if (pma->charwise) {
-        const HostCharPma &c = pma->chost;
-        info->match_kind = c.match_kind;
-        info->num_states = c.num_states;
-        info->states_len = c.states.size();
-        info->outputs_len = c.outputs.size();
-        info->heap_bytes = c.heap_bytes();
-        info->max_pattern_len = c.max_pattern_len();
-        info->charwise = 1;
-        info->alphabet_size = c.alphabet_size;
-        return DAAC_OK;
+        const bool standard = pma->chost.match_kind == DAAC_STANDARD;
+        if (standard) {
+            set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_DARRAY, DAAC_KERNEL_MICRO, DAAC_WHY_CHARWISE);
+            set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_DARRAY, DAAC_KERNEL_MICRO, DAAC_WHY_CHARWISE);
+            set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_DARRAY, DAAC_KERNEL_SEGMENT, DAAC_WHY_CHARWISE);
+            set(DAAC_REQ_NO_SUFFIX, DAAC_ENGINE_DARRAY, DAAC_KERNEL_SEGMENT, DAAC_WHY_CHARWISE);
+            set(DAAC_REQ_FIND, DAAC_ENGINE_DARRAY, DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);
+        } else {
+            set(DAAC_REQ_LEFTMOST_FIND, DAAC_ENGINE_DARRAY, DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);
+        }
+        return;
     }
     const HostPma &h = pma->host;
-    info->match_kind = h.match_kind;
-    info->num_states = h.num_states;
-    info->states_len = h.states_len();
-    info->outputs_len = h.outputs.size();
-    info->heap_bytes = h.heap_bytes();
-    info->max_pattern_len = h.max_pattern_len();
-    std::lock_guard<std::mutex> g(const_cast<daac_pma *>(pma)->mu);
-    if (!pma->dev.empty()) {
-        const DeviceTables *t = pma->dev.begin()->second.get();
-        info->tiered_available = t->tier_ok;
-        if (t->tier_ok) {
-            info->num_classes = t->tier.C;
-            info->tier_dense_states = t->tier.NA;
-            info->tier_lds_states = t->tier.NB;
-            info->tier_lds_bytes = t->tier.lds_bytes;
-        }
-        info->gram_available = t->gram_ok || t->gram2_ok;
-        if (t->gram_ok) {
-            info->gram_k = t->gram.K;
-            info->gram_lds_bytes = t->gram.lds_bytes;
-        }
-        if (t->gramw_ok) { info->gram_available = 1; info->gram_k = 2; info->gram_lds_bytes = t->gramw.lds_count; info->num_classes = t->gramw.C; info->gram_wide = 1; }
-        info->gram2_available = t->gram2_ok;
-        if (t->gram2_ok) {
-            info->gram2_k = t->gram2.K;
-            info->gram2_exact = t->gram2.exact_ok;
-            info->gram2_lds_count = t->gram2.lds_count;
-            info->gram2_lds_exact = t->gram2.lds_exact;
-            if (!t->gram_ok) { info->gram_k = t->gram2.K; info->gram_lds_bytes = t->gram2.lds_count; }
-        }
+    if (!h.is_standard()) {
+        set(DAAC_REQ_LEFTMOST_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);
+        return;
     }
+    // why the byte-class tables were declined, as far as it is known
+    int why_no_gram = DAAC_WHY_TRIE_SHAPE;
+    if (pma->root_has_output()) why_no_gram = DAAC_WHY_EMPTY_PATTERN;
+    else if (t->n_distinct_bytes > 61) why_no_gram = DAAC_WHY_ALPHABET;
+    else if (t->n_distinct_bytes != 0) why_no_gram = DAAC_WHY_LDS;
+    const int seg_engine = t->tier_ok ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY;
+    const int micro = g_opt.overlap_micro.load() >= (t->tier_ok ? 2 : 1) ? DAAC_KERNEL_MICRO : DAAC_KERNEL_SEGMENT;
+    const int micro_engine = micro == DAAC_KERNEL_MICRO ? DAAC_ENGINE_DARRAY : seg_engine;
+    const int64_t gv = g_opt.gram_version.load();
+    if (t->gram2_ok && gv != 1) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_COUNT, DAAC_WHY_FASTEST);
+    else if (t->gram_ok) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EXACT, DAAC_WHY_FASTEST);
+    else if (t->gramw_ok) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_WIDE, DAAC_WHY_FASTEST);
+    else if (t->pfx_ok) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, why_no_gram);
+    else set(DAAC_REQ_OVERLAPPING_COUNT, micro_engine, micro, why_no_gram);
+    if (t->gram_ok || (t->gram2_ok && t->gram2.exact_ok)) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EXACT, DAAC_WHY_FASTEST);
+    else if (t->gramw_ok && t->gramw.exact_ok) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_WIDE, DAAC_WHY_FASTEST);
+    else set(DAAC_REQ_OVERLAPPING_CHECKSUM, micro_engine, micro, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);
+    if (t->emit_ok && g_opt.emit.load() != 0) set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EMIT, DAAC_WHY_FASTEST);
+    else set(DAAC_REQ_OVERLAPPING_TUPLES, seg_engine, DAAC_KERNEL_SEGMENT, t->gram2_ok ? DAAC_WHY_DUPLICATES : why_no_gram);
+    set(DAAC_REQ_NO_SUFFIX, seg_engine, DAAC_KERNEL_SEGMENT, DAAC_WHY_FASTEST);
+    set(DAAC_REQ_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);  // (the restart iterators run on the double array)
+}
+
+daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
+    if (!pma || !info) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    const uint32_t cap = info->struct_size;
+    if (cap < 8 || cap > (1u << 16)) {
+        set_error("daac_info.struct_size must hold sizeof(daac_info) of the caller (ABI version " + std::to_string(DAAC_ABI_VERSION) + ")");
+        return DAAC_ERR_INVALID_ARGUMENT;
+    }
+    daac_info full;
+    daac_info *f = &full;
+    std::memset(f, 0, sizeof(*f));
+    f->struct_size = static_cast<uint32_t>(sizeof(daac_info));
+    if (pma->charwise) {
+        const HostCharPma &c = pma->chost;
+        f->match_kind = c.match_kind;
+        f->num_states = c.num_states;
+        f->states_len = c.states.size();
+        f->outputs_len = c.outputs.size();
+        f->heap_bytes = c.heap_bytes();
+        f->max_pattern_len = c.max_pattern_len();
+        f->charwise = 1;
+        f->alphabet_size = c.alphabet_size;
+    } else {
+        const HostPma &h = pma->host;
+        f->match_kind = h.match_kind;
+        f->num_states = h.num_states;
+        f->states_len = h.states_len();
+        f->outputs_len = h.outputs.size();
+        f->heap_bytes = h.heap_bytes();
+        f->max_pattern_len = h.max_pattern_len();
+    }
+    {
+        std::lock_guard<std::mutex> g(const_cast<daac_pma *>(pma)->mu);
+        const DeviceTables *t = pma->dev.empty() ? nullptr : pma->dev.begin()->second.get();
+        if (t && !pma->charwise) {
+            f->tiered_available = t->tier_ok;
+            if (t->tier_ok) {
+                f->num_classes = t->tier.C;
+                f->tier_dense_states = t->tier.NA;
+                f->tier_lds_states = t->tier.NB;
+                f->tier_lds_bytes = t->tier.lds_bytes;
+            }
+            f->gram_available = t->gram_ok || t->gram2_ok;
+            if (t->gram_ok) {
+                f->gram_k = t->gram.K;
+                f->gram_lds_bytes = t->gram.lds_bytes;
+            }
+            if (t->gramw_ok) { f->gram_available = 1; f->gram_k = 2; f->gram_lds_bytes = t->gramw.lds_count; f->num_classes = t->gramw.C; f->gram_wide = 1; }
+            f->gram2_available = t->gram2_ok;
+            if (t->gram2_ok) {
+                f->gram2_k = t->gram2.K;
+                f->gram2_exact = t->gram2.exact_ok;
+                f->gram2_lds_count = t->gram2.lds_count;
+                f->gram2_lds_exact = t->gram2.lds_exact;
+                if (!t->gram_ok) { f->gram_k = t->gram2.K; f->gram_lds_bytes = t->gram2.lds_count; }
+            }
+            f->pfx_available = t->pfx_ok;
+            if (t->pfx_ok) { f->pfx_key_bytes = t->pfx.G; f->pfx_lds_bytes = t->pfx.lds_bytes; }
+        }
+        fill_plan(pma, t, *f);
+    }
+    std::memcpy(info, f, std::min<size_t>(cap, sizeof(daac_info)));
+    info->struct_size = static_cast<uint32_t>(std::min<size_t>(cap, sizeof(daac_info)));
     return DAAC_OK;
+}
+
+size_t daac_pma_explain(const daac_pma *pma, char *buf, size_t cap) {
+    if (!pma) return 0;
+    daac_info f;
+    f.struct_size = static_cast<uint32_t>(sizeof(f));
+    if (daac_pma_info(pma, &f) != DAAC_OK) return 0;
+    static const char *req[] = {"find_overlapping_iter(h).count()", "find_overlapping count + checksum", "find_overlapping tuples", "find_iter",
+                                "leftmost_find_iter", "find_overlapping_no_suffix_iter"};
+    static const char *eng[] = {"auto", "tiered", "darray", "gram", "pfx"};
+    static const char *ker[] = {"- (the crate panics: wrong MatchKind)", "gram3 count kernel (one LDS lookup per byte)", "gram count + checksum kernel",
+                                "gram wide-alphabet kernel (31-62 byte classes)", "gram tuple emitter", "pfx (hashed prefix filter + start-anchored walks, any alphabet)",
+                                "segment scanners (one lane per segment)", "micro-step walker over the double array", "chain walkers (speculate / reconcile / emit)"};
+    static const char *why[] = {"", "not uploaded yet", "more distinct pattern bytes than the byte-class tables take", "tables do not fit the LDS",
+                                "\"\" is a pattern", "duplicate patterns the tables cannot encode", "the iterator is a chain through its own matches",
+                                "charwise automaton", "trie shape / table limits"};
+    std::string s;
+    for (int r = 0; r < DAAC_REQ_N; ++r) {
+        s += req[r];
+        s += ": ";
+        if (f.plan_kernel[r] == DAAC_KERNEL_NONE && f.plan_reason[r] != DAAC_WHY_NOT_UPLOADED) { s += ker[0]; s += "\n"; continue; }
+        s += "engine "; s += eng[f.plan_engine[r] <= 4 ? f.plan_engine[r] : 0];
+        s += ", "; s += ker[f.plan_kernel[r] <= 8 ? f.plan_kernel[r] : 0];
+        if (f.plan_reason[r] != DAAC_WHY_FASTEST) { s += "  [not the fastest family: "; s += why[f.plan_reason[r] <= 8 ? f.plan_reason[r] : 0]; s += "]"; }
+        s += "\n";
+    }
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, s.size());
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size() + 1;
 }
 
 void daac_pma_free(daac_pma *pma) { delete pma; }

@@ -21,6 +21,7 @@ bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
     std::vector<uint32_t> depth(n, kNone), order{kRoot}, k0(n, 0), k1(n, 0), parent(n, kNone);
     std::vector<uint8_t> label(n, 0);
     depth[kRoot] = 0;
+    bool seen_byte[256] = {false};
     for (size_t qi = 0; qi < order.size(); ++qi) {
         const uint32_t s = order[qi], base = p.states[s].base;
         if (base == 0) continue;
@@ -31,11 +32,13 @@ bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
             depth[t] = depth[s] + 1;
             parent[t] = s;
             label[t] = static_cast<uint8_t>(c);
+            seen_byte[c] = true;
             k0[t] = k0[s]; k1[t] = k1[s];
             if (depth[s] < 4) k0[t] |= c << (8 * depth[s]); else if (depth[s] < 8) k1[t] |= c << (8 * (depth[s] - 4));
             order.push_back(t);
         }
     }
+    for (bool b : seen_byte) out.n_distinct_bytes += b ? 1u : 0u;
     // ---- patterns that END in a state (its own, not those of its suffixes): list entries as long as the state is deep ----
     std::vector<uint32_t> own(n, 0);
     uint32_t min_len2 = kNone;

@@ -45,6 +45,7 @@ struct PfxTables {
     uint32_t n_slots = 0;            // entries of SLOTS
     uint32_t seed = 0;               // xor-ed into the second operand of the bucket / slot hashes (changed until the displacement search succeeds)
     uint32_t n_keys = 0;
+    uint32_t n_distinct_bytes = 0;   // distinct byte values on the trie's edges (set even when the tables are declined after the walk)
     std::vector<uint32_t> bloom;
     std::vector<uint16_t> cnt1;      // 256
     std::vector<uint16_t> disp;

@@ -27,6 +27,13 @@
 extern "C" {
 #endif
 
+/* Version of this header's ABI: struct layouts and the meaning of enum values.  daac_abi_version() returns the version the
+ * loaded library was built with; a binding checks it once (the ctypes and C++ mirrors here do).
+ *   3 (round 3): daac_info starts with struct_size and carries the per-request engine plan; DAAC_ENGINE_PFX; daac_match16 /
+ *                daac_scan_device16. */
+#define DAAC_ABI_VERSION 3
+uint32_t daac_abi_version(void);
+
 /* src/errors.rs:10-22 (first four), plus the panics / extras of this boundary */
 typedef enum {
     DAAC_OK = 0,
@@ -77,7 +84,44 @@ typedef struct {
     uint32_t value;
 } daac_match16;
 
+/* What a request is served by (daac_info.plan_*): the engine AUTO resolves to, the kernel family behind it, and — where that is not
+ * the fastest family — why.  The families differ by an order of magnitude: this is the performance contract of a handle,
+ * visible before the first scan. */
+typedef enum {
+    DAAC_REQ_OVERLAPPING_COUNT = 0,     /* find_overlapping_iter(h).count()        daac_scan_count_only_range           */
+    DAAC_REQ_OVERLAPPING_CHECKSUM = 1,  /* count + checksum of that stream         daac_scan_count / _range             */
+    DAAC_REQ_OVERLAPPING_TUPLES = 2,    /* the tuples                              daac_scan / daac_scan_device[16] / daac_iter_* */
+    DAAC_REQ_FIND = 3,                  /* find_iter, any form                                                            */
+    DAAC_REQ_LEFTMOST_FIND = 4,         /* leftmost_find_iter, any form                                                   */
+    DAAC_REQ_NO_SUFFIX = 5,             /* find_overlapping_no_suffix_iter, any form                                      */
+    DAAC_REQ_N = 6
+} daac_request;
+typedef enum {
+    DAAC_KERNEL_NONE = 0,        /* the request does not apply to this automaton's MatchKind (the crate panics) */
+    DAAC_KERNEL_GRAM_COUNT = 1,  /* gram3_kernels.hip: one LDS lookup per byte, lane-local hit masks           (cfg3: 1.3 TB/s) */
+    DAAC_KERNEL_GRAM_EXACT = 2,  /* gram_kernels.hip / gram2_kernels.hip with the checksum                      (cfg3: 1.0 TB/s) */
+    DAAC_KERNEL_GRAM_WIDE = 3,   /* gram2w_kernels.hip: 31 .. 62 byte classes                                   (1.0 / 0.9 TB/s) */
+    DAAC_KERNEL_GRAM_EMIT = 4,   /* gram2_emit_kernels.hip: tuples in reference order                           (cfg3: 0.12 TB/s of haystack) */
+    DAAC_KERNEL_PFX = 5,         /* pfx_kernels.hip: any byte alphabet, `.count()`                              (0.6 - 1.3 TB/s) */
+    DAAC_KERNEL_SEGMENT = 6,     /* scan_kernels.hip: one lane per segment, TIERED or DARRAY tables             (0.03 - 0.4 TB/s) */
+    DAAC_KERNEL_MICRO = 7,       /* chain_scan.hpp overlap_count_body: micro-step walker over the double array  (0.08 - 0.4 TB/s) */
+    DAAC_KERNEL_CHAIN = 8        /* chain_scan.hpp: speculate / reconcile / emit for the restart iterators      (0.1 - 0.3 TB/s) */
+} daac_kernel_family;
+typedef enum {
+    DAAC_WHY_FASTEST = 0,        /* nothing faster exists for this request */
+    DAAC_WHY_NOT_UPLOADED = 1,   /* daac_pma_upload has not run: the plan is not known yet */
+    DAAC_WHY_ALPHABET = 2,       /* more distinct pattern bytes than the byte-class tables take (30 / 62) */
+    DAAC_WHY_LDS = 3,            /* the tables do not fit the 160 KB of LDS */
+    DAAC_WHY_EMPTY_PATTERN = 4,  /* "" is a pattern: every position matches */
+    DAAC_WHY_DUPLICATES = 5,     /* duplicate patterns beyond what the tables encode (more than 3 ending after one context; among patterns of at most K bytes for tuples) */
+    DAAC_WHY_CHAIN = 6,          /* the iterator is a chain through its own matches: no position-parallel form */
+    DAAC_WHY_CHARWISE = 7,       /* a charwise automaton: scanned over its own double array */
+    DAAC_WHY_TRIE_SHAPE = 8      /* not a tree-shaped trie / other table limits */
+} daac_plan_reason;
+
 typedef struct {
+    uint32_t struct_size;     /* IN: sizeof(daac_info) as the caller was compiled (0 = the round-2 layout is NOT assumed: the call fails);
+                               * the library fills at most this many bytes */
     uint8_t match_kind;       /* DoubleArrayAhoCorasick::match_kind()  bytewise.rs:735-737 */
     uint32_t num_states;      /* ::num_states()                        bytewise.rs:785-787 */
     uint64_t states_len;      /* double-array elements (multiple of 256) */
@@ -101,6 +145,13 @@ typedef struct {
     uint32_t gram2_lds_count;    /* LDS bytes per workgroup, count only / with checksum */
     uint32_t gram2_lds_exact;
     uint8_t gram_wide;           /* 31 .. 62 byte classes: the GRAM engine runs on 64-bit words with K = 2 (gram2w.hpp) */
+    uint8_t pfx_available;       /* the PFX tables were built (any byte alphabet, `.count()`) */
+    uint32_t pfx_key_bytes;      /* G: bytes of a PFX filter key */
+    uint32_t pfx_lds_bytes;
+    /* the engine plan, indexed by daac_request; valid after upload, for engine AUTO */
+    uint8_t plan_engine[8];      /* daac_engine reported by daac_last_engine() after such a request */
+    uint8_t plan_kernel[8];      /* daac_kernel_family */
+    uint8_t plan_reason[8];      /* daac_plan_reason: why not the fastest family */
 } daac_info;
 
 typedef struct daac_pma daac_pma;         /* an automaton (host copy + per-device re-pack) */
@@ -154,7 +205,11 @@ daac_status daac_charwise_build(const uint8_t *blob, const uint64_t *offsets, co
 
 /* ::serialize (bytewise.rs:801-820 / charwise.rs:831-848); free the buffer with daac_free. */
 daac_status daac_pma_serialize(const daac_pma *pma, uint8_t **buf, size_t *len);
+/* `info->struct_size` must be set by the caller (see daac_info). */
 daac_status daac_pma_info(const daac_pma *pma, daac_info *info);
+/* One line of text per request of the plan ("find_overlapping_iter().count(): engine gram, kernel gram3 ..."); returns the
+ * number of bytes the full text needs (incl. the terminating 0); writes at most `cap`. */
+size_t daac_pma_explain(const daac_pma *pma, char *buf, size_t cap);
 void daac_pma_free(daac_pma *pma);
 
 /* Re-packs the automaton for the GPU and copies it to `device` (idempotent).  Scans upload

@@ -247,6 +247,7 @@ private:
     explicit BasicAhoCorasick(daac_pma *h) : h_(h) {}
     daac_info info() const {
         daac_info i;
+        i.struct_size = static_cast<uint32_t>(sizeof(i));
         daac_pma_info(h_.get(), &i);
         return i;
     }

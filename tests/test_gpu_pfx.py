@@ -131,3 +131,36 @@ def test_pfx_on_a_vector_of_window_counts():
         got = np.array([_count(p, dev[:int(h)], begin=int(l)) for l, h in zip(los, his)])
         bad = np.nonzero(got != want)[0]
         assert len(bad) == 0, (name, bad[:8], got[bad[:8]], want[bad[:8]], los[bad[:8]], his[bad[:8]])
+
+
+def test_engine_plan_says_what_will_run():
+    """daac_info.plan_* / daac_pma_explain: the engine a request gets is known before the scan, and it is the engine that then serves it"""
+    import torch
+    da.set_option("pfx", 1)
+    REQ = {"count": 0, "checksum": 1, "tuples": 2, "find": 3, "leftmost": 4, "nosuffix": 5}
+    hay = torch.from_numpy(synth.uniform_haystack(1 << 20, 3, synth.ALPHA_LOWER_SPACE)).cuda()
+    for pats, kind, expect in ((synth.patterns_cfg3(5000), 0, {"count": (Engine.Gram, 1), "checksum": (Engine.Gram, 2), "tuples": (Engine.Gram, 4)}),
+                               (synth.patterns_binary256(5000), 0, {"count": (Engine.Pfx, 5)}),
+                               (synth.patterns_cfg3(2000) + [b""], 0, {})):
+        o = orc.OraclePma.build(pats)
+        p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+        assert list(p.info().plan_reason)[:6] == [1] * 6  # not uploaded yet
+        info = p.upload().info()
+        assert info.struct_size > 100
+        text = p.explain()
+        assert len(text.splitlines()) == 6 and "leftmost_find_iter: - (the crate panics" in text
+        for req, (eng, kernel) in expect.items():
+            assert info.plan_engine[REQ[req]] == int(eng) and info.plan_kernel[REQ[req]] == kernel, (req, text)
+        # what the plan says is what runs
+        p.count(ScanMode.FindOverlapping, hay)
+        assert da.last_engine() == info.plan_engine[0], text
+        p.scan_count(ScanMode.FindOverlapping, hay)
+        assert da.last_engine() == info.plan_engine[1], text
+        p.scan_device(ScanMode.FindOverlapping, hay[:1 << 16]).free()
+        assert da.last_engine() == info.plan_engine[2], text
+        p.scan_count(ScanMode.Find, hay[:1 << 16])
+        assert da.last_engine() == info.plan_engine[3], text
+    o = orc.OraclePma.build(synth.patterns_cfg3(2000), kind="LeftmostLongest")
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    info = p.upload().info()
+    assert info.plan_kernel[4] == 8 and info.plan_kernel[0] == 0  # chain walkers; find_overlapping does not apply to the kind
