@@ -61,6 +61,22 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def hbm_traffic(workload_key, kernel_filter=None):
+    """HBM bytes per launch of a workload's dominant kernel from the committed PMC passes (tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs of this same command, warm-ups dropped; 2 * FETCH + WRITE per MI355X_MICROARCH.md's gfx950 correction).
+    -> (bytes or None, where the figure comes from).  Counters cannot be collected inside the timed run itself."""
+    path = os.environ.get("DAAC_HBM_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        t = json.load(open(path))
+        kernels = t[workload_key]
+        pick = [v for k, v in kernels.items() if kernel_filter is None or kernel_filter in k]
+        best = max(pick, key=lambda v: v["bytes_per_launch"])
+        return best["bytes_per_launch"], (f"{os.path.relpath(path, ROOT)} [{workload_key}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this command "
+                                          f"({best['launches']} timed launches), 2*FETCH + WRITE; " + str(t.get("_source", "")))
+    except Exception:
+        return None, None
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -292,15 +308,8 @@ def main():
         "match_count": total_count, "match_checksum": f"{checksum:016x}" if checksum is not None else None,
         "distributed": dist_used,
     }
-    pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            t = json.load(open(pmc))
-            out["roofline"]["traffic"] = t.get(f"{args.workload}_{args.haystack}_{args.op}_bytes_per_launch", t.get(f"{args.workload}_{args.haystack}_bytes_per_launch"))
-            out["roofline"]["traffic_source"] = "static: " + str(t.get("source", "profiles/hbm_traffic.json (rocprofv3 --pmc passes of an earlier run, "
-                                                                            "2*FETCH_SIZE + WRITE_SIZE), not measured in this run"))
-        except Exception:
-            pass
+    tr = hbm_traffic({"cfg3": "cfg3", "cfg2": "cfg2"}[args.workload] + ("_count" if args.workload == "cfg2" else f"_{args.haystack}_{args.op}"))
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
 
     # ---- tuples (reported, not the metric): device-resident list of a 1 GiB prefix in both device formats, and a list copied to the host ----
     if args.materialize_mib > 0 and world == 1:
@@ -404,7 +413,8 @@ def main():
             "op": other, "value": round(nbytes / k_s / 1e9, 2), "unit": "GB/s", "frac": round(nbytes / k_s / 1e9 / HBM_PEAK_GBS, 4),
             "kernel_ms": round(k_s * 1e3, 4), "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"),
             "match_count": oc, "match_checksum": f"{ocs:016x}" if other == "checksum" else None,
-            "count_agrees_with_primary": bool(oc == total_count)}
+            "count_agrees_with_primary": bool(oc == total_count),
+            "traffic": hbm_traffic(f"cfg3_{args.haystack}_{other}")[0] if args.workload == "cfg3" else None}
         if other == "checksum":
             out["value_count_checksum"] = out["with_checksum"]["value"]  # the op rounds 1 timed: compare THIS with BENCH_r01's `value`
         op["v"] = args.op
@@ -416,7 +426,8 @@ def main():
         cnt = int(result[0].item())
         out["dense"] = {"haystack": "dense (word soup)", "value": round(nbytes / k_s / 1e9, 2), "unit": "GB/s",
                         "frac": round(nbytes / k_s / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(k_s * 1e3, 4),
-                        "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"), "matches_per_byte": round(cnt / nbytes, 4)}
+                        "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"), "matches_per_byte": round(cnt / nbytes, 4),
+                        "traffic": hbm_traffic("cfg3_dense_count")[0] if args.workload == "cfg3" and args.op == "count" else None}
     # ---- a dictionary beyond 31 byte classes: the cfg3 words in mixed case + digits (60 pattern bytes) -----------------
     if world == 1 and not args.no_dense and args.workload == "cfg3":
         del hay

@@ -51,6 +51,7 @@ struct Options {
     std::atomic<int64_t> emit_rec_cap{256};     // deep-match records per wave and tile before the scan falls back
     std::atomic<int64_t> restart_tier{0};       // 1: find_iter of Standard bytewise automata chains over the TIERED tables (measured 7-9 % slower
                                                 // than over the double array on cfg3: half the waves per CU, and a match costs a gather more)
+    std::atomic<int64_t> restart_bpc{8};        // 256-thread workgroups per CU of the chain walkers
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
     std::atomic<int64_t> overlap_micro{1};      // counts of overlapping scans outside GRAM: 1 micro-step walker (charwise, DARRAY), 2 also instead of TIERED, 0 off
@@ -733,7 +734,7 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
     pl.a.total_len = end;
     if (pl.restart) {
         pl.threads = 256;
-        pl.blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 8, (nseg + 255) / 256)));
+        pl.blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * static_cast<uint64_t>(std::max<int64_t>(1, g_opt.restart_bpc.load())), (nseg + 255) / 256)));
         pl.tier_chain = !pl.charwise && !pl.leftmost && t->tier_ok && t->tier.root_flag == 0 && g_opt.restart_tier.load() != 0 &&
                         t->tier.lds_bytes + 512u <= 160u * 1024u;
     }
@@ -1827,6 +1828,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "emit_rec_cap") g_opt.emit_rec_cap = value;
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;
+    else if (n == "restart_bpc") g_opt.restart_bpc = value;
     else if (n == "chain_rounds") g_opt.chain_rounds = value;
     else if (n == "overlap_micro") g_opt.overlap_micro = value;
     else if (n == "pool") g_opt.pool = value;

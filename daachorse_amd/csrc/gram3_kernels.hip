@@ -152,7 +152,7 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
         for (uint32_t base = 0; base < wq_n; base += 64u * W) {
             uint4 r[W];
             uint64_t vnext[W];
-            uint32_t kn[W], n_ah[W];
+            uint32_t kn[W], n_ah[W] = {0u, 0u};
             unsigned long long ahead[W];
             bool go[W];
 #pragma unroll
@@ -164,14 +164,15 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
                     if (TAIL) {
                         const uint4 e4 = slab4[i];
                         e = uint2{e4.x, e4.y};
-                        ahead[w] = (static_cast<unsigned long long>(e4.w) << 32) | e4.z;  // the seven bytes from vnext on
+                        ahead[w] = (static_cast<unsigned long long>(e4.w & 0xffffffu) << 32) | e4.z;  // the bytes from vnext on (e4.w >> 24 of them)
+                        n_ah[w] = e4.w >> 24;
                     } else {
                         e = slab2[i];
                     }
                 }
                 vnext[w] = ((static_cast<uint64_t>(slab_hi) << 32) | e.x) + 2;  // the state consumed the byte before vnext
                 kn[w] = e.y >> 27;
-                n_ah[w] = TAIL ? 7u : 0u;
+                if (!TAIL) n_ah[w] = 0u;
                 r[w] = uint4{0u, 0u, 0u, 0u};  // (an idle slot: counts nothing, leads nowhere)
                 if (i < wq_n) r[w] = recs[e.y & 0x07ffffffu];  // {cmap, first_child, own_cnt, -} or a tail record
             }
@@ -190,7 +191,7 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
                 if (go[w]) {
                     r[w] = recs[r[w].y + __popc(r[w].x & ((1u << kn[w]) - 1u))];
                     ++vnext[w];
-                    if (TAIL) { ahead[w] >>= 8; n_ah[w] = 6; }
+                    if (TAIL) { ahead[w] >>= 8; n_ah[w] -= 1u; }
                     else { ahead[w] = read_ahead(vnext[w]); n_ah[w] = 8; }
                 }
             }
@@ -233,7 +234,51 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
     uint32_t pend_pos = 0, pend_k = 0; // position of the hit byte; classes of the two bytes behind it (k1 | k2 << 8)
     uint32_t pend_t0 = 0, pend_t1 = 0; // TAIL: the eight bytes from position + 1 on
     bool pend_valid = false;           // wave-uniform
+    // TAIL: a branch that goes on past the hit's state asks for the record of the NEXT state at once (p2) instead of going through the
+    // slab: nine in ten such records are tail records and settle the branch with one compare; only what still goes on is queued.
+    // (On word soup the slab round trip of every walker was 2 GB written and read back per 4 GiB: profiles/r03_hbm_traffic.json.)
+    uint4 p2 = uint4{0u, 0u, 0u, 0u};    // record of the state below the hit's; zero for idle lanes
+    uint32_t p2_pos = 0, p2_t0 = 0, p2_t1 = 0, p2_state = 0;  // position of the hit byte; the seven bytes from position + 2 on; the state asked for | class of the byte at position + 2 << 27
+    bool p2_live = false, p2_any = false;        // per lane / wave-uniform
+    auto push_walker = [&](bool go, uint32_t pos, uint32_t st_k, uint32_t t0, uint32_t t1n) {
+        const unsigned long long m = __ballot(go);
+        if (m != 0) {
+            if (go) {
+                const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+                if (TAIL) slab4[at] = uint4{pos, st_k, t0, t1n};   // t1n: text bytes 4-6 | number of valid text bytes << 24
+                else slab2[at] = uint2{pos, st_k};
+            }
+            wq_n += __popcll(m);
+        }
+    };
+    auto finish_second = [&]() {
+        if (!TAIL || !p2_any) return;
+        p2_any = false;
+        const uint4 r = p2;
+        const unsigned long long text = (static_cast<unsigned long long>(p2_t1) << 32) | p2_t0;  // seven valid bytes
+        bool again = false;           // still going on: to the slab (or a tail of eight edges: the drain has the eighth byte fetched)
+        uint32_t st_k = 0, pos = p2_pos, t0 = p2_t0, t1n = (p2_t1 & 0xffffffu) | (7u << 24);
+        if (p2_live) {
+            if (r.x >> 31) {
+                if ((r.x & 15u) <= 7u) cnt32 += tail_count(r, text);
+                else { again = true; st_k = p2_state; }  // eight edges, seven bytes at hand: the drain looks at the record again with the eighth byte fetched
+            } else {
+                cnt32 += r.z;
+                const uint32_t k = cls_of(p2_t0 & 0xffu);
+                if ((r.x >> k) & 1u) {   // (class 0: bit 0 of a walk record's child map is never set)
+                    again = true;
+                    st_k = (r.y + __popc(r.x & ((1u << k) - 1u))) | (cls_of((p2_t0 >> 8) & 0xffu) << 27);
+                    pos = p2_pos + 1u;
+                    t0 = static_cast<uint32_t>(text >> 8);
+                    t1n = (static_cast<uint32_t>(text >> 40) & 0xffffffu) | (6u << 24);
+                }
+            }
+        }
+        p2_live = false;
+        push_walker(again, pos, st_k, t0, t1n);
+    };
     auto consume_pending = [&]() {
+        finish_second();
         if (!pend_valid) return;
         pend_valid = false;
         const uint4 r = pend;
@@ -250,15 +295,20 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
             go = k1 != 0 && ((r.x >> k1) & 1u);
 #endif
         }
-        const unsigned long long m = __ballot(go);
-        if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker
+        const uint32_t child = r.y + __popc(r.x & ((1u << k1) - 2u));
+        if (TAIL) {
+            p2 = uint4{0u, 0u, 0u, 0u};
+            p2_live = go;
+            p2_any = __ballot(go) != 0;
             if (go) {
-                const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
-                const uint32_t st = (r.y + __popc(r.x & ((1u << k1) - 2u))) | ((pend_k >> 8) << 27);
-                if (TAIL) slab4[at] = uint4{pend_pos, st, __builtin_amdgcn_alignbyte(pend_t1, pend_t0, 1u), pend_t1 >> 8};  // text from position + 2 on
-                else slab2[at] = uint2{pend_pos, st};
+                p2 = g.drec_t[child];
+                p2_pos = pend_pos;
+                p2_t0 = __builtin_amdgcn_alignbyte(pend_t1, pend_t0, 1u);  // text from position + 2 on
+                p2_t1 = pend_t1 >> 8;
+                p2_state = child | ((pend_k >> 8) << 27);
             }
-            wq_n += __popcll(m);
+        } else {
+            push_walker(go, pend_pos, child | ((pend_k >> 8) << 27), 0u, 0u);
         }
     };
     auto process_batch = [&](uint32_t n) {  // n <= 64 entries from the head of the queue
@@ -470,6 +520,7 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
       if (q_tail != q_head) process_batch(q_tail - q_head);
       carry_in = 0;
       consume_pending();
+      finish_second();
       drain();
       tot_cnt += cnt32;
       cnt32 = 0;
