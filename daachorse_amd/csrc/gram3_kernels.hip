@@ -180,7 +180,7 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
             // AT vnext.  Only a branch that goes on asks for more.
 #pragma unroll
             for (int w = 0; w < W; ++w) {
-                if (TAIL && (r[w].x >> 31)) {  // (its path is no longer than the seven bytes at hand unless it has eight edges)
+                if (r[w].x >> 31) {  // a tail record (TAIL: its path is no longer than the bytes at hand unless it has eight edges)
                     if (n_ah[w] < (r[w].x & 15u)) ahead[w] = read_ahead(vnext[w]);
                     cnt32 += tail_count(r[w], ahead[w]);
                     go[w] = false;
@@ -234,11 +234,13 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
     uint32_t pend_pos = 0, pend_k = 0; // position of the hit byte; classes of the two bytes behind it (k1 | k2 << 8)
     uint32_t pend_t0 = 0, pend_t1 = 0; // TAIL: the eight bytes from position + 1 on
     bool pend_valid = false;           // wave-uniform
-    // TAIL: a branch that goes on past the hit's state asks for the record of the NEXT state at once (p2) instead of going through the
-    // slab: nine in ten such records are tail records and settle the branch with one compare; only what still goes on is queued.
-    // (On word soup the slab round trip of every walker was 2 GB written and read back per 4 GiB: profiles/r03_hbm_traffic.json.)
+    // A branch that goes on past the hit's state asks for the record of the NEXT state at once (p2, looked at one batch later) instead
+    // of going through the slab: most branches end there — with TAIL nine in ten such records are tail records and settle the branch with
+    // one compare — and only what still goes on is queued for the drain.  (On word soup the slab round trip of every walker was 2 GB
+    // written and read back per 4 GiB: profiles/r03_hbm_traffic.json.)
     uint4 p2 = uint4{0u, 0u, 0u, 0u};    // record of the state below the hit's; zero for idle lanes
-    uint32_t p2_pos = 0, p2_t0 = 0, p2_t1 = 0, p2_state = 0;  // position of the hit byte; the seven bytes from position + 2 on; the state asked for | class of the byte at position + 2 << 27
+    uint32_t p2_pos = 0, p2_state = 0;   // position of the hit byte; the state asked for | class of the byte at position + 2 << 27
+    uint32_t p2_t0 = 0, p2_t1 = 0;       // the seven bytes from position + 2 on
     bool p2_live = false, p2_any = false;        // per lane / wave-uniform
     auto push_walker = [&](bool go, uint32_t pos, uint32_t st_k, uint32_t t0, uint32_t t1n) {
         const unsigned long long m = __ballot(go);
@@ -255,22 +257,24 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
         if (!TAIL || !p2_any) return;
         p2_any = false;
         const uint4 r = p2;
-        const unsigned long long text = (static_cast<unsigned long long>(p2_t1) << 32) | p2_t0;  // seven valid bytes
         bool again = false;           // still going on: to the slab (or a tail of eight edges: the drain has the eighth byte fetched)
         uint32_t st_k = 0, pos = p2_pos, t0 = p2_t0, t1n = (p2_t1 & 0xffffffu) | (7u << 24);
         if (p2_live) {
-            if (r.x >> 31) {
-                if ((r.x & 15u) <= 7u) cnt32 += tail_count(r, text);
+            if (TAIL && (r.x >> 31)) {
+                if ((r.x & 15u) <= 7u) cnt32 += tail_count(r, (static_cast<unsigned long long>(p2_t1) << 32) | p2_t0);
                 else { again = true; st_k = p2_state; }  // eight edges, seven bytes at hand: the drain looks at the record again with the eighth byte fetched
             } else {
                 cnt32 += r.z;
-                const uint32_t k = cls_of(p2_t0 & 0xffu);
+                const uint32_t k = p2_state >> 27;
                 if ((r.x >> k) & 1u) {   // (class 0: bit 0 of a walk record's child map is never set)
                     again = true;
-                    st_k = (r.y + __popc(r.x & ((1u << k) - 1u))) | (cls_of((p2_t0 >> 8) & 0xffu) << 27);
+                    const uint32_t k3 = cls_of((p2_t0 >> 8) & 0xffu);
+                    st_k = (r.y + __popc(r.x & ((1u << k) - 1u))) | (k3 << 27);
                     pos = p2_pos + 1u;
-                    t0 = static_cast<uint32_t>(text >> 8);
-                    t1n = (static_cast<uint32_t>(text >> 40) & 0xffffffu) | (6u << 24);
+                    if (TAIL) {
+                        t0 = __builtin_amdgcn_alignbyte(p2_t1, p2_t0, 1u);
+                        t1n = ((p2_t1 >> 8) & 0xffffu) | (6u << 24);
+                    }
                 }
             }
         }
@@ -296,19 +300,21 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
 #endif
         }
         const uint32_t child = r.y + __popc(r.x & ((1u << k1) - 2u));
-        if (TAIL) {
-            p2 = uint4{0u, 0u, 0u, 0u};
-            p2_live = go;
-            p2_any = __ballot(go) != 0;
-            if (go) {
-                p2 = g.drec_t[child];
-                p2_pos = pend_pos;
-                p2_t0 = __builtin_amdgcn_alignbyte(pend_t1, pend_t0, 1u);  // text from position + 2 on
-                p2_t1 = pend_t1 >> 8;
-                p2_state = child | ((pend_k >> 8) << 27);
-            }
-        } else {
-            push_walker(go, pend_pos, child | ((pend_k >> 8) << 27), 0u, 0u);
+        if (!TAIL) {
+            // (without tail records the second stage does not pay: asked for at once the next record cost uniform text 5 %,
+            // profiles/r03_gram3_ab.txt — there one hit in seventeen goes on at all)
+            push_walker(go, pend_pos, child | (((pend_k >> 8) & 0xffu) << 27), 0u, 0u);
+            return;
+        }
+        p2 = uint4{0u, 0u, 0u, 0u};
+        p2_live = go;
+        p2_any = __ballot(go) != 0;
+        if (go) {
+            p2 = g.drec_t[child];
+            p2_pos = pend_pos;
+            p2_state = child | (((pend_k >> 8) & 0xffu) << 27);
+            p2_t0 = __builtin_amdgcn_alignbyte(pend_t1, pend_t0, 1u);  // text from position + 2 on
+            p2_t1 = pend_t1 >> 8;
         }
     };
     auto process_batch = [&](uint32_t n) {  // n <= 64 entries from the head of the queue
