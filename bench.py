@@ -482,17 +482,32 @@ def main():
             ms = e0.elapsed_time(e1) / 5
             gpu_cnt = int(result[0].item())
             used = ENGINE_NAMES.get(da.last_engine(), "?")
+            # the same with the checksum of every (start, end, value)
+            fnx = lambda: ap.scan_count(ScanMode.FindOverlapping, ahay, stream=stream, result_dev=result.data_ptr())
+            fnx()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fnx()
+            e1.record()
+            torch.cuda.synchronize()
+            msx = e0.elapsed_time(e1) / 5
+            used_x = ENGINE_NAMES.get(da.last_engine(), "?")
             # parity on a 64 MiB prefix against the oracle (the whole GiB would take the CPU a minute)
             pn = (64 << 20) - ((64 << 20) % synth.CFG5_SLOT if name == "utf8jp" else 0)
             ok = None
             if not args.no_cpu:
                 from oracle import oracle as orc2
                 oo = orc2.OraclePma.deserialize(ap.serialize())
-                ok = bool(ap.count(ScanMode.FindOverlapping, ahay[:pn]) == oo.overlapping_count(ahay[:pn].cpu().numpy(), threads=16)[0])
+                want_a = oo.overlapping_count(ahay[:pn].cpu().numpy(), threads=16)
+                ok = bool(ap.count(ScanMode.FindOverlapping, ahay[:pn]) == want_a[0] and ap.scan_count(ScanMode.FindOverlapping, ahay[:pn]) == want_a)
             anyab[name] = {"dictionary": ("100 000 random patterns of 3-12 bytes over all 256 byte values; haystack: uniform random bytes" if name == "binary256"
                                           else "cfg5's 50 000 UTF-8 patterns (2-8 three-byte scalars, Zipf) scanned BYTEWISE; haystack: cfg5's Zipf text"),
                             "bytes": an, "value": round(an / ms / 1e6, 2), "unit": "GB/s", "frac": round(an / ms / 1e6 / HBM_PEAK_GBS, 4),
-                            "kernel_ms": round(ms, 4), "engine_used": used, "match_count": gpu_cnt, "parity_64mib_prefix_vs_oracle": ok}
+                            "kernel_ms": round(ms, 4), "engine_used": used, "match_count": gpu_cnt,
+                            "with_checksum": {"value": round(an / msx / 1e6, 2), "unit": "GB/s", "kernel_ms": round(msx, 4), "engine_used": used_x},
+                            "parity_64mib_prefix_vs_oracle": ok}
             del ahay, ap
             torch.cuda.empty_cache()
         out["any_alphabet"] = anyab

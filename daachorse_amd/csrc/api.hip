@@ -609,7 +609,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     // PFX engine: `.count()` for every bytewise Standard automaton the GRAM tables do not serve (any alphabet); pfx = 2 builds it always
     if (g_opt.pfx.load() == 2 || (g_opt.pfx.load() == 1 && !t->gram_ok && !t->gram2_ok && !t->gramw_ok)) {
         PfxTables px;
-        const bool px_ok = build_pfx_tables(h, 160u * 1024u - 16u * (2u * 1056u + 512u) - 64u, px);
+        const bool px_ok = build_pfx_tables(h, 160u * 1024u - 16u * (2u * 1056u + 512u) - 64u - 1024u, px);
         t->n_distinct_bytes = px.n_distinct_bytes;
         if (px_ok) {
             PfxDev &d = t->pfx;
@@ -621,6 +621,9 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             if ((st = t->put(px.disp, d.disp)) != DAAC_OK) return st;
             if ((st = t->put(px.slots, sl)) != DAAC_OK) return st;
             if ((st = t->put(px.wrec, wr)) != DAAC_OK) return st;
+            { const U32x4 *x; if ((st = t->put(px.slots_x, x)) != DAAC_OK) return st; d.slots_x = reinterpret_cast<const uint4 *>(x); }
+            { const U32x4 *x; if ((st = t->put(px.wrec_x, x)) != DAAC_OK) return st; d.wrec_x = reinterpret_cast<const uint4 *>(x); }
+            if ((st = t->put(px.hs1, d.hs1)) != DAAC_OK) return st;
             d.slots = reinterpret_cast<const uint4 *>(sl);
             d.wrec = reinterpret_cast<const uint2 *>(wr);
             d.G = px.G; d.has_len1 = px.has_len1; d.bloom_words = px.bloom_words; d.buckets = px.buckets; d.n_slots = px.n_slots;
@@ -1253,6 +1256,7 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
     else set(DAAC_REQ_OVERLAPPING_COUNT, micro_engine, micro, why_no_gram);
     if (t->gram_ok || (t->gram2_ok && t->gram2.exact_ok)) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EXACT, DAAC_WHY_FASTEST);
     else if (t->gramw_ok && t->gramw.exact_ok) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_WIDE, DAAC_WHY_FASTEST);
+    else if (t->pfx_ok && !(t->gram_ok || t->gram2_ok || t->gramw_ok)) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, why_no_gram);
     else set(DAAC_REQ_OVERLAPPING_CHECKSUM, micro_engine, micro, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);
     if (t->emit_ok && g_opt.emit.load() != 0) set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EMIT, DAAC_WHY_FASTEST);
     else set(DAAC_REQ_OVERLAPPING_TUPLES, seg_engine, DAAC_KERNEL_SEGMENT, t->gram2_ok ? DAAC_WHY_DUPLICATES : why_no_gram);
@@ -1388,10 +1392,10 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len - begin < (1ull << 35) &&
                           (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (g2_can || g1_can || gw_can)));
     // PFX: `.count()` for automata over any byte alphabet — what AUTO takes where the GRAM tables do not apply
-    const bool use_pfx = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && !want_checksum && t->pfx_ok &&
+    const bool use_pfx = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && t->pfx_ok &&
                          len - begin < (1ull << 35) && (engine == DAAC_ENGINE_PFX || (engine == DAAC_ENGINE_AUTO && !use_gram));
     if (engine == DAAC_ENGINE_PFX && !use_pfx) {
-        set_error("PFX engine not available for this automaton / request (bytewise Standard automata without \"\", `.count()` of find_overlapping)");
+        set_error("PFX engine not available for this automaton / request (bytewise Standard automata without \"\", count (+ checksum) of find_overlapping)");
         return DAAC_ERR_UNSUPPORTED;
     }
     if (engine == DAAC_ENGINE_GRAM && (!use_gram || !(g2_can || g1_can || gw_can))) {
@@ -1493,15 +1497,15 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         // the option decides, every workgroup samples the haystack at its start and runs the variant the text calls for
         const int64_t tail_opt = g_opt.gram3_tail.load();
         void *wq = nullptr;
-        HIP_TRY(hipMallocAsync(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * ((use_g3 || use_pfx) ? sizeof(uint4) : sizeof(uint2)), stream));
+        HIP_TRY(dev_malloc(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * ((use_g3 || use_pfx) ? sizeof(uint4) : sizeof(uint2)), stream));
         ga.wq = static_cast<uint2 *>(wq);
         ga.sel_want = tail_opt < 0 ? ((len - begin) >= (1ull << 20) ? 2u : 0u) : tail_opt > 0 ? 1u : 0u;
-        const hipError_t le = use_pfx ? launch_pfx_scan(t->pfx, ga, blocks, stream)
+        const hipError_t le = use_pfx ? launch_pfx_scan(t->pfx, ga, want_checksum, blocks, stream)
                               : use_g3 ? launch_gram3_scan(t->gram2, ga, g3l, blocks, stream)
                               : use_gw ? launch_gram2w_scan(t->gramw, ga, want_checksum, blocks, stream)
                               : use_g2 ? launch_gram2_scan(t->gram2, ga, want_checksum, blocks, threads, stream)
                                        : launch_gram_scan(t->gram, ga, blocks, threads, stream);
-        HIP_TRY(hipFreeAsync(wq, stream));
+        dev_free(wq, stream);
         HIP_TRY(le);
         if (begin != 0) {
             unsigned long long add[3] = {0, 0, 0};

@@ -30,15 +30,10 @@
 
 #include "device_tables.hpp"
 
-#ifndef DAAC_WIN_AHEAD
+// settings of the round-2 chain-walker experiments (profiles/r02_bench_restart_scanners.txt), frozen at the measured best
 #define DAAC_WIN_AHEAD 1
-#endif
-#ifndef DAAC_TALLY_DEFER
 #define DAAC_TALLY_DEFER 1
-#endif
-#ifndef DAAC_CW_MICRO
 #define DAAC_CW_MICRO 1
-#endif
 
 namespace daac {
 

@@ -227,13 +227,16 @@ struct PfxDev {
     const uint16_t *disp;    // one displacement per bucket of the perfect hash
     const uint4 *slots;      // n_slots x {key bytes 0-3, key bytes 4-5 | flags, BASE of the depth-G state, patterns that are the key} or a tail record (pfx.hpp)
     const uint2 *wrec;       // per double-array slot {BASE, CHECK | patterns that end in this state << 8}
+    const uint4 *slots_x;    // count + checksum: {key 0-3, key 4-5 | own << 16, BASE, sum of h32 of the patterns that are the key}
+    const uint4 *wrec_x;     // count + checksum: {BASE, CHECK | own << 8, sum of h32 of the patterns that end there, 0}
+    const uint32_t *hs1;     // 256: sum of h32 of the one-byte patterns (staged behind CNT1)
     uint32_t G, has_len1, bloom_words, buckets, n_slots, seed;
     uint32_t bloom_bytes, disp_bytes;                       // multiples of 16
     uint32_t off_disp, off_cnt1, off_wave, wave_stride, lds_bytes, threads;   // pfx_plan
     uint32_t n_keys;
 };
 bool pfx_plan(PfxDev &d, uint32_t lds_limit);
-hipError_t launch_pfx_scan(const PfxDev &dev, const GramArgs &a, uint32_t blocks, hipStream_t stream);
+hipError_t launch_pfx_scan(const PfxDev &dev, const GramArgs &a, bool exact, uint32_t blocks, hipStream_t stream);
 
 hipError_t launch_overlap_count(const DArrayDev &dev, const ScanArgs &a, bool heads, uint32_t blocks, hipStream_t stream);
 hipError_t launch_char_overlap_count(const CharDev &dev, const ScanArgs &a, bool heads, uint32_t blocks, hipStream_t stream);

@@ -24,19 +24,11 @@ namespace daac {
 namespace {
 
 typedef uint32_t g2_u32x4_t __attribute__((ext_vector_type(4)));
-// build-time knobs for A/B runs of library variants (tools/mkvar2.sh); the defaults are the measured best
-#ifndef DAAC_G2_TAILS
+// settings of the round-2 A/B runs, frozen at the measured best
 #define DAAC_G2_TAILS 1
-#endif
-#ifndef DAAC_G2_DRAIN_W
 #define DAAC_G2_DRAIN_W 2
-#endif
-#ifndef G2_GROUP
 #define G2_GROUP 8
-#endif
-#ifndef G2_GROUPED_BALLOT
 #define G2_GROUPED_BALLOT 1
-#endif
 constexpr int kGroup2 = G2_GROUP;   // positions whose LDS reads are issued together
 constexpr uint32_t kRing2 = 128;    // entries of a wave's hit stack in LDS (at most 63 left over + 64 new)
 constexpr uint32_t kMaskBits = 0x3fffffffu;

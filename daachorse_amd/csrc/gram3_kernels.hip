@@ -24,6 +24,8 @@
 //     the kernel's time (profiles/r03_gram3_decomposition.txt).
 //
 // Roofline: HBM bytes of haystack (1 B read per byte); integer/bit work only, no MFMA.
+// G3X_NO_* : decomposition builds only (tools/ab_libs3.sh, profiles/r03_gram3_decomposition.txt) — they cut a stage out to price it, the counts they give are WRONG, and
+// nothing in the shipped library defines them (_build.py passes no -D).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

@@ -40,13 +40,14 @@ bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
     }
     for (bool b : seen_byte) out.n_distinct_bytes += b ? 1u : 0u;
     // ---- patterns that END in a state (its own, not those of its suffixes): list entries as long as the state is deep ----
-    std::vector<uint32_t> own(n, 0);
+    std::vector<uint32_t> own(n, 0), own_hs(n, 0);
     uint32_t min_len2 = kNone;
     bool has_len1 = false;
     for (const uint32_t s : order) {
         uint32_t op = output_pos_of(p.states[s].opos_ch);
         while (op != 0 && p.outputs[op - 1].length == depth[s]) {
             ++own[s];
+            own_hs[s] += match_hash32(p.outputs[op - 1].value, p.outputs[op - 1].length);
             op = p.outputs[op - 1].parent;
         }
         if (own[s] >= (1u << 24)) return false;
@@ -99,10 +100,12 @@ bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
     }
     // ---- CNT1 ----
     out.cnt1.assign(256, 0);
+    out.hs1.assign(256, 0);
     for (const uint32_t s : order)
         if (depth[s] == 1) {
             if (own[s] > 0xffff) return false;
             out.cnt1[k0[s] & 0xffu] = static_cast<uint16_t>(own[s]);
+            out.hs1[k0[s] & 0xffu] = own_hs[s];
         }
 
     // ---- hash and displace ----
@@ -146,8 +149,11 @@ bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
         out.seed = seed;
         out.disp = std::move(disp);
         out.slots.assign(M, U32x4{0u, kPfxEmpty, 0u, 0u});
+        out.slots_x.assign(M, U32x4{0u, kPfxEmpty, 0u, 0u});
         for (uint32_t i = 0; i < nk; ++i) {
             const uint32_t s = keys[i].state;
+            if (own[s] >= (1u << 14)) return false;
+            out.slots_x[slot_of[i]] = U32x4{keys[i].k0, keys[i].k1 | (own[s] << 16), p.states[s].base, own_hs[s]};
             if (path_len[s] != 0xff && path_len[s] != 0) {  // one path below the key: the record carries it
                 uint64_t bytes = 0;
                 uint32_t ends = own[s] ? 1u : 0u, cur = s;
@@ -180,10 +186,12 @@ bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
 
     // ---- WREC ----
     out.wrec.resize(n);
+    out.wrec_x.resize(n);
     for (uint32_t s = 0; s < n; ++s) {
         // vacant slots keep a CHECK no transition can produce (builder.rs:391-400): they are copied as they are, with nothing ending there
         const uint32_t o = depth[s] != kNone ? own[s] : 0u;
         out.wrec[s] = U32x2{p.states[s].base, static_cast<uint32_t>(check_of(p.states[s].opos_ch)) | (o << 8)};
+        out.wrec_x[s] = U32x4{p.states[s].base, static_cast<uint32_t>(check_of(p.states[s].opos_ch)) | (o << 8), depth[s] != kNone ? own_hs[s] : 0u, 0u};
     }
     out.available = true;
     return true;

@@ -55,6 +55,11 @@ struct PfxTables {
     std::vector<U32x4> slots;
     uint32_t n_tails = 0;
     std::vector<U32x2> wrec;         // per double-array slot {base, check | own << 8}
+    // count + checksum (the kernel's EXACT variant): no tail records and no path filter — every match has to be met as its own state, because
+    // its h32 goes into the sums with its own end position
+    std::vector<U32x4> slots_x;      // {k0, k1 | own << 16, base, sum of h32 of the patterns that are the key}
+    std::vector<U32x4> wrec_x;       // per double-array slot {base, check | own << 8, sum of h32 of the patterns that end there, 0}
+    std::vector<uint32_t> hs1;       // 256: sum of h32 of the one-byte patterns
     uint32_t lds_tables = 0;         // BLOOM + CNT1 + DISP bytes
 };
 

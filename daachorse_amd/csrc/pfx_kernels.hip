@@ -11,6 +11,8 @@
 // of records in flight, walkers in per-wave slabs.
 //
 // Roofline: HBM bytes of haystack (1 B read per byte); integer work only, no MFMA.
+// PFX_NO_* : decomposition builds only (tools/ab_libs_pfx.sh, profiles/r03_pfx_decomposition.txt) — they cut a stage out to price it, the counts they give are WRONG, and
+// nothing in the shipped library defines them (_build.py passes no -D).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -48,8 +50,9 @@ __device__ __forceinline__ void px_copy(void *dst, const void *src, uint32_t byt
 
 }  // namespace
 
-// G = key bytes (2 .. 6); LEN1 = the dictionary has one-byte patterns
-template <int G, bool LEN1, int TPB>
+// G = key bytes (2 .. 6); LEN1 = the dictionary has one-byte patterns; EXACT = count + checksum: every match is met as its own state (no tail
+// records, no path filter: slots_x / wrec_x) and adds h32 and h32 * end to the sums
+template <int G, bool LEN1, bool EXACT, int TPB>
 __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs a) {
     constexpr int P = 16;
     constexpr uint32_t SB = 64u * P;          // bytes a wave takes per step
@@ -60,6 +63,7 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
     px_copy(smem, g.bloom, g.bloom_bytes);
     px_copy(smem + g.off_disp, g.disp, g.disp_bytes);
     px_copy(smem + g.off_cnt1, g.cnt1, 512);
+    if (EXACT) px_copy(smem + g.off_cnt1 + 512, g.hs1, 1024);
     __syncthreads();
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // tables are read through absolute LDS addresses
     auto lds_u32 = [&](uint32_t addr) -> uint32_t { return *reinterpret_cast<ldsp_cu32 *>(static_cast<uintptr_t>(addr)); };
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
 
     unsigned long long tot_cnt = 0;
     uint32_t cnt32 = 0;
+    uint32_t s1 = 0, s2 = 0;   // EXACT: sum of h32, sum of h32 * end (mod 2^32; ends count from the haystack's first byte)
 
     auto load_chunk = [&](uint64_t v) -> uint4 {
         if (v >= a.vlen) return uint4{0u, 0u, 0u, 0u};
@@ -116,14 +121,16 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
                 if (vn[w] >= a.vlen) b[w] = 0;
             }
             for (;;) {
-                uint2 r[W];
+                uint4 r[W];
                 bool any = false;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
-                    r[w] = uint2{0u, 0u};
+                    r[w] = uint4{0u, 0u, 0u, 0u};
                     if (b[w] != 0) {
                         if (n_ahead[w] == 0) { ah[w] = read_ahead(vn[w]); n_ahead[w] = 8; }
-                        r[w] = g.wrec[b[w] ^ (static_cast<uint32_t>(ah[w]) & 0xffu)];
+                        const uint32_t slot = b[w] ^ (static_cast<uint32_t>(ah[w]) & 0xffu);
+                        if (EXACT) r[w] = g.wrec_x[slot];
+                        else { const uint2 q = g.wrec[slot]; r[w] = uint4{q.x, q.y, 0u, 0u}; }
                         any = true;
                     }
                 }
@@ -136,6 +143,7 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
                     cnt32 += r[w].y >> 8;
                     b[w] = r[w].x;
                     ++vn[w];
+                    if (EXACT) { s1 += r[w].z; s2 += r[w].z * (static_cast<uint32_t>(vn[w]) - a.lead); }  // the match ends behind the byte just taken
                     ah[w] >>= 8;
                     --n_ahead[w];
                     if (vn[w] >= a.vlen) b[w] = 0;
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
         const bool match = r.x == pend_k0 && (r.y & 0x8000ffffu) == pend_k1;
         bool go = false;
         if (match) {
-            if (r.y & kPfxTail) {  // one path below the key: compared with the text behind it, no walk
+            if (!EXACT && (r.y & kPfxTail)) {  // one path below the key: compared with the text behind it, no walk
                 const uint32_t edges = (r.y >> 16) & 15u;
                 const unsigned long long path = (static_cast<unsigned long long>(r.w) << 32) | r.z;
                 const unsigned long long text = (static_cast<unsigned long long>(pend_t1) << 32) | pend_t0;
@@ -173,9 +181,15 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
                 cnt32 += __popc((r.y >> 20) & ((2u << same) - 1u) & 0x1ffu);
             } else {
                 cnt32 += (r.y >> 16) & 0x3fffu;
-                // the two bytes behind the key against the record's filter of two-byte paths (with fewer than two bytes left: walk)
-                const uint64_t after = ((static_cast<uint64_t>(slab_hi) << 32) | pend_pos) + G;
-                go = r.z != 0 && (((r.w >> pfx_pair_bit(pend_t0)) & 1u) || after + 2 > a.vlen);
+                if (EXACT) {   // r.w: sum of h32 of the patterns that are the key
+                    s1 += r.w;
+                    s2 += r.w * (pend_pos - a.lead + G);
+                    go = r.z != 0;
+                } else {
+                    // the two bytes behind the key against the record's filter of two-byte paths (with fewer than two bytes left: walk)
+                    const uint64_t after = ((static_cast<uint64_t>(slab_hi) << 32) | pend_pos) + G;
+                    go = r.z != 0 && (((r.w >> pfx_pair_bit(pend_t0)) & 1u) || after + 2 > a.vlen);
+                }
             }
         }
 #ifdef PFX_NO_WALKERS
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
             const uint32_t ms = key0 * kPfxMulSlot0 + (key1 ^ g.seed) * kPfxMulSlot1;
             const uint32_t bucket = __umulhi(mb, g.buckets);
             const uint32_t d = lds_u16(g.off_disp + (bucket << 1));
-            pend = g.slots[pfx_slot(ms, d, g.n_slots)];
+            pend = (EXACT ? g.slots_x : g.slots)[pfx_slot(ms, d, g.n_slots)];
         }
         q_head += n;
         pend_valid = true;
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
             uint32_t W[6] = {cur.x, cur.y, cur.z, cur.w, 0u, 0u};
             W[4] = wave_shl1_p(cur.x, __builtin_amdgcn_readfirstlane(pf0.x));
             W[5] = wave_shl1_p(cur.y, __builtin_amdgcn_readfirstlane(pf0.y));
-            uint32_t H = 0, c1 = 0;
+            uint32_t H = 0, c1 = 0, h1 = 0, h2 = 0;   // EXACT, one-byte patterns: sum of h, sum of h * j
 #pragma unroll
             for (int j = 0; j < P; ++j) {
                 const int q = j >> 2, r = j & 3;
@@ -282,7 +296,11 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
                 const uint32_t word = lds_u32(__umulhi(m, g.bloom_words) << 2);   // BLOOM sits at LDS offset 0
                 const uint32_t m2 = m * kPfxMulBits;
                 H |= (__builtin_amdgcn_ubfe(word, m2 >> kPfxBit1, 1) & __builtin_amdgcn_ubfe(word, m2 >> kPfxBit2, 1)) << j;
-                if (LEN1) c1 += lds_u16(g.off_cnt1 + (((W[q] >> (8 * r)) & 0xffu) << 1));
+                if (LEN1) {
+                    const uint32_t byte = (W[q] >> (8 * r)) & 0xffu;
+                    c1 += lds_u16(g.off_cnt1 + (byte << 1));
+                    if (EXACT) { const uint32_t h = lds_u32(g.off_cnt1 + 512u + (byte << 2)); h1 += h; h2 += h * static_cast<uint32_t>(j); }
+                }
             }
             // starts before the haystack's first byte or too close to its end do not count (first / last step only)
             if (v < a.lead || sb + SB + G > a.vlen + 1 || (LEN1 && sb + SB > a.vlen)) {
@@ -291,12 +309,17 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
                 keep &= lo >= 16 ? 0u : ~((1u << lo) - 1u);
                 H &= keep;
                 if (LEN1) {
-                    c1 = 0;
+                    c1 = 0; h1 = 0; h2 = 0;
                     for (int j = 0; j < P; ++j)
-                        if (v + j >= a.lead && v + j < a.vlen) c1 += lds_u16(g.off_cnt1 + (((W[j >> 2] >> (8 * (j & 3))) & 0xffu) << 1));
+                        if (v + j >= a.lead && v + j < a.vlen) {
+                            const uint32_t byte = (W[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                            c1 += lds_u16(g.off_cnt1 + (byte << 1));
+                            if (EXACT) { const uint32_t h = lds_u32(g.off_cnt1 + 512u + (byte << 2)); h1 += h; h2 += h * static_cast<uint32_t>(j); }
+                        }
                 }
             }
             cnt32 += c1;
+            if (EXACT && LEN1) { s1 += h1; s2 += h1 * (static_cast<uint32_t>(v) - a.lead + 1u) + h2; }  // a one-byte match at position v + j ends at v + j + 1
 
 #ifdef PFX_NO_PRODUCER
             H = 0;
@@ -332,50 +355,52 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
       cnt32 = 0;
     }
     {
-        const unsigned long long c = px_wave_sum(tot_cnt);
+        const unsigned long long c = px_wave_sum(tot_cnt), x1 = px_wave_sum(s1), x2 = px_wave_sum(s2);
         __syncthreads();
         unsigned long long *scratch = reinterpret_cast<unsigned long long *>(smem);
-        if (lane == 0) scratch[wave_in_wg] = c;
+        if (lane == 0) { scratch[wave_in_wg * 3] = c; scratch[wave_in_wg * 3 + 1] = x1; scratch[wave_in_wg * 3 + 2] = x2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned long long r0 = 0;
-            for (int w = 0; w < static_cast<int>((blockDim.x + 63) >> 6); ++w) r0 += scratch[w];
+            unsigned long long r0 = 0, r1 = 0, r2 = 0;
+            for (int w = 0; w < static_cast<int>((blockDim.x + 63) >> 6); ++w) { r0 += scratch[w * 3]; r1 += scratch[w * 3 + 1]; r2 += scratch[w * 3 + 2]; }
             if (r0) atomicAdd(a.result, r0);
+            if (EXACT && (r1 | r2)) { atomicAdd(a.result + 1, r1); atomicAdd(a.result + 2, r2); }
         }
     }
 }
 
-template <int G, bool LEN1>
+template <int G, bool LEN1, bool EXACT>
 static hipError_t launch_pfx_inst(const PfxDev &dev, const GramArgs &a, uint32_t blocks, hipStream_t stream) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfx_kernel<G, LEN1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfx_kernel<G, LEN1, EXACT, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(dev.lds_bytes));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((pfx_kernel<G, LEN1, 1024>), dim3(blocks), dim3(1024), dev.lds_bytes, stream, dev, a);
+    hipLaunchKernelGGL((pfx_kernel<G, LEN1, EXACT, 1024>), dim3(blocks), dim3(1024), dev.lds_bytes, stream, dev, a);
     return hipGetLastError();
 }
 template <int G>
-static hipError_t launch_pfx_g(const PfxDev &dev, const GramArgs &a, uint32_t blocks, hipStream_t stream) {
-    return dev.has_len1 ? launch_pfx_inst<G, true>(dev, a, blocks, stream) : launch_pfx_inst<G, false>(dev, a, blocks, stream);
+static hipError_t launch_pfx_g(const PfxDev &dev, const GramArgs &a, bool exact, uint32_t blocks, hipStream_t stream) {
+    if (exact) return dev.has_len1 ? launch_pfx_inst<G, true, true>(dev, a, blocks, stream) : launch_pfx_inst<G, false, true>(dev, a, blocks, stream);
+    return dev.has_len1 ? launch_pfx_inst<G, true, false>(dev, a, blocks, stream) : launch_pfx_inst<G, false, false>(dev, a, blocks, stream);
 }
 
 // LDS plan: BLOOM at 0, DISP, CNT1, then 16 waves x (two text slots + the survivor queue)
 bool pfx_plan(PfxDev &d, uint32_t lds_limit) {
     d.off_disp = d.bloom_bytes;
     d.off_cnt1 = d.off_disp + d.disp_bytes;
-    d.off_wave = d.off_cnt1 + 512u;
+    d.off_wave = d.off_cnt1 + 512u + 1024u;   // CNT1 (u16 x 256), then the h32 sums of the one-byte patterns (u32 x 256, count + checksum only)
     d.wave_stride = 2u * (1024u + 32u) + kRingP * 4u;
     d.lds_bytes = d.off_wave + 16u * d.wave_stride;
     d.threads = 1024;
     return d.lds_bytes <= lds_limit;
 }
 
-hipError_t launch_pfx_scan(const PfxDev &dev, const GramArgs &a, uint32_t blocks, hipStream_t stream) {
+hipError_t launch_pfx_scan(const PfxDev &dev, const GramArgs &a, bool exact, uint32_t blocks, hipStream_t stream) {
     switch (dev.G) {
-        case 2: return launch_pfx_g<2>(dev, a, blocks, stream);
-        case 3: return launch_pfx_g<3>(dev, a, blocks, stream);
-        case 4: return launch_pfx_g<4>(dev, a, blocks, stream);
-        case 5: return launch_pfx_g<5>(dev, a, blocks, stream);
-        default: return launch_pfx_g<6>(dev, a, blocks, stream);
+        case 2: return launch_pfx_g<2>(dev, a, exact, blocks, stream);
+        case 3: return launch_pfx_g<3>(dev, a, exact, blocks, stream);
+        case 4: return launch_pfx_g<4>(dev, a, exact, blocks, stream);
+        case 5: return launch_pfx_g<5>(dev, a, exact, blocks, stream);
+        default: return launch_pfx_g<6>(dev, a, exact, blocks, stream);
     }
 }
 

@@ -25,9 +25,7 @@
 
 #include <cstdint>
 
-#ifndef DAAC_RS_MICRO
 #define DAAC_RS_MICRO 1
-#endif
 #include "chain_scan.hpp"
 #include "device_tables.hpp"
 

@@ -1,6 +1,7 @@
 // Host-logic test for the PFX tables, pfx.hpp (no GPU needed): counts the find_overlapping stream from the tables, position by
 // position with the rules of pfx_kernels.hip (Bloom bit, displacement, slot record, goto-only walk over WREC, CNT1), and
-// compares with the literal automaton walk on the original double array.
+// compares with the literal automaton walk on the original double array; then the same for the count + checksum tables
+// (slots_x / wrec_x / hs1: every match met as its own state) against the sums of h32 and h32 * end of that walk.
 //   usage: pfx_check <blob> <lds_budget> <haystack-file>
 #include <cstdio>
 #include <cstdlib>
@@ -29,10 +30,15 @@ int main(int argc, char **argv) {
     const long long n = static_cast<long long>(hay.size());
 
     uint64_t rc = 0;
-    uint32_t st = 0;
+    uint32_t st = 0, r1 = 0, r2 = 0;
     for (long long i = 0; i < n; ++i) {
         st = p.next_state(st, hay[i]);
-        for (uint32_t op = output_pos_of(p.states[st].opos_ch); op != 0; op = p.outputs[op - 1].parent) rc++;
+        for (uint32_t op = output_pos_of(p.states[st].opos_ch); op != 0; op = p.outputs[op - 1].parent) {
+            rc++;
+            const uint32_t h = match_hash32(p.outputs[op - 1].value, p.outputs[op - 1].length);
+            r1 += h;
+            r2 += h * static_cast<uint32_t>(i + 1);
+        }
     }
 
     const uint32_t G = g.G, M = g.n_slots;
@@ -73,6 +79,43 @@ int main(int argc, char **argv) {
             b = w.x;
             ++vn;
         }
+    }
+    // count + checksum tables
+    uint64_t xc = 0;
+    uint32_t x1 = 0, x2 = 0;
+    for (long long s = 0; s < n; ++s) {
+        if (g.has_len1) { xc += g.cnt1[hay[s]]; x1 += g.hs1[hay[s]]; x2 += g.hs1[hay[s]] * static_cast<uint32_t>(s + 1); }
+        if (s + G > n) continue;
+        uint32_t k0 = 0, k1 = 0;
+        for (uint32_t i = 0; i < G; ++i) {
+            if (i < 4) k0 |= static_cast<uint32_t>(hay[s + i]) << (8 * i); else k1 |= static_cast<uint32_t>(hay[s + i]) << (8 * (i - 4));
+        }
+        const uint32_t m = k0 * kPfxMulBloom0 + k1 * kPfxMulBloom1;
+        const uint32_t word = g.bloom[static_cast<uint32_t>((static_cast<uint64_t>(m) * g.bloom_words) >> 32)];
+        const uint32_t m2 = m * kPfxMulBits;
+        if (!((word >> ((m2 >> kPfxBit1) & 31u)) & (word >> ((m2 >> kPfxBit2) & 31u)) & 1u)) continue;
+        const uint32_t mb = k0 * kPfxMulBucket0 + (k1 ^ g.seed) * kPfxMulBucket1, ms = k0 * kPfxMulSlot0 + (k1 ^ g.seed) * kPfxMulSlot1;
+        const U32x4 r = g.slots_x[pfx_slot(ms, g.disp[static_cast<uint32_t>((static_cast<uint64_t>(mb) * g.buckets) >> 32)], M)];
+        if (r.x != k0 || (r.y & 0xffffu) != k1 || (r.y & kPfxEmpty)) continue;
+        long long vn = s + G;
+        xc += (r.y >> 16) & 0x3fffu;
+        x1 += r.w;
+        x2 += r.w * static_cast<uint32_t>(vn);
+        uint32_t b = r.z;
+        while (b != 0 && vn < n) {
+            const uint32_t c = hay[vn];
+            const U32x4 w = g.wrec_x[b ^ c];
+            if ((w.y & 0xffu) != c) break;
+            ++vn;
+            xc += w.y >> 8;
+            x1 += w.z;
+            x2 += w.z * static_cast<uint32_t>(vn);
+            b = w.x;
+        }
+    }
+    if (xc != rc || x1 != r1 || x2 != r2) {
+        std::printf("MISMATCH count+checksum tables: %llu %u %u != %llu %u %u\n", (unsigned long long)xc, x1, x2, (unsigned long long)rc, r1, r2);
+        return 1;
     }
     if (gc != rc) { std::printf("MISMATCH count %llu != %llu\n", (unsigned long long)gc, (unsigned long long)rc); return 1; }
     std::printf("OK G=%u len1=%d keys=%u tails=%u bloom_words=%u buckets=%u slots=%u seed=%u lds=%u count=%llu survivors/byte=%.4f false_pos/byte=%.4f walkers/byte=%.4f\n",

@@ -33,6 +33,18 @@ def _count(p, hay, **kw):
     return got
 
 
+def _count_checksum(p, hay, **kw):
+    got = p.scan_count(ScanMode.FindOverlapping, hay, engine=Engine.Pfx, **kw)
+    assert da.last_engine() == int(Engine.Pfx)
+    return got
+
+
+def _add(a, b):
+    """(count, checksum) of two shards: the checksum is two sums mod 2^32 side by side"""
+    m = 0xffffffff
+    return a[0] + b[0], ((((a[1] >> 32) + (b[1] >> 32)) & m) << 32) | ((a[1] + b[1]) & m)
+
+
 def test_pfx_against_the_oracle():
     import torch
     rng = np.random.default_rng(2024)
@@ -53,13 +65,17 @@ def test_pfx_against_the_oracle():
     for pats, hay in cases:
         o, p = _pma(pats)
         p.upload()
-        want = o.overlapping_count(hay, threads=8)[0]
+        both = o.overlapping_count(hay, threads=8)
+        want = both[0]
         dev = torch.from_numpy(np.concatenate([np.zeros(7, dtype=np.uint8), hay])).cuda()[7:]  # not 16-byte aligned
         assert _count(p, dev) == want, (len(pats), len(hay))
+        assert _count_checksum(p, dev) == both, (len(pats), len(hay))
         cut = int(rng.integers(1, len(hay)))
         assert _count(p, dev[:cut]) + _count(p, dev, begin=cut) == want, cut
+        assert _add(_count_checksum(p, dev[:cut]), _count_checksum(p, dev, begin=cut)) == both, cut
         da.set_option("gram_region", 2048)
         assert _count(p, dev) == want
+        assert _count_checksum(p, dev) == both
         da.set_option("gram_region", 0)
 
 
@@ -76,12 +92,13 @@ def test_pfx_short_and_ragged_haystacks():
     lengths += [int(x) for x in rng.integers(1, 1 << 17, size=12)]
     for n in lengths:
         off = int(rng.integers(0, 32))
-        want = o.overlapping_count(base[off:off + n], threads=1)[0] if n else 0
-        assert _count(p, buf[off:off + n]) == want, (n, off)
+        both = o.overlapping_count(base[off:off + n], threads=1) if n else (0, 0)
+        assert _count(p, buf[off:off + n]) == both[0], (n, off)
+        assert _count_checksum(p, buf[off:off + n]) == both, (n, off)
 
 
 def test_pfx_is_what_auto_takes_for_wide_alphabets():
-    """256 pattern bytes: no GRAM table set applies; `.count()` runs on PFX (count + checksum stays on the double array)"""
+    """256 pattern bytes: no GRAM table set applies; `.count()` and count + checksum run on PFX"""
     import torch
     da.set_option("pfx", 1)
     pats = synth.patterns_binary256(30000)
@@ -92,7 +109,7 @@ def test_pfx_is_what_auto_takes_for_wide_alphabets():
     synth.device_uniform(dev, synth.SEEDS["bin_hay"], synth.ALPHA_BYTES)
     want = o.overlapping_count(dev.cpu().numpy(), threads=16)
     assert p.count(ScanMode.FindOverlapping, dev) == want[0] and da.last_engine() == int(Engine.Pfx)
-    assert p.scan_count(ScanMode.FindOverlapping, dev) == want and da.last_engine() in (int(Engine.DArray), int(Engine.Tiered))
+    assert p.scan_count(ScanMode.FindOverlapping, dev) == want and da.last_engine() == int(Engine.Pfx)
     # the UTF-8 dictionary of cfg5 scanned bytewise
     jp = synth.patterns_cfg5(20000)
     o, p = _pma(jp)
@@ -102,6 +119,7 @@ def test_pfx_is_what_auto_takes_for_wide_alphabets():
     synth.device_zipf_text(dev)
     want = o.overlapping_count(dev.cpu().numpy(), threads=16)
     assert p.count(ScanMode.FindOverlapping, dev) == want[0] and da.last_engine() == int(Engine.Pfx)
+    assert p.scan_count(ScanMode.FindOverlapping, dev) == want and da.last_engine() == int(Engine.Pfx)
 
 
 def test_pfx_on_a_vector_of_window_counts():
@@ -140,7 +158,7 @@ def test_engine_plan_says_what_will_run():
     REQ = {"count": 0, "checksum": 1, "tuples": 2, "find": 3, "leftmost": 4, "nosuffix": 5}
     hay = torch.from_numpy(synth.uniform_haystack(1 << 20, 3, synth.ALPHA_LOWER_SPACE)).cuda()
     for pats, kind, expect in ((synth.patterns_cfg3(5000), 0, {"count": (Engine.Gram, 1), "checksum": (Engine.Gram, 2), "tuples": (Engine.Gram, 4)}),
-                               (synth.patterns_binary256(5000), 0, {"count": (Engine.Pfx, 5)}),
+                               (synth.patterns_binary256(5000), 0, {"count": (Engine.Pfx, 5), "checksum": (Engine.Pfx, 5)}),
                                (synth.patterns_cfg3(2000) + [b""], 0, {})):
         o = orc.OraclePma.build(pats)
         p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())

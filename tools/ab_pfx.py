@@ -46,4 +46,16 @@ for name in ("binary256", "utf8jp"):
             print(f"{name:10s} {ename:7s} {hay.numel() / ms / 1e6:8.1f} GB/s {ms:9.3f} ms  count {cnt} {'ok' if cnt == ref else 'MISMATCH'} engine_used={da.last_engine()}", flush=True)
         except Exception as ex:  # noqa
             print(f"{name:10s} {ename:7s} failed: {ex}", flush=True)
+    for ename, eng in (("pfx", Engine.Pfx), ("darray", Engine.DArray)):  # count + checksum
+        for _ in range(2):
+            pma.scan_count(ScanMode.FindOverlapping, hay, engine=eng, stream=stream, result_dev=res.data_ptr())
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            pma.scan_count(ScanMode.FindOverlapping, hay, engine=eng, stream=stream, result_dev=res.data_ptr())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 2
+        print(f"{name:10s} {ename:7s} count+checksum {hay.numel() / ms / 1e6:8.1f} GB/s {ms:9.3f} ms  {[int(x) & 0xffffffff for x in res.tolist()]} engine_used={da.last_engine()}", flush=True)
     del hay
