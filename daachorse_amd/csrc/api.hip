@@ -51,9 +51,6 @@ struct Options {
     std::atomic<int64_t> emit_rec_cap{256};     // deep-match records per wave and tile before the scan falls back
     std::atomic<int64_t> restart_tier{0};       // 1: find_iter of Standard bytewise automata chains over the TIERED tables (measured 7-9 % slower
                                                 // than over the double array on cfg3: half the waves per CU, and a match costs a gather more)
-    std::atomic<int64_t> interleave{0};         // 1: chain walkers / micro-step walker read a segment-interleaved copy of the haystack (ranges of 8 MiB and more).
-                                                // Measured (profiles/r03_interleave_experiment.txt): the speculation pass's HBM fetches fall 2.4x, its time does not move
-                                                // (the walkers wait for the automaton's round trips, not for text), and the copy costs 0.43 ms per GiB: off
     std::atomic<int64_t> restart_bpc{8};        // 256-thread workgroups per CU of the chain walkers
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
@@ -728,11 +725,6 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
         S = std::max(S, min_seg);
     }
     S = (std::max<uint64_t>(S, 16) + 15) & ~15ull;
-    if (g_opt.interleave.load() != 0 && g_opt.seg_bytes.load() == 0 && (pl.restart || pl.charwise || !pl.tier)) {
-        uint64_t p2 = 128;  // (the interleaved copy addresses granule k of segment s by shifts)
-        while (p2 < S) p2 <<= 1;
-        S = p2;
-    }
     const uint64_t nseg = len ? (len + S - 1) / S : 0;
     pl.threads = threads;
     pl.blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (nseg + threads - 1) / threads)));
@@ -787,37 +779,6 @@ struct ChainBuffers {
     hipStream_t s = nullptr;
     ~ChainBuffers() { dev_free(buf, s); }
 };
-
-// The segment-interleaved copy of the part of the haystack a chain / micro-step scan reads (HayInterleave): made when the scan
-// uses HayStream (restart iterators; overlapping counts of charwise automata and of the double array), the range is large enough to
-// pay for the copy, and the text beyond the range's end (links run on to the haystack's real end) is not most of it.
-static daac_status maybe_interleave(Plan &pl, const DeviceTables *t, const uint8_t *dev_hay, bool micro_count, hipStream_t stream, DevBuf &buf) {
-    (void)t;
-    pl.a.il = HayInterleave{};
-    if (g_opt.interleave.load() == 0 || pl.a.nseg == 0) return DAAC_OK;
-    if (!(pl.restart || micro_count)) return DAAC_OK;
-    const uint64_t S = pl.a.seg_bytes;
-    if (S < 128 || (S & (S - 1)) != 0) return DAAC_OK;
-    const uint64_t range = pl.a.len - pl.a.begin;
-    if (range < (8ull << 20)) return DAAC_OK;
-    const uint64_t first = pl.a.begin > pl.a.halo ? pl.a.begin - pl.a.halo : 0;  // (nothing before it is read: a staged host haystack begins here)
-    const uint64_t span_lin = pl.a.total_len - first;
-    if (span_lin > 2 * range + (1ull << 20)) return DAAC_OK;
-    const unsigned long long a0 = (reinterpret_cast<unsigned long long>(dev_hay) + first) & ~15ull;
-    const unsigned long long end_addr = reinterpret_cast<unsigned long long>(dev_hay) + pl.a.total_len;
-    const uint64_t nseg = (end_addr - a0 + S - 1) / S + 1;
-    if (nseg >= (1ull << 31)) return DAAC_OK;
-    if (buf.alloc(nseg * S + 256, stream) != hipSuccess) { (void)hipGetLastError(); buf.p = nullptr; return DAAC_OK; }  // no room: read linearly
-    HayInterleave il;
-    il.base = static_cast<const uint8_t *>(buf.p);
-    il.a0 = a0;
-    il.nseg = static_cast<uint32_t>(nseg);
-    il.gps_log2 = 0;
-    while ((16ull << il.gps_log2) < S) ++il.gps_log2;
-    HIP_TRY(launch_interleave(dev_hay + pl.a.total_len, il, stream));
-    pl.a.il = il;
-    return DAAC_OK;
-}
 
 // a few page-locked words per host thread for flags read back between passes
 static unsigned int *pinned_words() {
@@ -1055,8 +1016,6 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
     unsigned long long *d_next = d_counts + pl.a.nseg + 1;
     HIP_TRY(hipMemsetAsync(d_next, 0, 2 * sizeof(unsigned long long), stream));
     pl.a.flags = d_next + 1;
-    DevBuf il_buf;
-    if ((st = maybe_interleave(pl, t, dev_hay, false, stream, il_buf)) != DAAC_OK) return st;
     ChainBuffers chain_buffers;
     if ((st = chain_resolve(pma, t, pl, stream, chain_buffers)) != DAAC_OK) return st;
     HIP_TRY(launch(t, pl, 1, heads, stream, d_next));
@@ -1436,12 +1395,6 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     if (!d_res) { HIP_TRY(hipMalloc(&own, 3 * sizeof(unsigned long long))); d_res = static_cast<unsigned long long *>(own); }
     std::unique_ptr<void, void (*)(void *)> g2(own, [](void *p) { if (p) (void)hipFree(p); });
     pl.a.result = d_res;
-    DevBuf il_buf;
-    if (!use_gram && !use_pfx) {
-        const bool micro_count = !pl.restart && g_opt.overlap_micro.load() != 0 && (pl.charwise || !pl.tier || g_opt.overlap_micro.load() == 2);
-        pl.a.total_len = len;
-        if ((st = maybe_interleave(pl, t, dev_hay, micro_count, stream, il_buf)) != DAAC_OK) return st;
-    }
     ChainBuffers chain_buffers;
     if (pl.a.nseg != 0 && (st = chain_resolve(pma, t, pl, stream, chain_buffers)) != DAAC_OK) return st;
     HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
@@ -1880,7 +1833,6 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;
     else if (n == "restart_bpc") g_opt.restart_bpc = value;
-    else if (n == "interleave") g_opt.interleave = value;
     else if (n == "chain_rounds") g_opt.chain_rounds = value;
     else if (n == "overlap_micro") g_opt.overlap_micro = value;
     else if (n == "pool") g_opt.pool = value;

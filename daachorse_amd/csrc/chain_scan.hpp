@@ -69,14 +69,6 @@ struct HayStream {
     typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
     const uint8_t *org = nullptr;  // positions are 32-bit offsets from here
     uintptr_t limit = 0;           // granules beginning at or beyond this address are never read
-    HayInterleave il;              // granules are fetched from the segment-interleaved copy when there is one
-    // where the aligned granule at linear address b is read from
-    __device__ __forceinline__ uintptr_t at(uintptr_t b) const {
-        if (il.base == nullptr) return b;
-        const unsigned long long g = (static_cast<unsigned long long>(b) - il.a0) >> 4;
-        const unsigned long long seg = g >> il.gps_log2, k = g & ((1ull << il.gps_log2) - 1ull);
-        return reinterpret_cast<uintptr_t>(il.base) + static_cast<uintptr_t>((k * il.nseg + seg) << 4);
-    }
     uint32_t boff = 0x80000000u;   // offset of the window's first byte (far from any position: the first request is cold)
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, n0 = 0, n1 = 0, n2 = 0, n3 = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0;
 
@@ -104,14 +96,14 @@ struct HayStream {
                 const uintptr_t b2 = two ? b + 16 : b;
                 U32x4 v0, v1;
                 asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off\n\ts_waitcnt vmcnt(0)"
-                             : "=&v"(v0), "=&v"(v1) : "v"(at(b)), "v"(at(b2)) : "memory");
+                             : "=&v"(v0), "=&v"(v1) : "v"(b), "v"(b2) : "memory");
                 w0 = v0.x; w1 = v0.y; w2 = v0.z; w3 = v0.w;
                 n0 = two ? v1.x : 0u; n1 = two ? v1.y : 0u; n2 = two ? v1.z : 0u; n3 = two ? v1.w : 0u;
                 boff = pos - (static_cast<uint32_t>(addr) & 15u);
             }
             const uintptr_t g = addr_of(boff + 32u);
             U32x4 v = U32x4{0u, 0u, 0u, 0u};
-            if (g < limit) v = *reinterpret_cast<const U32x4 __attribute__((address_space(1))) *>(at(g));
+            if (g < limit) v = *reinterpret_cast<const U32x4 __attribute__((address_space(1))) *>(g);
             f0 = v.x; f1 = v.y; f2 = v.z; f3 = v.w;
             off = pos - boff;
         }
@@ -335,7 +327,6 @@ __device__ __forceinline__ void overlap_count_body(const T &t, const ScanArgs &a
     unsigned long long tot_cnt = 0;
     uint32_t tot_s1 = 0, tot_s2 = 0;
     HayStream str;
-    str.il = a.il;
     str.limit = reinterpret_cast<uintptr_t>(t.hay) + a.total_len;
     for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
         const uint64_t lo = a.begin + seg * a.seg_bytes;
@@ -429,7 +420,6 @@ template <class T, bool LEFTMOST>
 __device__ __forceinline__ void chain_spec_body(const T &t, const ScanArgs &a, const ChainArgs &c, const uint32_t *ohash) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     ChainWalker<T, LEFTMOST> w{t, a.total_len, c.cap};
-    w.str.il = a.il;
     for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
         const uint64_t lo = a.begin + seg * a.seg_bytes;
         const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
@@ -445,7 +435,6 @@ template <class T, bool LEFTMOST>
 __device__ __forceinline__ void chain_fix_body(const T &t, const ScanArgs &a, const ChainArgs &c, const uint32_t *ohash) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     ChainWalker<T, LEFTMOST> w{t, a.total_len, c.cap};
-    w.str.il = a.il;
     bool changed = false;
     for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
         const uint64_t lo = a.begin + seg * a.seg_bytes;
@@ -518,7 +507,6 @@ __device__ __forceinline__ void chain_emit_body(const T &t, const ScanArgs &a, c
                                                 unsigned long long *next_begin, unsigned long long *scratch) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     ChainWalker<T, LEFTMOST> w{t, a.total_len, c.cap};
-    w.str.il = a.il;
     unsigned long long tot_cnt = 0;
     uint32_t tot_s1 = 0, tot_s2 = 0;
     for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {

@@ -55,18 +55,6 @@ struct CharDev {
     uint32_t row_in_lds;         // ROOT's row fits LDS beside the mapper (and every entry can be packed)
 };
 
-// Segment-interleaved copy of the haystack for the walkers that read it one lane = one stream (chain_scan.hpp HayStream): granule
-// k (16 bytes) of segment s sits at base + ((k * nseg + s) << 4), so that the lanes of a wave — one segment each, all at about
-// the same k — ask for neighbouring granules of the same cache lines.  Read linearly, 2048 lanes per CU each touching their own
-// 128-byte line for 16 bytes at a time evict one another's lines long before they come back for the next 16: the chain kernels
-// fetched 8-15 x the text from HBM (profiles/r03_hbm_traffic.json).  base == nullptr: not in use.
-struct HayInterleave {
-    const uint8_t *base = nullptr;
-    unsigned long long a0 = 0;     // linear ADDRESS (16-byte aligned) of granule 0 of segment 0
-    uint32_t gps_log2 = 0;         // log2 of the granules per segment
-    uint32_t nseg = 0;
-};
-
 struct ScanArgs {
     const uint8_t *hay;  // address of haystack byte 0 (only bytes >= begin - halo are read)
     uint64_t begin;      // scan range is [begin, len): matches with end in (begin, len] are reported
@@ -79,10 +67,7 @@ struct ScanArgs {
     daac_match *out;                 // MODE 2
     uint64_t total_len;              // restart scanners: real end of the haystack (a.len is the nominal end of this window)
     unsigned long long *flags;       // optional, 1 x u64: bit 0 = the reference would not terminate on this input
-    HayInterleave il;                // chain walkers / micro-step walker: the haystack's segment-interleaved copy, if one was made
 };
-// copies [a0, a0 + nseg << (gps_log2 + 4)) of the linear haystack into its interleaved form; granules at or beyond `limit` read as zero
-hipError_t launch_interleave(const uint8_t *limit, const HayInterleave &il, hipStream_t stream);
 
 // Passes of the restart scanners in their speculate / reconcile / emit form (chain_scan.hpp)
 struct ChainArgs {

@@ -468,38 +468,4 @@ hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned lon
     return hipGetLastError();
 }
 
-// ---- segment-interleaved copy of a haystack (HayInterleave, device_tables.hpp) -----------------------------------------------------
-// A tile of 64 segments x 8 granules goes through LDS: read along the text (the 8 granules of a segment are one 128-byte line),
-// written along the segments (64 neighbouring granules = 1 KiB): both sides coalesced.
-__global__ __launch_bounds__(512) void interleave_kernel(const uint8_t *limit, const HayInterleave il) {
-    __shared__ uint4 tile[64][9];
-    const uint32_t gps = 1u << il.gps_log2, tiles_k = gps >> 3;
-    const uint64_t tile_id = blockIdx.x;
-    const uint64_t seg0 = (tile_id / tiles_k) * 64ull;
-    const uint32_t k0 = static_cast<uint32_t>(tile_id % tiles_k) * 8u;
-    const uint32_t t = threadIdx.x;
-    {
-        const uint64_t seg = seg0 + (t >> 3);
-        const uint32_t k = k0 + (t & 7u);
-        uint4 v = uint4{0u, 0u, 0u, 0u};
-        const unsigned long long src = il.a0 + (((seg << il.gps_log2) + k) << 4);
-        if (seg < il.nseg && src < reinterpret_cast<unsigned long long>(limit)) v = *reinterpret_cast<const uint4 *>(static_cast<uintptr_t>(src));
-        tile[t >> 3][t & 7u] = v;
-    }
-    __syncthreads();
-    {
-        const uint64_t seg = seg0 + (t & 63u);
-        const uint32_t k = k0 + (t >> 6);
-        if (seg < il.nseg) reinterpret_cast<uint4 *>(const_cast<uint8_t *>(il.base))[static_cast<uint64_t>(k) * il.nseg + seg] = tile[t & 63u][t >> 6];
-    }
-}
-
-hipError_t launch_interleave(const uint8_t *limit, const HayInterleave &il, hipStream_t stream) {
-    if (il.base == nullptr || il.nseg == 0 || il.gps_log2 < 3) return hipErrorInvalidValue;
-    const uint64_t tiles = ((static_cast<uint64_t>(il.nseg) + 63) / 64) * ((1ull << il.gps_log2) >> 3);
-    if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(interleave_kernel, dim3(static_cast<uint32_t>(tiles)), dim3(512), 0, stream, limit, il);
-    return hipGetLastError();
-}
-
 }  // namespace daac
