@@ -362,9 +362,14 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         if ((st = t->put(da.root, root)) != DAAC_OK) return st;
         if ((st = t->put(da.osum, osum)) != DAAC_OK) return st;
         {
-            std::vector<uint32_t> rec(da.hot.size() * 3);
-            for (size_t i = 0; i < da.hot.size(); ++i) { rec[3 * i] = da.hot[i].x; rec[3 * i + 1] = da.hot[i].y; rec[3 * i + 2] = da.fail[i]; }
-            if ((st = t->put(rec, t->da.rec)) != DAAC_OK) return st;
+            std::vector<U32x4> rec(da.hot.size());
+            for (size_t i = 0; i < da.hot.size(); ++i) rec[i] = U32x4{da.hot[i].x, da.hot[i].y, da.fail[i], da.fmap[i]};
+            const U32x4 *drec;
+            if ((st = t->put(rec, drec)) != DAAC_OK) return st;
+            t->da.rec = reinterpret_cast<const uint4 *>(drec);
+            const U32x4 *droot;
+            if ((st = t->put(da.root_chain, droot)) != DAAC_OK) return st;
+            t->da.root_chain = reinterpret_cast<const uint4 *>(droot);
         }
         t->da.hot = reinterpret_cast<const uint2 *>(hot);
         t->da.fail = fail;

@@ -75,6 +75,14 @@ struct HayStream {
     __device__ __forceinline__ uintptr_t addr_of(uint32_t off) const {
         return reinterpret_cast<uintptr_t>(org) + static_cast<uintptr_t>(static_cast<intptr_t>(static_cast<int32_t>(off)));
     }
+    // a new run: positions count from `first`; nothing at or beyond `end` is read
+    template <class T>
+    __device__ __forceinline__ void open(const T &, const uint8_t *first, const uint8_t *end) {
+        org = first;
+        limit = reinterpret_cast<uintptr_t>(end);
+        boff = 0x80000000u;
+        cpos = 0x80000000u;
+    }
     uint32_t cword = 0, cpos = 0x80000000u;  // byte_at: the last word fetched and where it begins
     // one byte; three of four requests are answered by the word the previous one fetched
     __device__ __forceinline__ uint32_t byte_at(uint32_t pos) {
@@ -125,7 +133,7 @@ struct ChainWalker {
     uint64_t cap;
     bool overflow = false;
     HayWindow win;
-    HayStream str;  // run_micro's window
+    typename T::Stream str;  // run_micro's window
 
     // One link of the chain from position r (reference bytewise/iter.rs:87-112 / 272-340, charwise/iter.rs:
     // 133-156 / 325-399, one call of next()); returns the next chain position, > r.
@@ -254,10 +262,7 @@ __device__ __forceinline__ uint64_t ChainWalker<T, LEFTMOST>::run_micro(uint64_t
     const uint32_t end32 = room > 0xffffff00ull ? 0xffffff00u : static_cast<uint32_t>(room);  // the haystack's end
     const uint32_t hi32 = static_cast<uint32_t>(hi - entry);
     const uint32_t cap32 = cap > 0x3fffffffull ? 0x3fffffffu : static_cast<uint32_t>(cap);
-    str.limit = reinterpret_cast<uintptr_t>(t.hay) + len;
-    str.org = t.hay + entry;
-    str.boff = 0x80000000u;
-    str.cpos = 0x80000000u;
+    str.open(t, t.hay + entry, t.hay + len);
     typename T::State st = t.root();
     uint32_t pos = 0, clen = 0, code = 0, phase = 0;
     bool pending = false;   // a symbol has been read and its transition is under way
@@ -326,8 +331,7 @@ __device__ __forceinline__ void overlap_count_body(const T &t, const ScanArgs &a
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
     unsigned long long tot_cnt = 0;
     uint32_t tot_s1 = 0, tot_s2 = 0;
-    HayStream str;
-    str.limit = reinterpret_cast<uintptr_t>(t.hay) + a.total_len;
+    typename T::Stream str;
     for (uint64_t seg = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; seg < a.nseg; seg += stride) {
         const uint64_t lo = a.begin + seg * a.seg_bytes;
         const uint64_t hi = (lo + a.seg_bytes < a.len) ? lo + a.seg_bytes : a.len;
@@ -337,9 +341,7 @@ __device__ __forceinline__ void overlap_count_body(const T &t, const ScanArgs &a
         const uint32_t end32 = static_cast<uint32_t>(hi - p0);
         const uint64_t room = a.total_len - p0;
         const uint32_t text32 = room > 0xffffff00ull ? 0xffffff00u : static_cast<uint32_t>(room);
-        str.org = t.hay + p0;
-        str.boff = 0x80000000u;
-        str.cpos = 0x80000000u;
+        str.open(t, t.hay + p0, t.hay + a.total_len);
         typename T::State st = t.root();
         uint32_t pos = 0, clen = 0, code = 0, phase = 0;
         bool pending = false;
@@ -372,6 +374,7 @@ __device__ __forceinline__ void overlap_count_body(const T &t, const ScanArgs &a
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { cc += __shfl_down(cc, off, 64); x1 += __shfl_down(x1, off, 64); x2 += __shfl_down(x2, off, 64); }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();  // (`scratch` may lie over tables the walkers of other waves were still using)
     if (lane == 0) { scratch[wave * 3] = cc; scratch[wave * 3 + 1] = x1; scratch[wave * 3 + 2] = x2; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -491,6 +494,7 @@ __device__ __forceinline__ void chain_sum_body(const ScanArgs &a, const ChainArg
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { cc += __shfl_down(cc, off, 64); x1 += __shfl_down(x1, off, 64); x2 += __shfl_down(x2, off, 64); }
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        __syncthreads();  // (`scratch` may lie over tables the walkers of other waves were still using)
         if (lane == 0) { scratch[wave * 3] = cc; scratch[wave * 3 + 1] = x1; scratch[wave * 3 + 2] = x2; }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -543,6 +547,7 @@ __device__ __forceinline__ void chain_emit_body(const T &t, const ScanArgs &a, c
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { cc += __shfl_down(cc, off, 64); x1 += __shfl_down(x1, off, 64); x2 += __shfl_down(x2, off, 64); }
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        __syncthreads();  // (`scratch` may lie over tables the walkers of other waves were still using)
         if (lane == 0) { scratch[wave * 3] = cc; scratch[wave * 3 + 1] = x1; scratch[wave * 3 + 2] = x2; }
         __syncthreads();
         if (threadIdx.x == 0) {

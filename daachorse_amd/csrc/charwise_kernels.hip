@@ -30,6 +30,7 @@ template <int LVL>  // what is staged in LDS: 0 nothing, 1 the code mapper, 2 th
 struct CwTablesT {
     static constexpr bool MAPLDS = LVL >= 1, ROWLDS = LVL >= 2;
     using State = CwState;
+    using Stream = HayStream;
     static constexpr bool kMicro = DAAC_CW_MICRO != 0;  // chain_scan.hpp: the walker takes the transition one memory round trip at a time
     const CharDev &d;
     uint4 root_rec;

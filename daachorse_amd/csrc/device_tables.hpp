@@ -31,7 +31,8 @@ struct DArrayDev {
     const uint2 *hot;        // {base, opos_ch} per slot
     const uint32_t *fail;    // per slot (the automaton's own links; leftmost kinds: 1 = DEAD)
     const uint32_t *fail_plain;  // classic links of the same trie (== fail for Standard automata)
-    const uint32_t *rec;         // 3 words per slot {base, opos_ch, fail}: the chain walkers' one-request record
+    const uint4 *rec;            // per slot {base, opos_ch, fail, child filter}: the chain walkers' one-request record (repack.hpp, fmap)
+    const uint4 *root_chain;     // 256 x {child, child.base, child.output_pos << 8 | child.fail, child's filter}: ROOT's row for the chain walkers (LDS)
     const uint4 *root;       // 256 x {child, child.base, child.opos_ch, 0}, staged into LDS
     const uint2 *osum;       // per output record {chain count, chain sum of h32}
     const uint32_t *outputs; // n_outputs x {value, length, parent}

@@ -52,6 +52,27 @@ void build_darray_tables(const HostPma &p, DArrayTables &out) {
     }
     build_chain_sums(p, out.osum);
 
+    // child filters: every base belongs to one state, so the parent of an element t is the owner of base t ^ check(t)
+    // (vacant elements carry a CHECK no transition can land on, reference src/bytewise/builder.rs:391-400: no owner)
+    out.fmap.assign(n, 0);
+    {
+        std::vector<uint32_t> owner(n, 0xffffffffu);
+        for (size_t s = 0; s < n; ++s) {
+            const uint32_t b = p.base(static_cast<uint32_t>(s));
+            if (b != 0 && b < n) owner[b] = static_cast<uint32_t>(s);
+        }
+        for (size_t t = 0; t < n; ++t) {
+            if (t == kRoot) continue;
+            const uint32_t c = check_of(p.opos_ch(static_cast<uint32_t>(t))), b = static_cast<uint32_t>(t) ^ c;
+            if (b < n && owner[b] != 0xffffffffu) out.fmap[owner[b]] |= 1u << (c & 31u);
+        }
+    }
+    out.root_chain.assign(256, U32x4{0, 0, 0, 0});
+    for (uint32_t c = 0; c < 256 && n; ++c) {
+        const U32x4 &r = out.root[c];
+        out.root_chain[c] = U32x4{r.x, r.y, (r.z & ~0xffu) | (r.w & 0xffu), out.fmap[r.x]};  // (r.w is 0 or 1 here)
+    }
+
     // Leftmost automata cut their failure links at output states (reference src/nfa_builder.rs:146-201).
     // The restart scanners additionally need to know where NO occurrence can span a position; that is
     // "the classic automaton is at ROOT", so the classic links are recomputed here over the same trie

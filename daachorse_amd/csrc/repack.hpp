@@ -47,6 +47,13 @@ struct DArrayTables {
                                        // used to find positions no occurrence spans (restart-scan sync points)
     std::vector<U32x4> root;       // 256 x {child idx, child base, child opos_ch, child fail}; no child: the ROOT record
     std::vector<OutSum> osum;      // per output record
+    // chain walkers: bit (c & 31) of fmap[s] is set iff s has a child on some byte c' with c' & 31 == c & 31 — a probe of base ^ c that
+    // the filter rules out is a miss without a memory request (failed probes land anywhere in the array: they were the walkers'
+    // cache misses)
+    std::vector<uint32_t> fmap;
+    // ROOT's row for the chain walkers: {child, child.base, child.output_pos << 8 | child.fail (0 = ROOT, 1 = DEAD: a child of ROOT has
+    // no other link; its CHECK byte is the index itself), child's filter}
+    std::vector<U32x4> root_chain;
 };
 
 struct TierTables {

@@ -37,14 +37,15 @@ __device__ __forceinline__ uint64_t rs_mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-struct RsState { uint32_t idx, base, opos_ch, fail; };  // fail: only kept by the micro-step walker (chain_scan.hpp, run_micro)
+struct RsState { uint32_t idx, base, opos_ch, fail, fmap; };  // fail, fmap (the child filter): only kept by the micro-step walker (chain_scan.hpp, run_micro)
 
 struct RestartTables {
     using State = RsState;
     static constexpr bool kMicro = DAAC_RS_MICRO != 0;  // chain_scan.hpp: the walker takes the transition one memory round trip at a time
     const DArrayDev &d;
-    const uint4 *l_root;  // 256 x {child, child.base, child.opos_ch, 0} in LDS
+    const uint4 *l_root;  // in LDS: 256 x {child, child.base, child.opos_ch, child.fail} (restart_scan_kernel), or DArrayDev::root_chain (the walkers)
     const uint8_t *__restrict__ hay = nullptr;
+    using Stream = HayStream;
 
     // the automaton as chain_scan.hpp wants it
     __device__ __forceinline__ RsState root() const { return RsState{0, 0, 0}; }
@@ -54,34 +55,43 @@ struct RestartTables {
     __device__ __forceinline__ uint64_t boundary_at_or_after(uint64_t x) const { return x; }
 
     // ---- the micro-step walker's view (chain_scan.hpp, run_micro) ----
-    __device__ __forceinline__ uint32_t symbol_code(HayStream &win, uint32_t pos, uint32_t, uint32_t &clen) const {
+    __device__ __forceinline__ uint32_t symbol_code(Stream &win, uint32_t pos, uint32_t, uint32_t &clen) const {
         clen = 1;
         return win.byte_at(pos);
     }
-    // One memory round trip of the transition on byte c (bytewise.rs:1063-1088 / 1094-1128 taken apart) over the 12-byte
-    // records {base, opos_ch, fail}: phase 0 probes the child slot, phase 1 fetches the record a failure link leads to.
-    // ROOT's row is in LDS: a lane at ROOT, or one whose failed probe leaves it with a link to ROOT, is through without
-    // asking memory.  Every lane loads, every turn (an idle lane asks for slot 0); the outcome is a handful of selects.
+    // One memory round trip of the transition on byte c (bytewise.rs:1063-1088 / 1094-1128 taken apart) over the 16-byte
+    // records {base, opos_ch, fail, child filter}: phase 0 probes the child slot, phase 1 fetches the record a failure link
+    // leads to.  ROOT's row is in LDS: a lane at ROOT, or one whose failed probe leaves it with a link to ROOT, is through
+    // without asking memory — and so is a probe the state's child filter rules out (no child on any byte with these low five
+    // bits): a failed probe lands on an arbitrary element of the array, i.e. on a cache line nobody else wants, and on text
+    // that leaves the dictionary's words after three or four bytes those were most of the walkers' misses.  Every lane loads,
+    // every turn (an idle lane asks for slot 0); the outcome is a handful of selects.
     template <bool LM>
     __device__ __forceinline__ bool micro(RsState &st, uint32_t c, uint32_t &phase, bool act) const {
-        const bool probe = phase == 0;
         const bool at_root = st.idx == 0;
-        const bool ask = act && (probe ? (!at_root && st.base != 0) : true);
-        const uint32_t slot = ask ? (probe ? (st.base ^ c) : st.fail) : 0u;
+        const bool child_possible = st.base != 0 && ((st.fmap >> (c & 31u)) & 1u) != 0;
+        // what this turn asks memory: the child slot (a probe), or — after a failed probe (phase 1), or at once when the filter
+        // rules the child out — the record the failure link leads to, unless that link ends the walk (DEAD) or leads to ROOT
+        const bool probe = act && phase == 0 && !at_root && child_possible;
+        const bool no_child = act && !at_root && !probe;
+        const bool stop = LM && st.fail == 1u;          // the link is DEAD: the walk ends
+        const bool follow = no_child && !stop && st.fail != 0;
+        const uint32_t slot = probe ? (st.base ^ c) : follow ? st.fail : 0u;
         const uint4 rr = l_root[c];
-        typedef uint32_t U32x3 __attribute__((ext_vector_type(3)));
-        U32x3 r;
-        asm volatile("global_load_dwordx3 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(d.rec + 3ull * slot) : "memory");
-        const bool hit = ask && probe && (r.y & 0xffu) == c;
-        const bool take = hit || (ask && !probe);
-        const bool miss = act && probe && !hit;
-        const bool dead = miss && !at_root && LM && st.fail == 1u;
-        const bool rootward = miss && !dead && (at_root || st.fail == 0);
-        phase = (miss && !dead && !rootward) ? 1u : 0u;
+        typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+        U32x4 r;
+        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(d.rec + slot) : "memory");
+        const bool hit = probe && (r.y & 0xffu) == c;
+        const bool miss = probe && !hit;
+        const bool dead = (no_child || miss) && stop;
+        const bool rootward = act && !dead && (at_root || ((no_child || miss) && st.fail == 0));
+        const bool take = hit || follow;
+        phase = (miss && !dead && !rootward) ? 1u : 0u;   // a failed probe whose link leads on: that record next turn
         st.idx = take ? slot : rootward ? rr.x : dead ? 0u : st.idx;
         st.base = take ? r.x : rootward ? rr.y : dead ? 0u : st.base;
         st.opos_ch = take ? r.y : rootward ? rr.z : dead ? 0u : st.opos_ch;
-        st.fail = take ? r.z : rootward ? rr.w : dead ? 0u : st.fail;
+        st.fail = take ? r.z : rootward ? (rr.z & 0xffu) : dead ? 0u : st.fail;
+        st.fmap = take ? r.w : rootward ? rr.w : dead ? 0u : st.fmap;
         return hit || dead || rootward;
     }
 
@@ -283,8 +293,8 @@ __global__ __launch_bounds__(256) void restart_scan_kernel(const DArrayDev dev, 
 template <bool LEFTMOST, int PASS, int KMODE>
 __global__ __launch_bounds__(256) void chain_kernel(const DArrayDev dev, const ScanArgs a, const ChainArgs c, unsigned long long *next_begin) {
     __shared__ uint4 l_root[256];
-    __shared__ unsigned long long scratch[3 * 4];
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root[i];
+    unsigned long long *scratch = reinterpret_cast<unsigned long long *>(l_root);  // (used behind a barrier, when the walkers are through)
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root_chain[i];
     __syncthreads();
     const RestartTables T{dev, l_root, a.hay};
     if (PASS == 0) chain_spec_body<RestartTables, LEFTMOST>(T, a, c, dev.ohash);
@@ -298,8 +308,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const DArrayDev dev, const S
 template <bool HEADS>
 __global__ __launch_bounds__(256) void overlap_count_kernel(const DArrayDev dev, const ScanArgs a) {
     __shared__ uint4 l_root[256];
-    __shared__ unsigned long long scratch[3 * 4];
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root[i];
+    unsigned long long *scratch = reinterpret_cast<unsigned long long *>(l_root);  // (used behind a barrier, when the walkers are through)
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) l_root[i] = dev.root_chain[i];
     __syncthreads();
     const RestartTables T{dev, l_root, a.hay};
     overlap_count_body<RestartTables, HEADS>(T, a, dev.osum, dev.ohash, scratch);

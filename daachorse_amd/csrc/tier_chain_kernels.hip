@@ -23,6 +23,7 @@ template <bool ROW32>
 struct TierChainTables {
     using Row = typename std::conditional<ROW32, uint32_t, uint16_t>::type;
     static constexpr bool kMicro = false;
+    using Stream = HayStream;
     struct State { uint32_t id, out; };  // out: the state carries an output list (known from the row entry / the parent's omap)
 
     const TierDev &d;

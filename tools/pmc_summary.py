@@ -7,7 +7,7 @@ import glob
 import os
 import sys
 
-KEYS = os.environ.get("DAAC_PMC_FILTER", "gram,scan_kernel").split(",")
+KEYS = [k.replace(". ", ", ") for k in os.environ.get("DAAC_PMC_FILTER", "gram,scan_kernel").split(",")]  # (". " stands for ", " inside a template argument list)
 
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
