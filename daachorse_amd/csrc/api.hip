@@ -317,11 +317,34 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             c.map_in_lds = g_opt.char_map_lds.load() != 0 && lo < c.table_len && pma->chost.alphabet_size < 0xffffu &&
                            staged * 4u >= pma->chost.alphabet_size * 3u;
         }
+        // the walkers' records: the output_pos word also carries the state's child filter (device_tables.hpp, CharDev::wstates)
+        std::vector<uint32_t> filt(ct.states.size(), 0u);
+        {
+            const size_t n_out = pma->chost.outputs.size();
+            c.obits = n_out < (1u << 16) ? 16u : n_out < (1u << 24) ? 24u : 0u;
+            c.fbits = c.obits == 16u ? 16u : c.obits == 24u ? 8u : 0u;
+            std::vector<CStateRec> ws(ct.states);
+            if (c.fbits != 0) {
+                // a slot t >= 2 whose CHECK names a state p other than DEAD is p's child on code t ^ base(p) (vacant slots: CHECK = DEAD,
+                // reference src/charwise.rs:1103-1112)
+                for (size_t tt = 2; tt < ct.states.size(); ++tt) {
+                    const uint32_t pp = ct.states[tt].check;
+                    if (pp == 1u || pp >= ct.states.size() || ct.states[pp].base == 0) continue;
+                    const uint32_t code = static_cast<uint32_t>(tt) ^ ct.states[pp].base;
+                    if (code >= pma->chost.alphabet_size) continue;
+                    filt[pp] |= 1u << (code & (c.fbits - 1u));
+                }
+                for (size_t i = 0; i < ws.size(); ++i) ws[i].output_pos |= filt[i] << c.obits;
+            }
+            const CStateRec *dws;
+            if ((st = t->put(ws, dws)) != DAAC_OK) return st;
+            c.wstates = reinterpret_cast<const uint4 *>(dws);
+        }
         // ROOT's row of children for the chain walkers: a lane at ROOT (where failed walks end) then needs no memory at all.
         // Staged beside the mapper when both fit 80 KB (two 1024-lane workgroups per CU) and every child packs into 8 bytes.
         {
             const uint32_t A = pma->chost.alphabet_size;
-            std::vector<U32x2> row(A, U32x2{0u, 2u});
+            std::vector<U32x2> row(A, U32x2{2u << 30, 0u});
             bool ok = c.map_in_lds != 0 && g_opt.char_row_lds.load() != 0 && A != 0;
             const CStateRec &rt = ct.states[0];
             for (uint32_t code = 0; ok && code < A; ++code) {
@@ -330,8 +353,8 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 if (child >= ct.states.size() || ct.states[child].check != 0) continue;
                 const CStateRec &ch = ct.states[child];
                 const uint32_t fl = (c.leftmost || ct.fail_plain.empty()) ? ch.fail : ct.fail_plain[child];
-                if (fl > 1u || (fl == 1u && !c.leftmost) || ch.output_pos >= (1u << 30)) ok = false;
-                row[code] = U32x2{ch.base, (ch.output_pos << 2) | fl};
+                if (fl > 1u || (fl == 1u && !c.leftmost) || ch.base >= (1u << 30)) ok = false;
+                row[code] = U32x2{ch.base | (fl << 30), ch.output_pos | (c.fbits ? filt[child] << c.obits : 0u)};
             }
             const uint32_t map_bytes = ((128u + c.table_len - c.map_lo) * 2u + 15u) & ~15u;
             ok = ok && map_bytes + A * 8u <= 80u * 1024u;

@@ -22,7 +22,7 @@ __device__ __forceinline__ uint64_t cw_mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-struct CwState { uint32_t idx, base, fail, opos; };
+struct CwState { uint32_t idx, base, fail, opos, filt; };  // filt (the child filter): only kept by the micro-step walker
 
 // MAPLDS: ASCII and the populated stretch [map_lo, table_len) of the code mapper are staged in LDS as u16 (0xffff =
 // unmapped): one L2 round trip less per character; the code points in between (rare in CJK text) go to the L2 copy
@@ -37,9 +37,12 @@ struct CwTablesT {
     const uint8_t *__restrict__ hay;
     uint64_t len;  // real end of the haystack: nothing at or beyond it is read
     const uint16_t *l_map = nullptr;
-    const uint2 *l_row = nullptr;  // per code: {child.base, child.output_pos << 2 | child.fail (0 ROOT, 1 DEAD)}, or {0, 2}: no such child
+    const uint2 *l_row = nullptr;  // CharDev::root_row in LDS
 
-    __device__ __forceinline__ CwState root() const { return CwState{0, root_rec.x, root_rec.z, root_rec.w}; }
+    // (word 3 of a walkers' record: output_pos | child filter << obits; the plain records have no filter bits)
+    __device__ __forceinline__ uint32_t opos_of(uint32_t w) const { return d.fbits ? (w & ((1u << d.obits) - 1u)) : w; }
+    __device__ __forceinline__ uint32_t filt_of(uint32_t w) const { return d.fbits ? (w >> d.obits) : 0xffffffffu; }
+    __device__ __forceinline__ CwState root() const { return CwState{0, root_rec.x, root_rec.z, opos_of(root_rec.w), filt_of(root_rec.w)}; }
     // the automaton as chain_scan.hpp wants it
     // one scalar through the lane's haystack window (same decoding as scalar_at below)
     __device__ __forceinline__ uint32_t symbol_at(HayWindow &win, uint64_t pos, uint32_t &clen) const {
@@ -101,43 +104,48 @@ struct CwTablesT {
         clen = n;
         return code_of(((lead << 18) | tail) >> (24u - 6u * n));
     }
-    // One memory round trip of the transition on `code` (charwise.rs:1022-1050 / 1056-1092 taken apart): phase 0 probes the
-    // child slot, phase 1 fetches the record a failure link leads to; a link to ROOT needs no memory (that record is at hand),
-    // the symbol is tried again from there in the next turn.  True once the transition is complete.  Every lane loads, every
-    // turn (an idle lane asks for slot 0), and the outcome is a handful of selects.
+    // One memory round trip of the transition on `code` (charwise.rs:1022-1050 / 1056-1092 taken apart): a probe of the child
+    // slot, or — after a failed probe (phase 1), or at once when the state's child filter rules the child out — the record the
+    // failure link leads to; a link to ROOT needs no memory (ROOT's row, or its record, is at hand), a DEAD link ends the walk.
+    // True once the transition is complete.  Every lane loads, every turn (an idle lane asks for slot 0), and the outcome is a
+    // handful of selects.
     template <bool LM>
     __device__ __forceinline__ bool micro(CwState &st, uint32_t code, uint32_t &phase, bool act) const {
-        const bool known = code != 0xffffffffu;  // charwise.rs:1031-1035
-        const bool probe = phase == 0;
+        const bool known = act && code != 0xffffffffu;  // charwise.rs:1031-1035
         const bool at_root = st.idx == 0;
-        // with ROOT's row at hand a lane standing at ROOT asks memory nothing, and a failed probe whose failure link leads to
-        // ROOT is settled in the same turn
-        const bool ask = act && known && (probe ? (st.base != 0 && !(ROWLDS && at_root)) : true);
-        const uint32_t slot = ask ? (probe ? (st.base ^ code) : st.fail) : 0u;
-        uint2 e = uint2{0u, 2u};
+        const bool possible = st.base != 0 && ((st.filt >> (code & (d.fbits ? d.fbits - 1u : 0u))) & 1u) != 0;
+        // with ROOT's row at hand a lane standing at ROOT asks memory nothing
+        const bool probe = known && phase == 0 && possible && !(ROWLDS && at_root);
+        const bool no_child = known && !probe;
+        const bool stop = LM && st.fail == 1u;
+        const bool follow = no_child && !at_root && !stop && st.fail != 0;
+        const uint32_t slot = probe ? (st.base ^ code) : follow ? st.fail : 0u;
+        uint2 e = uint2{2u << 30, 0u};
         if (ROWLDS) e = l_row[known ? code : 0u];
         // the turn's one memory round trip: all four words in one request, and the turn's one full wait with it
         typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
         U32x4 rv;
-        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(rv) : "v"(d.states + slot) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(rv) : "v"(d.wstates + slot) : "memory");
         const uint4 r = uint4{rv.x, rv.y, rv.z, rv.w};
         uint32_t f = r.z;
         if (!LM && d.fail_plain) f = d.fail_plain[slot];
-        const bool hit = ask && probe && r.y == st.idx;
-        const bool take = hit || (ask && !probe);                  // the record read becomes the state
-        const bool miss = act && known && probe && !hit;           // no such child (at ROOT with the row: not asked)
-        const bool dead = miss && !at_root && LM && st.fail == 1u;
-        const bool rootward = miss && !dead && (at_root || st.fail == 0);  // the symbol is ROOT's to take
+        const bool hit = probe && r.y == st.idx;
+        const bool fell = no_child || (probe && !hit);             // no child on this symbol
+        const bool take = hit || follow;                           // the record read becomes the state
+        const bool dead = fell && !at_root && stop;
+        const bool rootward = fell && !dead && (at_root || st.fail == 0);  // the symbol is ROOT's to take
         const bool by_row = ROWLDS && rootward;
-        const bool child = by_row && (e.y & 3u) != 2u;
+        const bool child = by_row && (e.x >> 30) != 2u;
         const bool to_root = (act && !known) || dead || (rootward && !child);
-        const bool done = (act && !known) || hit || dead || by_row || (miss && at_root);
-        phase = (miss && !dead && !rootward) ? 1u : 0u;
+        const bool done = (act && !known) || hit || dead || by_row || (fell && at_root);
+        phase = (probe && !hit && !dead && !rootward) ? 1u : 0u;   // a failed probe whose link leads on: that record next turn
         const CwState rt = root();
         st.idx = take ? slot : child ? (rt.base ^ code) : to_root ? rt.idx : st.idx;
-        st.base = take ? r.x : child ? e.x : to_root ? rt.base : st.base;
-        st.fail = take ? f : child ? (e.y & 3u) : to_root ? rt.fail : st.fail;
-        st.opos = take ? r.w : child ? (e.y >> 2) : to_root ? rt.opos : st.opos;
+        st.base = take ? r.x : child ? (e.x & 0x3fffffffu) : to_root ? rt.base : st.base;
+        st.fail = take ? f : child ? (e.x >> 30) : to_root ? rt.fail : st.fail;
+        const uint32_t w = take ? r.w : e.y;
+        st.opos = (take || child) ? opos_of(w) : to_root ? rt.opos : st.opos;
+        st.filt = (take || child) ? filt_of(w) : to_root ? rt.filt : st.filt;
         return done;
     }
     __device__ __forceinline__ void load(CwState &st, uint32_t slot, bool plain) const {
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(LVL == 2 ? 1024 : LVL == 1 ? 512 : 256) void char_c
             for (uint32_t i = threadIdx.x; i < dev.alphabet; i += blockDim.x) l_row[i] = dev.root_row[i];
         __syncthreads();
     }
-    const CwTablesT<LVL> T{dev, dev.states[0], a.hay, a.total_len, l_map, l_row};
+    const CwTablesT<LVL> T{dev, dev.wstates[0], a.hay, a.total_len, l_map, l_row};
     if (PASS == 0) chain_spec_body<CwTablesT<LVL>, LEFTMOST>(T, a, c, dev.ohash);
     else if (PASS == 1) chain_fix_body<CwTablesT<LVL>, LEFTMOST>(T, a, c, dev.ohash);
     else if (PASS == 3) chain_sum_body<KMODE>(a, c, next_begin, scratch);
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(LVL == 2 ? 1024 : LVL == 1 ? 512 : 256) void char_o
             for (uint32_t i = threadIdx.x; i < dev.alphabet; i += blockDim.x) l_row[i] = dev.root_row[i];
         __syncthreads();
     }
-    const CwTablesT<LVL> T{dev, dev.states[0], a.hay, a.total_len, l_map, l_row};
+    const CwTablesT<LVL> T{dev, dev.wstates[0], a.hay, a.total_len, l_map, l_row};
     overlap_count_body<CwTablesT<LVL>, HEADS>(T, a, dev.osum, dev.ohash, scratch);
 }
 

@@ -51,9 +51,15 @@ struct CharDev {
     uint32_t table_len, n, root_flag, leftmost;
     uint32_t map_in_lds;         // the populated stretch of the mapper fits LDS as u16 codes ((table_len - map_lo) * 2 <= 32 KB)
     uint32_t map_lo;             // first code point worth staging (the dense tail of the table starts here)
-    const uint2 *root_row;       // per code: {child.base, child.output_pos << 2 | child.fail}, {0, 2} = ROOT has no such child
+    const uint2 *root_row;       // per code: {child.base | child.fail << 30 (0 ROOT, 1 DEAD; 2: ROOT has no such child), output_pos | filter << obits}
     uint32_t alphabet;           // number of codes
     uint32_t row_in_lds;         // ROOT's row fits LDS beside the mapper (and every entry can be packed)
+    // the chain walkers' copy of `states`: word 3 = output_pos | child filter << obits.  Bit (code & (fbits - 1)) of the filter is set iff
+    // the state has a child on a code with those low bits: a probe the filter rules out is a miss without a memory request (and the
+    // failure link's record is asked for in its place).  fbits = 16 / 8 with fewer than 2^16 / 2^24 output records, else 0 (no filter;
+    // obits = 0 then and the word is the output_pos alone).  root_row[].y is packed the same way, root_row[].x = child.base | fail << 30.
+    const uint4 *wstates;
+    uint32_t obits, fbits;
 };
 
 struct ScanArgs {
