@@ -71,7 +71,8 @@ def hbm_traffic(workload_key, kernel_filter=None):
         kernels = t[workload_key]
         pick = [v for k, v in kernels.items() if kernel_filter is None or kernel_filter in k]
         best = max(pick, key=lambda v: v["bytes_per_launch"])
-        return best["bytes_per_launch"], (f"{os.path.relpath(path, ROOT)} [{workload_key}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this command "
+        name = [k for k, v in kernels.items() if v is best][0]
+        return best["bytes_per_launch"], (f"{os.path.relpath(path, ROOT)} [{workload_key}][{name[:60]}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this command "
                                           f"({best['launches']} timed launches), 2*FETCH + WRITE; " + str(t.get("_source", "")))
     except Exception:
         return None, None
@@ -308,7 +309,8 @@ def main():
         "match_count": total_count, "match_checksum": f"{checksum:016x}" if checksum is not None else None,
         "distributed": dist_used,
     }
-    tr = hbm_traffic({"cfg3": "cfg3", "cfg2": "cfg2"}[args.workload] + ("_count" if args.workload == "cfg2" else f"_{args.haystack}_{args.op}"))
+    tr = hbm_traffic({"cfg3": "cfg3", "cfg2": "cfg2"}[args.workload] + ("_count" if args.workload == "cfg2" else f"_{args.haystack}_{args.op}"),
+                     out["roofline"]["kernel"].split("::")[-1])  # the entry of the kernel the roofline names
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
 
     # ---- tuples (reported, not the metric): device-resident list of a 1 GiB prefix in both device formats, and a list copied to the host ----
@@ -414,7 +416,7 @@ def main():
             "kernel_ms": round(k_s * 1e3, 4), "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"),
             "match_count": oc, "match_checksum": f"{ocs:016x}" if other == "checksum" else None,
             "count_agrees_with_primary": bool(oc == total_count),
-            "traffic": hbm_traffic(f"cfg3_{args.haystack}_{other}")[0] if args.workload == "cfg3" else None}
+            "traffic": hbm_traffic(f"cfg3_{args.haystack}_{other}", "gram_count_kernel" if other == "checksum" else "gram3_kernel")[0] if args.workload == "cfg3" else None}
         if other == "checksum":
             out["value_count_checksum"] = out["with_checksum"]["value"]  # the op rounds 1 timed: compare THIS with BENCH_r01's `value`
         op["v"] = args.op
@@ -427,7 +429,7 @@ def main():
         out["dense"] = {"haystack": "dense (word soup)", "value": round(nbytes / k_s / 1e9, 2), "unit": "GB/s",
                         "frac": round(nbytes / k_s / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(k_s * 1e3, 4),
                         "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"), "matches_per_byte": round(cnt / nbytes, 4),
-                        "traffic": hbm_traffic("cfg3_dense_count")[0] if args.workload == "cfg3" and args.op == "count" else None}
+                        "traffic": hbm_traffic("cfg3_dense_count", "gram3_kernel")[0] if args.workload == "cfg3" and args.op == "count" else None}
     # ---- a dictionary beyond 31 byte classes: the cfg3 words in mixed case + digits (60 pattern bytes) -----------------
     if world == 1 and not args.no_dense and args.workload == "cfg3":
         del hay
