@@ -298,14 +298,20 @@ void daac_stream_close(daac_stream *s);
  *   seg_bytes (0 = auto)        bytes of haystack per lane-segment of the segment scanners
  *   threads (1024), blocks_per_cu (0 = auto)   launch shape of the overlapping scanners
  *   lds_budget (98304), dense_depth (-1 = auto), rows_share_pct (45)   TIERED re-pack
- *   gram_lds_budget (161792), gram_region (0 = auto: 16384 / 65536 for the first / second table set; rounded down to a power of two >= 2048), gram_slab (4096), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto),
+ *   gram_lds_budget (161792), gram_region (0 = auto: 16384 for the first table set, 65536 for the second and PFX, 262144 from 2 GiB on; rounded down to a power of two >= 2048), gram_slab (4096), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto),
  *   gram_ppl (0 = auto: 32 positions per lane and step for automata without short patterns, else 16)
- *   gram_version (0 = second table set where it applies, 1 = first only, 2 = second only), gram2_dpp (1: DPP wave shifts)
+ *   gram_version (0 = auto: `.count()` on the gram3 kernel over the second table set, count + checksum on the first where it applies;
+ *                 1 = first table set only, 2 = gram2 kernels only, 3 = gram3 for `.count()`), gram2_dpp (1: DPP wave shifts),
+ *   gram2_rfull (1)             rank directory with one entry per M word when LDS allows (0: one per four words)
+ *   gram3_tail (-1 = every workgroup samples its text and picks; 0 / 1: the plain / the tail-record body of the gram3 kernel)
+ *   pfx (1)                     PFX tables (any byte alphabet): 1 = built where no GRAM table set applies, 2 = for every automaton they can
+ *                               serve (DAAC_ENGINE_PFX then selects them explicitly), 0 = never; read at upload
  *   emit (1)                    materialising overlapping scans through the GRAM tuple emitter where it applies (0: segment scanners);
  *   emit_tiles (64), emit_rec_cap (256)   tiles of 1024 positions per wave region / deep-match records per wave and tile
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
  *   restart_tier (0)            1: find_iter of Standard bytewise automata runs its chains over the TIERED tables instead of the double array
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners
+ *   restart_bpc (8)             256-lane workgroups per CU of the chain walkers (they are bound by VALU issue at full occupancy)
  *   char_map_lds (1)            charwise walkers: ASCII and the populated stretch of the code mapper staged in LDS when they fit 32 KB
  *   char_row_lds (1)            ... and ROOT's row of children beside it when both fit 80 KB (read at upload)
  *   overlap_micro (1)           count (+ checksum) of overlapping scans the GRAM tables do not serve: 1 = the micro-step walker for

@@ -1,6 +1,6 @@
 #!/bin/bash
 # mkvar2.sh NAME [-DFLAG=..]... -> abtmp/lib_NAME.so: the library with ${SRC:-gram2_kernels}.hip compiled with the given flags
-# (for tools/ab_libs2.sh).  Needs an up-to-date daachorse_amd/build/ (python daachorse_amd/_build.py).
+# (for tools/ab_libs3.sh, tools/ab_libs_find.sh, tools/ab_libs_pfx.sh, tools/ab_emit.sh).  Needs an up-to-date daachorse_amd/build/ (python daachorse_amd/_build.py).
 set -e; mkdir -p /tmp/daac_var
 R=/root/repo; mkdir -p $R/abtmp
 N=$1; shift
