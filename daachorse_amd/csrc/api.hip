@@ -66,6 +66,7 @@ static thread_local int g_last_engine = DAAC_ENGINE_AUTO;  // engine of this thr
 
 static daac_status hip_fail(hipError_t e, const char *what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));
+    (void)hipGetLastError();  // the runtime also remembers the error: left there, the next successful launch would report it as its own
     return DAAC_ERR_DEVICE;
 }
 #define HIP_TRY(expr)                                                      \
@@ -438,7 +439,9 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             t->tier_ok = true;
             // GRAM count engine, derived from the tier tables
             GramTables gt;
-            if (tt.N < (1u << 27) && build_gram_tables(h, tt, static_cast<uint32_t>(g_opt.gram_lds_budget.load()), gt)) {
+            // (the budget is for tables AND the hit rings of a 1024-thread workgroup, as for the second table set below)
+            const int64_t g1_budget = g_opt.gram_lds_budget.load() - 16 * 128 * 8;
+            if (tt.N < (1u << 27) && g1_budget > 0 && build_gram_tables(h, tt, static_cast<uint32_t>(g1_budget), gt)) {
                 GramDev &g = t->gram;
                 const U32x2 *combo; const U32x4 *drec; const U32x2 *dhit;
                 std::vector<uint32_t> cls32(gt.cls.begin(), gt.cls.end());
@@ -480,7 +483,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 g.level_start = gt.level_start;
                 g.unused_byte = gt.unused_byte;
                 g.n_deep = static_cast<uint32_t>(gt.dhit.size());
-                t->gram_ok = true;
+                t->gram_ok = g.lds_bytes <= 160u * 1024u;  // (what a workgroup can have on gfx950)
             }
             // keep the sizes for daac_pma_info
             tt.rows16.clear(); tt.rows32.clear(); tt.bcmap.clear(); tt.bfail.clear(); tt.grec.clear(); tt.ssum.clear(); tt.sopos.clear(); tt.old_of_new.clear();

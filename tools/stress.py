@@ -164,10 +164,88 @@ def gram_soak(seconds, seed, max_cases=None):
     print(f"gram soak ok: {n_auto} automata ({n_gram} on the GRAM engine) in {time.time() - t0:.0f} s (seed {seed})")
 
 
+def engines_soak(seconds, seed, max_cases=None):
+    """The engines of round 3 against the oracle on random dictionaries over random ALPHABETS (2 .. 256 byte values): `.count()` on the gram3
+    kernel in every body / launch shape, `.count()` and count + checksum on PFX, and the tuple list of the emitter in both device formats —
+    with duplicate patterns, one-byte patterns and patterns of up to 60 bytes in the mix."""
+    import torch
+    from daachorse_amd import Engine
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    n_auto = n_g3 = n_pfx = n_emit = 0
+    da.set_option("pfx", 2)
+    while (n_auto < max_cases) if max_cases is not None else (time.time() - t0 < seconds):
+        nsym = int(rng.choice([2, 5, 12, 26, 29, 31, 60, 256]))
+        syms = rng.choice(np.arange(256), size=nsym, replace=False).astype(np.uint8)
+        npat = int(rng.choice([3, 40, 600, 6000]))
+        lo = int(rng.integers(1, 5))
+        hi = int(rng.choice([lo + 1, 8, 14, 24, 60]))
+        pats = [bytes(syms[rng.integers(0, nsym, size=int(rng.integers(lo, hi + 1)))]) for _ in range(npat)]
+        if rng.random() < 0.5:
+            pats += [pats[int(i)] for i in rng.integers(0, npat, size=max(1, npat // 10))]  # duplicates: every copy is a match of its own
+        n = int(rng.integers(1000, 1_500_000))
+        if rng.random() < 0.5:
+            hay = syms[rng.integers(0, nsym, size=n)]
+        else:  # text made of the patterns themselves
+            hay = np.frombuffer(b"".join(pats[int(i)] for i in rng.integers(0, len(pats), size=n // max(1, (lo + hi) // 2) + 1))[:n], dtype=np.uint8).copy()
+        o = orc.OraclePma.build(pats)
+        da.set_option("gram_lds_budget", int(rng.choice([158 * 1024, 40 * 1024])))
+        opts = {"gram_region": int(rng.choice([0, 2048, 65536])), "gram_ppl": int(rng.choice([0, 16, 32])), "gram3_tail": int(rng.choice([-1, 0, 1])),
+                "gram_version": int(rng.choice([0, 3])), "gram2_rfull": int(rng.choice([0, 1])), "threads": int(rng.choice([1024, 512]))}
+        for k, v in opts.items():
+            da.set_option(k, v)
+        p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+        info = p.upload().info()
+        dev = torch.from_numpy(hay).cuda()[int(rng.integers(0, 16)):]
+        host = dev.cpu().numpy()
+        want = o.overlapping_count(host, threads=8)
+        n_auto += 1
+        ctx = (nsym, npat, lo, hi, len(host), opts)
+        which = "count"
+        try:
+            assert p.count(ScanMode.FindOverlapping, dev) == want[0], ("auto count", ctx, p.explain())
+            which = "count + checksum"
+            assert p.scan_count(ScanMode.FindOverlapping, dev) == want, ("auto checksum", ctx, p.explain())
+        except da.DaachorseError as e:
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.savez(f"gpurun_out/engines_fail_{seed}_{n_auto}.npz", hay=host, blob=np.frombuffer(o.serialize(), dtype=np.uint8),
+                     opts=np.array([f"{k}={v}" for k, v in opts.items()]))
+            raise AssertionError(("auto", which, str(e), ctx, p.explain(), {f: getattr(info, f) for f in ("num_classes", "gram_available", "gram2_available", "gram2_exact", "pfx_available", "pfx_key_bytes", "pfx_lds_bytes")}))
+        if info.gram2_available:
+            assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want[0], ("gram count", ctx)
+            n_g3 += 1
+        if info.pfx_available:
+            assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Pfx) == want[0], ("pfx count", ctx)
+            assert p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Pfx) == want, ("pfx checksum", ctx)
+            begin = int(rng.integers(1, len(host)))
+            assert p.count(ScanMode.FindOverlapping, dev[:begin], engine=Engine.Pfx) + p.count(ScanMode.FindOverlapping, dev, engine=Engine.Pfx, begin=begin) == want[0], ("pfx shards", begin, ctx)
+            n_pfx += 1
+        # the tuple list, both device formats, against the oracle's (a prefix keeps the oracle's list small)
+        m = min(len(host), 200_000)
+        ref = o.find_overlapping_iter(host[:m])
+        for fmt16 in (True, False):
+            dm = p.scan_device(ScanMode.FindOverlapping, dev[:m], fmt16=fmt16)
+            got = dm.to_numpy()
+            dm.free()
+            assert len(got) == len(ref), ("tuples", fmt16, len(got), len(ref), ctx)
+            if fmt16:
+                ok = np.array_equal(got["end"], ref["end"]) and np.array_equal(got["length"], ref["end"] - ref["start"]) and np.array_equal(got["value"], ref["value"])
+            else:
+                ok = all(np.array_equal(got[f], ref[f]) for f in ("start", "end", "value"))
+            assert ok, ("tuples", fmt16, ctx)
+        n_emit += da.last_engine() == int(Engine.Gram)
+    for k, v in (("gram_lds_budget", 158 * 1024), ("gram_region", 0), ("gram_ppl", 0), ("gram3_tail", -1), ("gram_version", 0), ("gram2_rfull", 1), ("threads", 1024),
+                 ("pfx", 1)):
+        da.set_option(k, v)
+    print(f"engines soak ok: {n_auto} automata ({n_g3} with GRAM tables, {n_pfx} with PFX tables, {n_emit} tuple lists from the GRAM emitter) in {time.time() - t0:.0f} s (seed {seed})")
+
+
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     if len(sys.argv) > 3 and sys.argv[3] == "gram":
         gram_soak(budget, seed + 1000)
+    elif len(sys.argv) > 3 and sys.argv[3] == "engines":
+        engines_soak(budget, seed + 2000)
     else:
         iter_soak(budget, seed)
