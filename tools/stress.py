@@ -221,7 +221,7 @@ def engines_soak(seconds, seed, max_cases=None):
             assert p.count(ScanMode.FindOverlapping, dev[:begin], engine=Engine.Pfx) + p.count(ScanMode.FindOverlapping, dev, engine=Engine.Pfx, begin=begin) == want[0], ("pfx shards", begin, ctx)
             n_pfx += 1
         # the tuple list, both device formats, against the oracle's (a prefix keeps the oracle's list small)
-        m = min(len(host), 200_000)
+        m = max(1, min(len(host), 200_000, int(4e6 / max(want[0] / len(host), 1e-9))))  # (dictionaries of one- and two-byte duplicates match thousands of times per byte)
         ref = o.find_overlapping_iter(host[:m])
         for fmt16 in (True, False):
             dm = p.scan_device(ScanMode.FindOverlapping, dev[:m], fmt16=fmt16)
