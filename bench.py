@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-ENGINE_NAMES = {0: "auto", 1: "tiered", 2: "darray", 3: "gram", 4: "pfx"}
+ENGINE_NAMES = {0: "auto", 1: "tiered", 2: "darray", 3: "gram", 4: "pfx", 5: "jump"}
 
 
 def parse_args(argv=None):

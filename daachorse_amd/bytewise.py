@@ -39,6 +39,7 @@ class Engine(enum.IntEnum):
     DArray = 2
     Gram = 3
     Pfx = 4
+    Jump = 5  # reported by last_engine() only (find_iter counts over jump tables)
 
 
 class Match:

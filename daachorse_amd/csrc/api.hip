@@ -17,6 +17,7 @@
 #include "gram.hpp"
 #include "gram2.hpp"
 #include "gram2w.hpp"
+#include "jump.hpp"
 #include "pfx.hpp"
 #include "pma.hpp"
 #include "repack.hpp"
@@ -43,6 +44,8 @@ struct Options {
     std::atomic<int64_t> gram_version{0};       // 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram3 on the v2 tables), 1 = v1 only,
                                                 // 2 = v2 tables with gram2_kernels.hip, 3 = v2 tables with gram3_kernels.hip for `.count()`
     std::atomic<int64_t> gram2_dpp{1};
+    std::atomic<int64_t> jump{0};               // JUMP engine (experiment, off): find_iter count (+ checksum) of Standard bytewise automata over per-position jump tables
+                                                // instead of the chain walkers; measured 3x SLOWER than they are (profiles/r03_jump_experiment.txt); read at upload and at every scan
     std::atomic<int64_t> pfx{1};                // PFX engine: 1 = built for automata the GRAM tables do not serve, 2 = always, 0 = never (read at upload)
     std::atomic<int64_t> gram3_tail{-1};        // gram3: tail records from the hit record on (-1 = decide per launch)
     std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
@@ -146,6 +149,8 @@ struct DeviceTables {
     bool pfx_ok = false;       // any byte alphabet, `.count()` (pfx.hpp)
     uint32_t n_distinct_bytes = 0;  // distinct pattern bytes (known when the PFX builder ran)
     PfxDev pfx{};
+    bool jump_ok = false;      // find_iter over jump tables (jump.hpp)
+    JumpDev jump{};
     Gram2WDev gramw{};
     bool emit_ok = false;      // tuple emission on the second table set (gram2_emit_kernels.hip)
     Gram2EmitDev emit{};
@@ -661,6 +666,30 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             t->pfx_ok = pfx_plan(d, 160u * 1024u);
         }
     }
+    // JUMP engine: find_iter of Standard automata over per-position jump tables
+    if (!pma->charwise && h.is_standard() && g_opt.jump.load() != 0) {
+        JumpTables jt;
+        if (build_jump_tables(h, jt)) {
+            JumpDev &d = t->jump;
+            const U32x4 *jh; const U32x4 *jr;
+            if ((st = t->put(jt.cls, d.cls)) != DAAC_OK) return st;
+            if ((st = t->put(jt.ms, d.ms)) != DAAC_OK) return st;
+            if ((st = t->put(jt.sdir, d.sdir)) != DAAC_OK) return st;
+            if ((st = t->put(jt.jhit, jh)) != DAAC_OK) return st;
+            if ((st = t->put(jt.jrec, jr)) != DAAC_OK) return st;
+            if ((st = t->put(jt.h1, d.h1)) != DAAC_OK) return st;
+            if ((st = t->put(jt.h2, d.h2)) != DAAC_OK) return st;
+            if ((st = t->put(jt.h3, d.h3)) != DAAC_OK) return st;
+            d.jhit = reinterpret_cast<const uint4 *>(jh);
+            d.jrec = reinterpret_cast<const uint4 *>(jr);
+            d.C = jt.C;
+            d.ms_bytes = static_cast<uint32_t>(jt.ms.size() * 4);
+            d.sdir_bytes = static_cast<uint32_t>((jt.sdir.size() * 4 + 15) & ~size_t(15));
+            d.max_len = jt.max_len;
+            d.unused_byte = jt.unused_byte;
+            t->jump_ok = jump_len_lds_bytes(d) <= 160u * 1024u;
+        }
+    }
     HIP_TRY(hipDeviceSynchronize());
     *out = t.get();
     pma->dev[device] = std::move(t);
@@ -706,6 +735,8 @@ struct Plan {
     bool restart = false;   // find_iter / leftmost_find_iter: the restart scanners (DARRAY tables)
     bool tier_chain = false;  // ... find_iter of a Standard bytewise automaton: the chain passes run over the TIERED tables
     bool leftmost = false;
+    bool jump = false;        // find_iter count over the jump tables (jump_kernels.hip): `jargs` are in place
+    JumpArgs jargs{};
     uint32_t blocks, threads;
     ScanArgs a;
 };
@@ -778,6 +809,7 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
 hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, hipStream_t s, unsigned long long *next_begin = nullptr) {
     if (pl.restart && pl.chain.x_prev != nullptr) {  // totals and per-segment counts are sums of tallies; only writing re-scans
         const int pass = kmode == 2 ? 2 : 3;
+        if (pl.jump && pass == 3) return launch_jump_chain(t->jump, pl.jargs, pl.a, pl.chain, 3, pl.blocks, s);
         if (pl.tier_chain)
             return launch_tier_chain(t->tier, pl.a, pl.chain, pass, kmode, next_begin,
                                      static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(t->num_cu, (pl.a.nseg + 1023) / 1024))), s);
@@ -839,6 +871,7 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
     c.tally_delta = tallies + n;
     c.x_out = x_spec;
     auto run = [&](int pass) {
+        if (pl.jump) return launch_jump_chain(t->jump, pl.jargs, pl.a, c, pass, pl.blocks, stream);
         if (pl.tier_chain)
             return launch_tier_chain(t->tier, pl.a, c, pass, 0, nullptr,
                                      static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(t->num_cu, (pl.a.nseg + 1023) / 1024))), stream);
@@ -1251,7 +1284,8 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
     if (t->emit_ok && g_opt.emit.load() != 0) set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EMIT, DAAC_WHY_FASTEST);
     else set(DAAC_REQ_OVERLAPPING_TUPLES, seg_engine, DAAC_KERNEL_SEGMENT, t->gram2_ok ? DAAC_WHY_DUPLICATES : why_no_gram);
     set(DAAC_REQ_NO_SUFFIX, seg_engine, DAAC_KERNEL_SEGMENT, DAAC_WHY_FASTEST);
-    set(DAAC_REQ_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);  // (the restart iterators run on the double array)
+    if (t->jump_ok && g_opt.jump.load() != 0 && pma->host.is_standard()) set(DAAC_REQ_FIND, DAAC_ENGINE_JUMP, DAAC_KERNEL_JUMP, DAAC_WHY_FASTEST);
+    else set(DAAC_REQ_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);  // (the restart iterators run on the double array)
 }
 
 daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
@@ -1326,10 +1360,11 @@ size_t daac_pma_explain(const daac_pma *pma, char *buf, size_t cap) {
     if (daac_pma_info(pma, &f) != DAAC_OK) return 0;
     static const char *req[] = {"find_overlapping_iter(h).count()", "find_overlapping count + checksum", "find_overlapping tuples", "find_iter",
                                 "leftmost_find_iter", "find_overlapping_no_suffix_iter"};
-    static const char *eng[] = {"auto", "tiered", "darray", "gram", "pfx"};
+    static const char *eng[] = {"auto", "tiered", "darray", "gram", "pfx", "jump"};
     static const char *ker[] = {"- (the crate panics: wrong MatchKind)", "gram3 count kernel (one LDS lookup per byte)", "gram count + checksum kernel",
                                 "gram wide-alphabet kernel (31-62 byte classes)", "gram tuple emitter", "pfx (hashed prefix filter + start-anchored walks, any alphabet)",
-                                "segment scanners (one lane per segment)", "micro-step walker over the double array", "chain walkers (speculate / reconcile / emit)"};
+                                "segment scanners (one lane per segment)", "micro-step walker over the double array", "chain walkers (speculate / reconcile / emit)",
+                                "jump tables (shortest pattern per start, suffix minimum, one load per match); tuples: chain walkers"};
     static const char *why[] = {"", "not uploaded yet", "more distinct pattern bytes than the byte-class tables take", "tables do not fit the LDS",
                                 "\"\" is a pattern", "duplicate patterns the tables cannot encode", "the iterator is a chain through its own matches",
                                 "charwise automaton", "trie shape / table limits"};
@@ -1426,8 +1461,37 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     if (!d_res) { HIP_TRY(hipMalloc(&own, 3 * sizeof(unsigned long long))); d_res = static_cast<unsigned long long *>(own); }
     std::unique_ptr<void, void (*)(void *)> g2(own, [](void *p) { if (p) (void)hipFree(p); });
     pl.a.result = d_res;
+    // find_iter of a Standard bytewise automaton: L, then N / D for every position of the range, and the chain over those (jump.hpp)
+    DevBuf jump_buf;
+    if (pl.restart && !pl.leftmost && !pl.charwise && t->jump_ok && g_opt.jump.load() != 0 && g_opt.restart_chain.load() != 0 &&
+        !pma->root_has_output() && pl.a.nseg != 0 && len > begin) {
+        const uint8_t *sub = dev_hay + begin;
+        JumpArgs ja{};
+        ja.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sub) & 15u);
+        ja.hay_al = sub - ja.lead;
+        ja.vlen = ja.lead + static_cast<uint64_t>(len - begin);
+        ja.nsteps = (ja.vlen + 2 + 1023) / 1024;
+        ja.nd_chunks = (ja.vlen + 2 + 1791) / 1792;
+        const uint64_t written = ja.nsteps * 1024;
+        const uint64_t lsh_bytes = (std::max<uint64_t>(written, ja.nd_chunks * 1792 + 2048) + 255) & ~255ull;
+        const uint64_t nd_bytes = (ja.nd_chunks * 1792 * 2 + 255) & ~255ull;
+        const uint64_t hd_bytes = written * 4;
+        if (jump_buf.alloc(lsh_bytes + nd_bytes + hd_bytes, stream) == hipSuccess) {
+            ja.lsh = static_cast<uint8_t *>(jump_buf.p);
+            ja.nd = reinterpret_cast<uint16_t *>(ja.lsh + lsh_bytes);
+            ja.hdeep = reinterpret_cast<uint32_t *>(ja.lsh + lsh_bytes + nd_bytes);
+            if (lsh_bytes > written) HIP_TRY(hipMemsetAsync(ja.lsh + written, 0, lsh_bytes - written, stream));
+            HIP_TRY(launch_jump_tables(t->jump, ja, t->num_cu, stream));
+            pl.jump = true;
+            pl.jargs = ja;
+            pl.tier_chain = false;
+        } else {
+            (void)hipGetLastError();  // not enough memory for 7 bytes of tables per byte of text: the chain walkers take the scan
+        }
+    }
     ChainBuffers chain_buffers;
     if (pl.a.nseg != 0 && (st = chain_resolve(pma, t, pl, stream, chain_buffers)) != DAAC_OK) return st;
+    if (pl.jump && pl.chain.x_prev == nullptr) pl.jump = false;  // (the chain did not settle: the sync-point scanners)
     HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
     void *flagbuf = nullptr;
     if (pl.leftmost && pma->root_has_output()) {  // the one scan that can hit the non-terminating corner
@@ -1437,6 +1501,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     }
     std::unique_ptr<void, void (*)(void *)> g3(flagbuf, [](void *p) { if (p) (void)hipFree(p); });
     g_last_engine = use_pfx ? DAAC_ENGINE_PFX : use_gram ? DAAC_ENGINE_GRAM : (pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY);
+    if (pl.jump) g_last_engine = DAAC_ENGINE_JUMP;
     if ((use_gram || use_pfx) && len != begin) {
         // A shard [begin, len) is scanned as a haystack of its own: that counts every occurrence lying inside it,
         // with ends relative to `begin`.  What is missing are the occurrences that start before `begin` and end
@@ -1857,6 +1922,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
     else if (n == "gram3_tail") g_opt.gram3_tail = value;
     else if (n == "pfx") g_opt.pfx = value;
+    else if (n == "jump") g_opt.jump = value;
     else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles") g_opt.emit_tiles = value;

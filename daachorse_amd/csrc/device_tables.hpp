@@ -76,6 +76,32 @@ struct ScanArgs {
     unsigned long long *flags;       // optional, 1 x u64: bit 0 = the reference would not terminate on this input
 };
 
+// JUMP engine (jump.hpp, jump_kernels.hip): find_iter of a Standard bytewise automaton over per-position jump tables
+struct JumpDev {
+    const uint8_t *cls;       // 256
+    const uint32_t *ms;       // C^3 words (padded to a multiple of 4): shortest short pattern << 30 | continuation bits
+    const uint32_t *sdir;     // per 4 words: continuation bits set before the group
+    const uint4 *jhit;        // depth-4 states by rank {cmap | own, first_child, own h32, depth}
+    const uint4 *jrec;        // every state, breadth-first
+    const uint32_t *h1, *h2, *h3;  // h32 of the first-registered pattern that IS the 1- / 2- / 3-gram
+    uint32_t C, ms_bytes, sdir_bytes, max_len, unused_byte;
+};
+struct JumpArgs {
+    const uint8_t *hay_al;    // 16-byte aligned address at or before the first byte of the scanned range
+    uint32_t lead;            // bytes between hay_al and that byte (0..15)
+    uint64_t vlen;            // lead + length of the range ("virtual" positions count from hay_al)
+    uint8_t *lsh;             // LSH[i] = L(i - 2): at least nsteps * 1024 (pass A writes whole KiB) and nd_chunks * 1792 + 2048 bytes
+    uint16_t *nd;             // ND[i] = N(i - 2) | D(i - 2) << 8: nd_chunks * 1792 entries
+    uint32_t *hdeep;          // HDEEP[i]: h32 of the pattern found by a walk from start i - 2
+    uint64_t nsteps;          // KiB of pass A
+    uint64_t nd_chunks;       // chunks of 1792 positions of pass B
+};
+uint32_t jump_len_lds_bytes(const JumpDev &g);
+hipError_t launch_jump_tables(const JumpDev &g, const JumpArgs &a, uint32_t num_cu, hipStream_t stream);
+struct ScanArgs;
+struct ChainArgs;
+hipError_t launch_jump_chain(const JumpDev &g, const JumpArgs &ja, const ScanArgs &a, const ChainArgs &c, int pass, uint32_t blocks, hipStream_t stream);
+
 // Passes of the restart scanners in their speculate / reconcile / emit form (chain_scan.hpp)
 struct ChainArgs {
     const unsigned long long *x_spec;  // per segment: exit of the speculative chain

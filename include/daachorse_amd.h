@@ -64,8 +64,10 @@ typedef enum {
     DAAC_ENGINE_TIERED = 1, /* re-packed bitmap-rank trie, top levels dense in LDS */
     DAAC_ENGINE_DARRAY = 2, /* the reference's own double array, hot/cold split   */
     DAAC_ENGINE_GRAM = 3,   /* k-gram context tables in LDS, no state chain: count / checksum, and tuples of FIND_OVERLAPPING */
-    DAAC_ENGINE_PFX = 4     /* hashed prefix filter in LDS + goto-only walks from the start of an occurrence: `.count()` of
+    DAAC_ENGINE_PFX = 4,    /* hashed prefix filter in LDS + goto-only walks from the start of an occurrence: `.count()` of
                              * FIND_OVERLAPPING for dictionaries over any byte alphabet (what AUTO takes where GRAM's byte classes run out) */
+    DAAC_ENGINE_JUMP = 5    /* reported by daac_last_engine / the engine plan only: count (+ checksum) of DAAC_FIND over per-position jump
+                             * tables (the shortest pattern at every start, a suffix minimum, one load per match; option "jump") */
 } daac_engine;
 
 /* Match<u32> (src/lib.rs:286-320): start() = end - length, end(), value() */
@@ -105,7 +107,8 @@ typedef enum {
     DAAC_KERNEL_PFX = 5,         /* pfx_kernels.hip: any byte alphabet, `.count()`                              (0.6 - 1.3 TB/s) */
     DAAC_KERNEL_SEGMENT = 6,     /* scan_kernels.hip: one lane per segment, TIERED or DARRAY tables             (0.03 - 0.4 TB/s) */
     DAAC_KERNEL_MICRO = 7,       /* chain_scan.hpp overlap_count_body: micro-step walker over the double array  (0.08 - 0.4 TB/s) */
-    DAAC_KERNEL_CHAIN = 8        /* chain_scan.hpp: speculate / reconcile / emit for the restart iterators      (0.1 - 0.3 TB/s) */
+    DAAC_KERNEL_CHAIN = 8,       /* chain_scan.hpp: speculate / reconcile / emit for the restart iterators      (0.1 - 0.3 TB/s) */
+    DAAC_KERNEL_JUMP = 9         /* jump_kernels.hip: find_iter count over per-position jump tables */
 } daac_kernel_family;
 typedef enum {
     DAAC_WHY_FASTEST = 0,        /* nothing faster exists for this request */
@@ -304,6 +307,9 @@ void daac_stream_close(daac_stream *s);
  *                 1 = first table set only, 2 = gram2 kernels only, 3 = gram3 for `.count()`), gram2_dpp (1: DPP wave shifts),
  *   gram2_rfull (1)             rank directory with one entry per M word when LDS allows (0: one per four words)
  *   gram3_tail (-1 = every workgroup samples its text and picks; 0 / 1: the plain / the tail-record body of the gram3 kernel)
+ *   jump (0)                    experiment: 1 = find_iter count (+ checksum) of Standard bytewise automata over per-position jump tables where
+ *                               they apply (at most 29 byte classes, patterns of at most 127 bytes, no "") instead of the chain walkers; exact, but
+ *                               bound by the rate of uncoalesced requests and 3x slower than the walkers; read at upload and per scan
  *   pfx (1)                     PFX tables (any byte alphabet): 1 = built where no GRAM table set applies, 2 = for every automaton they can
  *                               serve (DAAC_ENGINE_PFX then selects them explicitly), 0 = never; read at upload
  *   emit (1)                    materialising overlapping scans through the GRAM tuple emitter where it applies (0: segment scanners);
