@@ -444,8 +444,8 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             t->tier_ok = true;
             // GRAM count engine, derived from the tier tables
             GramTables gt;
-            // (the budget is for tables AND the hit rings of a 1024-thread workgroup, as for the second table set below)
-            const int64_t g1_budget = g_opt.gram_lds_budget.load() - 16 * 128 * 8;
+            // (the option bounds the tables; tables AND the hit rings of a 1024-thread workgroup have to fit the 160 KB a workgroup can have)
+            const int64_t g1_budget = std::min<int64_t>(g_opt.gram_lds_budget.load(), 160 * 1024 - 16 * 128 * 8);
             if (tt.N < (1u << 27) && g1_budget > 0 && build_gram_tables(h, tt, static_cast<uint32_t>(g1_budget), gt)) {
                 GramDev &g = t->gram;
                 const U32x2 *combo; const U32x4 *drec; const U32x2 *dhit;
