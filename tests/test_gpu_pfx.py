@@ -182,3 +182,28 @@ def test_engine_plan_says_what_will_run():
     p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
     info = p.upload().info()
     assert info.plan_kernel[4] == 8 and info.plan_kernel[0] == 0  # chain walkers; find_overlapping does not apply to the kind
+
+
+def test_round3_engines_take_host_haystacks_and_streams():
+    """the same answers from a host buffer (staged by the library), from a device tensor, and on a caller's stream"""
+    import torch
+    rng = np.random.default_rng(9)
+    for pats, hay in ((synth.patterns_binary256(5000), rng.integers(0, 256, size=(1 << 20) + 3).astype(np.uint8)),
+                      (synth.patterns_cfg3(5000), synth.wordsoup_haystack((1 << 20) + 5, 3, synth.patterns_cfg3(5000), 20))):
+        o, p = _pma(pats)
+        p.upload()
+        want = o.overlapping_count(hay, threads=4)
+        dev = torch.from_numpy(hay).cuda()
+        s = torch.cuda.Stream()
+        for h in (hay, dev):
+            assert p.count(ScanMode.FindOverlapping, h) == want[0]
+            assert p.scan_count(ScanMode.FindOverlapping, h) == want
+            assert p.count(ScanMode.FindOverlapping, h, stream=s.cuda_stream) == want[0]
+            cut = 333_333
+            assert p.count(ScanMode.FindOverlapping, h[:cut]) + p.count(ScanMode.FindOverlapping, h, begin=cut) == want[0]
+        ref = o.find_overlapping_iter(hay[:200_000])
+        for h in (hay[:200_000], dev[:200_000]):
+            dm = p.scan_device(ScanMode.FindOverlapping, h, fmt16=True)
+            got = dm.to_numpy()
+            dm.free()
+            assert np.array_equal(got["end"], ref["end"]) and np.array_equal(got["value"], ref["value"]) and np.array_equal(got["length"], ref["end"] - ref["start"])
