@@ -579,7 +579,9 @@ def test_concurrent_scans_share_one_handle():
     hay = synth.wordsoup_haystack(400_000, synth.SEEDS["cfg3_dense"], pats, 20)
     dev = torch.from_numpy(hay).cuda()
     want = {"ov": o.find_overlapping_iter(hay), "find": o.find_iter(hay), "lm": ol.leftmost_find_iter(hay)}
+    da.set_option("pfx", 2)
     p.upload(0)
+    da.set_option("pfx", 1)
     pl.upload(0)
     errors = []
 
@@ -589,6 +591,8 @@ def test_concurrent_scans_share_one_handle():
             for rep in range(6):
                 assert _same(p.scan(ScanMode.FindOverlapping, dev, stream=s.cuda_stream), want["ov"])
                 assert p.scan_count(ScanMode.FindOverlapping, dev, stream=s.cuda_stream) == (len(want["ov"]), orc.matches_checksum(want["ov"]))
+                assert p.count(ScanMode.FindOverlapping, dev, stream=s.cuda_stream) == len(want["ov"])                      # gram3
+                assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Pfx, stream=s.cuda_stream) == len(want["ov"])   # PFX
                 assert _same(p.scan(ScanMode.Find, dev, stream=s.cuda_stream), want["find"])
                 assert pl.scan_count(ScanMode.LeftmostFind, dev, stream=s.cuda_stream) == (len(want["lm"]), orc.matches_checksum(want["lm"]))
                 assert [(m.start(), m.end()) for m, _ in zip(p.find_iter(hay[:5000]), range(50))] == \
@@ -616,10 +620,16 @@ def test_gram_haystack_beyond_4_gib():
     buf = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
     dev = buf[3:3 + n]
     synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20)
+    da.set_option("pfx", 2)
+    p.upload()
+    da.set_option("pfx", 1)
     got = p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram)
     host = dev.cpu().numpy()
     want = o.overlapping_count(host, threads=min(128, os.cpu_count() or 1))
     assert got == want
+    assert p.count(ScanMode.FindOverlapping, dev) == want[0] and da.last_engine() == int(Engine.Gram)   # the gram3 kernel
+    assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Pfx) == want[0]
+    assert p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Pfx) == want
     cut = (4 << 30) - 7  # tail shard through the materialising engines' count mode
     head = p.scan_count(ScanMode.FindOverlapping, dev[:cut], engine=Engine.Gram)
     tail = p.scan_count(ScanMode.FindOverlapping, dev, begin=cut)
