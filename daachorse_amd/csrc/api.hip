@@ -52,6 +52,8 @@ struct Options {
     std::atomic<int64_t> emit{1};               // materialising overlapping scans: GRAM tuple emission where it applies (0: segment scanners)
     std::atomic<int64_t> emit_tiles{64};        // tiles of 1024 positions a wave takes at a time
     std::atomic<int64_t> emit_rec_cap{256};     // deep-match records per wave and tile before the scan falls back
+    std::atomic<int64_t> emit_version{0};       // 0 = auto (emit3_kernels.hip: detection once, then expansion), 1 = gram2_emit_kernels.hip (COUNT + WRITE)
+    std::atomic<int64_t> emit_rec_per_kib{32};  // emit3: deep-match records the list is first sized for, per KiB of haystack (a rerun sizes it exactly)
     std::atomic<int64_t> restart_tier{0};       // 1: find_iter of Standard bytewise automata chains over the TIERED tables (measured 7-9 % slower
                                                 // than over the double array on cfg3: half the waves per CU, and a match costs a gather more)
     std::atomic<int64_t> restart_bpc{8};        // 256-thread workgroups per CU of the chain walkers
@@ -154,6 +156,9 @@ struct DeviceTables {
     Gram2WDev gramw{};
     bool emit_ok = false;      // tuple emission on the second table set (gram2_emit_kernels.hip)
     Gram2EmitDev emit{};
+    bool emit3_ok = false;     // ... with detection done once (emit3_kernels.hip)
+    Gram3Lds emit3_lds{};
+    std::atomic<uint32_t> emit3_rec_per_kib{0};  // deep-match records per KiB the last scans met (sizes the next scan's list)
     CharDev chr{};  // charwise automata only
 
     ~DeviceTables() {
@@ -599,6 +604,9 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 e.lds_bytes = e.off_wave + 16u * (2048u + 256u + 256u + 64u * 8u + 32u);  // kWaveLds of gram2_emit_kernels.hip
                 e.K = g2.K; e.C = g2.C; e.s16 = g2.s16; e.unused_byte = g2.unused_byte;
                 t->emit_ok = e.lds_bytes <= 160u * 1024u;
+                // emit3: DETECT as a 16-wave workgroup when the tables leave room for the text slots, else 8 waves
+                t->emit3_ok = emit3_plan(e, 16, 160u * 1024u, t->emit3_lds) || emit3_plan(e, 8, 160u * 1024u, t->emit3_lds);
+                t->emit3_ok = t->emit3_ok && emit3_expand_lds_bytes(e, 4) <= 64u * 1024u;
             }
         }
     }
@@ -940,6 +948,159 @@ struct DevMatches {
     daac_match *release_keep_n() { daac_match *q = p; p = nullptr; return q; }
 };
 
+// FindOverlappingIterator of a bytewise Standard automaton through the one-detection tuple emitter (emit3_kernels.hip):
+// DETECT (annotated class stream, tile counts, deep-match records) -> scans of the tile counts -> BIN (records by tile) -> EXPAND.
+// *served = false when the automaton / request does not qualify or the haystack is of the adversarial kind the kernels give up on
+// (then nothing is returned and the other engines take over).
+daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t end, hipStream_t stream,
+                              DevMatches &out, bool *served) {
+    *served = false;
+    if (!t->emit3_ok || g_opt.emit.load() == 0 || end <= begin) return DAAC_OK;
+    const Gram2EmitDev &e = t->emit;
+    const Gram3Lds &L = t->emit3_lds;
+    const uint64_t halo = pma->halo();
+    // windows of at most 1 GiB of end positions: virtual positions inside a window fit 32 bits
+    const uint64_t kWin = 1ull << 30;
+    constexpr uint32_t kStep = 2048;   // bytes of a DETECT wave-step
+    struct Win { uint64_t wb, we, from; uint32_t lead, vlen, emit_from, nsteps, ntiles; uint64_t tile0, ann0; const uint8_t *hay_al; };
+    std::vector<Win> wins;
+    uint64_t tiles_total = 0, ann_total = 0;
+    for (uint64_t wb = begin; wb < end; wb += kWin) {
+        Win w{};
+        w.wb = wb; w.we = std::min(end, wb + kWin);
+        w.from = wb > halo ? wb - halo : 0;
+        const uint8_t *first = dev_hay + w.from;
+        w.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(first) & 15u);
+        w.hay_al = first - w.lead;
+        const uint64_t vlen64 = w.lead + (w.we - w.from);
+        if (vlen64 >= (1ull << 31)) return DAAC_OK;   // (a dictionary with a pattern of a GiB: not this engine's business)
+        w.vlen = static_cast<uint32_t>(vlen64);
+        w.emit_from = static_cast<uint32_t>(w.lead + (wb - w.from));
+        w.nsteps = (w.vlen + kStep - 1) / kStep;
+        w.ntiles = w.nsteps * (kStep / kEmit3Tile);
+        w.tile0 = tiles_total;
+        w.ann0 = ann_total;
+        tiles_total += w.ntiles;
+        ann_total += static_cast<uint64_t>(w.nsteps) * kStep;
+        wins.push_back(w);
+    }
+    if (tiles_total >= (1ull << 32)) return DAAC_OK;
+    // DETECT geometry (gram3's): regions of 64 KiB (256 KiB for the large windows), one 16- or 8-wave workgroup per CU
+    uint32_t region = (end - begin) >= (1ull << 31) ? 262144u : 65536u;
+    if (g_opt.gram_region.load() >= 2048) { region = 2048; while (region * 2 <= static_cast<uint64_t>(g_opt.gram_region.load()) && region < (1u << 20)) region *= 2; }
+    const uint32_t wpb = L.threads / 64;
+    uint64_t max_regions = 0;
+    for (const Win &w : wins) max_regions = std::max<uint64_t>(max_regions, (static_cast<uint64_t>(w.vlen) + region - 1) / region);
+    const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (max_regions + wpb - 1) / wpb)));
+    const uint64_t nwaves = static_cast<uint64_t>(blocks) * wpb;
+    const uint32_t wq_slab = static_cast<uint32_t>(std::max<int64_t>(64 * 32 + 128 + 64, g_opt.gram_slab.load()));
+
+    const size_t scan_words = tiles_total + 2 + exclusive_scan_scratch(tiles_total);
+    const size_t off_short = 0, off_deep = off_short + ((tiles_total * 4 + 255) & ~size_t(255));
+    const size_t off_a = off_deep + ((tiles_total * 4 + 255) & ~size_t(255)), off_b = off_a + ((scan_words * 8 + 255) & ~size_t(255));
+    const size_t off_ctl = off_b + ((scan_words * 8 + 255) & ~size_t(255));   // {chunk_next, fail}
+    const size_t off_wq = off_ctl + 256, off_ann = off_wq + ((nwaves * wq_slab * sizeof(uint2) + 255) & ~size_t(255));
+    DevBuf g1, g_recs, g_bins;
+    HIP_TRY(g1.alloc(off_ann + ann_total + 256, stream));
+    char *base = static_cast<char *>(g1.p);
+    uint32_t *d_short = reinterpret_cast<uint32_t *>(base + off_short), *d_deep = reinterpret_cast<uint32_t *>(base + off_deep);
+    unsigned long long *d_a = reinterpret_cast<unsigned long long *>(base + off_a), *d_b = reinterpret_cast<unsigned long long *>(base + off_b);
+    uint32_t *d_ctl = reinterpret_cast<uint32_t *>(base + off_ctl);
+    uint8_t *d_ann = reinterpret_cast<uint8_t *>(base + off_ann);
+
+    // the record list: sized for what the last scans of this automaton met (or the option's guess), rerun once with the exact number
+    uint32_t per_kib = t->emit3_rec_per_kib.load();
+    if (per_kib == 0) per_kib = static_cast<uint32_t>(std::max<int64_t>(1, g_opt.emit_rec_per_kib.load()));
+    uint64_t chunk_cap = ((end - begin) / 1024 + 1) * per_kib / kEmit3Chunk * 2 + 2 * nwaves + 16;
+    unsigned long long total = 0, deep_total = 0;
+    uint32_t ctl[2] = {0, 0};
+    for (int attempt = 0;; ++attempt) {
+        if (chunk_cap >= (1ull << 32) / kEmit3Chunk) return DAAC_OK;
+        dev_free(g_recs.p, g_recs.s); g_recs.p = nullptr;
+        HIP_TRY(g_recs.alloc(chunk_cap * (static_cast<size_t>(kEmit3Chunk) * sizeof(uint4) + 4), stream));
+        uint4 *d_recs = static_cast<uint4 *>(g_recs.p);
+        uint32_t *d_fill = reinterpret_cast<uint32_t *>(d_recs + chunk_cap * kEmit3Chunk);
+        HIP_TRY(hipMemsetAsync(d_fill, 0, chunk_cap * 4, stream));
+        HIP_TRY(hipMemsetAsync(d_deep, 0, tiles_total * 4, stream));
+        HIP_TRY(hipMemsetAsync(d_ctl, 0, 256, stream));
+        for (const Win &w : wins) {
+            Emit3Args a{};
+            a.hay_al = w.hay_al; a.lead = w.lead; a.vlen = w.vlen; a.emit_from = w.emit_from;
+            a.ann = d_ann + w.ann0;
+            a.tile_short = d_short + w.tile0; a.tile_deep = d_deep + w.tile0; a.tile0 = static_cast<uint32_t>(w.tile0);
+            a.recs = d_recs; a.chunk_fill = d_fill; a.chunk_next = d_ctl; a.chunk_cap = static_cast<uint32_t>(chunk_cap);
+            a.wq = reinterpret_cast<uint2 *>(base + off_wq); a.wq_slab = wq_slab;
+            a.region_bytes = region; a.nregions = static_cast<uint32_t>((static_cast<uint64_t>(w.vlen) + region - 1) / region);
+            a.fail = d_ctl + 1;
+            HIP_TRY(launch_emit3_detect(e, a, L, blocks, stream));
+        }
+        HIP_TRY(launch_emit3_combine(d_short, d_deep, d_a, d_b, tiles_total, stream));
+        HIP_TRY(launch_exclusive_scan(d_a, tiles_total, d_a + tiles_total, d_a + tiles_total + 2, stream));
+        HIP_TRY(launch_exclusive_scan(d_b, tiles_total, d_b + tiles_total, d_b + tiles_total + 2, stream));
+        {
+            unsigned long long *pin = reinterpret_cast<unsigned long long *>(pinned_words());
+            HIP_TRY(hipMemcpyAsync(pin ? pin : &total, d_a + tiles_total, 8, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(pin ? pin + 1 : &deep_total, d_b + tiles_total, 8, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(pin ? reinterpret_cast<uint32_t *>(pin + 2) : ctl, d_ctl, 8, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (pin) { total = pin[0]; deep_total = pin[1]; std::memcpy(ctl, pin + 2, 8); }
+        }
+        if (ctl[1] != 0) { set_error("GRAM emitter: a wave met more deep matches between two checkpoints than a chunk holds (code " + std::to_string(ctl[1]) + ")"); return DAAC_OK; }
+        if (ctl[0] <= chunk_cap) break;
+        if (attempt != 0) { set_error("GRAM emitter: the record list overflowed twice"); return DAAC_OK; }
+        chunk_cap = static_cast<uint64_t>(ctl[0]) + 2 * nwaves + 16;   // (chunks are closed at least half full: the rerun takes no more of them)
+    }
+    t->emit3_rec_per_kib.store(static_cast<uint32_t>(std::min<uint64_t>(1u << 20, deep_total * 5 / 4 / ((end - begin) / 1024 + 1) + 1)));
+    g_last_engine = DAAC_ENGINE_GRAM;
+    const size_t tuple_bytes = out.f16 ? 16 : sizeof(daac_match);
+    if (total == 0) { *served = true; return DAAC_OK; }
+    if (total * tuple_bytes > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+        set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
+        return DAAC_ERR_AUTOMATON_SCALE;
+    }
+    HIP_TRY(g_bins.alloc(static_cast<size_t>(deep_total + 1) * sizeof(uint4), stream));
+    if (deep_total != 0) {
+        uint4 *d_recs = static_cast<uint4 *>(g_recs.p);
+        const uint32_t *d_fill = reinterpret_cast<const uint32_t *>(d_recs + chunk_cap * kEmit3Chunk);
+        HIP_TRY(launch_emit3_bin(d_recs, d_fill, d_ctl, static_cast<uint32_t>(chunk_cap), d_b, d_deep, static_cast<uint4 *>(g_bins.p),
+                                 static_cast<uint32_t>(std::min<uint64_t>(ctl[0], static_cast<uint64_t>(t->num_cu) * 16)), stream));
+    }
+    daac_match *d_out = nullptr;
+    HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_out), total * tuple_bytes, stream));
+    out.p = d_out;
+    out.s = stream;
+    out.n = total;
+    HIP_TRY(hipMemsetAsync(d_ctl + 1, 0, 4, stream));
+    for (const Win &w : wins) {
+        Expand3Args a{};
+        a.ann = d_ann + w.ann0;
+        a.ntiles = (w.vlen + kEmit3Tile - 1) / kEmit3Tile;
+        a.tile_off = d_a + w.tile0; a.bin_off = d_b + w.tile0;
+        a.binned = static_cast<const uint4 *>(g_bins.p);
+        a.out = d_out;
+        a.pos_base = w.from - w.lead + 1;  // (mod 2^64: a match ends one past its last byte)
+        a.off_wave = e.v1_bytes + e.v2_bytes;
+        a.fail = d_ctl + 1;
+        const uint32_t xblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 4, (a.ntiles + 3) / 4)));
+        HIP_TRY(launch_emit3_expand(e, a, out.f16, xblocks, stream));
+    }
+    {
+        unsigned int fail = 0;
+        unsigned int *pin = pinned_words();
+        HIP_TRY(hipMemcpyAsync(pin ? pin : &fail, d_ctl + 1, sizeof(fail), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (pin) fail = *pin;
+        if (fail != 0) {  // more extras in one tile than EXPAND places: left to the other engines
+            set_error("GRAM emitter: the expansion gave up (code " + std::to_string(fail) + ")");
+            dev_free(out.release(), stream);
+            return DAAC_OK;
+        }
+    }
+    out.f16_done = out.f16;
+    *served = true;
+    return DAAC_OK;
+}
+
 // FindOverlappingIterator of a bytewise Standard automaton through the GRAM tuple emitter (gram2_emit_kernels.hip):
 // COUNT pass -> exclusive scan of the per-tile counts -> WRITE pass.  *served = false when the automaton / request does
 // not qualify or a wave ran out of record space (then nothing is returned and the segment scanners take over).
@@ -1060,8 +1221,14 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
     if (next_begin) *next_begin = end;
     if (!pma->charwise && mode == DAAC_FIND_OVERLAPPING && (engine == DAAC_ENGINE_AUTO || want_gram)) {
         bool served = false;
-        if ((st = emit_overlapping(pma, t, dev_hay, begin, end, stream, out, &served)) != DAAC_OK) return st;
-        if (served) return DAAC_OK;
+        if (g_opt.emit_version.load() != 1) {
+            if ((st = emit_overlapping3(pma, t, dev_hay, begin, end, stream, out, &served)) != DAAC_OK) return st;
+            if (served) return DAAC_OK;
+        }
+        if (g_opt.emit_version.load() != 3) {   // (3: the new emitter or nothing — tests)
+            if ((st = emit_overlapping(pma, t, dev_hay, begin, end, stream, out, &served)) != DAAC_OK) return st;
+            if (served) return DAAC_OK;
+        }
     }
     if (want_gram) {
         set_error(std::string("the GRAM engine cannot emit tuples for this automaton / request [") + last_error_cstr() + "]");
@@ -1927,6 +2094,8 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles") g_opt.emit_tiles = value;
     else if (n == "emit_rec_cap") g_opt.emit_rec_cap = value;
+    else if (n == "emit_version") g_opt.emit_version = value;
+    else if (n == "emit_rec_per_kib") g_opt.emit_rec_per_kib = value;
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;
     else if (n == "restart_bpc") g_opt.restart_bpc = value;

@@ -226,6 +226,7 @@ struct EmitArgs {
     unsigned int *fail;           // set when a record list overflowed (the caller falls back to the segment scanners)
 };
 hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, int em, bool f16, uint32_t blocks, hipStream_t stream);
+
 hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool exact, uint32_t blocks, uint32_t threads, hipStream_t stream);
 
 // `.count()` with lane-local hit masks and the step's text staged in LDS (gram3_kernels.hip); tables of Gram2Dev.
@@ -237,6 +238,53 @@ struct Gram3Lds {
 };
 bool gram3_plan(const Gram2Dev &dev, uint32_t ppl, uint32_t waves, bool want_rfull, uint32_t lds_limit, Gram3Lds &L);
 hipError_t launch_gram3_scan(const Gram2Dev &dev, const GramArgs &a, const Gram3Lds &L, uint32_t blocks, hipStream_t stream);
+
+// GRAM tuple emission with detection done ONCE (emit3_kernels.hip): DETECT leaves, per haystack byte, one "annotated class"
+// byte (class | which short patterns end here << 5), per tile of 1024 positions the number of short tuples, and every deep match
+// (longer than K bytes) as a record in a chunked list; the records are binned by tile, the tile counts scanned, and EXPAND turns
+// stream + bins into tuples — lanes on CONSECUTIVE positions, so that one store instruction fills neighbouring slots.
+constexpr uint32_t kEmit3Tile = 1024;        // positions per tile (one wave-step of EXPAND; half a wave-step of DETECT)
+constexpr uint32_t kEmit3Chunk = 1024;       // records per chunk of the list (a wave owns one open chunk at a time)
+constexpr uint32_t kEmit3MaxExtras = 64;     // records per tile the per-position length bits cannot carry (as gram2_emit_kernels.hip)
+constexpr uint32_t kEmit3ExpandWave = 1040 + 4096 + 2048 + kEmit3MaxExtras * 16 + 16;  // EXPAND, per wave: stream | length bits | slot of each position | extras | counter
+struct Emit3Args {
+    const uint8_t *hay_al;        // window address rounded down to 16 bytes ("virtual" positions count from here)
+    uint32_t lead;                // bytes between hay_al and the first byte of the window
+    uint32_t vlen;                // lead + window length
+    uint32_t emit_from;           // matches whose last byte lies at a virtual position >= this are reported
+    uint8_t *ann;                 // out: one byte per virtual position (whole wave-steps: nsteps * 2048 bytes)
+    uint32_t *tile_short;         // out, per tile of this window: tuples of patterns of at most K bytes
+    uint32_t *tile_deep;          // out (atomic adds, zeroed by the caller), per tile of this window: deep matches that end in the tile
+    uint32_t tile0;               // global number of this window's tile 0 (goes into the records)
+    uint4 *recs;                  // record list: chunk_cap chunks of kEmit3Chunk x {virtual position of the last byte, length | copy << 24, value, global tile}
+    uint32_t *chunk_fill;         // per chunk: records in it (zeroed by the caller)
+    uint32_t *chunk_next;         // next free chunk (may run past chunk_cap: the caller then knows how many a rerun needs)
+    uint32_t chunk_cap;
+    uint2 *wq;                    // per-wave walker slabs
+    uint32_t wq_slab;
+    uint32_t region_bytes;        // contiguous bytes a wave takes at a time (multiple of 2048)
+    uint32_t nregions;
+    unsigned int *fail;           // bit 1: a wave logged more records between two checkpoints than a chunk holds (-> other engines)
+};
+struct Expand3Args {
+    const uint8_t *ann;
+    uint32_t ntiles;
+    const unsigned long long *tile_off;  // this window's tiles: exclusive tuple offsets ([ntiles] is valid)
+    const unsigned long long *bin_off;   // this window's tiles: exclusive record offsets ([ntiles] is valid)
+    const uint4 *binned;                 // the records, grouped by global tile
+    void *out;                           // daac_match (24 bytes) or {end u64, length u32, value u32} (16 bytes) tuples
+    unsigned long long pos_base;         // end (haystack coordinates) of a match whose last byte is at virtual position v = pos_base + v
+    uint32_t off_wave;                   // LDS: V1 at 0, V2 behind it, the per-wave areas from here
+    unsigned int *fail;                  // bit 2: more extras in one tile than EXPAND places; bit 3: a slot outside its tile (a bug)
+};
+bool emit3_plan(const Gram2EmitDev &dev, uint32_t waves, uint32_t lds_limit, Gram3Lds &L);
+hipError_t launch_emit3_detect(const Gram2EmitDev &dev, const Emit3Args &a, const Gram3Lds &L, uint32_t blocks, hipStream_t stream);
+hipError_t launch_emit3_combine(const uint32_t *tile_short, const uint32_t *tile_deep, unsigned long long *total, unsigned long long *deep, uint64_t n,
+                                hipStream_t stream);
+hipError_t launch_emit3_bin(const uint4 *recs, const uint32_t *chunk_fill, const uint32_t *chunk_next, uint32_t chunk_cap, const unsigned long long *bin_off,
+                            uint32_t *cursor, uint4 *binned, uint32_t blocks, hipStream_t stream);
+hipError_t launch_emit3_expand(const Gram2EmitDev &dev, const Expand3Args &a, bool f16, uint32_t blocks, hipStream_t stream);
+uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves);
 
 // PFX engine (pfx.hpp): `.count()` for bytewise automata over any byte alphabet.  LDS: BLOOM at 0 | DISP | CNT1 | per-wave areas
 struct PfxDev {

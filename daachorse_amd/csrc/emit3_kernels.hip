@@ -1,0 +1,706 @@
+// GRAM engine, tuple emission with detection done ONCE (gfx950): the find_overlapping match stream as (start, end, value) tuples in
+// the reference's order (bytewise/iter.rs:133-176: by end, longest first; lib.rs:286-320: Match), written to device memory.
+//
+// gram2_emit_kernels.hip ran the detection twice (COUNT, then WRITE) and gave every lane 16 consecutive end positions, so that a
+// store instruction's 64 lanes wrote to 64 different 128-byte lines (profiles/r03_emit.txt: 1.92 + 6.95 ms per GiB of cfg3, 6.3 ms
+// of it the stores).  Here:
+//
+//   DETECT  = the `.count()` kernel's main path and hit path (gram3_kernels.hip: one M word per position, lane-local hit masks,
+//             iteration-major queueing, consumer 64 hits wide, goto-only walkers) over the emission tables (gram2.hpp: ME words carry
+//             one flag per short pattern length; hit and walk records carry values).  It leaves
+//               * ANN[v]: one byte per position = class | flags << 5 (which patterns of 1 .. K bytes end here) — everything EXPAND
+//                 needs to know about the short matches of a position and the two positions before it;
+//               * per tile of 1024 positions the number of short tuples (plain store by the owning wave) and of deep matches that END
+//                 in it (atomic adds: a deep match is found from its START, by whichever wave owns that byte);
+//               * every deep match as a 16-byte record {last byte, length | copy, value, tile} in a chunked list: a wave appends to
+//                 its own open chunk through an LDS cursor and takes a new chunk (one global atomic) when the open one is half full.
+//             No prologue and no carry lists: a match that starts in one region and ends in another is logged by the wave that found it.
+//   (host)    tile totals -> exclusive scans (tuple offsets, record offsets); BIN: records grouped by the tile they end in.
+//   EXPAND  = a pure expansion of (ANN, bins): the tile's stream goes through LDS so that lane l of column i looks at position
+//             64 i + l; per column one wave scan of the per-position tuple counts; a store instruction then writes the tuples of 64
+//             CONSECUTIVE positions = neighbouring slots of a handful of lines (the L2 merges them).  Deep matches set a length bit
+//             per position (LDS), which gives each its rank; those the bits cannot carry (longer than K + 16 bytes, further copies of
+//             a duplicate pattern) are "extras", at most 64 per tile, placed by comparison among themselves.
+//
+// Roofline: DETECT reads 1 B and writes 1 B (+ records) per haystack byte; EXPAND reads that byte and writes 16 (24) B per tuple:
+// HBM write bytes bound the pair (cfg3: 9.5 B of tuples per haystack byte).  Integer / bit work only, no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_tables.hpp"
+
+namespace daac {
+
+namespace {
+
+typedef uint32_t e3_u32x4_t __attribute__((ext_vector_type(4)));
+constexpr uint32_t kRingE3 = 128;        // entries of a wave's hit queue (FIFO; at most 63 left over + 64 new)
+constexpr uint32_t kOffME3 = 256;        // LDS offset of ME (classes at 0)
+constexpr uint32_t kContBitsE3 = 0x1ffffffeu;  // continuation bits of an ME word (classes 1 .. 28)
+typedef __attribute__((address_space(3))) const uint32_t ldsx_cu32;
+typedef __attribute__((address_space(3))) uint32_t ldsx_u32;
+typedef __attribute__((address_space(3))) const uint16_t ldsx_cu16;
+typedef __attribute__((address_space(3))) const uint8_t ldsx_cu8;
+typedef __attribute__((address_space(3))) e3_u32x4_t ldsx_u32x4;
+
+__device__ __forceinline__ uint32_t pinx(uint32_t x) {
+    asm("" : "+v"(x));
+    return x;
+}
+// lane i <- lane i - 1 of `v`; lane 0 keeps `lane0`
+__device__ __forceinline__ uint32_t wave_shr1_x(uint32_t v, uint32_t lane0) {
+    uint32_t d = lane0;
+    asm volatile("s_nop 1\nv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(v));
+    return d;
+}
+__device__ __forceinline__ void e3_copy(void *dst, const void *src, uint32_t bytes) {
+    const uint4 *s = reinterpret_cast<const uint4 *>(src);
+    uint4 *d = reinterpret_cast<uint4 *>(dst);
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+// inclusive scan over the 64 lanes on the VALU (DPP row shifts + row broadcasts); all lanes must be active
+__device__ __forceinline__ uint32_t wave_incl_scan_x(uint32_t x) {
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+// One tuple.  daac_match (24 bytes: start, end, value) takes a 16-byte and an 8-byte store; daac_match16 (the crate's own Match
+// fields, src/lib.rs:287-291: end, length, value) ONE 16-byte store.  Plain stores: it is the L2 that puts the lines together.
+template <bool F16>
+__device__ __forceinline__ void put_tuple_x(void *out, unsigned long long slot, unsigned long long end, uint32_t len, uint32_t value) {
+#ifdef E3X_NO_STORES
+    if (len != 0xdeadbeefu) return;
+#endif
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    if (F16) {
+        const u32x4 t = {static_cast<uint32_t>(end), static_cast<uint32_t>(end >> 32), len, value};
+        *reinterpret_cast<u32x4 *>(static_cast<char *>(out) + slot * 16ull) = t;
+    } else {
+        char *dst = static_cast<char *>(out) + slot * 24ull;
+        const u64x2 se = {end - len, end};
+        const u32x2 vp = {value, 0u};
+        *reinterpret_cast<u64x2 *>(dst) = se;
+        *reinterpret_cast<u32x2 *>(dst + 16) = vp;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================================ DETECT
+// K = context length; S16 = rank directory entries are u16.  32 positions per lane and step (2 KiB per wave-step = two tiles).
+template <int K, bool S16>
+__global__ __launch_bounds__(1024) void emit3_detect_kernel(const Gram2EmitDev g, const Emit3Args a, const Gram3Lds L) {
+    constexpr int Q = 2;
+    constexpr int P = 16 * Q;
+    constexpr uint32_t SB = 64u * P;          // bytes a wave takes per step
+    constexpr uint32_t SLOT = SB + 32u;       // [0,4) slot 0 only: the wave's record cursor | [12,16) the four bytes before the step | [16, 16 + SB) the step | 16 bytes of the next
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t offM = kOffME3, offS = L.off_s;
+    e3_copy(smem, g.cls, 256);
+    e3_copy(smem + offM, g.me, g.m_bytes);
+    e3_copy(smem + offS, g.sdir, g.s_bytes);
+    __syncthreads();
+    // tables are read through absolute LDS addresses (this kernel has no static LDS: the dynamic segment starts at 0)
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
+    auto cls_of = [&](uint32_t byte) -> uint32_t { return *reinterpret_cast<ldsx_cu8 *>(static_cast<uintptr_t>(byte)); };
+    auto lds_u32 = [&](uint32_t addr) -> uint32_t { return *reinterpret_cast<ldsx_cu32 *>(static_cast<uintptr_t>(addr)); };
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t C4 = g.C * 4u, CC4 = g.C * g.C * 4u;
+    const uint32_t ub4 = g.unused_byte * 0x01010101u;
+    const uint8_t *__restrict__ hay = a.hay_al;
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    // per-wave LDS: two text slots, then the hit queue
+    const uint32_t tb = L.off_wave + wave_in_wg * L.wave_stride;   // wave-uniform
+    const uint32_t ringb = tb + 2u * SLOT;
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(smem + tb);    // records in the wave's open chunk (the first bytes of a slot are padding)
+    uint2 *__restrict__ slab = a.wq + static_cast<uint64_t>(wave_global) * a.wq_slab;
+    uint32_t wq_n = 0;  // wave-uniform
+
+    // ---- the record list: this wave's open chunk ----
+    uint32_t chunk = 0;       // wave-uniform
+    bool chunk_ok = false;    // wave-uniform: the chunk lies inside the list (else the records are only counted: the caller reruns with a longer list)
+    auto take_chunk = [&]() {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(a.chunk_next, 1u);
+        chunk = __builtin_amdgcn_readfirstlane(c);
+        chunk_ok = chunk < a.chunk_cap;
+    };
+    // (wave-uniform places only) the open chunk is closed once it is half full: whatever is logged before the next checkpoint then fits
+    auto rec_checkpoint = [&]() {
+        const uint32_t n = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(cursor));
+        if (n > kEmit3Chunk / 2u) {
+            if (lane == 0) {
+                if (chunk_ok) a.chunk_fill[chunk] = n < kEmit3Chunk ? n : kEmit3Chunk;
+                *reinterpret_cast<volatile uint32_t *>(cursor) = 0u;
+            }
+            take_chunk();
+        }
+    };
+    if (lane == 0) *reinterpret_cast<volatile uint32_t *>(cursor) = 0u;
+    take_chunk();
+
+    // a deep match: `p` = virtual position of its last byte, `len` its length; `copy` > 0: a further copy of a pattern registered more than once
+    auto log_deep = [&](uint32_t p, uint32_t len, uint32_t value, uint32_t copy) {
+        if (p < a.emit_from) return;
+#ifdef E3X_NO_REC
+        return;
+#endif
+        const uint32_t slot = atomicAdd(cursor, 1u);
+        atomicAdd(&a.tile_deep[p >> 10], 1u);
+        if (slot >= kEmit3Chunk) { atomicOr(a.fail, 2u); return; }
+        if (chunk_ok) a.recs[static_cast<uint64_t>(chunk) * kEmit3Chunk + slot] = uint4{p, len | (copy << 24), value, a.tile0 + (p >> 10)};
+    };
+    // a state that ends a pattern: its own match, then the further copies of a duplicate (erec.w / ehit4.w: count << 24)
+    auto log_state = [&](uint32_t p, uint32_t len, uint32_t value, uint32_t ncopies, uint32_t state) {
+        log_deep(p, len, value, 0u);
+        if (ncopies != 0) {
+            const uint32_t off = g.dupo[state];
+            for (uint32_t k = 0; k < ncopies; ++k) log_deep(p, len, g.dupv[off + k], k + 1u);
+        }
+    };
+
+    auto load_chunk = [&](uint32_t v) -> uint4 {
+        if (v >= a.vlen) return uint4{ub4, ub4, ub4, ub4};
+        const e3_u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const e3_u32x4_t *>(hay + v));
+        uint4 r{q.x, q.y, q.z, q.w};
+        if (v < a.lead || v + 16 > a.vlen) {  // first / last chunk of the window only
+            uint32_t w[4] = {r.x, r.y, r.z, r.w};
+            for (int b = 0; b < 16; ++b) {
+                const uint32_t p = v + b;
+                if (p < a.lead || p >= a.vlen) w[b >> 2] = (w[b >> 2] & ~(0xffu << (8 * (b & 3)))) | (g.unused_byte << (8 * (b & 3)));
+            }
+            r = uint4{w[0], w[1], w[2], w[3]};
+        }
+        return r;
+    };
+    auto raw_at = [&](uint32_t p) -> uint32_t { return (p >= a.lead && p < a.vlen) ? hay[p] : g.unused_byte; };
+    auto read_ahead = [&](uint32_t v) -> unsigned long long {
+        unsigned long long x;
+        if (v >= a.lead && v + 8 <= a.vlen) {
+            __builtin_memcpy(&x, hay + v, 8);
+        } else {
+            x = 0;
+            for (int b = 7; b >= 0; --b) x = (x << 8) | ((v + b >= a.lead && v + b < a.vlen) ? hay[v + b] : g.unused_byte);
+        }
+        return x;
+    };
+
+    // walkers: {byte position p of the last byte of a (K+1)-gram, the depth-(K+2) state reached on the byte at p + 1 | class of
+    // the byte at p + 2 << 27}.  What one lane stored to the slab is read back by another lane: the stores have to be out first.
+    auto drain = [&]() {
+        if (wq_n != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t base = 0; base < wq_n; base += 64u) {
+            rec_checkpoint();
+            const uint32_t i = base + lane;
+            if (i < wq_n) {
+                const uint2 e = slab[i];
+                uint32_t vnext = e.x + 2u;   // the state consumed the byte before vnext
+                uint32_t state = e.y & 0x07ffffffu;
+                uint4 r = g.erec[state];     // {cmap | own, first_child, own_value, depth | further copies << 24}
+                uint32_t kn = e.y >> 27;
+                unsigned long long ahead = 0;
+                uint32_t n_ahead = 0;
+                for (;;) {
+                    if (r.x & 1u) log_state(vnext - 1u, r.w & 0xffffffu, r.z, r.w >> 24, state);
+                    if (((r.x >> kn) & 1u) == 0 || kn == 0) break;
+                    state = r.y + __popc(r.x & ((1u << kn) - 2u));
+                    r = g.erec[state];
+                    ++vnext;
+                    if (n_ahead == 0) { ahead = read_ahead(vnext); n_ahead = 8; }
+                    kn = cls_of(static_cast<uint32_t>(ahead) & 0xffu);
+                    ahead >>= 8;
+                    --n_ahead;
+                }
+            }
+        }
+        wq_n = 0;
+    };
+
+    // ---- the hit queue: entry = LDS address of the hit byte in one of the wave's two text slots (gram3_kernels.hip) ----
+    uint32_t q_head = 0, q_tail = 0;   // wave-uniform, free running; entries live at (index & (kRingE3 - 1))
+    uint32_t posbias0 = 0, posbias1 = 0;  // per slot: (virtual position of a byte) - (its LDS address)
+    uint4 pend = uint4{0u, 0u, 0u, 0u};  // hit record read for the previous batch, not yet consumed; zero for idle lanes
+                                         // {cmap | own, own_value, first_child, further copies << 24}
+    uint32_t pend_pos = 0, pend_k = 0, pend_rank = 0;  // position of the hit byte; classes of the two bytes behind it (k1 | k2 << 8); rank of the hit's state
+    bool pend_valid = false;           // wave-uniform
+    auto consume_pending = [&]() {
+        if (!pend_valid) return;
+        pend_valid = false;
+        const uint4 r = pend;
+        if (r.x & 1u) log_state(pend_pos, K + 1, r.y, r.w >> 24, g.level_start + pend_rank);
+        const uint32_t k1 = pend_k & 0xffu;  // (class 0: bit 0 is not an edge)
+        const bool go = k1 != 0 && ((r.x >> k1) & 1u);
+        const unsigned long long m = __ballot(go);
+        if (m != 0) {
+            if (go)
+                (slab + wq_n)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u))] =
+                    uint2{pend_pos, (r.z + __popc(r.x & ((1u << k1) - 2u))) | ((pend_k >> 8) << 27)};
+            wq_n += static_cast<uint32_t>(__popcll(m));
+        }
+    };
+    auto process_batch = [&](uint32_t n) {  // n <= 64 entries from the head of the queue
+        __builtin_amdgcn_s_setprio(2);
+        rec_checkpoint();
+        consume_pending();
+        pend = uint4{0u, 0u, 0u, 0u};
+        pend_k = 0;
+        if (lane < n) {
+            const uint32_t e = lds_u32(ringb + (((q_head + lane) & (kRingE3 - 1u)) << 2));
+            pend_pos = e + ((e - tb) >= SLOT ? posbias1 : posbias0);
+            const uint32_t t3 = e - 3u;
+            const uint32_t a0 = t3 & ~3u, sh = t3 & 3u;
+            // the dwords around the hit byte (slots are self-contained: never outside [slot + 12, slot + SLOT))
+            const uint32_t d0 = lds_u32(a0), d1 = lds_u32(a0 + 4u), d2 = lds_u32(a0 + 8u);
+            const uint32_t x_lo = __builtin_amdgcn_alignbyte(d1, d0, sh);  // bytes p-3 .. p
+            const uint32_t x_hi = __builtin_amdgcn_alignbyte(d2, d1, sh);  // bytes p+1 .. p+4
+            const uint32_t c0 = cls_of(x_lo & 0xffu), c1 = cls_of((x_lo >> 8) & 0xffu), c2 = cls_of((x_lo >> 16) & 0xffu), d = cls_of(x_lo >> 24);
+            const uint32_t k1 = cls_of(x_hi & 0xffu), k2 = cls_of((x_hi >> 8) & 0xffu);
+            pend_k = k1 | (k2 << 8);
+            uint32_t am = (c2 << 2) + offM;
+            am = __umul24(c1, C4) + am;
+            if (K == 3) am = __umul24(c0, CC4) + am; else (void)c0;
+            // rank of continuation bit d of that word among all set bits = offset of the depth-(K+1) state
+            const uint32_t rel = am - offM, grp = offM + (rel & ~15u);
+            const uint32_t own = lds_u32(am), qx = lds_u32(grp), qy = lds_u32(grp + 4u), qz = lds_u32(grp + 8u);
+            const uint32_t idx = (rel >> 2) & 3u;
+            const uint32_t base = S16 ? *reinterpret_cast<ldsx_cu16 *>(static_cast<uintptr_t>(offS + ((rel >> 4) << 1)))
+                                      : *reinterpret_cast<ldsx_cu32 *>(static_cast<uintptr_t>(offS + ((rel >> 4) << 2)));
+            uint32_t below = __popc(own & kContBitsE3 & ((1u << d) - 1u));
+            below += idx > 0 ? __popc(qx & kContBitsE3) : 0u;
+            below += idx > 1 ? __popc(qy & kContBitsE3) : 0u;
+            below += idx > 2 ? __popc(qz & kContBitsE3) : 0u;
+            pend_rank = base + below;
+            pend = g.ehit4[pend_rank];
+        }
+        q_head += n;
+        pend_valid = true;
+    };
+
+    uint32_t sl = 0;          // slot of the current step (wave-uniform)
+    uint32_t carry_in = 0;    // queued entries that belong to the step before the current one
+    for (uint32_t region = wave_global; region < a.nregions; region += nwaves) {
+        const uint32_t rbase = region * a.region_bytes;
+        const uint32_t rend = rbase + a.region_bytes < a.vlen ? rbase + a.region_bytes : a.vlen;
+        // classes of the K bytes before the region, oldest in the low byte; the four raw bytes before it
+        uint32_t carry = 0, tail4 = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) carry |= (rbase >= static_cast<uint32_t>(K - i) ? cls_of(raw_at(rbase - (K - i))) : 0u) << (8 * i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tail4 |= (rbase >= static_cast<uint32_t>(4 - i) ? raw_at(rbase - (4 - i)) : static_cast<uint32_t>(g.unused_byte)) << (8 * i);
+        tail4 = __builtin_amdgcn_readfirstlane(tail4);
+        uint32_t mcarry;  // ME word of the K-gram ending just before the region
+        {
+            uint32_t x = (((carry >> (8 * (K - 1))) & 0xffu) << 2) + offM;
+            x += __umul24((carry >> (8 * (K - 2))) & 0xffu, C4);
+            if (K == 3) x += __umul24(carry & 0xffu, CC4);
+            mcarry = __builtin_amdgcn_readfirstlane(lds_u32(x));
+        }
+
+        // the chunks of the step at s0; past the region's end only lane 0's first chunk (it feeds the last step's trailer)
+        auto fetch = [&](uint32_t s0, uint4 (&out)[Q]) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) out[q] = uint4{ub4, ub4, ub4, ub4};
+            if (s0 < rend) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) out[q] = load_chunk(s0 + lane * P + 16u * q);
+            } else if (lane == 0 && s0 < rend + SB) {
+                out[0] = load_chunk(s0);
+            }
+        };
+        uint4 pf0[Q], pf1[Q];
+        fetch(rbase, pf0);
+        fetch(rbase + SB, pf1);
+
+        for (uint32_t sb = rbase; sb < rend; sb += SB) {
+            if (wq_n + 64u * P + 128u > a.wq_slab) drain();
+            const uint32_t v = sb + lane * P;
+            uint4 cur[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { cur[q] = pf0[q]; pf0[q] = pf1[q]; }
+            rec_checkpoint();
+            consume_pending();  // before the next chunk is requested: loads retire in order
+            __builtin_amdgcn_s_setprio(0);
+            fetch(sb + 2u * SB, pf1);
+
+            // ---- this step's text into its slot (whatever was queued from the step before last has been consumed) ----
+            const uint32_t slot = tb + sl * SLOT;                 // wave-uniform
+            const uint32_t my_text = slot + 16u + lane * P;       // LDS address of this lane's first byte
+            {
+                const uint32_t bias = sb - (slot + 16u);
+                if (sl) posbias1 = bias; else posbias0 = bias;
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                *reinterpret_cast<ldsx_u32x4 *>(static_cast<uintptr_t>(my_text + 16u * q)) = e3_u32x4_t{cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+            if (lane == 0) {
+                *reinterpret_cast<ldsx_u32 *>(static_cast<uintptr_t>(slot + 12u)) = tail4;
+                *reinterpret_cast<ldsx_u32x4 *>(static_cast<uintptr_t>(slot + 16u + SB)) = e3_u32x4_t{pf0[0].x, pf0[0].y, pf0[0].z, pf0[0].w};
+            }
+            tail4 = __builtin_amdgcn_readlane(cur[Q - 1].w, 63);
+
+            // ---- byte classes of this lane's P positions plus K to the left ----
+            uint32_t kx[K + P];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const uint32_t w[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    kx[K + 16 * q + b] = pinx(cls_of((w[b >> 2] >> (8 * (b & 3))) & 0xffu));
+                    __builtin_assume(kx[K + 16 * q + b] < 32u);
+                }
+            }
+            uint32_t pk = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) pk |= kx[P + i] << (8 * i);  // this lane's last K classes, oldest low
+            const uint32_t left = wave_shr1_x(pk, carry);
+            carry = __builtin_amdgcn_readlane(pk, 63);
+#pragma unroll
+            for (int i = 0; i < K; ++i) { kx[i] = (left >> (8 * i)) & 0xffu; __builtin_assume(kx[i] < 32u); }
+
+            // ---- ME words of the K-grams ending at j = 0 .. P-1: hit bits into the lane's mask, flag bits + class into the stream ----
+            uint32_t H = 0, mprev = 0;
+            uint32_t annw[P / 4];
+#pragma unroll
+            for (int grp = 0; grp < P / 8; ++grp) {
+                uint32_t mw[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j = grp * 8 + jj;
+                    uint32_t x = pinx((kx[K + j] << 2) + offM);                       // 4 c_j + offM              (v_lshl_add_u32)
+                    x = __umul24(kx[K + j - 1], C4) + x;                              // + 4 C c_(j-1)             (v_mad_u32_u24)
+                    if (K == 3) x = __umul24(kx[K + j - 2], CC4) + pinx(x);           // + 4 C^2 c_(j-2)           (v_mad_u32_u24)
+                    mw[jj] = lds_u32(x);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j = grp * 8 + jj;
+                    if (j > 0) H |= __builtin_amdgcn_ubfe(jj == 0 ? mprev : mw[jj - 1], kx[K + j], 1) << j;
+                }
+                mprev = mw[7];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j0 = grp * 8 + 4 * h;
+                    // the top bytes of four words (flags in bits 5-7 of each) | the four classes
+                    const uint32_t t01 = __builtin_amdgcn_perm(mw[4 * h + 1], mw[4 * h], 0x0c0c0703u);
+                    const uint32_t t23 = __builtin_amdgcn_perm(mw[4 * h + 3], mw[4 * h + 2], 0x07030c0cu);
+                    const uint32_t cpk = kx[K + j0] | (kx[K + j0 + 1] << 8) | (kx[K + j0 + 2] << 16) | (kx[K + j0 + 3] << 24);
+                    annw[grp * 2 + h] = ((t01 | t23) & 0xe0e0e0e0u) | cpk;
+                }
+            }
+            {   // position 0 against the ME word of the K-gram ending just before this lane's share
+                const uint32_t mleft = wave_shr1_x(mprev, mcarry);
+                mcarry = __builtin_amdgcn_readlane(mprev, 63);
+                H |= __builtin_amdgcn_ubfe(mleft, kx[K], 1);
+            }
+            if (sb < a.emit_from) {   // (the first step(s) of a window: ends before emit_from belong to the window before)
+#pragma unroll
+                for (int i = 0; i < P / 4; ++i) {
+                    const uint32_t p0 = v + 4u * i;
+                    const uint32_t nb = a.emit_from > p0 ? (a.emit_from - p0 < 4u ? a.emit_from - p0 : 4u) : 0u;
+                    annw[i] &= nb >= 4u ? 0x1f1f1f1fu : ~(0xe0e0e0e0u & ((1u << (8u * nb)) - 1u));
+                }
+            }
+            uint32_t nshort = 0;
+#pragma unroll
+            for (int i = 0; i < P / 4; ++i) nshort += __popc(annw[i] & 0xe0e0e0e0u);
+            {
+                uint4 *dst = reinterpret_cast<uint4 *>(a.ann + v);
+#ifdef E3X_NO_ANN
+                if (nshort == 0xdeadbeefu)
+#endif
+                {
+                dst[0] = uint4{annw[0], annw[1], annw[2], annw[3]};
+                dst[1] = uint4{annw[4], annw[5], annw[6], annw[7]};
+                }
+                const uint32_t incl = wave_incl_scan_x(nshort);
+                const uint32_t s31 = __builtin_amdgcn_readlane(incl, 31), s63 = __builtin_amdgcn_readlane(incl, 63);
+                if (lane == 0) {
+                    a.tile_short[sb >> 10] = s31;
+                    a.tile_short[(sb >> 10) + 1u] = s63 - s31;
+                }
+            }
+
+            // ---- queue the hits, one per lane and turn ----
+            bool did_batch = false;
+            for (;;) {
+                const bool has = H != 0;
+                const unsigned long long m = __ballot(has);
+                if (m == 0) break;
+                if (has) {
+                    const uint32_t b = static_cast<uint32_t>(__builtin_ctz(H));
+                    H &= H - 1u;
+                    const uint32_t at = q_tail + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+                    *reinterpret_cast<ldsx_u32 *>(static_cast<uintptr_t>(ringb + ((at & (kRingE3 - 1u)) << 2))) = my_text + b;
+                }
+                q_tail += static_cast<uint32_t>(__popcll(m));
+                if (q_tail - q_head >= 64u) { process_batch(64u); did_batch = true; }
+            }
+            // whatever was queued a step ago must be gone before its slot is written again
+            if (carry_in != 0 && !did_batch) process_batch(q_tail - q_head);
+            carry_in = q_tail - q_head;
+            sl ^= 1u;
+        }
+    }
+    if (q_tail != q_head) process_batch(q_tail - q_head);
+    rec_checkpoint();
+    consume_pending();
+    drain();
+    {   // close the open chunk
+        const uint32_t n = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(cursor));
+        if (lane == 0 && chunk_ok) a.chunk_fill[chunk] = n < kEmit3Chunk ? n : kEmit3Chunk;
+    }
+}
+
+// ================================================================================================================ host-side glue kernels
+__global__ __launch_bounds__(256) void emit3_combine_kernel(const uint32_t *__restrict__ tile_short, const uint32_t *__restrict__ tile_deep,
+                                                            unsigned long long *__restrict__ total, unsigned long long *__restrict__ deep, uint64_t n) {
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint32_t s = tile_short[i], d = tile_deep[i];
+        total[i] = static_cast<unsigned long long>(s) + d;
+        deep[i] = d;
+    }
+}
+// records -> the bin of the tile they end in; `cursor` = the per-tile record counts, counted down
+__global__ __launch_bounds__(256) void emit3_bin_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__ chunk_fill, const uint32_t *__restrict__ chunk_next,
+                                                        uint32_t chunk_cap, const unsigned long long *__restrict__ bin_off, uint32_t *__restrict__ cursor,
+                                                        uint4 *__restrict__ binned) {
+    const uint32_t used = *chunk_next < chunk_cap ? *chunk_next : chunk_cap;
+    for (uint32_t c = blockIdx.x; c < used; c += gridDim.x) {
+        const uint32_t fill = chunk_fill[c];
+        for (uint32_t i = threadIdx.x; i < fill; i += blockDim.x) {
+            const uint4 r = recs[static_cast<uint64_t>(c) * kEmit3Chunk + i];
+            const uint32_t k = atomicSub(&cursor[r.w], 1u) - 1u;
+            binned[bin_off[r.w] + k] = r;
+        }
+    }
+}
+
+// ================================================================================================================ EXPAND
+// One wave per tile of 1024 positions.  LDS per workgroup: V1 | V2 | per wave {16 + 1024 stream bytes, 1024 x u32 length bits | extras << 16,
+// 1024 x u16 first slot of the position, 64 extras, counter}.
+template <int K, bool F16>
+__global__ __launch_bounds__(256) void emit3_expand_kernel(const Gram2EmitDev g, const Expand3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    e3_copy(smem, g.v1, g.v1_bytes);
+    e3_copy(smem + g.v1_bytes, g.v2, g.v2_bytes);
+    __syncthreads();
+    const uint32_t *v1 = reinterpret_cast<const uint32_t *>(smem);
+    const uint32_t *v2 = reinterpret_cast<const uint32_t *>(smem + g.v1_bytes);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    const uint32_t C = g.C, CC = g.C * g.C;
+    char *wl = smem + a.off_wave + wave_in_wg * kEmit3ExpandWave;
+    uint8_t *annb = reinterpret_cast<uint8_t *>(wl);                    // [0,16) the 16 bytes before the tile | the tile
+    uint32_t *dmx = reinterpret_cast<uint32_t *>(wl + 1040);            // per position: bit (len - K - 1) per deep match | extras << 16
+    uint16_t *posoff = reinterpret_cast<uint16_t *>(wl + 1040 + 4096);  // per position: tile-relative slot of its first tuple
+    uint4 *xs = reinterpret_cast<uint4 *>(wl + 1040 + 4096 + 2048);     // the tile's extras {position in tile, length | copy << 24, value, -}
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(wl + 1040 + 4096 + 2048 + kEmit3MaxExtras * 16);
+    bool dirty = true;  // wave-uniform: dmx holds bits of the previous tile
+
+    for (uint32_t t = wave_global; t < a.ntiles; t += nwaves) {
+        const uint32_t v0 = t * kEmit3Tile;
+        {
+            const uint4 ch = *reinterpret_cast<const uint4 *>(a.ann + v0 + lane * 16u);
+            *reinterpret_cast<uint4 *>(annb + 16u + lane * 16u) = ch;
+            if (lane == 0) *reinterpret_cast<uint4 *>(annb) = t > 0 ? *reinterpret_cast<const uint4 *>(a.ann + v0 - 16u) : uint4{0u, 0u, 0u, 0u};
+        }
+        const unsigned long long tile_base = a.tile_off[t];
+        const uint32_t tile_n = static_cast<uint32_t>(a.tile_off[t + 1] - tile_base);
+        const unsigned long long bin0 = a.bin_off[t];
+        const uint32_t n = static_cast<uint32_t>(a.bin_off[t + 1] - bin0);   // wave-uniform
+        const bool deep = n != 0;
+        if (tile_n == 0) continue;
+        void *__restrict__ out = reinterpret_cast<char *>(a.out) + tile_base * (F16 ? 16ull : 24ull);
+
+        // ---- the tile's deep matches: a length bit per position; extras counted and listed ----
+        uint32_t xn = 0;
+        if (deep || dirty) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reinterpret_cast<uint4 *>(dmx)[lane + 64 * q] = uint4{0u, 0u, 0u, 0u};
+        }
+        dirty = deep;
+        if (deep) {
+            if (lane == 0) *reinterpret_cast<volatile uint32_t *>(ctr) = 0u;
+            for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                if (i < n) {
+                    const uint4 r = a.binned[bin0 + i];
+                    const uint32_t p = (r.x - v0) & (kEmit3Tile - 1u), len = r.y & 0xffffffu, copy = r.y >> 24, lb = len - (K + 1);
+                    if (lb < 16u && copy == 0u) {
+                        atomicOr(&dmx[p], 1u << lb);
+                    } else {
+                        atomicAdd(&dmx[p], 1u << 16);
+                        const uint32_t idx = atomicAdd(ctr, 1u);
+                        if (idx < kEmit3MaxExtras) xs[idx] = uint4{p, r.y, r.z, 0u};
+                    }
+                }
+            }
+            xn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(ctr));
+            if (xn > kEmit3MaxExtras) {   // left to the other engines (the caller looks at the flag before it hands anything out)
+                if (lane == 0) atomicOr(a.fail, 4u);
+                continue;
+            }
+        }
+
+        // ---- column i: lane l looks at position 64 i + l ----
+        // (the values of the 3-byte patterns come from L2: all sixteen columns' requests go out before the first column is placed —
+        // asked for column by column, every column waited for its own round trip)
+        constexpr uint32_t NCOL = kEmit3Tile / 64u;
+        uint32_t w01[NCOL], val3[NCOL];
+#pragma unroll
+        for (uint32_t i = 0; i < NCOL; ++i) {
+            const uint32_t p = 64u * i + lane;
+            const uint32_t b0 = annb[16u + p], b1 = annb[15u + p];
+            w01[i] = b0 | (b1 << 8);
+            val3[i] = 0;
+#ifndef E3X_NO_V3
+            if (K == 3 && (b0 & 0x80u)) val3[i] = g.v3[(annb[14u + p] & 31u) * CC + (b1 & 31u) * C + (b0 & 31u)];
+#endif
+        }
+        uint32_t colbase = 0;   // wave-uniform: tuples of the columns before
+#pragma unroll
+        for (uint32_t i = 0; i < NCOL; ++i) {
+            const uint32_t p = 64u * i + lane;
+            const uint32_t b0 = w01[i] & 0xffu, b1 = w01[i] >> 8;
+            const uint32_t f = b0 >> 5;
+            const uint32_t d = deep ? dmx[p] : 0u;
+            const uint32_t nd = __popc(d & 0xffffu) + (d >> 16);
+            const uint32_t c = __popc(f) + nd;
+            const uint32_t incl = wave_incl_scan_x(c);
+            const uint32_t slot0 = colbase + incl - c;
+            colbase += __builtin_amdgcn_readlane(incl, 63);
+            if (deep) posoff[p] = static_cast<uint16_t>(slot0);
+            uint32_t s = slot0 + nd;   // the short ones follow the deep ones, longest first
+#ifdef E3X_DENSE_STORES
+            s = 40u * i + lane / 2u;
+#endif
+            const unsigned long long end = a.pos_base + v0 + p;
+            if (K == 3 && __ballot((f & 4u) != 0) != 0) {
+                if ((f & 4u) && s < tile_n) put_tuple_x<F16>(out, s, end, 3u, val3[i]);
+                s += (f >> 2) & 1u;
+            }
+            if (__ballot((f & 2u) != 0) != 0) {
+                if ((f & 2u) && s < tile_n) put_tuple_x<F16>(out, s, end, 2u, v2[(b1 & 31u) * C + (b0 & 31u)]);
+                s += (f >> 1) & 1u;
+            }
+            if (__ballot((f & 1u) != 0) != 0) {
+                if ((f & 1u) && s < tile_n) put_tuple_x<F16>(out, s, end, 1u, v1[b0 & 31u]);
+                s += f & 1u;
+            }
+            if (s > tile_n) atomicOr(a.fail, 8u);
+        }
+
+        // ---- the deep matches into their slots: first slot of the position + the longer ones at the same position ----
+        if (deep) {
+            uint4 ex = uint4{0xffffffffu, 0u, 0u, 0u};
+            if (lane < xn) ex = xs[lane];
+            // extras at position p that sort before the key (length descending, copy ascending); all lanes walk the list together
+            auto extras_before = [&](uint32_t p, uint32_t len, uint32_t copy) -> uint32_t {
+                uint32_t cnt = 0;
+                for (uint32_t k = 0; k < xn; ++k) {
+                    const uint32_t ep = __builtin_amdgcn_readlane(ex.x, k), ey = __builtin_amdgcn_readlane(ex.y, k);
+                    const uint32_t el = ey & 0xffffffu, ec = ey >> 24;
+                    cnt += (ep == p && (el > len || (el == len && ec < copy))) ? 1u : 0u;
+                }
+                return cnt;
+            };
+            for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                uint4 r = uint4{0u, 0u, 0u, 0u};
+                if (i < n) r = a.binned[bin0 + i];
+                const uint32_t p = (r.x - v0) & (kEmit3Tile - 1u), len = r.y & 0xffffffu, copy = r.y >> 24, lb = len - (K + 1);
+                const bool normal = i < n && lb < 16u && copy == 0u;
+                uint32_t slot = 0;
+                if (normal) slot = posoff[p] + __popc((dmx[p] & 0xffffu) >> (lb + 1u));
+                if (xn != 0) slot += extras_before(normal ? p : 0xfffffffeu, len, 0u);
+                if (normal) {
+                    if (slot < tile_n) put_tuple_x<F16>(out, slot, a.pos_base + r.x, len, r.z);
+                    else atomicOr(a.fail, 8u);
+                }
+            }
+            if (xn != 0) {  // the extras themselves, one per lane
+                const bool mine = lane < xn;
+                const uint32_t p = ex.x & (kEmit3Tile - 1u), el = ex.y & 0xffffffu, ec = ex.y >> 24, lb = el - (K + 1);
+                uint32_t slot = 0;
+                if (mine) {
+                    const uint32_t d = dmx[p];
+                    slot = posoff[p];
+                    if (lb < 16u) slot += __popc((d & 0xffffu) >> (lb + 1u)) + ((d >> lb) & 1u);  // the longer ones and its own original
+                }
+                slot += extras_before(mine ? p : 0xfffffffeu, el, ec);
+                if (mine) {
+                    if (slot < tile_n) put_tuple_x<F16>(out, slot, a.pos_base + v0 + p, el, ex.z);
+                    else atomicOr(a.fail, 8u);
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================================ launchers
+bool emit3_plan(const Gram2EmitDev &dev, uint32_t waves, uint32_t lds_limit, Gram3Lds &L) {
+    L = Gram3Lds{};
+    const uint32_t slot = 64u * 32u + 32u;
+    L.wave_stride = 2u * slot + kRingE3 * 4u;
+    L.off_s = kOffME3 + dev.m_bytes;
+    L.off_wave = L.off_s + dev.s_bytes;
+    L.lds_bytes = L.off_wave + waves * L.wave_stride;
+    L.threads = waves * 64u;
+    L.rfull = 0;
+    return L.lds_bytes <= lds_limit;
+}
+
+template <int K, bool S16>
+static hipError_t launch_detect_inst(const Gram2EmitDev &dev, const Emit3Args &a, const Gram3Lds &L, uint32_t blocks, hipStream_t stream) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(emit3_detect_kernel<K, S16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(L.lds_bytes));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((emit3_detect_kernel<K, S16>), dim3(blocks), dim3(L.threads), L.lds_bytes, stream, dev, a, L);
+    return hipGetLastError();
+}
+hipError_t launch_emit3_detect(const Gram2EmitDev &dev, const Emit3Args &a, const Gram3Lds &L, uint32_t blocks, hipStream_t stream) {
+    if (dev.K == 3) return dev.s16 ? launch_detect_inst<3, true>(dev, a, L, blocks, stream) : launch_detect_inst<3, false>(dev, a, L, blocks, stream);
+    return dev.s16 ? launch_detect_inst<2, true>(dev, a, L, blocks, stream) : launch_detect_inst<2, false>(dev, a, L, blocks, stream);
+}
+
+hipError_t launch_emit3_combine(const uint32_t *tile_short, const uint32_t *tile_deep, unsigned long long *total, unsigned long long *deep, uint64_t n,
+                                hipStream_t stream) {
+    const uint32_t blocks = static_cast<uint32_t>(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
+    hipLaunchKernelGGL(emit3_combine_kernel, dim3(blocks), dim3(256), 0, stream, tile_short, tile_deep, total, deep, n);
+    return hipGetLastError();
+}
+hipError_t launch_emit3_bin(const uint4 *recs, const uint32_t *chunk_fill, const uint32_t *chunk_next, uint32_t chunk_cap, const unsigned long long *bin_off,
+                            uint32_t *cursor, uint4 *binned, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(emit3_bin_kernel, dim3(blocks), dim3(256), 0, stream, recs, chunk_fill, chunk_next, chunk_cap, bin_off, cursor, binned);
+    return hipGetLastError();
+}
+
+uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves) { return dev.v1_bytes + dev.v2_bytes + waves * kEmit3ExpandWave; }
+
+template <int K, bool F16>
+static hipError_t launch_expand_inst(const Gram2EmitDev &dev, const Expand3Args &a, uint32_t blocks, hipStream_t stream) {
+    const uint32_t lds = emit3_expand_lds_bytes(dev, 4);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(emit3_expand_kernel<K, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((emit3_expand_kernel<K, F16>), dim3(blocks), dim3(256), lds, stream, dev, a);
+    return hipGetLastError();
+}
+hipError_t launch_emit3_expand(const Gram2EmitDev &dev, const Expand3Args &a, bool f16, uint32_t blocks, hipStream_t stream) {
+    if (dev.K == 3) return f16 ? launch_expand_inst<3, true>(dev, a, blocks, stream) : launch_expand_inst<3, false>(dev, a, blocks, stream);
+    return f16 ? launch_expand_inst<2, true>(dev, a, blocks, stream) : launch_expand_inst<2, false>(dev, a, blocks, stream);
+}
+
+}  // namespace daac

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Device-resident tuple emission (daac_scan_device) on cfg3: GB/s of haystack and of tuples written, GRAM emitter vs the
-segment scanners.  usage: python tools/time_emit.py [mib] [sparse|dense] [reps]"""
+segment scanners.  usage: python tools/time_emit.py [mib] [sparse|dense] [reps] [emit_version]"""
 import os
 import sys
 import time
@@ -21,7 +21,10 @@ if hk == "sparse":
     synth.device_uniform(hay, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
 else:
     synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
-for emit, fmt16 in ((1, True), (1, False), (0, False)):  # the GRAM emitter in both device formats, then the segment scanners
+ver = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # emit_version: 0 / 3 = emit3_kernels.hip, 1 = the COUNT + WRITE emitter
+da.set_option("emit_version", ver)
+only16 = len(sys.argv) > 5 and sys.argv[5] == "only16"
+for emit, fmt16 in (((1, True),) if only16 else ((1, True), (1, False), (0, False))):  # the GRAM emitter in both device formats, then the segment scanners
     da.set_option("emit", emit)
     pma = da.DoubleArrayAhoCorasick.new(pats)
     pma.upload(0)
@@ -39,5 +42,5 @@ for emit, fmt16 in ((1, True), (1, False), (0, False)):  # the GRAM emitter in b
         best = min(best, time.perf_counter() - t0)
         dm.free()
     tb = 16 if fmt16 else 24
-    print(f"emit={emit} tuple_bytes={tb} engine_used={da.last_engine()} {hk} {n >> 20} MiB: {cnt} tuples, {best * 1e3:.2f} ms  ->  {n / best / 1e9:.1f} GB/s of haystack, "
+    print(f"emit={emit} version={ver} tuple_bytes={tb} engine_used={da.last_engine()} {hk} {n >> 20} MiB: {cnt} tuples, {best * 1e3:.2f} ms  ->  {n / best / 1e9:.1f} GB/s of haystack, "
           f"{cnt * tb / best / 1e9:.1f} GB/s of tuples written ({cnt / n:.3f} tuples/byte)", flush=True)
