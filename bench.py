@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-ENGINE_NAMES = {0: "auto", 1: "tiered", 2: "darray", 3: "gram", 4: "pfx", 5: "jump"}
+ENGINE_NAMES = {0: "auto", 1: "tiered", 2: "darray", 3: "gram", 4: "pfx"}
 
 
 def parse_args(argv=None):
@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--opt", action="append", default=[], help="name=value tuning option (daac_set_option)")
     ap.add_argument("--materialize-mib", type=int, default=64, help="also time a materialising scan of this prefix")
+    ap.add_argument("--no-extra", action="store_true", help="skip the restart-iterator, cfg5 and lazy-iterator objects")
     ap.add_argument("--plumbing", action="store_true",
                     help="no GPU, no scan: every rank contributes a fixed triple; exercises launch, rendezvous, reduction and the "
                          "JSON line only (used by the CPU test of the N > 1 path; prints value null)")
@@ -135,6 +136,141 @@ def plumbing(args, rank, world):
         print(json.dumps({"metric": "plumbing only (no scan)", "value": None, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 4), "higher_is_better": True,
                           "scaling": args.scaling, "vs_baseline": None, "plumbing_only": True, "reduced": [tot[0], tot[1]]}))
+
+
+def _event_ms(torch, fn, reps):
+    """average milliseconds of fn() over `reps` launches, HIP events on the current stream (one warm-up)"""
+    fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in ev) / reps
+
+
+def restart_legs(da, synth, torch, patterns, local_rank, stream, result, no_cpu, seed_sparse, seed_dense, alpha):
+    """find_iter / leftmost_find_iter (bytewise/iter.rs:58-113, 272-340) of the cfg3 dictionary: count + checksum over 1 GiB of the
+    sparse and of the dense haystack, under the same clock as the headline number; prefix parity against the oracle."""
+    from daachorse_amd import ScanMode
+    n = 1 << 30
+    hay = torch.empty(n, dtype=torch.uint8, device="cuda")
+    out = {"bytes": n, "op": "count + checksum of the iterator's match stream (daac_scan_count)"}
+    for kind_name, kind, mode, api in (("find_iter", da.MatchKind.Standard, ScanMode.Find, "find_iter"),
+                                       ("leftmost_find_iter", da.MatchKind.LeftmostLongest, ScanMode.LeftmostFind, "leftmost_find_iter")):
+        pma = da.DoubleArrayAhoCorasickBuilder().match_kind(kind).build(patterns)
+        pma.upload(local_rank)
+        oo = None
+        if not no_cpu:
+            from oracle import oracle as orc
+            oo = orc.OraclePma.deserialize(pma.serialize())
+        for hk in ("sparse", "dense"):
+            if hk == "sparse":
+                synth.device_uniform(hay, seed_sparse, alpha)
+            else:
+                synth.device_wordsoup(hay, seed_dense, patterns, 20, noise_256=77)
+            torch.cuda.synchronize()
+            fn = lambda: pma.scan_count(mode, hay, stream=stream, result_dev=result.data_ptr())
+            ms = _event_ms(torch, fn, 3)
+            r = result.tolist()
+            ok = None
+            if oo is not None:
+                pn = 16 << 20
+                sample = hay[:pn].cpu().numpy()
+                want = getattr(oo, api)(sample)
+                ok = bool(pma.scan_count(mode, sample) == (len(want), orc.matches_checksum(want)))
+            tr = hbm_traffic(f"{'find' if kind_name == 'find_iter' else 'leftmost'}_{hk}", "chain")
+            out[f"{kind_name}_{hk}"] = {"value": round(n / ms / 1e6, 2), "unit": "GB/s", "frac": round(n / ms / 1e6 / HBM_PEAK_GBS, 4), "kernel_ms": round(ms, 3),
+                                        "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"), "match_count": int(r[0]),
+                                        "matches_per_byte": round(int(r[0]) / n, 4), "traffic": tr[0], "parity_16mib_prefix_vs_oracle": ok}
+        del pma
+    del hay
+    torch.cuda.empty_cache()
+    return out
+
+
+def cfg5_legs(da, synth, torch, local_rank, stream, result, no_cpu):
+    """BASELINE.json configs[4]: CharwiseDoubleArrayAhoCorasick, 50 k UTF-8 patterns, the full 1 GiB multi-byte haystack:
+    leftmost_find_iter (LeftmostLongest; charwise/iter.rs:328-399), find_iter, find_overlapping_iter — count + checksum each."""
+    from daachorse_amd import ScanMode
+    pats = synth.patterns_cfg5()
+    nbytes = synth.cfg5_haystack_bytes(1 << 30)
+    hay = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    synth.device_zipf_text(hay)
+    torch.cuda.synchronize()
+    out = {"bytes": nbytes, "workload": "cfg5 (SURVEY 8d): 50k patterns of 2-8 scalars, Zipf(1.0) over 6000 symbols; text of the same distribution + 10% ASCII"}
+    for name, kind, mode, api in (("leftmost_find_iter", da.MatchKind.LeftmostLongest, ScanMode.LeftmostFind, "leftmost_find_iter"),
+                                  ("find_iter", da.MatchKind.Standard, ScanMode.Find, "find_iter"),
+                                  ("find_overlapping_iter", da.MatchKind.Standard, ScanMode.FindOverlapping, "find_overlapping_iter")):
+        pma = da.CharwiseDoubleArrayAhoCorasickBuilder().match_kind(kind).build(pats)
+        pma.upload(local_rank)
+        fn = lambda: pma.scan_count(mode, hay, stream=stream, result_dev=result.data_ptr())
+        ms = _event_ms(torch, fn, 3)
+        r = result.tolist()
+        ok = None
+        if not no_cpu:
+            from oracle import oracle as orc
+            oo = orc.OracleCharwisePma.deserialize(pma.serialize())
+            pn = synth.cfg5_haystack_bytes(16 << 20)
+            sample = hay[:pn].cpu().numpy()
+            want = getattr(oo, api)(sample)
+            ok = bool(pma.scan_count(mode, sample) == (len(want), orc.matches_checksum(want)))
+        tr = hbm_traffic({"leftmost_find_iter": "cfg5_leftmost", "find_iter": "cfg5_find", "find_overlapping_iter": "cfg5_overlapping"}[name], "daac::char_")
+        out[name] = {"value": round(nbytes / ms / 1e6, 2), "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "kernel_ms": round(ms, 3),
+                     "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"), "match_count": int(r[0]), "matches_per_byte": round(int(r[0]) / nbytes, 4),
+                     "traffic": tr[0], "parity_16mib_prefix_vs_oracle": ok}
+        del pma
+    del hay
+    torch.cuda.empty_cache()
+    return out
+
+
+def iterator_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha):
+    """Iterator::next driven to exhaustion over HOST haystacks (page-locked): daac_iter_next_batch run by run, every tuple looked at
+    (runs counted; a third pass also sums the ends on one host thread).  cfg3 (0.6 matches per byte: bound by the tuples' way back over PCIe) and cfg2's sparse haystack
+    (bound by the haystack's way to the device)."""
+    from daachorse_amd import ScanMode
+    n = 1 << 30
+    out = {"bytes": n, "op": "daac_iter_open + daac_iter_next_batch to exhaustion over a page-locked host haystack (zero-copy runs of 16-byte tuples, counted)",
+           "window_bytes": 64 << 20}
+    host = torch.empty(n, dtype=torch.uint8).pin_memory()
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    p2 = da.DoubleArrayAhoCorasick.new(synth.patterns_cfg2())
+    p2.upload(local_rank)
+    for name, pma, fill in (("cfg3", pma_cfg3, lambda: synth.device_uniform(dev, seed_sparse, alpha)),
+                            ("cfg2_sparse", p2, lambda: synth.device_uniform(dev, synth.SEEDS["cfg2_hay"], synth.ALPHA_PRINTABLE))):
+        fill()
+        host.copy_(dev)
+        torch.cuda.synchronize()
+        h = host.numpy()
+        best, cnt, best_sum, ends = None, 0, None, 0
+        for rep in range(3):   # the first pass also pays for pinning the window buffers; the last one reads every tuple on the host
+            t0 = time.perf_counter()
+            it = pma.find_overlapping_iter(h)
+            cnt, ends = 0, 0
+            while True:
+                run = it.next_batch()
+                if run is None:
+                    break
+                cnt += len(run)
+                if rep == 2:
+                    ends += int(run["end"].sum(dtype=np.uint64))
+            it.close()
+            dt = time.perf_counter() - t0
+            if rep == 2:
+                best_sum = dt
+            else:
+                best = dt if best is None else min(best, dt)
+        want = pma.count(ScanMode.FindOverlapping, dev)
+        out[name] = {"GB/s": round(n / best / 1e9, 2), "seconds": round(best, 4), "matches": cnt, "matches_per_byte": round(cnt / n, 4),
+                     "tuple_GB/s_over_pcie": round(cnt * 16 / best / 1e9, 2), "count_agrees_with_count_kernel": bool(cnt == want),
+                     "GB/s_with_a_numpy_pass_over_every_tuple": round(n / best_sum / 1e9, 2),
+                     "engine_used": ENGINE_NAMES.get(da.last_engine(), "?")}
+    del host, dev, p2
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -242,27 +378,33 @@ def main():
         if base32:  # ends were relative to this rank's buffer: S2 += S1 * (offset of the buffer in the haystack)  (mod 2^32)
             result[2] += (result[1] & 0xFFFFFFFF) * base32
 
+    diag = {}  # what the last timed() saw on THIS rank: kernel and reduce times by HIP events
+
     def timed(steps, warmup):
         for _ in range(warmup):
             scan_step()
             if dist is not None:
                 reduce_counts(result)  # RCCL over xGMI: the trivial match-count reduction
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for a, b in ev:
+        for a, b, c in ev:
             a.record()
             scan_step()
             b.record()
             if dist is not None:
                 reduce_counts(result)
+                c.record()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        kernel_ms = [a.elapsed_time(b) for a, b in ev]  # memset + scan kernel on the launch stream
+        kernel_ms = [a.elapsed_time(b) for a, b, _ in ev]  # memset + scan kernel on the launch stream
+        diag["kernel_ms"] = float(np.mean(kernel_ms))
+        diag["reduce_ms"] = float(np.mean([b.elapsed_time(c) for _, b, c in ev])) if dist is not None else None
+        diag["elapsed_s"] = elapsed
         return ddist.max_over_ranks(elapsed, device="cuda" if backend == "nccl" else None), float(np.mean(kernel_ms)) / 1e3
 
     elapsed, avg_kernel_s = timed(args.steps, args.warmup)
@@ -274,6 +416,39 @@ def main():
     dist_used = None
     if dist is not None:  # every rank leaves the group together; rank 0 reports on its own
         dist_used = {"backend": backend, "world_size": dist.get_world_size(), "all_reduces": args.steps + args.warmup}
+        # what each rank measured, gathered to rank 0: where a non-linear scaling curve comes from (a slow rank, the reduce, the launch)
+        per_rank = torch.tensor([diag["kernel_ms"], diag["reduce_ms"] or 0.0, diag["elapsed_s"] * 1e3 / max(1, args.steps), float(nbytes)],
+                                dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        gathered = [torch.zeros_like(per_rank) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, per_rank)
+        rows = [[float(x) for x in g.tolist()] for g in gathered]
+        km = [r[0] for r in rows]
+        dist_used.update({
+            "n_ranks_seen": len(rows),
+            "per_rank_kernel_ms": {"min": round(min(km), 4), "max": round(max(km), 4), "mean": round(sum(km) / len(km), 4),
+                                   "slowest_rank": int(km.index(max(km))), "all": [round(x, 4) for x in km]},
+            "reduce_ms": {"mean_over_ranks": round(sum(r[1] for r in rows) / len(rows), 4), "max": round(max(r[1] for r in rows), 4),
+                          "note": "HIP events around the all-reduce of {count, S1, S2} on the launch stream (includes waiting for the slowest rank)"},
+            "per_rank_ms_per_step": [round(r[2], 4) for r in rows],
+            "per_rank_bytes": [int(r[3]) for r in rows],
+            "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" and hasattr(torch.cuda, "nccl") else None),
+        })
+        # strong scaling: the job's count (+ checksum) must be what ONE device finds in the whole haystack — checked here, not only in the tests
+        if args.scaling == "strong" and world > 1 and total <= (8 << 30):
+            ok = None
+            if rank == 0:
+                whole = torch.empty(total, dtype=torch.uint8, device="cuda")
+                if args.haystack == "sparse":
+                    synth.device_uniform(whole, seed_sparse, alpha)
+                else:
+                    synth.device_wordsoup(whole, seed_dense, patterns, slot, noise_256=noise)
+                if args.op == "count":
+                    ok = bool(pma.count(ScanMode.FindOverlapping, whole, engine=engine) == int(result[0].item()))
+                else:
+                    one = pma.scan_count(ScanMode.FindOverlapping, whole, engine=engine)
+                    ok = bool(one == (int(result[0].item()), ((int(result[1].item()) & 0xFFFFFFFF) << 32) | (int(result[2].item()) & 0xFFFFFFFF)))
+                del whole
+            dist_used["strong_equals_one_rank"] = ok
         dist.barrier()
         dist.destroy_process_group()
         dist = None
@@ -513,6 +688,17 @@ def main():
             del ahay, ap
             torch.cuda.empty_cache()
         out["any_alphabet"] = anyab
+    # ---- the other iterators of the path and configs[4], under this same clock; the lazy iterator over host haystacks ----
+    if world == 1 and not args.no_extra and args.workload == "cfg3" and args.haystack == "sparse":
+        try:
+            hay_alive = hay  # noqa: F841
+            del hay
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        out["restart"] = restart_legs(da, synth, torch, patterns, local_rank, stream, result, args.no_cpu, seed_sparse, seed_dense, alpha)
+        out["cfg5"] = cfg5_legs(da, synth, torch, local_rank, stream, result, args.no_cpu)
+        out["iterator"] = iterator_legs(da, synth, torch, np, pma, local_rank, seed_sparse, alpha)
     print(json.dumps(out))
 
 

@@ -37,7 +37,7 @@ class Info(C.Structure):
                 ("plan_engine", C.c_uint8 * 8), ("plan_kernel", C.c_uint8 * 8), ("plan_reason", C.c_uint8 * 8)]
 
 
-ABI_VERSION = 3  # DAAC_ABI_VERSION of include/daachorse_amd.h this mirror was written against
+ABI_VERSION = 4  # DAAC_ABI_VERSION of include/daachorse_amd.h this mirror was written against
 
 
 def lib():
@@ -84,6 +84,8 @@ def lib():
     L.daac_iter_open.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp)]
     L.daac_iter_next.argtypes = [vp, P(Match)]
     L.daac_iter_next.restype = C.c_int
+    L.daac_iter_next_batch.argtypes = [vp, P(vp), P(sz)]
+    L.daac_iter_next_batch.restype = C.c_int
     L.daac_iter_close.argtypes = [vp]
     L.daac_stream_open.argtypes = [vp, C.c_int, C.c_int, vp, P(vp)]
     L.daac_stream_feed.argtypes = [vp, u8p, sz, C.c_int, P(vp)]

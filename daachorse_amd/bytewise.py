@@ -39,7 +39,6 @@ class Engine(enum.IntEnum):
     DArray = 2
     Gram = 3
     Pfx = 4
-    Jump = 5  # reported by last_engine() only (find_iter counts over jump tables)
 
 
 class Match:
@@ -167,6 +166,24 @@ class _LazyIter:
         if r == 0:
             raise StopIteration
         _ffi.check(-r)
+
+    def next_batch(self):
+        """daac_iter_next_batch: the next run of matches as a structured numpy VIEW {end u64, length u32, value u32} of the iterator's
+        own window buffer (valid until the next call), or None when the iterator is exhausted."""
+        import numpy as np
+        p, n = C.c_void_p(), C.c_size_t()
+        r = _ffi.lib().daac_iter_next_batch(self._it, C.byref(p), C.byref(n))
+        if r == 0:
+            return None
+        if r < 0:
+            _ffi.check(-r)
+        buf = (C.c_char * (n.value * 16)).from_address(p.value)
+        return np.frombuffer(buf, dtype=MATCH16_DTYPE)
+
+    def close(self):
+        if self._it:
+            _ffi.lib().daac_iter_close(self._it)
+            self._it = None
 
     def __del__(self):
         try:

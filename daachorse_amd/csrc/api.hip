@@ -8,8 +8,10 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "charwise.hpp"
@@ -17,7 +19,6 @@
 #include "gram.hpp"
 #include "gram2.hpp"
 #include "gram2w.hpp"
-#include "jump.hpp"
 #include "pfx.hpp"
 #include "pma.hpp"
 #include "repack.hpp"
@@ -44,8 +45,6 @@ struct Options {
     std::atomic<int64_t> gram_version{0};       // 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram3 on the v2 tables), 1 = v1 only,
                                                 // 2 = v2 tables with gram2_kernels.hip, 3 = v2 tables with gram3_kernels.hip for `.count()`
     std::atomic<int64_t> gram2_dpp{1};
-    std::atomic<int64_t> jump{0};               // JUMP engine (experiment, off): find_iter count (+ checksum) of Standard bytewise automata over per-position jump tables
-                                                // instead of the chain walkers; measured 3x SLOWER than they are (profiles/r03_jump_experiment.txt); read at upload and at every scan
     std::atomic<int64_t> pfx{1};                // PFX engine: 1 = built for automata the GRAM tables do not serve, 2 = always, 0 = never (read at upload)
     std::atomic<int64_t> gram3_tail{-1};        // gram3: tail records from the hit record on (-1 = decide per launch)
     std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
@@ -53,6 +52,8 @@ struct Options {
     std::atomic<int64_t> emit_tiles{64};        // tiles of 1024 positions a wave takes at a time
     std::atomic<int64_t> emit_rec_cap{256};     // deep-match records per wave and tile before the scan falls back
     std::atomic<int64_t> emit_version{0};       // 0 = auto (emit3_kernels.hip: detection once, then expansion), 1 = gram2_emit_kernels.hip (COUNT + WRITE)
+    std::atomic<int64_t> emit_v3_lds{1};        // emit3 EXPAND: values of the 3-byte patterns from a rank structure in LDS when it fits (0: from L2)
+    std::atomic<int64_t> emit_stagger{0};       // emit3 EXPAND: the waves of a CU start this many x 1024 cycles apart (0: together)
     std::atomic<int64_t> emit_rec_per_kib{32};  // emit3: deep-match records the list is first sized for, per KiB of haystack (a rerun sizes it exactly)
     std::atomic<int64_t> restart_tier{0};       // 1: find_iter of Standard bytewise automata chains over the TIERED tables (measured 7-9 % slower
                                                 // than over the double array on cfg3: half the waves per CU, and a match costs a gather more)
@@ -151,14 +152,16 @@ struct DeviceTables {
     bool pfx_ok = false;       // any byte alphabet, `.count()` (pfx.hpp)
     uint32_t n_distinct_bytes = 0;  // distinct pattern bytes (known when the PFX builder ran)
     PfxDev pfx{};
-    bool jump_ok = false;      // find_iter over jump tables (jump.hpp)
-    JumpDev jump{};
     Gram2WDev gramw{};
     bool emit_ok = false;      // tuple emission on the second table set (gram2_emit_kernels.hip)
     Gram2EmitDev emit{};
     bool emit3_ok = false;     // ... with detection done once (emit3_kernels.hip)
     Gram3Lds emit3_lds{};
+    bool emit3_has_len1 = false;   // some pattern is a single byte
     std::atomic<uint32_t> emit3_rec_per_kib{0};  // deep-match records per KiB the last scans met (sizes the next scan's list)
+    // scans in a row on which an emitter gave up on the TEXT (more deep matches or extras than it places: known only after its detection
+    // has run): from the second on the handle stops trying and the plan says so (a served scan resets the count)
+    std::atomic<uint32_t> emit3_gave_up{0}, emit_gave_up{0};
     CharDev chr{};  // charwise automata only
 
     ~DeviceTables() {
@@ -606,7 +609,30 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 t->emit_ok = e.lds_bytes <= 160u * 1024u;
                 // emit3: DETECT as a 16-wave workgroup when the tables leave room for the text slots, else 8 waves
                 t->emit3_ok = emit3_plan(e, 16, 160u * 1024u, t->emit3_lds) || emit3_plan(e, 8, 160u * 1024u, t->emit3_lds);
-                t->emit3_ok = t->emit3_ok && emit3_expand_lds_bytes(e, 4) <= 64u * 1024u;
+                // the values of the 3-byte patterns as a rank structure for EXPAND's LDS (device_tables.hpp: v3c)
+                e.v3c = nullptr; e.v3c_bytes = e.v3c_dir = e.v3c_val = 0;
+                if (g2.K == 3) {
+                    const uint32_t n3 = static_cast<uint32_t>(g2.v3.size()), nw = (n3 + 31) / 32;
+                    std::vector<uint32_t> bm(nw, 0), vals;
+                    std::vector<uint16_t> dir(nw + (nw & 1), 0);
+                    for (uint32_t i = 0; i < n3; ++i) {
+                        if ((i & 31) == 0) dir[i >> 5] = static_cast<uint16_t>(vals.size());
+                        if ((g2.me[i] >> 31) & 1u) { bm[i >> 5] |= 1u << (i & 31); vals.push_back(g2.v3[i]); }
+                    }
+                    if (vals.size() < 65536) {
+                        std::vector<uint32_t> blob(bm);
+                        e.v3c_dir = static_cast<uint32_t>(blob.size() * 4);
+                        for (size_t i = 0; i < dir.size(); i += 2) blob.push_back(dir[i] | (static_cast<uint32_t>(dir[i + 1]) << 16));
+                        e.v3c_val = static_cast<uint32_t>(blob.size() * 4);
+                        blob.insert(blob.end(), vals.begin(), vals.end());
+                        while (blob.size() & 3) blob.push_back(0);
+                        e.v3c_bytes = static_cast<uint32_t>(blob.size() * 4);
+                        if ((st = t->put(blob, e.v3c)) != DAAC_OK) return st;
+                    }
+                }
+                // (a staged tuple keeps its length in 22 bits)
+                t->emit3_ok = t->emit3_ok && emit3_expand_lds_bytes(e, 4, false, false) <= 64u * 1024u && g2.max_len < (1u << 22);
+                for (uint32_t w : g2.me) t->emit3_has_len1 = t->emit3_has_len1 || ((w >> 29) & 1u) != 0;
             }
         }
     }
@@ -674,30 +700,6 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             t->pfx_ok = pfx_plan(d, 160u * 1024u);
         }
     }
-    // JUMP engine: find_iter of Standard automata over per-position jump tables
-    if (!pma->charwise && h.is_standard() && g_opt.jump.load() != 0) {
-        JumpTables jt;
-        if (build_jump_tables(h, jt)) {
-            JumpDev &d = t->jump;
-            const U32x4 *jh; const U32x4 *jr;
-            if ((st = t->put(jt.cls, d.cls)) != DAAC_OK) return st;
-            if ((st = t->put(jt.ms, d.ms)) != DAAC_OK) return st;
-            if ((st = t->put(jt.sdir, d.sdir)) != DAAC_OK) return st;
-            if ((st = t->put(jt.jhit, jh)) != DAAC_OK) return st;
-            if ((st = t->put(jt.jrec, jr)) != DAAC_OK) return st;
-            if ((st = t->put(jt.h1, d.h1)) != DAAC_OK) return st;
-            if ((st = t->put(jt.h2, d.h2)) != DAAC_OK) return st;
-            if ((st = t->put(jt.h3, d.h3)) != DAAC_OK) return st;
-            d.jhit = reinterpret_cast<const uint4 *>(jh);
-            d.jrec = reinterpret_cast<const uint4 *>(jr);
-            d.C = jt.C;
-            d.ms_bytes = static_cast<uint32_t>(jt.ms.size() * 4);
-            d.sdir_bytes = static_cast<uint32_t>((jt.sdir.size() * 4 + 15) & ~size_t(15));
-            d.max_len = jt.max_len;
-            d.unused_byte = jt.unused_byte;
-            t->jump_ok = jump_len_lds_bytes(d) <= 160u * 1024u;
-        }
-    }
     HIP_TRY(hipDeviceSynchronize());
     *out = t.get();
     pma->dev[device] = std::move(t);
@@ -743,8 +745,6 @@ struct Plan {
     bool restart = false;   // find_iter / leftmost_find_iter: the restart scanners (DARRAY tables)
     bool tier_chain = false;  // ... find_iter of a Standard bytewise automaton: the chain passes run over the TIERED tables
     bool leftmost = false;
-    bool jump = false;        // find_iter count over the jump tables (jump_kernels.hip): `jargs` are in place
-    JumpArgs jargs{};
     uint32_t blocks, threads;
     ScanArgs a;
 };
@@ -773,6 +773,12 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
     }
     if (engine == DAAC_ENGINE_GRAM) {
         set_error("the GRAM engine only serves daac_scan_count(DAAC_FIND_OVERLAPPING)");
+        return DAAC_ERR_UNSUPPORTED;
+    }
+    if (engine != DAAC_ENGINE_AUTO && engine != DAAC_ENGINE_TIERED && engine != DAAC_ENGINE_DARRAY) {
+        // (PFX counts; an unknown number is nobody's engine: a scan that silently ran on the double array instead would be ten times
+        // slower than what the caller asked for, with daac_last_engine() saying DARRAY)
+        set_error(engine == DAAC_ENGINE_PFX ? "the PFX engine only serves count (+ checksum) of DAAC_FIND_OVERLAPPING" : "unknown engine");
         return DAAC_ERR_UNSUPPORTED;
     }
     pl.tier = !pl.charwise && !pl.restart && (engine == DAAC_ENGINE_TIERED || (engine == DAAC_ENGINE_AUTO && t->tier_ok));
@@ -817,7 +823,6 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
 hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, hipStream_t s, unsigned long long *next_begin = nullptr) {
     if (pl.restart && pl.chain.x_prev != nullptr) {  // totals and per-segment counts are sums of tallies; only writing re-scans
         const int pass = kmode == 2 ? 2 : 3;
-        if (pl.jump && pass == 3) return launch_jump_chain(t->jump, pl.jargs, pl.a, pl.chain, 3, pl.blocks, s);
         if (pl.tier_chain)
             return launch_tier_chain(t->tier, pl.a, pl.chain, pass, kmode, next_begin,
                                      static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(t->num_cu, (pl.a.nseg + 1023) / 1024))), s);
@@ -879,7 +884,6 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
     c.tally_delta = tallies + n;
     c.x_out = x_spec;
     auto run = [&](int pass) {
-        if (pl.jump) return launch_jump_chain(t->jump, pl.jargs, pl.a, c, pass, pl.blocks, stream);
         if (pl.tier_chain)
             return launch_tier_chain(t->tier, pl.a, c, pass, 0, nullptr,
                                      static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(t->num_cu, (pl.a.nseg + 1023) / 1024))), stream);
@@ -956,6 +960,7 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
                               DevMatches &out, bool *served) {
     *served = false;
     if (!t->emit3_ok || g_opt.emit.load() == 0 || end <= begin) return DAAC_OK;
+    if (t->emit3_gave_up.load() >= 2 && end - begin >= (1u << 20)) return DAAC_OK;   // (short scans may still try: they cost little)
     const Gram2EmitDev &e = t->emit;
     const Gram3Lds &L = t->emit3_lds;
     const uint64_t halo = pma->halo();
@@ -1045,7 +1050,11 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
             HIP_TRY(hipStreamSynchronize(stream));
             if (pin) { total = pin[0]; deep_total = pin[1]; std::memcpy(ctl, pin + 2, 8); }
         }
-        if (ctl[1] != 0) { set_error("GRAM emitter: a wave met more deep matches between two checkpoints than a chunk holds (code " + std::to_string(ctl[1]) + ")"); return DAAC_OK; }
+        if (ctl[1] != 0) {
+            t->emit3_gave_up.fetch_add(1);
+            set_error("GRAM emitter: a wave met more deep matches between two checkpoints than a chunk holds (code " + std::to_string(ctl[1]) + ")");
+            return DAAC_OK;
+        }
         if (ctl[0] <= chunk_cap) break;
         if (attempt != 0) { set_error("GRAM emitter: the record list overflowed twice"); return DAAC_OK; }
         chunk_cap = static_cast<uint64_t>(ctl[0]) + 2 * nwaves + 16;   // (chunks are closed at least half full: the rerun takes no more of them)
@@ -1079,7 +1088,11 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         a.binned = static_cast<const uint4 *>(g_bins.p);
         a.out = d_out;
         a.pos_base = w.from - w.lead + 1;  // (mod 2^64: a match ends one past its last byte)
-        a.off_wave = e.v1_bytes + e.v2_bytes;
+        a.has_len1 = t->emit3_has_len1 ? 1u : 0u;
+        // the rank structure goes to LDS when three workgroups per CU still fit with it
+        a.v3_in_lds = (e.v3c != nullptr && g_opt.emit_v3_lds.load() != 0 && emit3_expand_lds_bytes(e, 4, out.f16, true) <= (160u * 1024u) / 3u) ? 1u : 0u;
+        a.off_wave = e.v1_bytes + e.v2_bytes + (a.v3_in_lds ? e.v3c_bytes : 0u);
+        a.stagger = a.ntiles >= 65536u ? static_cast<uint32_t>(std::max<int64_t>(0, std::min<int64_t>(64, g_opt.emit_stagger.load()))) : 0u;
         a.fail = d_ctl + 1;
         const uint32_t xblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 4, (a.ntiles + 3) / 4)));
         HIP_TRY(launch_emit3_expand(e, a, out.f16, xblocks, stream));
@@ -1091,12 +1104,14 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         HIP_TRY(hipStreamSynchronize(stream));
         if (pin) fail = *pin;
         if (fail != 0) {  // more extras in one tile than EXPAND places: left to the other engines
+            t->emit3_gave_up.fetch_add(1);
             set_error("GRAM emitter: the expansion gave up (code " + std::to_string(fail) + ")");
             dev_free(out.release(), stream);
             return DAAC_OK;
         }
     }
     out.f16_done = out.f16;
+    t->emit3_gave_up.store(0);
     *served = true;
     return DAAC_OK;
 }
@@ -1108,6 +1123,7 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
                              DevMatches &out, bool *served) {
     *served = false;
     if (!t->emit_ok || g_opt.emit.load() == 0 || end <= begin) return DAAC_OK;
+    if (t->emit_gave_up.load() >= 2 && end - begin >= (1u << 20)) return DAAC_OK;
     const Gram2EmitDev &e = t->emit;
     const uint64_t halo = pma->halo();
     // windows of at most 1 GiB of end positions: virtual positions inside a window fit 32 bits
@@ -1171,7 +1187,7 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
         HIP_TRY(hipStreamSynchronize(stream));
         if (pin) { total = pin[0]; fail = *reinterpret_cast<unsigned int *>(pin + 1); }
     }
-    if (fail != 0) { set_error("GRAM emitter: record lists overflowed in the count pass (code " + std::to_string(fail) + ")"); return DAAC_OK; }  // left to the segment scanners
+    if (fail != 0) { t->emit_gave_up.fetch_add(1); set_error("GRAM emitter: record lists overflowed in the count pass (code " + std::to_string(fail) + ")"); return DAAC_OK; }  // left to the segment scanners
     g_last_engine = DAAC_ENGINE_GRAM;
     const size_t tuple_bytes = out.f16 ? 16 : sizeof(daac_match);
     if (total == 0) { *served = true; return DAAC_OK; }
@@ -1196,11 +1212,13 @@ daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_
         if (pin) fail = *pin;
     }
     if (fail != 0) {  // more extras in one tile than the write pass places (the COUNT pass cannot know): leave it to the segment scanners
+        t->emit_gave_up.fetch_add(1);
         set_error("GRAM emitter: the write pass gave up (code " + std::to_string(fail) + ")");
         dev_free(out.release(), stream);
         return DAAC_OK;
     }
     out.f16_done = out.f16;
+    t->emit_gave_up.store(0);
     *served = true;
     return DAAC_OK;
 }
@@ -1446,13 +1464,13 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
     else set(DAAC_REQ_OVERLAPPING_COUNT, micro_engine, micro, why_no_gram);
     if (t->gram_ok || (t->gram2_ok && t->gram2.exact_ok)) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EXACT, DAAC_WHY_FASTEST);
     else if (t->gramw_ok && t->gramw.exact_ok) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_WIDE, DAAC_WHY_FASTEST);
-    else if (t->pfx_ok && !(t->gram_ok || t->gram2_ok || t->gramw_ok)) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, why_no_gram);
+    else if (t->pfx_ok) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);  // (as scan_count_impl: PFX wherever no GRAM table set serves the request)
     else set(DAAC_REQ_OVERLAPPING_CHECKSUM, micro_engine, micro, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);
-    if (t->emit_ok && g_opt.emit.load() != 0) set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EMIT, DAAC_WHY_FASTEST);
+    if (((t->emit3_ok && t->emit3_gave_up.load() < 2) || (t->emit_ok && t->emit_gave_up.load() < 2)) && g_opt.emit.load() != 0)
+        set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EMIT, DAAC_WHY_FASTEST);
     else set(DAAC_REQ_OVERLAPPING_TUPLES, seg_engine, DAAC_KERNEL_SEGMENT, t->gram2_ok ? DAAC_WHY_DUPLICATES : why_no_gram);
     set(DAAC_REQ_NO_SUFFIX, seg_engine, DAAC_KERNEL_SEGMENT, DAAC_WHY_FASTEST);
-    if (t->jump_ok && g_opt.jump.load() != 0 && pma->host.is_standard()) set(DAAC_REQ_FIND, DAAC_ENGINE_JUMP, DAAC_KERNEL_JUMP, DAAC_WHY_FASTEST);
-    else set(DAAC_REQ_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);  // (the restart iterators run on the double array)
+    set(DAAC_REQ_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);  // (the restart iterators run on the double array)
 }
 
 daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
@@ -1527,11 +1545,10 @@ size_t daac_pma_explain(const daac_pma *pma, char *buf, size_t cap) {
     if (daac_pma_info(pma, &f) != DAAC_OK) return 0;
     static const char *req[] = {"find_overlapping_iter(h).count()", "find_overlapping count + checksum", "find_overlapping tuples", "find_iter",
                                 "leftmost_find_iter", "find_overlapping_no_suffix_iter"};
-    static const char *eng[] = {"auto", "tiered", "darray", "gram", "pfx", "jump"};
+    static const char *eng[] = {"auto", "tiered", "darray", "gram", "pfx"};
     static const char *ker[] = {"- (the crate panics: wrong MatchKind)", "gram3 count kernel (one LDS lookup per byte)", "gram count + checksum kernel",
                                 "gram wide-alphabet kernel (31-62 byte classes)", "gram tuple emitter", "pfx (hashed prefix filter + start-anchored walks, any alphabet)",
-                                "segment scanners (one lane per segment)", "micro-step walker over the double array", "chain walkers (speculate / reconcile / emit)",
-                                "jump tables (shortest pattern per start, suffix minimum, one load per match); tuples: chain walkers"};
+                                "segment scanners (one lane per segment)", "micro-step walker over the double array", "chain walkers (speculate / reconcile / emit)"};
     static const char *why[] = {"", "not uploaded yet", "more distinct pattern bytes than the byte-class tables take", "tables do not fit the LDS",
                                 "\"\" is a pattern", "duplicate patterns the tables cannot encode", "the iterator is a chain through its own matches",
                                 "charwise automaton", "trie shape / table limits"};
@@ -1539,10 +1556,11 @@ size_t daac_pma_explain(const daac_pma *pma, char *buf, size_t cap) {
     for (int r = 0; r < DAAC_REQ_N; ++r) {
         s += req[r];
         s += ": ";
-        if (f.plan_kernel[r] == DAAC_KERNEL_NONE && f.plan_reason[r] != DAAC_WHY_NOT_UPLOADED) { s += ker[0]; s += "\n"; continue; }
-        s += "engine "; s += eng[f.plan_engine[r] <= 4 ? f.plan_engine[r] : 0];
-        s += ", "; s += ker[f.plan_kernel[r] <= 8 ? f.plan_kernel[r] : 0];
-        if (f.plan_reason[r] != DAAC_WHY_FASTEST) { s += "  [not the fastest family: "; s += why[f.plan_reason[r] <= 8 ? f.plan_reason[r] : 0]; s += "]"; }
+        if (f.plan_reason[r] == DAAC_WHY_NOT_UPLOADED) { s += "not uploaded yet (daac_pma_upload decides the plan)\n"; continue; }
+        if (f.plan_kernel[r] == DAAC_KERNEL_NONE) { s += ker[0]; s += "\n"; continue; }
+        s += "engine "; s += eng[f.plan_engine[r] < sizeof(eng) / sizeof(*eng) ? f.plan_engine[r] : 0];
+        s += ", "; s += ker[f.plan_kernel[r] < sizeof(ker) / sizeof(*ker) ? f.plan_kernel[r] : 0];
+        if (f.plan_reason[r] != DAAC_WHY_FASTEST) { s += "  [not the fastest family: "; s += why[f.plan_reason[r] < sizeof(why) / sizeof(*why) ? f.plan_reason[r] : 0]; s += "]"; }
         s += "\n";
     }
     if (buf && cap) {
@@ -1628,37 +1646,8 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     if (!d_res) { HIP_TRY(hipMalloc(&own, 3 * sizeof(unsigned long long))); d_res = static_cast<unsigned long long *>(own); }
     std::unique_ptr<void, void (*)(void *)> g2(own, [](void *p) { if (p) (void)hipFree(p); });
     pl.a.result = d_res;
-    // find_iter of a Standard bytewise automaton: L, then N / D for every position of the range, and the chain over those (jump.hpp)
-    DevBuf jump_buf;
-    if (pl.restart && !pl.leftmost && !pl.charwise && t->jump_ok && g_opt.jump.load() != 0 && g_opt.restart_chain.load() != 0 &&
-        !pma->root_has_output() && pl.a.nseg != 0 && len > begin) {
-        const uint8_t *sub = dev_hay + begin;
-        JumpArgs ja{};
-        ja.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sub) & 15u);
-        ja.hay_al = sub - ja.lead;
-        ja.vlen = ja.lead + static_cast<uint64_t>(len - begin);
-        ja.nsteps = (ja.vlen + 2 + 1023) / 1024;
-        ja.nd_chunks = (ja.vlen + 2 + 1791) / 1792;
-        const uint64_t written = ja.nsteps * 1024;
-        const uint64_t lsh_bytes = (std::max<uint64_t>(written, ja.nd_chunks * 1792 + 2048) + 255) & ~255ull;
-        const uint64_t nd_bytes = (ja.nd_chunks * 1792 * 2 + 255) & ~255ull;
-        const uint64_t hd_bytes = written * 4;
-        if (jump_buf.alloc(lsh_bytes + nd_bytes + hd_bytes, stream) == hipSuccess) {
-            ja.lsh = static_cast<uint8_t *>(jump_buf.p);
-            ja.nd = reinterpret_cast<uint16_t *>(ja.lsh + lsh_bytes);
-            ja.hdeep = reinterpret_cast<uint32_t *>(ja.lsh + lsh_bytes + nd_bytes);
-            if (lsh_bytes > written) HIP_TRY(hipMemsetAsync(ja.lsh + written, 0, lsh_bytes - written, stream));
-            HIP_TRY(launch_jump_tables(t->jump, ja, t->num_cu, stream));
-            pl.jump = true;
-            pl.jargs = ja;
-            pl.tier_chain = false;
-        } else {
-            (void)hipGetLastError();  // not enough memory for 7 bytes of tables per byte of text: the chain walkers take the scan
-        }
-    }
     ChainBuffers chain_buffers;
     if (pl.a.nseg != 0 && (st = chain_resolve(pma, t, pl, stream, chain_buffers)) != DAAC_OK) return st;
-    if (pl.jump && pl.chain.x_prev == nullptr) pl.jump = false;  // (the chain did not settle: the sync-point scanners)
     HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
     void *flagbuf = nullptr;
     if (pl.leftmost && pma->root_has_output()) {  // the one scan that can hit the non-terminating corner
@@ -1668,7 +1657,6 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     }
     std::unique_ptr<void, void (*)(void *)> g3(flagbuf, [](void *p) { if (p) (void)hipFree(p); });
     g_last_engine = use_pfx ? DAAC_ENGINE_PFX : use_gram ? DAAC_ENGINE_GRAM : (pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY);
-    if (pl.jump) g_last_engine = DAAC_ENGINE_JUMP;
     if ((use_gram || use_pfx) && len != begin) {
         // A shard [begin, len) is scanned as a haystack of its own: that counts every occurrence lying inside it,
         // with ends relative to `begin`.  What is missing are the occurrences that start before `begin` and end
@@ -1860,20 +1848,215 @@ void daac_matches_free(daac_matches *m) { delete m; }
 }  // extern "C"
 
 // ------------------------------------------------------------------------------ lazy iterator
+// Iterator::next() over a haystack scanned window by window.  A worker thread runs the windows ahead of the consumer, three stages in
+// flight on three streams: the H2D copy of window k + 1 (host haystacks), the scan of window k, the D2H copy of window k - 1's tuples
+// — 16-byte tuples {end, length, value} (the crate's own Match fields), expanded to daac_match by daac_iter_next, handed out as they
+// are by daac_iter_next_batch.  Staging buffers, result lists (stream-ordered pool) and the page-locked host buffers are reused from
+// window to window; round 3 allocated, copied, scanned and copied back one window at a time (3.5 GB/s on cfg3).
+namespace {
+
+// page-locked blocks kept for the next iterator (pinning a GB costs ~50 ms); never freed at exit: the HIP runtime may be gone by then
+struct PinnedPool {
+    std::mutex mu;
+    struct Block { void *p; size_t bytes; };
+    std::vector<Block> free_blocks;
+    void *take(size_t want, size_t *got) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = free_blocks.size();
+            for (size_t i = 0; i < free_blocks.size(); ++i)
+                if (free_blocks[i].bytes >= want && (best == free_blocks.size() || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
+            if (best != free_blocks.size() && free_blocks[best].bytes <= 4 * want + (64u << 20)) {
+                void *p = free_blocks[best].p;
+                *got = free_blocks[best].bytes;
+                free_blocks.erase(free_blocks.begin() + static_cast<long>(best));
+                return p;
+            }
+        }
+        void *q = nullptr;
+        if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        *got = want;
+        return q;
+    }
+    void give(void *p, size_t bytes) {
+        if (!p) return;
+        void *drop = nullptr;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            free_blocks.push_back(Block{p, bytes});
+            if (free_blocks.size() > 4) {   // the smallest goes
+                size_t k = 0;
+                for (size_t i = 1; i < free_blocks.size(); ++i) if (free_blocks[i].bytes < free_blocks[k].bytes) k = i;
+                drop = free_blocks[k].p;
+                free_blocks.erase(free_blocks.begin() + static_cast<long>(k));
+            }
+        }
+        if (drop) (void)hipHostFree(drop);
+    }
+};
+PinnedPool &pinned_pool() { static PinnedPool *p = new PinnedPool; return *p; }
+
+constexpr int kIterSlots = 3;
+struct IterWindow {
+    daac_status st = DAAC_OK;
+    std::string err;
+    uint64_t n = 0;                 // tuples of the window
+    daac_match16 *host = nullptr;   // page-locked (pageable if pinning failed)
+    size_t host_bytes = 0;
+    bool host_pinned = false;
+    hipEvent_t copied = nullptr;    // the tuples are in `host`
+    int engine = DAAC_ENGINE_AUTO;
+};
+
+}  // namespace
+
 struct daac_iter {
-    daac_pma *pma;
-    int mode, engine;
-    const uint8_t *hay;
-    uint64_t len;
-    bool hay_is_device;
-    hipStream_t stream;
-    uint64_t next_begin = 0;   // first byte of the next window
-    bool started = false, done = false;
+    daac_pma *pma = nullptr;
+    int mode = 0, engine = 0, device = 0;
+    const uint8_t *hay = nullptr;
+    uint64_t len = 0;
+    bool hay_is_device = false;
     bool restart = false;          // find_iter / leftmost_find_iter: windows end at sync points
     void *owned_dev = nullptr;     // host haystack staged once (restart modes read past a window's nominal end)
-    MatchBuf buf;
-    size_t pos = 0;
+    hipStream_t user_stream = nullptr;
+    // the worker and its three streams
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    IterWindow win[kIterSlots];
+    uint64_t produced = 0, consumed = 0;   // windows handed to / taken back from the consumer
+    bool stop = false, finished = false;
+    hipStream_t s_scan = nullptr, s_h2d = nullptr, s_d2h = nullptr;
+    // the consumer's view of the window it is reading
+    const daac_match16 *cur = nullptr;
+    size_t cur_n = 0, pos = 0;
+    bool holding = false;
+
+    void run();
 };
+
+void daac_iter::run() {
+    (void)hipSetDevice(device);
+    auto fail_with = [&](IterWindow &w, daac_status st) { w.st = st; w.err = last_error_cstr(); w.n = 0; };
+    DeviceTables *t = nullptr;
+    const uint64_t window = std::max<uint64_t>(4096, static_cast<uint64_t>(g_opt.iter_window.load()));
+    const uint64_t halo = pma->halo();
+    const bool per_window_copy = !hay_is_device;   // (restart modes were staged whole at open)
+    void *stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    hipEvent_t staged_ev[2] = {nullptr, nullptr};
+    uint64_t begin = 0;
+    daac_status st0 = get_tables(pma, &t);
+    if (st0 == DAAC_OK && per_window_copy) {
+        stage_bytes = static_cast<size_t>(std::min<uint64_t>(len, window) + halo + 64);
+        for (int i = 0; i < 2 && st0 == DAAC_OK; ++i) {
+            if (hipMalloc(&stage[i], stage_bytes) != hipSuccess || hipEventCreateWithFlags(&staged_ev[i], hipEventDisableTiming) != hipSuccess) {
+                st0 = hip_fail(hipGetLastError(), "iterator staging buffers");
+            }
+        }
+    }
+    // window k of a host haystack: bytes [from, end) -> stage[k & 1], asynchronously on the copy stream
+    auto issue_stage = [&](uint64_t k, uint64_t wb) -> hipError_t {
+        const uint64_t we = std::min<uint64_t>(len, wb + window);
+        const uint64_t from = wb > halo ? wb - halo : 0;
+        const uint64_t skew = from & 15;  // keep the haystack's 16-byte phase for the vector loop
+        if (we > from) {
+            const hipError_t e = hipMemcpyAsync(static_cast<uint8_t *>(stage[k & 1]) + skew, hay + from, we - from, hipMemcpyHostToDevice, s_h2d);
+            if (e != hipSuccess) return e;
+        }
+        return hipEventRecord(staged_ev[k & 1], s_h2d);
+    };
+    if (st0 == DAAC_OK && per_window_copy && len != 0) {
+        const hipError_t e = issue_stage(0, 0);
+        if (e != hipSuccess) st0 = hip_fail(e, "iterator: host-to-device copy");
+    }
+    for (uint64_t k = 0;; ++k) {
+        {   // a free slot (the consumer is at most kIterSlots - 1 windows behind)
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return stop || produced - consumed < static_cast<uint64_t>(kIterSlots); });
+            if (stop) break;
+        }
+        IterWindow &w = win[k % kIterSlots];
+        w.st = DAAC_OK; w.err.clear(); w.n = 0;
+        bool last = false;
+        if (st0 != DAAC_OK) {
+            fail_with(w, st0);
+            last = true;
+        } else {
+            const uint64_t end = std::min<uint64_t>(len, begin + window);
+            const uint8_t *dev_hay = hay;
+            if (per_window_copy) {
+                const uint64_t from = begin > halo ? begin - halo : 0;
+                dev_hay = static_cast<const uint8_t *>(stage[k & 1]) + (from & 15) - from;
+                (void)hipStreamWaitEvent(s_scan, staged_ev[k & 1], 0);
+            }
+            uint64_t next_begin = end;
+            DevMatches dm;
+            dm.f16 = true;
+            daac_status st = DAAC_OK;
+            // the next window's bytes go to the other staging buffer while this window is scanned (its last reader, the scan of
+            // window k - 1, is through; only the overlapping modes come here, and their windows begin where the last one ended)
+            if (per_window_copy && end < len) {
+                const hipError_t e = issue_stage(k + 1, end);
+                if (e != hipSuccess) st = hip_fail(e, "iterator: host-to-device copy");
+            }
+            if (st == DAAC_OK) st = scan_range_device(pma, t, mode, engine, dev_hay, begin, end, len, s_scan, dm, &next_begin);
+            w.engine = g_last_engine;
+            if (st == DAAC_OK && !dm.f16_done && dm.n != 0) {   // an engine that writes daac_match: repacked on the device
+                void *d16 = nullptr;
+                if (dev_malloc(&d16, dm.n * 16, s_scan) != hipSuccess) { st = hip_fail(hipGetLastError(), "iterator: repack buffer"); }
+                else {
+                    hipLaunchKernelGGL(repack16_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>(65535, (dm.n + 255) / 256))), dim3(256), 0, s_scan, dm.p,
+                                       static_cast<uint4 *>(d16), static_cast<unsigned long long>(dm.n));
+                    dev_free(dm.release_keep_n(), s_scan);
+                    dm.p = static_cast<daac_match *>(d16);
+                }
+            }
+            // the list (repacked or not) is complete before another stream copies it, and before the staging buffer is written again
+            if (st == DAAC_OK && hipStreamSynchronize(s_scan) != hipSuccess) st = hip_fail(hipGetLastError(), "iterator: scan");
+            if (st == DAAC_OK && dm.n != 0) {
+                const size_t need = dm.n * sizeof(daac_match16);
+                if (w.host_bytes < need) {
+                    if (w.host) { if (w.host_pinned) pinned_pool().give(w.host, w.host_bytes); else std::free(w.host); }
+                    w.host = nullptr; w.host_bytes = 0;
+                    size_t got = 0;
+                    void *q = pinned_pool().take(need + need / 4, &got);
+                    w.host_pinned = q != nullptr;
+                    if (!q) { q = std::malloc(need); got = need; }
+                    if (!q) { set_error("out of host memory for the match list"); st = DAAC_ERR_AUTOMATON_SCALE; }
+                    w.host = static_cast<daac_match16 *>(q);
+                    w.host_bytes = q ? got : 0;
+                }
+                if (st == DAAC_OK) {
+                    // (the list is complete: s_scan was waited for above) the copy runs beside the next window's scan
+                    hipError_t e = hipMemcpyAsync(w.host, dm.p, need, hipMemcpyDeviceToHost, s_d2h);
+                    if (e == hipSuccess) e = hipEventRecord(w.copied, s_d2h);
+                    if (e != hipSuccess) st = hip_fail(e, "iterator: device-to-host copy");
+                    dm.s = s_d2h;   // released behind the copy
+                    w.n = dm.n;
+                }
+            }
+            if (st != DAAC_OK) { fail_with(w, st); last = true; }
+            begin = next_begin;
+            if (next_begin >= len) last = true;
+        }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            ++produced;
+            if (last) finished = true;
+        }
+        cv.notify_all();
+        if (last) break;
+    }
+    (void)hipStreamSynchronize(s_d2h);
+    (void)hipStreamSynchronize(s_scan);
+    for (int i = 0; i < 2; ++i) { if (stage[i]) (void)hipFree(stage[i]); if (staged_ev[i]) (void)hipEventDestroy(staged_ev[i]); }
+    {
+        std::lock_guard<std::mutex> g(mu);
+        finished = true;
+    }
+    cv.notify_all();
+}
 
 extern "C" {
 
@@ -1886,53 +2069,97 @@ daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *h
     if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
     Plan pl;
     bool heads;
-    if ((st = make_plan(pma, t, mode, engine, 0, len, pl, heads)) != DAAC_OK) return st;  // kind / mode checks up front
-    daac_iter *it = new daac_iter;
+    if ((st = make_plan(pma, t, mode, engine == DAAC_ENGINE_GRAM ? DAAC_ENGINE_AUTO : engine, 0, len, pl, heads)) != DAAC_OK) return st;  // kind / mode checks up front
+    std::unique_ptr<daac_iter> it(new daac_iter);
     it->pma = pma; it->mode = mode; it->engine = engine; it->hay = hay; it->len = len;
     it->hay_is_device = hay_is_device != 0;
-    it->stream = static_cast<hipStream_t>(stream);
+    it->user_stream = static_cast<hipStream_t>(stream);
     it->restart = pl.restart;
+    HIP_TRY(hipGetDevice(&it->device));
     if (it->restart && !it->hay_is_device && len) {
         const uint8_t *virt = nullptr;
-        if ((st = stage_window(hay, 0, len, it->stream, &it->owned_dev, &virt)) != DAAC_OK) { delete it; return st; }
+        if ((st = stage_window(hay, 0, len, it->user_stream, &it->owned_dev, &virt)) != DAAC_OK) return st;
         it->hay = virt;
         it->hay_is_device = true;
     }
-    *out = it;
+    // whatever the caller queued on its stream (a device haystack being written, the staging copy above) comes first
+    HIP_TRY(hipStreamSynchronize(it->user_stream));
+    HIP_TRY(hipStreamCreateWithFlags(&it->s_scan, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&it->s_h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&it->s_d2h, hipStreamNonBlocking));
+    for (IterWindow &w : it->win) HIP_TRY(hipEventCreateWithFlags(&w.copied, hipEventDisableTiming));
+    it->worker = std::thread([p = it.get()] { p->run(); });
+    *out = it.release();
     return DAAC_OK;
+}
+
+// The next window's tuples (blocks until the worker has them); 1 = it->cur / cur_n are set, 0 = exhausted, < 0 = -daac_status
+static int iter_advance(daac_iter *it) {
+    for (;;) {
+        if (it->holding) {   // give the slot back
+            { std::lock_guard<std::mutex> g(it->mu); ++it->consumed; }
+            it->cv.notify_all();
+            it->holding = false;
+            it->cur = nullptr; it->cur_n = 0; it->pos = 0;
+        }
+        {
+            std::unique_lock<std::mutex> g(it->mu);
+            it->cv.wait(g, [&] { return it->produced > it->consumed || it->finished; });
+            if (it->produced == it->consumed) return 0;
+        }
+        IterWindow &w = it->win[it->consumed % kIterSlots];
+        it->holding = true;
+        if (w.st != DAAC_OK) { set_error(w.err); return -static_cast<int>(w.st); }
+        g_last_engine = w.engine;
+        if (w.n == 0) continue;
+        if (hipEventSynchronize(w.copied) != hipSuccess) return -static_cast<int>(hip_fail(hipGetLastError(), "iterator: waiting for the tuples"));
+        it->cur = w.host; it->cur_n = static_cast<size_t>(w.n); it->pos = 0;
+        return 1;
+    }
 }
 
 int daac_iter_next(daac_iter *it, daac_match *m) {
     if (!it || !m) return -DAAC_ERR_INVALID_ARGUMENT;
-    for (;;) {
-        if (it->pos < it->buf.size()) { *m = it->buf.p[it->pos++]; return 1; }
-        if (it->done) return 0;
-        DeviceTables *t = nullptr;
-        daac_status st = get_tables(it->pma, &t);
-        if (st != DAAC_OK) return -st;
-        const uint64_t window = std::max<uint64_t>(4096, static_cast<uint64_t>(g_opt.iter_window.load()));
-        const uint64_t begin = it->next_begin;
-        const uint64_t end = std::min<uint64_t>(it->len, begin + window);
-        const uint64_t halo = it->pma->halo();
-        void *staged = nullptr;
-        const uint8_t *dev_hay = it->hay;
-        if (!it->hay_is_device && end > 0) {
-            const uint64_t from = begin > halo ? begin - halo : 0;
-            if ((st = stage_window(it->hay, from, end, it->stream, &staged, &dev_hay)) != DAAC_OK) return -st;
-        }
-        it->buf.clear();
-        it->pos = 0;
-        uint64_t next_begin = end;
-        st = scan_range_materialize(it->pma, t, it->mode, it->engine, dev_hay, begin, end, it->len, it->stream, it->buf, &next_begin);
-        if (staged) (void)hipFree(staged);
-        if (st != DAAC_OK) return -st;
-        it->next_begin = next_begin;
-        if (next_begin >= it->len) it->done = true;
+    if (it->pos >= it->cur_n) {
+        const int r = iter_advance(it);
+        if (r <= 0) return r;
     }
+    const daac_match16 &t = it->cur[it->pos++];
+    m->start = t.end - t.length; m->end = t.end; m->value = t.value; m->_pad = 0;
+    return 1;
+}
+
+int daac_iter_next_batch(daac_iter *it, const daac_match16 **batch, size_t *n) {
+    if (!it || !batch || !n) return -DAAC_ERR_INVALID_ARGUMENT;
+    if (it->pos >= it->cur_n) {
+        const int r = iter_advance(it);
+        if (r <= 0) { *batch = nullptr; *n = 0; return r; }
+    }
+    *batch = it->cur + it->pos;
+    *n = it->cur_n - it->pos;
+    it->pos = it->cur_n;
+    return 1;
 }
 
 void daac_iter_close(daac_iter *it) {
-    if (it && it->owned_dev) (void)hipFree(it->owned_dev);
+    if (!it) return;
+    {
+        std::lock_guard<std::mutex> g(it->mu);
+        it->stop = true;
+    }
+    it->cv.notify_all();
+    if (it->worker.joinable()) it->worker.join();
+    int prev = 0;
+    const bool switched = hipGetDevice(&prev) == hipSuccess && prev != it->device && hipSetDevice(it->device) == hipSuccess;
+    for (IterWindow &w : it->win) {
+        if (w.host) { if (w.host_pinned) pinned_pool().give(w.host, w.host_bytes); else std::free(w.host); }
+        if (w.copied) (void)hipEventDestroy(w.copied);
+    }
+    if (it->s_scan) (void)hipStreamDestroy(it->s_scan);
+    if (it->s_h2d) (void)hipStreamDestroy(it->s_h2d);
+    if (it->s_d2h) (void)hipStreamDestroy(it->s_d2h);
+    if (it->owned_dev) (void)hipFree(it->owned_dev);
+    if (switched) (void)hipSetDevice(prev);
     delete it;
 }
 
@@ -1994,7 +2221,8 @@ daac_status daac_stream_open(daac_pma *pma, int mode, int engine, void *stream, 
     }
     daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
-    if (pma->charwise ? (engine != DAAC_ENGINE_AUTO && engine != DAAC_ENGINE_DARRAY) : engine == DAAC_ENGINE_GRAM) {
+    if (pma->charwise ? (engine != DAAC_ENGINE_AUTO && engine != DAAC_ENGINE_DARRAY)
+                      : (engine != DAAC_ENGINE_AUTO && engine != DAAC_ENGINE_TIERED && engine != DAAC_ENGINE_DARRAY)) {
         set_error("engine cannot serve a stepper");
         return DAAC_ERR_UNSUPPORTED;
     }
@@ -2089,12 +2317,13 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
     else if (n == "gram3_tail") g_opt.gram3_tail = value;
     else if (n == "pfx") g_opt.pfx = value;
-    else if (n == "jump") g_opt.jump = value;
     else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles") g_opt.emit_tiles = value;
     else if (n == "emit_rec_cap") g_opt.emit_rec_cap = value;
     else if (n == "emit_version") g_opt.emit_version = value;
+    else if (n == "emit_stagger") g_opt.emit_stagger = value;
+    else if (n == "emit_v3_lds") g_opt.emit_v3_lds = value;
     else if (n == "emit_rec_per_kib") g_opt.emit_rec_per_kib = value;
     else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
     else if (n == "restart_chain") g_opt.restart_chain = value;

@@ -76,31 +76,8 @@ struct ScanArgs {
     unsigned long long *flags;       // optional, 1 x u64: bit 0 = the reference would not terminate on this input
 };
 
-// JUMP engine (jump.hpp, jump_kernels.hip): find_iter of a Standard bytewise automaton over per-position jump tables
-struct JumpDev {
-    const uint8_t *cls;       // 256
-    const uint32_t *ms;       // C^3 words (padded to a multiple of 4): shortest short pattern << 30 | continuation bits
-    const uint32_t *sdir;     // per 4 words: continuation bits set before the group
-    const uint4 *jhit;        // depth-4 states by rank {cmap | own, first_child, own h32, depth}
-    const uint4 *jrec;        // every state, breadth-first
-    const uint32_t *h1, *h2, *h3;  // h32 of the first-registered pattern that IS the 1- / 2- / 3-gram
-    uint32_t C, ms_bytes, sdir_bytes, max_len, unused_byte;
-};
-struct JumpArgs {
-    const uint8_t *hay_al;    // 16-byte aligned address at or before the first byte of the scanned range
-    uint32_t lead;            // bytes between hay_al and that byte (0..15)
-    uint64_t vlen;            // lead + length of the range ("virtual" positions count from hay_al)
-    uint8_t *lsh;             // LSH[i] = L(i - 2): at least nsteps * 1024 (pass A writes whole KiB) and nd_chunks * 1792 + 2048 bytes
-    uint16_t *nd;             // ND[i] = N(i - 2) | D(i - 2) << 8: nd_chunks * 1792 entries
-    uint32_t *hdeep;          // HDEEP[i]: h32 of the pattern found by a walk from start i - 2
-    uint64_t nsteps;          // KiB of pass A
-    uint64_t nd_chunks;       // chunks of 1792 positions of pass B
-};
-uint32_t jump_len_lds_bytes(const JumpDev &g);
-hipError_t launch_jump_tables(const JumpDev &g, const JumpArgs &a, uint32_t num_cu, hipStream_t stream);
 struct ScanArgs;
 struct ChainArgs;
-hipError_t launch_jump_chain(const JumpDev &g, const JumpArgs &ja, const ScanArgs &a, const ChainArgs &c, int pass, uint32_t blocks, hipStream_t stream);
 
 // Passes of the restart scanners in their speculate / reconcile / emit form (chain_scan.hpp)
 struct ChainArgs {
@@ -209,6 +186,11 @@ struct Gram2EmitDev {
     uint32_t m_bytes, s_bytes, v1_bytes, v2_bytes;
     uint32_t off_s, off_v1, off_v2, off_ring, off_wave, lds_bytes;
     uint32_t K, C, s16, unused_byte;
+    // emit3 EXPAND: the values of the 3-byte patterns as a rank structure small enough for LDS (a membership bit per 3-gram, a popcount
+    // directory per 32 bits, the values in rank order) — the 4 C^3-byte table v3 lives in L2, and a gather per 3-byte match ran at the
+    // L2's ~120 G requests/s (profiles/r04_emit3_experiments.txt).  Null when K = 2 or the structure is too large.
+    const uint32_t *v3c;      // [bitmap words | directory (u16 per word, padded to 4 bytes) | values]
+    uint32_t v3c_bytes, v3c_dir, v3c_val;   // size of the whole (multiple of 16), byte offsets of directory and values
 };
 struct EmitArgs {
     const uint8_t *hay_al;        // window address rounded down to 16 bytes ("virtual" positions count from here)
@@ -246,7 +228,11 @@ hipError_t launch_gram3_scan(const Gram2Dev &dev, const GramArgs &a, const Gram3
 constexpr uint32_t kEmit3Tile = 1024;        // positions per tile (one wave-step of EXPAND; half a wave-step of DETECT)
 constexpr uint32_t kEmit3Chunk = 1024;       // records per chunk of the list (a wave owns one open chunk at a time)
 constexpr uint32_t kEmit3MaxExtras = 64;     // records per tile the per-position length bits cannot carry (as gram2_emit_kernels.hip)
-constexpr uint32_t kEmit3ExpandWave = 1040 + 4096 + 2048 + kEmit3MaxExtras * 16 + 16;  // EXPAND, per wave: stream | length bits | slot of each position | extras | counter
+constexpr uint32_t kEmit3Stage = 960;        // EXPAND: staged tuples per wave and pass (a tile of more tuples takes several passes)
+// EXPAND, per wave: staged tuples + one dump entry per lane | length bits | first slot per lane | flag bytes per lane | extras | counter
+constexpr uint32_t kEmit3ExpandWave = (kEmit3Stage + 64) * 8 + 2048 + 256 + 1024 + kEmit3MaxExtras * 16 + 16;
+// ... of the 16-byte format: u16 entries + the tile's stream bytes | length bits | first slot per lane | flag bytes per lane | extras | counter
+constexpr uint32_t kEmit3ExpandWave16 = (kEmit3Stage + 64) * 2 + 1040 + 2048 + 256 + 1024 + kEmit3MaxExtras * 16 + 16;
 struct Emit3Args {
     const uint8_t *hay_al;        // window address rounded down to 16 bytes ("virtual" positions count from here)
     uint32_t lead;                // bytes between hay_al and the first byte of the window
@@ -275,6 +261,9 @@ struct Expand3Args {
     void *out;                           // daac_match (24 bytes) or {end u64, length u32, value u32} (16 bytes) tuples
     unsigned long long pos_base;         // end (haystack coordinates) of a match whose last byte is at virtual position v = pos_base + v
     uint32_t off_wave;                   // LDS: V1 at 0, V2 behind it, the per-wave areas from here
+    uint32_t has_len1;                   // the dictionary has one-byte patterns
+    uint32_t stagger;                    // start delay per wave of a CU, in units of 1024 cycles x (wave number mod 16)
+    uint32_t v3_in_lds;                  // the rank structure of the 3-byte patterns' values is staged behind V2 (else they are read from L2)
     unsigned int *fail;                  // bit 2: more extras in one tile than EXPAND places; bit 3: a slot outside its tile (a bug)
 };
 bool emit3_plan(const Gram2EmitDev &dev, uint32_t waves, uint32_t lds_limit, Gram3Lds &L);
@@ -284,7 +273,7 @@ hipError_t launch_emit3_combine(const uint32_t *tile_short, const uint32_t *tile
 hipError_t launch_emit3_bin(const uint4 *recs, const uint32_t *chunk_fill, const uint32_t *chunk_next, uint32_t chunk_cap, const unsigned long long *bin_off,
                             uint32_t *cursor, uint4 *binned, uint32_t blocks, hipStream_t stream);
 hipError_t launch_emit3_expand(const Gram2EmitDev &dev, const Expand3Args &a, bool f16, uint32_t blocks, hipStream_t stream);
-uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves);
+uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves, bool f16, bool v3_in_lds);
 
 // PFX engine (pfx.hpp): `.count()` for bytewise automata over any byte alphabet.  LDS: BLOOM at 0 | DISP | CNT1 | per-wave areas
 struct PfxDev {

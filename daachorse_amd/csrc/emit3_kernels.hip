@@ -74,7 +74,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan_x(uint32_t x) {
 template <bool F16>
 __device__ __forceinline__ void put_tuple_x(void *out, unsigned long long slot, unsigned long long end, uint32_t len, uint32_t value) {
 #ifdef E3X_NO_STORES
-    if (len != 0xdeadbeefu) return;
+    {   // everything but the store itself (timing only)
+        asm volatile("" ::"v"(static_cast<uint32_t>(end)), "v"(static_cast<uint32_t>(end >> 32)), "v"(len), "v"(value), "v"(static_cast<uint32_t>(slot)));
+        return;
+    }
 #endif
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -137,35 +140,37 @@ __global__ __launch_bounds__(1024) void emit3_detect_kernel(const Gram2EmitDev g
     };
     // (wave-uniform places only) the open chunk is closed once it is half full: whatever is logged before the next checkpoint then fits
     auto rec_checkpoint = [&]() {
-        const uint32_t n = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(cursor));
+        const uint32_t n = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile ldsx_u32 *>(static_cast<uintptr_t>(tb)));
         if (n > kEmit3Chunk / 2u) {
             if (lane == 0) {
                 if (chunk_ok) a.chunk_fill[chunk] = n < kEmit3Chunk ? n : kEmit3Chunk;
-                *reinterpret_cast<volatile uint32_t *>(cursor) = 0u;
+                *reinterpret_cast<volatile ldsx_u32 *>(static_cast<uintptr_t>(tb)) = 0u;
             }
             take_chunk();
         }
     };
-    if (lane == 0) *reinterpret_cast<volatile uint32_t *>(cursor) = 0u;
+    if (lane == 0) *reinterpret_cast<volatile ldsx_u32 *>(static_cast<uintptr_t>(tb)) = 0u;
     take_chunk();
 
     // a deep match: `p` = virtual position of its last byte, `len` its length; `copy` > 0: a further copy of a pattern registered more than once
-    auto log_deep = [&](uint32_t p, uint32_t len, uint32_t value, uint32_t copy) {
+    // `counted`: the caller has added the match to its tile's count already (one atomic per tile and batch instead of one per match:
+    // device-scope atomics run at ~15 G/s on this chip whatever their addresses, profiles/r04_emit3_experiments.txt)
+    auto log_deep = [&](uint32_t p, uint32_t len, uint32_t value, uint32_t copy, bool counted) {
         if (p < a.emit_from) return;
 #ifdef E3X_NO_REC
         return;
 #endif
         const uint32_t slot = atomicAdd(cursor, 1u);
-        atomicAdd(&a.tile_deep[p >> 10], 1u);
+        if (!counted) atomicAdd(&a.tile_deep[p >> 10], 1u);
         if (slot >= kEmit3Chunk) { atomicOr(a.fail, 2u); return; }
         if (chunk_ok) a.recs[static_cast<uint64_t>(chunk) * kEmit3Chunk + slot] = uint4{p, len | (copy << 24), value, a.tile0 + (p >> 10)};
     };
     // a state that ends a pattern: its own match, then the further copies of a duplicate (erec.w / ehit4.w: count << 24)
-    auto log_state = [&](uint32_t p, uint32_t len, uint32_t value, uint32_t ncopies, uint32_t state) {
-        log_deep(p, len, value, 0u);
+    auto log_state = [&](uint32_t p, uint32_t len, uint32_t value, uint32_t ncopies, uint32_t state, bool counted) {
+        log_deep(p, len, value, 0u, counted);
         if (ncopies != 0) {
             const uint32_t off = g.dupo[state];
-            for (uint32_t k = 0; k < ncopies; ++k) log_deep(p, len, g.dupv[off + k], k + 1u);
+            for (uint32_t k = 0; k < ncopies; ++k) log_deep(p, len, g.dupv[off + k], k + 1u, false);
         }
     };
 
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(1024) void emit3_detect_kernel(const Gram2EmitDev g
                 unsigned long long ahead = 0;
                 uint32_t n_ahead = 0;
                 for (;;) {
-                    if (r.x & 1u) log_state(vnext - 1u, r.w & 0xffffffu, r.z, r.w >> 24, state);
+                    if (r.x & 1u) log_state(vnext - 1u, r.w & 0xffffffu, r.z, r.w >> 24, state, false);
                     if (((r.x >> kn) & 1u) == 0 || kn == 0) break;
                     state = r.y + __popc(r.x & ((1u << kn) - 2u));
                     r = g.erec[state];
@@ -233,11 +238,36 @@ __global__ __launch_bounds__(1024) void emit3_detect_kernel(const Gram2EmitDev g
                                          // {cmap | own, own_value, first_child, further copies << 24}
     uint32_t pend_pos = 0, pend_k = 0, pend_rank = 0;  // position of the hit byte; classes of the two bytes behind it (k1 | k2 << 8); rank of the hit's state
     bool pend_valid = false;           // wave-uniform
+    uint32_t acc_tile = 0xffffffffu, acc_cnt = 0;   // (lanes 0 .. 3: see consume_pending)
     auto consume_pending = [&]() {
         if (!pend_valid) return;
         pend_valid = false;
         const uint4 r = pend;
-        if (r.x & 1u) log_state(pend_pos, K + 1, r.y, r.w >> 24, g.level_start + pend_rank);
+        {   // the batch's own matches: counted per tile by one lane each (a batch comes from one or two steps: a handful of tiles)
+            const bool own = (r.x & 1u) != 0 && pend_pos >= a.emit_from;
+            const uint32_t my_tile = pend_pos >> 10;
+            unsigned long long om = __ballot(own);
+#ifdef E3X_NO_REC
+            om = 0;
+#endif
+            while (om != 0) {
+                const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(om));
+                const uint32_t t0 = __builtin_amdgcn_readlane(my_tile, leader);
+                const unsigned long long same = __ballot(own && my_tile == t0);
+                // lanes 0 .. 3 of acc_tile / acc_cnt are a direct-mapped cache of tile counts (a step's batches keep hitting the same two
+                // or three tiles): the count goes to memory when another tile takes the entry — one atomic per tile and step, not per batch
+                if (lane == (t0 & 3u)) {
+                    if (acc_tile != t0) {
+                        if (acc_cnt != 0) atomicAdd(&a.tile_deep[acc_tile], acc_cnt);
+                        acc_tile = t0;
+                        acc_cnt = 0;
+                    }
+                    acc_cnt += static_cast<uint32_t>(__popcll(same));
+                }
+                om &= ~same;
+            }
+        }
+        if (r.x & 1u) log_state(pend_pos, K + 1, r.y, r.w >> 24, g.level_start + pend_rank, true);
         const uint32_t k1 = pend_k & 0xffu;  // (class 0: bit 0 is not an edge)
         const bool go = k1 != 0 && ((r.x >> k1) & 1u);
         const unsigned long long m = __ballot(go);
@@ -455,8 +485,9 @@ __global__ __launch_bounds__(1024) void emit3_detect_kernel(const Gram2EmitDev g
     rec_checkpoint();
     consume_pending();
     drain();
+    if (lane < 4u && acc_cnt != 0) atomicAdd(&a.tile_deep[acc_tile], acc_cnt);
     {   // close the open chunk
-        const uint32_t n = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(cursor));
+        const uint32_t n = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile ldsx_u32 *>(static_cast<uintptr_t>(tb)));
         if (lane == 0 && chunk_ok) a.chunk_fill[chunk] = n < kEmit3Chunk ? n : kEmit3Chunk;
     }
 }
@@ -470,182 +501,456 @@ __global__ __launch_bounds__(256) void emit3_combine_kernel(const uint32_t *__re
         deep[i] = d;
     }
 }
-// records -> the bin of the tile they end in; `cursor` = the per-tile record counts, counted down
+// records -> the bin of the tile they end in; `cursor` = the per-tile record counts, counted down.  A chunk holds one wave's records
+// in the order it met them: runs of the same tile, for which one lane takes the slots of the whole run (one atomic per run).
 __global__ __launch_bounds__(256) void emit3_bin_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__ chunk_fill, const uint32_t *__restrict__ chunk_next,
                                                         uint32_t chunk_cap, const unsigned long long *__restrict__ bin_off, uint32_t *__restrict__ cursor,
                                                         uint4 *__restrict__ binned) {
     const uint32_t used = *chunk_next < chunk_cap ? *chunk_next : chunk_cap;
+    const uint32_t lane = threadIdx.x & 63;
     for (uint32_t c = blockIdx.x; c < used; c += gridDim.x) {
         const uint32_t fill = chunk_fill[c];
-        for (uint32_t i = threadIdx.x; i < fill; i += blockDim.x) {
-            const uint4 r = recs[static_cast<uint64_t>(c) * kEmit3Chunk + i];
-            const uint32_t k = atomicSub(&cursor[r.w], 1u) - 1u;
-            binned[bin_off[r.w] + k] = r;
+        for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < fill; i0 += blockDim.x) {   // (wave-uniform bounds)
+            const uint32_t i = i0 + lane;
+            const bool valid = i < fill;
+            uint4 r = uint4{0u, 0u, 0u, 0xffffffffu};
+            if (valid) r = recs[static_cast<uint64_t>(c) * kEmit3Chunk + i];
+            const uint32_t prev = __shfl_up(r.w, 1, 64);
+            const bool head = valid && (lane == 0 || r.w != prev);
+            const unsigned long long hm = __ballot(head), vm = __ballot(valid);
+            const uint32_t nvalid = static_cast<uint32_t>(__popcll(vm));   // valid lanes are 0 .. nvalid - 1
+            const unsigned long long at_or_below = hm & (~0ull >> (63u - lane));
+            const uint32_t start = at_or_below ? 63u - static_cast<uint32_t>(__builtin_clzll(at_or_below)) : 0u;
+            const unsigned long long above = lane < 63u ? hm & (~0ull << (lane + 1u)) : 0ull;
+            const uint32_t next = above ? static_cast<uint32_t>(__builtin_ctzll(above)) : nvalid;
+            uint32_t base = 0;
+            if (head) base = atomicSub(&cursor[r.w], next - lane) - (next - lane);
+            base = __shfl(base, start, 64);
+            if (valid) binned[bin_off[r.w] + base + (lane - start)] = r;
         }
     }
 }
 
 // ================================================================================================================ EXPAND
-// One wave per tile of 1024 positions.  LDS per workgroup: V1 | V2 | per wave {16 + 1024 stream bytes, 1024 x u32 length bits | extras << 16,
-// 1024 x u16 first slot of the position, 64 extras, counter}.
-template <int K, bool F16>
-__global__ __launch_bounds__(256) void emit3_expand_kernel(const Gram2EmitDev g, const Expand3Args a) {
+// One wave per tile of 1024 positions; lane l owns the 16 consecutive positions 16 l .. 16 l + 15 (one 16-byte load of the stream).
+// LDS per workgroup: V1 | V2 | per wave {1024 staged tuples, 1024 x u16 length bits of the deep matches, per lane its first slot and its
+// flag bytes, 64 extras, counter}.
+//
+// Why the tuples go through LDS (profiles/r04_emit3_experiments.txt): a store instruction whose active lanes write 16 bytes each to slots
+// that are merely NEAR each other is not merged by the memory pipeline — a version that stored straight from a column-transposed loop
+// (lane = position, one wave scan per 64 positions) spent 4.4 of its 6.0 ms per GiB in those stores, no better than the 64 lines per
+// instruction of gram2_emit_kernels.hip.  Here every tuple of the tile is STAGED as {value, position | length << 10} at its slot
+// (ds_write_b64) — the short ones by the lane that owns the position, walking its 16 positions with a running slot, the deep ones by the
+// lane that holds the record — and the tile is then copied out 64 CONSECUTIVE slots per store instruction: one contiguous kilobyte.
+// A tile of more than 1024 tuples (dozens of deep matches per position) takes several passes over a window of slots.
+// HAS1: the dictionary has one-byte patterns (else that flag bit is never set and the walk leaves it out)
+template <int K, bool F16, bool HAS1>
+__global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gram2EmitDev g, const Expand3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     e3_copy(smem, g.v1, g.v1_bytes);
     e3_copy(smem + g.v1_bytes, g.v2, g.v2_bytes);
+    if (a.v3_in_lds) e3_copy(smem + g.v1_bytes + g.v2_bytes, g.v3c, g.v3c_bytes);
     __syncthreads();
     const uint32_t *v1 = reinterpret_cast<const uint32_t *>(smem);
     const uint32_t *v2 = reinterpret_cast<const uint32_t *>(smem + g.v1_bytes);
+    const uint32_t *v3bm = reinterpret_cast<const uint32_t *>(smem + g.v1_bytes + g.v2_bytes);
+    const uint16_t *v3dir = reinterpret_cast<const uint16_t *>(smem + g.v1_bytes + g.v2_bytes + g.v3c_dir);
+    const uint32_t *v3val = reinterpret_cast<const uint32_t *>(smem + g.v1_bytes + g.v2_bytes + g.v3c_val);
+    const bool v3l = a.v3_in_lds != 0;   // wave-uniform
+    // value of the 3-byte pattern that is the 3-gram `idx` (the caller knows it is one)
+    auto v3_of = [&](uint32_t idx) -> uint32_t {
+        if (v3l) {
+            const uint32_t w = v3bm[idx >> 5];
+            return v3val[v3dir[idx >> 5] + __popc(w & ((1u << (idx & 31u)) - 1u))];
+        }
+        return g.v3[idx];
+    };
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
     const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
     const uint32_t C = g.C, CC = g.C * g.C;
-    char *wl = smem + a.off_wave + wave_in_wg * kEmit3ExpandWave;
-    uint8_t *annb = reinterpret_cast<uint8_t *>(wl);                    // [0,16) the 16 bytes before the tile | the tile
-    uint32_t *dmx = reinterpret_cast<uint32_t *>(wl + 1040);            // per position: bit (len - K - 1) per deep match | extras << 16
-    uint16_t *posoff = reinterpret_cast<uint16_t *>(wl + 1040 + 4096);  // per position: tile-relative slot of its first tuple
-    uint4 *xs = reinterpret_cast<uint4 *>(wl + 1040 + 4096 + 2048);     // the tile's extras {position in tile, length | copy << 24, value, -}
-    uint32_t *ctr = reinterpret_cast<uint32_t *>(wl + 1040 + 4096 + 2048 + kEmit3MaxExtras * 16);
-    bool dirty = true;  // wave-uniform: dmx holds bits of the previous tile
+    constexpr uint32_t W = kEmit3Stage;   // slots per pass
+    // F24: W staged tuples of 8 bytes.  F16: W u16 entries {position | length << 10} and the tile's 16 + 1024 stream bytes (the values are
+    // looked up when the tile goes out).  Then one dump entry per lane (what a lane has NOT got to write goes there: no branch).
+    constexpr uint32_t SW = F16 ? (W + 64u) * 2u + 1040u : (W + 64u) * 8u;
+    constexpr uint32_t WAVE_BYTES = F16 ? kEmit3ExpandWave16 : kEmit3ExpandWave;
+    char *wl = smem + a.off_wave + wave_in_wg * WAVE_BYTES;
+    uint2 *stage = reinterpret_cast<uint2 *>(wl);                               // F24: W x {value, position in tile | length << 10}
+    uint16_t *stage16 = reinterpret_cast<uint16_t *>(wl);                       // F16: W x {position in tile | length << 10} (0: a deep match's slot)
+    uint8_t *annb = reinterpret_cast<uint8_t *>(wl + (W + 64u) * 2u);           // F16: [0,16) the stream bytes before the tile | the tile
+    uint32_t *dm32 = reinterpret_cast<uint32_t *>(wl + SW);                     // per position a u16: bit (len - K - 1) per deep match
+    uint16_t *dm16 = reinterpret_cast<uint16_t *>(wl + SW);
+    uint32_t *lbase = reinterpret_cast<uint32_t *>(wl + SW + 2048);             // per lane: tile-relative slot of its first tuple
+    uint4 *lflags = reinterpret_cast<uint4 *>(wl + SW + 2048 + 256);            // per lane: the flag bits of its 16 stream bytes
+    uint4 *xs = reinterpret_cast<uint4 *>(wl + SW + 2048 + 256 + 1024);         // the tile's extras {position in tile, length | copy << 24, value, -}
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(wl + SW + 2048 + 256 + 1024 + kEmit3MaxExtras * 16);
+    const uint32_t dump = W + lane;
+    bool dirty = true;  // wave-uniform: dm holds bits of the previous tile
 
-    for (uint32_t t = wave_global; t < a.ntiles; t += nwaves) {
+    // A tile's inputs are asked for one tile ahead (at the top of the tile before it), and everything a tile reads has arrived before its
+    // first tuple is stored: loads retire in order with the stores, and a wave that waited for its next stream bytes behind ten kilobytes
+    // of its own stores spent most of a tile's 14 us waiting (profiles/r04_emit3_experiments.txt).
+    struct TileIn { uint4 annq; uint32_t prev2; unsigned long long tile_base, tile_end, bin0, bin1; };
+    auto ask = [&](uint32_t t) -> TileIn {   // (no branches: a request under a condition is copied, and waited for, where the branches meet)
+        TileIn x;
+        t = t < a.ntiles ? t : a.ntiles - 1u;
         const uint32_t v0 = t * kEmit3Tile;
-        {
-            const uint4 ch = *reinterpret_cast<const uint4 *>(a.ann + v0 + lane * 16u);
-            *reinterpret_cast<uint4 *>(annb + 16u + lane * 16u) = ch;
-            if (lane == 0) *reinterpret_cast<uint4 *>(annb) = t > 0 ? *reinterpret_cast<const uint4 *>(a.ann + v0 - 16u) : uint4{0u, 0u, 0u, 0u};
-        }
-        const unsigned long long tile_base = a.tile_off[t];
-        const uint32_t tile_n = static_cast<uint32_t>(a.tile_off[t + 1] - tile_base);
-        const unsigned long long bin0 = a.bin_off[t];
-        const uint32_t n = static_cast<uint32_t>(a.bin_off[t + 1] - bin0);   // wave-uniform
+        x.annq = *reinterpret_cast<const uint4 *>(a.ann + v0 + lane * 16u);
+        x.prev2 = *reinterpret_cast<const uint16_t *>(a.ann + (v0 != 0 ? v0 - 2u : 0u));   // the two stream bytes before the tile (tile 0: not used)
+        x.tile_base = a.tile_off[t]; x.tile_end = a.tile_off[t + 1];
+        x.bin0 = a.bin_off[t]; x.bin1 = a.bin_off[t + 1];
+        return x;
+    };
+    const uint32_t ctr_at = a.off_wave + wave_in_wg * WAVE_BYTES + SW + 2048 + 256 + 1024 + kEmit3MaxExtras * 16;   // LDS address of `ctr`
+    // (two named sets of input registers, the loop unrolled by hand: with one set the compiler copied the freshly requested registers
+    // at the loop's edge and waited for the request there)
+    auto do_tile = [&](const uint32_t t, const TileIn &in, TileIn &nxt) {
+        const uint32_t v0 = t * kEmit3Tile;
+        const uint4 annq = in.annq;
+        const uint32_t prev2 = t > 0 ? in.prev2 : 0u;
+        const unsigned long long tile_base = in.tile_base;
+        const uint32_t tile_n = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(in.tile_end - tile_base));   // wave-uniform
+        const unsigned long long bin0 = in.bin0;
+        const uint32_t n = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(in.bin1 - bin0));   // wave-uniform
         const bool deep = n != 0;
-        if (tile_n == 0) continue;
-        void *__restrict__ out = reinterpret_cast<char *>(a.out) + tile_base * (F16 ? 16ull : 24ull);
+        // this tile's first 64 records are asked for BEFORE the next tile's inputs: loads come back in the order they went out
+        const uint4 rec0 = a.binned[bin0 + (lane < n ? lane : 0u)];   // (the list ends with one spare record: n may be 0 at its very end)
+        asm volatile("" ::: "memory");   // (keeps the two requests in this order)
+        nxt = ask(t + nwaves);
+        if (tile_n == 0) { __builtin_amdgcn_s_waitcnt(0x0f70); return; }
+        char *__restrict__ out = reinterpret_cast<char *>(a.out) + tile_base * (F16 ? 16ull : 24ull);
+        const unsigned long long end0 = a.pos_base + v0;   // end of a match whose last byte is the tile's position 0
+        const uint32_t aw[4] = {annq.x, annq.y, annq.z, annq.w};
+        // classes of positions -2 .. 15 of this lane (5 bits each), flags of positions 0 .. 15 (3 bits each)
+        const uint32_t left = wave_shr1_x(annq.w >> 16, prev2);
+        if (F16) {
+            *reinterpret_cast<uint4 *>(annb + 16u + lane * 16u) = annq;
+            if (lane == 0) *reinterpret_cast<uint16_t *>(annb + 14u) = static_cast<uint16_t>(prev2);
+        }
+        auto cls_at = [&](int j) -> uint32_t {   // j = -2 .. 15
+            return j < 0 ? (left >> (8 * (j + 2))) & 31u : (aw[j >> 2] >> (8 * (j & 3))) & 31u;
+        };
+        auto flags_at = [&](int j) -> uint32_t { return (aw[j >> 2] >> (8 * (j & 3) + 5)) & 7u; };
 
-        // ---- the tile's deep matches: a length bit per position; extras counted and listed ----
+        // ---- the tile's deep matches: a length bit per position; extras listed ----
         uint32_t xn = 0;
         if (deep || dirty) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) reinterpret_cast<uint4 *>(dmx)[lane + 64 * q] = uint4{0u, 0u, 0u, 0u};
+            for (int q = 0; q < 2; ++q) reinterpret_cast<uint4 *>(dm32)[lane + 64 * q] = uint4{0u, 0u, 0u, 0u};
         }
         dirty = deep;
+        uint4 ex = uint4{0xffffffffu, 0u, 0u, 0u};   // this lane's extra
         if (deep) {
-            if (lane == 0) *reinterpret_cast<volatile uint32_t *>(ctr) = 0u;
+            if (lane == 0) *reinterpret_cast<ldsx_u32 *>(static_cast<uintptr_t>(ctr_at)) = 0u;
             for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
                 const uint32_t i = i0 + lane;
                 if (i < n) {
-                    const uint4 r = a.binned[bin0 + i];
+                    const uint4 r = i0 == 0 ? rec0 : a.binned[bin0 + i];
                     const uint32_t p = (r.x - v0) & (kEmit3Tile - 1u), len = r.y & 0xffffffu, copy = r.y >> 24, lb = len - (K + 1);
                     if (lb < 16u && copy == 0u) {
-                        atomicOr(&dmx[p], 1u << lb);
+                        atomicOr(&dm32[p >> 1], 1u << (lb + 16u * (p & 1u)));
                     } else {
-                        atomicAdd(&dmx[p], 1u << 16);
                         const uint32_t idx = atomicAdd(ctr, 1u);
                         if (idx < kEmit3MaxExtras) xs[idx] = uint4{p, r.y, r.z, 0u};
                     }
                 }
             }
-            xn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(ctr));
+            xn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile ldsx_u32 *>(static_cast<uintptr_t>(ctr_at)));
             if (xn > kEmit3MaxExtras) {   // left to the other engines (the caller looks at the flag before it hands anything out)
                 if (lane == 0) atomicOr(a.fail, 4u);
-                continue;
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                return;
             }
-        }
-
-        // ---- column i: lane l looks at position 64 i + l ----
-        // (the values of the 3-byte patterns come from L2: all sixteen columns' requests go out before the first column is placed —
-        // asked for column by column, every column waited for its own round trip)
-        constexpr uint32_t NCOL = kEmit3Tile / 64u;
-        uint32_t w01[NCOL], val3[NCOL];
-#pragma unroll
-        for (uint32_t i = 0; i < NCOL; ++i) {
-            const uint32_t p = 64u * i + lane;
-            const uint32_t b0 = annb[16u + p], b1 = annb[15u + p];
-            w01[i] = b0 | (b1 << 8);
-            val3[i] = 0;
-#ifndef E3X_NO_V3
-            if (K == 3 && (b0 & 0x80u)) val3[i] = g.v3[(annb[14u + p] & 31u) * CC + (b1 & 31u) * C + (b0 & 31u)];
-#endif
-        }
-        uint32_t colbase = 0;   // wave-uniform: tuples of the columns before
-#pragma unroll
-        for (uint32_t i = 0; i < NCOL; ++i) {
-            const uint32_t p = 64u * i + lane;
-            const uint32_t b0 = w01[i] & 0xffu, b1 = w01[i] >> 8;
-            const uint32_t f = b0 >> 5;
-            const uint32_t d = deep ? dmx[p] : 0u;
-            const uint32_t nd = __popc(d & 0xffffu) + (d >> 16);
-            const uint32_t c = __popc(f) + nd;
-            const uint32_t incl = wave_incl_scan_x(c);
-            const uint32_t slot0 = colbase + incl - c;
-            colbase += __builtin_amdgcn_readlane(incl, 63);
-            if (deep) posoff[p] = static_cast<uint16_t>(slot0);
-            uint32_t s = slot0 + nd;   // the short ones follow the deep ones, longest first
-#ifdef E3X_DENSE_STORES
-            s = 40u * i + lane / 2u;
-#endif
-            const unsigned long long end = a.pos_base + v0 + p;
-            if (K == 3 && __ballot((f & 4u) != 0) != 0) {
-                if ((f & 4u) && s < tile_n) put_tuple_x<F16>(out, s, end, 3u, val3[i]);
-                s += (f >> 2) & 1u;
-            }
-            if (__ballot((f & 2u) != 0) != 0) {
-                if ((f & 2u) && s < tile_n) put_tuple_x<F16>(out, s, end, 2u, v2[(b1 & 31u) * C + (b0 & 31u)]);
-                s += (f >> 1) & 1u;
-            }
-            if (__ballot((f & 1u) != 0) != 0) {
-                if ((f & 1u) && s < tile_n) put_tuple_x<F16>(out, s, end, 1u, v1[b0 & 31u]);
-                s += f & 1u;
-            }
-            if (s > tile_n) atomicOr(a.fail, 8u);
-        }
-
-        // ---- the deep matches into their slots: first slot of the position + the longer ones at the same position ----
-        if (deep) {
-            uint4 ex = uint4{0xffffffffu, 0u, 0u, 0u};
             if (lane < xn) ex = xs[lane];
-            // extras at position p that sort before the key (length descending, copy ascending); all lanes walk the list together
-            auto extras_before = [&](uint32_t p, uint32_t len, uint32_t copy) -> uint32_t {
-                uint32_t cnt = 0;
-                for (uint32_t k = 0; k < xn; ++k) {
-                    const uint32_t ep = __builtin_amdgcn_readlane(ex.x, k), ey = __builtin_amdgcn_readlane(ex.y, k);
-                    const uint32_t el = ey & 0xffffffu, ec = ey >> 24;
-                    cnt += (ep == p && (el > len || (el == len && ec < copy))) ? 1u : 0u;
-                }
-                return cnt;
-            };
-            for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
-                const uint32_t i = i0 + lane;
-                uint4 r = uint4{0u, 0u, 0u, 0u};
-                if (i < n) r = a.binned[bin0 + i];
-                const uint32_t p = (r.x - v0) & (kEmit3Tile - 1u), len = r.y & 0xffffffu, copy = r.y >> 24, lb = len - (K + 1);
-                const bool normal = i < n && lb < 16u && copy == 0u;
-                uint32_t slot = 0;
-                if (normal) slot = posoff[p] + __popc((dmx[p] & 0xffffu) >> (lb + 1u));
-                if (xn != 0) slot += extras_before(normal ? p : 0xfffffffeu, len, 0u);
-                if (normal) {
-                    if (slot < tile_n) put_tuple_x<F16>(out, slot, a.pos_base + r.x, len, r.z);
-                    else atomicOr(a.fail, 8u);
-                }
-            }
-            if (xn != 0) {  // the extras themselves, one per lane
-                const bool mine = lane < xn;
-                const uint32_t p = ex.x & (kEmit3Tile - 1u), el = ex.y & 0xffffffu, ec = ex.y >> 24, lb = el - (K + 1);
-                uint32_t slot = 0;
-                if (mine) {
-                    const uint32_t d = dmx[p];
-                    slot = posoff[p];
-                    if (lb < 16u) slot += __popc((d & 0xffffu) >> (lb + 1u)) + ((d >> lb) & 1u);  // the longer ones and its own original
-                }
-                slot += extras_before(mine ? p : 0xfffffffeu, el, ec);
-                if (mine) {
-                    if (slot < tile_n) put_tuple_x<F16>(out, slot, a.pos_base + v0 + p, el, ex.z);
-                    else atomicOr(a.fail, 8u);
+        }
+
+        // ---- tuples per lane, one wave scan per tile ----
+        uint32_t dmw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // this lane's 16 u16 of length bits
+        unsigned long long xin = 0;                           // extras on this lane's 16 positions, four bits each
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cnt += __popc(aw[k] & 0xe0e0e0e0u);
+        if (deep) {
+            const uint4 d0 = reinterpret_cast<const uint4 *>(dm32)[lane * 2], d1 = reinterpret_cast<const uint4 *>(dm32)[lane * 2 + 1];
+            dmw[0] = d0.x; dmw[1] = d0.y; dmw[2] = d0.z; dmw[3] = d0.w; dmw[4] = d1.x; dmw[5] = d1.y; dmw[6] = d1.z; dmw[7] = d1.w;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cnt += __popc(dmw[k]);
+            for (uint32_t k = 0; k < xn; ++k) {
+                const uint32_t ep = __builtin_amdgcn_readlane(ex.x, k);
+                if ((ep >> 4) == lane) {
+                    if (((xin >> (4u * (ep & 15u))) & 15u) == 15u) atomicOr(a.fail, 4u);
+                    xin += 1ull << (4u * (ep & 15u));
+                    ++cnt;
                 }
             }
         }
+        const uint32_t incl = wave_incl_scan_x(cnt);
+        const uint32_t lanebase = incl - cnt;
+        if (__builtin_amdgcn_readlane(incl, 63) != tile_n) {   // (DETECT's count of this tile and EXPAND's differ: a bug)
+            if (lane == 0) atomicOr(a.fail, 16u);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            return;
+        }
+        if (deep) {
+            lbase[lane] = lanebase;
+            lflags[lane] = uint4{aw[0] & 0xe0e0e0e0u, aw[1] & 0xe0e0e0e0u, aw[2] & 0xe0e0e0e0u, aw[3] & 0xe0e0e0e0u};
+        }
+        uint32_t wbase = 0;
+        do {   // one pass unless the tile holds more than W tuples (do-while: the wait in front of the stores is on every path out of the tile)
+            // ---- the short matches: each lane walks its 16 positions; the deep ones of a position come first ----
+            // (branch-free: a tuple this pass does not take — flag not set, slot outside the window — is written to the lane's dump entry;
+            // an LDS store costs the same with any number of active lanes, and sixteen positions x three kinds of exec masks did not fit
+            // the scalar registers.  A 3-byte pattern is staged with its 3-gram: its value, from L2, is looked up when the tile goes out.)
+            // (Four positions — one stream dword — per turn of a loop that is NOT unrolled: unrolled sixteen-fold the compiler hoisted every
+            // table lookup to the top and spilled a hundred registers.)
+            uint32_t run = lanebase - wbase;
+            if (F16) {
+                // (F16: an entry is {position | length << 10}; per kind of a position: the flag as a mask (v_bfe_i32), the slot or nothing
+                // (v_bfi), the dump entry for nothing (v_min), the address, the entry, the store, the count)
+                uint32_t q0 = aw[0], q1 = aw[1], q2 = aw[2], q3 = aw[3];
+                uint32_t e0 = dmw[0], e1 = dmw[1], e2 = dmw[2], e3 = dmw[3], e4 = dmw[4], e5 = dmw[5], e6 = dmw[6], e7 = dmw[7];
+                unsigned long long xq = xin;
+                uint32_t pj = lane * 16u;
+#pragma unroll 1
+                for (int grp = 0; grp < 4; ++grp) {
+                    const uint32_t dd[2] = {e0, e1};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (deep) run += __popc((dd[j >> 1] >> (16 * (j & 1))) & 0xffffu) + static_cast<uint32_t>((xq >> (4 * j)) & 15u);
+                        if (K == 3) {
+                            const uint32_t m = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(q0), 8 * j + 7, 1));   // all ones: a 3-byte pattern ends here
+                            stage16[min((run & m) | ~m, dump)] = static_cast<uint16_t>(pj | (j | (3u << 10)));
+                            run -= m;
+                        }
+                        {
+                            const uint32_t m = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(q0), 8 * j + 6, 1));
+                            stage16[min((run & m) | ~m, dump)] = static_cast<uint16_t>(pj | (j | (2u << 10)));
+                            run -= m;
+                        }
+                        if (HAS1) {
+                            const uint32_t m = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(q0), 8 * j + 5, 1));
+                            stage16[min((run & m) | ~m, dump)] = static_cast<uint16_t>(pj | (j | (1u << 10)));
+                            run -= m;
+                        }
+                    }
+                    q0 = q1; q1 = q2; q2 = q3;
+                    e0 = e2; e1 = e3; e2 = e4; e3 = e5; e4 = e6; e5 = e7;
+                    xq >>= 16;
+                    pj += 4u;
+                }
+            } else {
+                uint32_t prevw = left << 16;                  // the two classes before the lane's first position, in bytes 2 and 3
+                uint32_t q0 = aw[0], q1 = aw[1], q2 = aw[2], q3 = aw[3];
+                uint32_t e0 = dmw[0], e1 = dmw[1], e2 = dmw[2], e3 = dmw[3], e4 = dmw[4], e5 = dmw[5], e6 = dmw[6], e7 = dmw[7];
+                unsigned long long xq = xin;
+                uint32_t pj = lane * 16u;
+#pragma unroll 1
+                for (int grp = 0; grp < 4; ++grp) {
+                    const uint32_t dd[2] = {e0, e1};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t byte_j = (q0 >> (8 * j)) & 0xffu;
+                        const uint32_t cj = byte_j & 31u;
+                        const uint32_t cm1 = (j >= 1 ? q0 >> (8 * (j - 1)) : prevw >> 24) & 31u;
+                        const uint32_t cm2 = (j >= 2 ? q0 >> (8 * (j - 2)) : prevw >> (8 * (j + 2))) & 31u;
+                        if (deep) run += __popc((dd[j >> 1] >> (16 * (j & 1))) & 0xffffu) + static_cast<uint32_t>((xq >> (4 * j)) & 15u);
+                        if (K == 3) {
+                            const uint32_t at = min((byte_j & 0x80u) ? run : 0xffffffffu, dump);
+                            stage[at] = uint2{cm2 * CC + cm1 * C + cj, (pj + j) | (3u << 10)};
+                            run += byte_j >> 7;
+                        }
+                        {
+                            const uint32_t at = min((byte_j & 0x40u) ? run : 0xffffffffu, dump);
+                            stage[at] = uint2{v2[cm1 * C + cj], (pj + j) | (2u << 10)};
+                            run += (byte_j >> 6) & 1u;
+                        }
+                        if (HAS1) {
+                            const uint32_t at = min((byte_j & 0x20u) ? run : 0xffffffffu, dump);
+                            stage[at] = uint2{v1[cj], (pj + j) | (1u << 10)};
+                            run += (byte_j >> 5) & 1u;
+                        }
+                    }
+                    prevw = q0; q0 = q1; q1 = q2; q2 = q3;
+                    e0 = e2; e1 = e3; e2 = e4; e3 = e5; e4 = e6; e5 = e7;
+                    xq >>= 16;
+                    pj += 4u;
+                }
+            }
+            // ---- the deep matches: first slot of the position + the longer ones at the same position ----
+            if (deep) {
+                // tuples of lane L that lie before its position j, extras left aside: deep ones (length bits) and short ones (flag bits)
+                auto before_of = [&](uint32_t L, uint32_t j, uint32_t &here16) -> uint32_t {
+                    const uint4 d0 = reinterpret_cast<const uint4 *>(dm32)[L * 2], d1 = reinterpret_cast<const uint4 *>(dm32)[L * 2 + 1];
+                    const uint32_t dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                    const uint4 fq = lflags[L];
+                    const uint32_t fw[4] = {fq.x, fq.y, fq.z, fq.w};
+                    uint32_t before = 0;
+#pragma unroll
+                    for (uint32_t w = 0; w < 8; ++w) {
+                        const uint32_t keep = 2 * w + 1 < j ? 0xffffffffu : 2 * w < j ? 0xffffu : 0u;  // positions 2w, 2w+1 below j
+                        before += __popc(dw[w] & keep);
+                    }
+#pragma unroll
+                    for (uint32_t w = 0; w < 4; ++w) {
+                        const uint32_t nb = j > 4 * w ? (j - 4 * w < 4u ? j - 4 * w : 4u) : 0u;       // bytes of this dword below j
+                        before += __popc(fw[w] & (nb >= 4u ? 0xffffffffu : (1u << (8u * nb)) - 1u));
+                    }
+                    here16 = dm16[L * 16u + j];
+                    return before;
+                };
+                // extras of the tile that come before the key: on an earlier position of the same lane, or on the same position and
+                // longer / an earlier copy.  All lanes walk the list together.
+                auto extras_before = [&](uint32_t p, uint32_t len, uint32_t copy) -> uint32_t {
+                    uint32_t c = 0;
+                    for (uint32_t k = 0; k < xn; ++k) {
+                        const uint32_t ep = __builtin_amdgcn_readlane(ex.x, k), ey = __builtin_amdgcn_readlane(ex.y, k);
+                        const uint32_t el = ey & 0xffffffu, ec = ey >> 24;
+                        if ((ep >> 4) != (p >> 4)) continue;
+                        c += (ep < p || (ep == p && (el > len || (el == len && ec < copy)))) ? 1u : 0u;
+                    }
+                    return c;
+                };
+                for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+                    const uint32_t i = i0 + lane;
+                    uint4 r = rec0;
+                    if (i0 != 0 && i < n) r = a.binned[bin0 + i];
+                    const uint32_t p = (r.x - v0) & (kEmit3Tile - 1u), len = r.y & 0xffffffu, copy = r.y >> 24, lb = len - (K + 1);
+                    const bool normal = i < n && lb < 16u && copy == 0u;
+                    uint32_t slot = 0;
+                    if (normal) {
+                        uint32_t here16;
+                        slot = lbase[p >> 4] + before_of(p >> 4, p & 15u, here16) + __popc(here16 >> (lb + 1u));
+                    }
+                    if (xn != 0) slot += extras_before(normal ? p : 0xfffffff0u, len, 0u);
+                    slot -= wbase;
+                    if (F16) {   // a deep match goes straight to memory (one in fifty tuples of cfg3); its slot stays empty for the copy-out
+                        stage16[min(normal ? slot : 0xffffffffu, dump)] = 0;
+                        if (normal && slot < W) put_tuple_x<true>(out, wbase + slot, a.pos_base + r.x, len, r.z);
+                    } else {
+                        stage[min(normal ? slot : 0xffffffffu, dump)] = uint2{r.z, p | (len << 10)};
+                    }
+                }
+                if (xn != 0) {  // the extras themselves, one per lane
+                    const bool mine = lane < xn;
+                    const uint32_t p = ex.x & (kEmit3Tile - 1u), el = ex.y & 0xffffffu, ec = ex.y >> 24, lb = el - (K + 1);
+                    uint32_t slot = 0;
+                    if (mine) {
+                        uint32_t here16;
+                        slot = lbase[p >> 4] + before_of(p >> 4, p & 15u, here16);
+                        if (lb < 16u) slot += __popc(here16 >> (lb + 1u)) + ((here16 >> lb) & 1u);  // the longer ones and its own original
+                    }
+                    slot += extras_before(mine ? p : 0xfffffff0u, el, ec);
+                    slot -= wbase;
+                    if (F16) {
+                        stage16[min(mine ? slot : 0xffffffffu, dump)] = 0;
+                        if (mine && slot < W) put_tuple_x<true>(out, wbase + slot, end0 + p, el, ex.z);
+                    } else {
+                        stage[min(mine ? slot : 0xffffffffu, dump)] = uint2{ex.z, p | (el << 10)};
+                    }
+                }
+            }
+            // ---- out: 64 consecutive slots per store instruction ----
+            const uint32_t wn = tile_n - wbase < W ? tile_n - wbase : W;
+            if (F16) {
+                // every slot of the window: its entry, the classes of the position and the two before it (the tile's stream bytes in LDS), the
+                // value from V1 / V2 (LDS) or V3 (L2: all of the window's requests in flight before the first tuple is stored)
+                constexpr uint32_t NIT = W / 64u;
+                uint32_t ent[NIT], val[NIT];
+#pragma unroll
+                for (uint32_t k = 0; k < NIT; ++k) {
+                    ent[k] = 0; val[k] = 0;
+                    if (k * 64u < wn) {
+                        const uint32_t s = k * 64u + lane;
+                        const uint32_t e = s < wn ? stage16[s] : 0u;
+                        const uint32_t p = e & 1023u, kind = e >> 10;
+                        const uint32_t c0 = annb[16u + p] & 31u, c1 = annb[15u + p] & 31u;
+                        const uint32_t i2 = __umul24(c1, C) + c0;
+                        uint32_t v = v2[i2];
+                        if (HAS1) v = kind == 1u ? v1[c0] : v;
+#ifndef E3X_NO_V3
+                        if (K == 3 && kind == 3u) v = v3_of(__umul24(annb[14u + p] & 31u, CC) + i2);
+#endif
+                        ent[k] = e; val[k] = v;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): values and the next tile's inputs are in their registers; nothing below waits for memory
+#pragma unroll
+                for (uint32_t k = 0; k < NIT; ++k) {
+                    if (k * 64u < wn) {
+                        const uint32_t s = k * 64u + lane;
+                        if (ent[k] != 0) put_tuple_x<true>(out, wbase + s, end0 + (ent[k] & 1023u), ent[k] >> 10, val[k]);
+                    }
+                }
+            } else {
+                // (K = 3: an entry of length 3 carries its 3-gram; the values come from L2 — every request of the window in flight before the
+                // first value is written back into its staged tuple)
+                if (K == 3) {
+                    constexpr uint32_t NIT = W / 64u;
+                    uint32_t val[NIT];
+#pragma unroll
+                    for (uint32_t k = 0; k < NIT; ++k) {
+                        val[k] = 0;
+                        if (k * 64u < wn) {
+                            const uint32_t s = k * 64u + lane;
+                            const uint2 e = stage[s];
+#ifndef E3X_NO_V3
+                            if ((e.y >> 10) == 3u && s < wn) val[k] = v3_of(e.x);
+#endif
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < NIT; ++k) {
+                        if (k * 64u < wn) {
+                            const uint32_t s = k * 64u + lane;
+                            const uint32_t len = stage[s].y >> 10;
+                            reinterpret_cast<uint32_t *>(stage)[2u * ((len == 3u && s < wn) ? s : dump)] = val[k];
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the next tile's inputs are in their registers; nothing below waits for memory
+                // daac_match is 24 bytes: 128 slots = 192 units of 16 bytes; unit u of a block holds, by u mod 3, {start, end} of tuple 2u/3 |
+                // {value, pad} of that tuple and {start} of the next | {end, value, pad} of tuple (2u + 1) / 3 ... one contiguous kilobyte per store
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const uint32_t units = (wn * 3u + 1u) / 2u;   // 16-byte units that hold the window's wn tuples (the last may be half used)
+                for (uint32_t u0 = 0; u0 < units; u0 += 64u) {
+                    const uint32_t u = u0 + lane;
+                    if (u < units) {
+                        const uint32_t m3 = u % 3u, t0 = (u / 3u) * 2u + (m3 == 2u ? 1u : 0u);   // the tuple the unit's first 8 bytes belong to
+                        const uint2 e0 = stage[t0 < wn ? t0 : wn - 1u], e1 = stage[t0 + 1u < wn ? t0 + 1u : wn - 1u];
+                        const unsigned long long end_a = end0 + (e0.y & 1023u), start_a = end_a - (e0.y >> 10);
+                        const unsigned long long end_b = end0 + (e1.y & 1023u), start_b = end_b - (e1.y >> 10);
+                        u32x4 q;
+                        if (m3 == 0u) q = u32x4{static_cast<uint32_t>(start_a), static_cast<uint32_t>(start_a >> 32), static_cast<uint32_t>(end_a), static_cast<uint32_t>(end_a >> 32)};
+                        else if (m3 == 1u) q = u32x4{e0.x, 0u, static_cast<uint32_t>(start_b), static_cast<uint32_t>(start_b >> 32)};
+                        else q = u32x4{static_cast<uint32_t>(end_a), static_cast<uint32_t>(end_a >> 32), e0.x, 0u};
+                        char *dst = out + static_cast<unsigned long long>(wbase) * 24ull + static_cast<unsigned long long>(u) * 16ull;
+                        if (m3 == 1u && t0 + 1u >= wn) {   // the window's last tuple ends in the middle of this unit
+                            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                            *reinterpret_cast<u32x2 *>(dst) = u32x2{q.x, q.y};
+                        } else {
+#ifdef E3X_NO_STORES
+                            if (q.y == 0xdeadbeefu)
+#endif
+                            *reinterpret_cast<u32x4 *>(dst) = q;
+                        }
+                    }
+                }
+            }
+            wbase += W;
+        } while (wbase < tile_n);
+    };
+    TileIn in_a = TileIn{}, in_b = TileIn{};
+    if (a.ntiles == 0) return;
+    // Waves that start together stay together: every wave of the chip computes a tile, then every wave stores ten kilobytes — 40 MB per
+    // round against 32 MB of L2 — and the store bursts and the compute phases do not overlap (profiles/r04_emit3_experiments.txt).  The
+    // sixteen waves of a CU therefore start a sixteenth of a tile's time apart.
+    for (uint32_t d = (wave_global & 15u) * a.stagger; d != 0; --d) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles each
+    in_a = ask(wave_global);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    for (uint32_t t = wave_global; t < a.ntiles; t += 2u * nwaves) {
+        do_tile(t, in_a, in_b);
+        if (t + nwaves < a.ntiles) do_tile(t + nwaves, in_b, in_a);
     }
 }
 
@@ -687,20 +992,26 @@ hipError_t launch_emit3_bin(const uint4 *recs, const uint32_t *chunk_fill, const
     return hipGetLastError();
 }
 
-uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves) { return dev.v1_bytes + dev.v2_bytes + waves * kEmit3ExpandWave; }
+uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves, bool f16, bool v3_in_lds) {
+    return dev.v1_bytes + dev.v2_bytes + (v3_in_lds ? dev.v3c_bytes : 0u) + waves * (f16 ? kEmit3ExpandWave16 : kEmit3ExpandWave);
+}
 
-template <int K, bool F16>
+template <int K, bool F16, bool HAS1>
 static hipError_t launch_expand_inst(const Gram2EmitDev &dev, const Expand3Args &a, uint32_t blocks, hipStream_t stream) {
-    const uint32_t lds = emit3_expand_lds_bytes(dev, 4);
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(emit3_expand_kernel<K, F16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const uint32_t lds = emit3_expand_lds_bytes(dev, 4, F16, a.v3_in_lds != 0);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(emit3_expand_kernel<K, F16, HAS1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((emit3_expand_kernel<K, F16>), dim3(blocks), dim3(256), lds, stream, dev, a);
+    hipLaunchKernelGGL((emit3_expand_kernel<K, F16, HAS1>), dim3(blocks), dim3(256), lds, stream, dev, a);
     return hipGetLastError();
 }
+template <int K, bool F16>
+static hipError_t launch_expand_k(const Gram2EmitDev &dev, const Expand3Args &a, uint32_t blocks, hipStream_t stream) {
+    return a.has_len1 ? launch_expand_inst<K, F16, true>(dev, a, blocks, stream) : launch_expand_inst<K, F16, false>(dev, a, blocks, stream);
+}
 hipError_t launch_emit3_expand(const Gram2EmitDev &dev, const Expand3Args &a, bool f16, uint32_t blocks, hipStream_t stream) {
-    if (dev.K == 3) return f16 ? launch_expand_inst<3, true>(dev, a, blocks, stream) : launch_expand_inst<3, false>(dev, a, blocks, stream);
-    return f16 ? launch_expand_inst<2, true>(dev, a, blocks, stream) : launch_expand_inst<2, false>(dev, a, blocks, stream);
+    if (dev.K == 3) return f16 ? launch_expand_k<3, true>(dev, a, blocks, stream) : launch_expand_k<3, false>(dev, a, blocks, stream);
+    return f16 ? launch_expand_k<2, true>(dev, a, blocks, stream) : launch_expand_k<2, false>(dev, a, blocks, stream);
 }
 
 }  // namespace daac

@@ -30,8 +30,10 @@ extern "C" {
 /* Version of this header's ABI: struct layouts and the meaning of enum values.  daac_abi_version() returns the version the
  * loaded library was built with; a binding checks it once (the ctypes and C++ mirrors here do).
  *   3 (round 3): daac_info starts with struct_size and carries the per-request engine plan; DAAC_ENGINE_PFX; daac_match16 /
- *                daac_scan_device16. */
-#define DAAC_ABI_VERSION 3
+ *                daac_scan_device16.
+ *   4 (round 4): daac_iter_next_batch; the lazy iterator runs its windows ahead of the consumer on a worker thread; DAAC_ENGINE_JUMP /
+ *                DAAC_KERNEL_JUMP are gone (the experiment lives under tools/experiments/jump). */
+#define DAAC_ABI_VERSION 4
 uint32_t daac_abi_version(void);
 
 /* src/errors.rs:10-22 (first four), plus the panics / extras of this boundary */
@@ -64,10 +66,8 @@ typedef enum {
     DAAC_ENGINE_TIERED = 1, /* re-packed bitmap-rank trie, top levels dense in LDS */
     DAAC_ENGINE_DARRAY = 2, /* the reference's own double array, hot/cold split   */
     DAAC_ENGINE_GRAM = 3,   /* k-gram context tables in LDS, no state chain: count / checksum, and tuples of FIND_OVERLAPPING */
-    DAAC_ENGINE_PFX = 4,    /* hashed prefix filter in LDS + goto-only walks from the start of an occurrence: `.count()` of
+    DAAC_ENGINE_PFX = 4     /* hashed prefix filter in LDS + goto-only walks from the start of an occurrence: `.count()` of
                              * FIND_OVERLAPPING for dictionaries over any byte alphabet (what AUTO takes where GRAM's byte classes run out) */
-    DAAC_ENGINE_JUMP = 5    /* reported by daac_last_engine / the engine plan only: count (+ checksum) of DAAC_FIND over per-position jump
-                             * tables (the shortest pattern at every start, a suffix minimum, one load per match; option "jump") */
 } daac_engine;
 
 /* Match<u32> (src/lib.rs:286-320): start() = end - length, end(), value() */
@@ -107,8 +107,7 @@ typedef enum {
     DAAC_KERNEL_PFX = 5,         /* pfx_kernels.hip: any byte alphabet, `.count()`                              (0.6 - 1.3 TB/s) */
     DAAC_KERNEL_SEGMENT = 6,     /* scan_kernels.hip: one lane per segment, TIERED or DARRAY tables             (0.03 - 0.4 TB/s) */
     DAAC_KERNEL_MICRO = 7,       /* chain_scan.hpp overlap_count_body: micro-step walker over the double array  (0.08 - 0.4 TB/s) */
-    DAAC_KERNEL_CHAIN = 8,       /* chain_scan.hpp: speculate / reconcile / emit for the restart iterators      (0.1 - 0.3 TB/s) */
-    DAAC_KERNEL_JUMP = 9         /* jump_kernels.hip: find_iter count over per-position jump tables */
+    DAAC_KERNEL_CHAIN = 8        /* chain_scan.hpp: speculate / reconcile / emit for the restart iterators      (0.1 - 0.3 TB/s) */
 } daac_kernel_family;
 typedef enum {
     DAAC_WHY_FASTEST = 0,        /* nothing faster exists for this request */
@@ -279,6 +278,12 @@ daac_status daac_scan_count_range(daac_pma *pma, int mode, int engine, const uin
 daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len,
                            int hay_is_device, void *stream, daac_iter **out);
 int daac_iter_next(daac_iter *it, daac_match *m); /* 1 = Some(m), 0 = None, <0 = -daac_status */
+/* The same stream, a run at a time and without a copy: `*batch` points at the next `*n` >= 1 matches in the iterator's own
+ * (page-locked) window buffer, as the crate keeps a Match (lib.rs:287-291: end, length, value); valid until the next call on this
+ * iterator.  1 = a run, 0 = exhausted, <0 = -daac_status.  May be mixed with daac_iter_next (both advance the same position).
+ * Behind both: a worker thread scans the windows (option iter_window, 64 MiB) ahead of the consumer with three stages in flight
+ * on three streams — host-to-device copy of window k + 1, scan of window k, device-to-host copy of window k - 1's 16-byte tuples. */
+int daac_iter_next_batch(daac_iter *it, const daac_match16 **batch, size_t *n);
 void daac_iter_close(daac_iter *it);
 
 /* Chunk-fed steppers = FindOverlappingStepper / FindStepper (bytewise/iter.rs:344-475, charwise/iter.rs:403-534)
@@ -307,13 +312,14 @@ void daac_stream_close(daac_stream *s);
  *                 1 = first table set only, 2 = gram2 kernels only, 3 = gram3 for `.count()`), gram2_dpp (1: DPP wave shifts),
  *   gram2_rfull (1)             rank directory with one entry per M word when LDS allows (0: one per four words)
  *   gram3_tail (-1 = every workgroup samples its text and picks; 0 / 1: the plain / the tail-record body of the gram3 kernel)
- *   jump (0)                    experiment: 1 = find_iter count (+ checksum) of Standard bytewise automata over per-position jump tables where
- *                               they apply (at most 29 byte classes, patterns of at most 127 bytes, no "") instead of the chain walkers; exact, but
- *                               bound by the rate of uncoalesced requests and 3x slower than the walkers; read at upload and per scan
  *   pfx (1)                     PFX tables (any byte alphabet): 1 = built where no GRAM table set applies, 2 = for every automaton they can
  *                               serve (DAAC_ENGINE_PFX then selects them explicitly), 0 = never; read at upload
  *   emit (1)                    materialising overlapping scans through the GRAM tuple emitter where it applies (0: segment scanners);
- *   emit_tiles (64), emit_rec_cap (256)   tiles of 1024 positions per wave region / deep-match records per wave and tile
+ *   emit_version (0)            0 = emit3_kernels.hip (detection once, then expansion) with the COUNT + WRITE emitter behind it, 1 = COUNT + WRITE only,
+ *                               3 = emit3 or nothing
+ *   emit_rec_per_kib (32)       emit3: deep-match records per KiB of haystack the record list is first sized for (a handle remembers what its
+ *                               last scan met; a list that proves too short is sized exactly and the detection is rerun once)
+ *   emit_tiles (64), emit_rec_cap (256)   COUNT + WRITE emitter: tiles of 1024 positions per wave region / deep-match records per wave and tile
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
  *   restart_tier (0)            1: find_iter of Standard bytewise automata runs its chains over the TIERED tables instead of the double array
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners

@@ -86,12 +86,16 @@ struct IterDeleter { void operator()(daac_iter *p) const { daac_iter_close(p); }
 // LeftmostFindIterator of src/bytewise/iter.rs, one type here because the device engine sits behind them.
 class MatchIterator {
 public:
+    // one 16-byte read from the run at hand; a library call per window of the haystack (daac_iter_next_batch), not per match
     std::optional<Match> next() {
-        daac_match m;
-        const int r = daac_iter_next(it_.get(), &m);
-        if (r == 1) return Match(m.start, m.end, m.value);
-        if (r == 0) return std::nullopt;
-        throw PanicError(std::string("device scan failed: ") + daac_last_error());
+        if (run_n_ == 0) {
+            const int r = daac_iter_next_batch(it_.get(), &run_, &run_n_);
+            if (r == 0) return std::nullopt;
+            if (r < 0) throw PanicError(std::string("device scan failed: ") + daac_last_error());
+        }
+        const daac_match16 t = *run_++;
+        --run_n_;
+        return Match(t.end - t.length, t.end, t.value);
     }
     std::vector<Match> collect() {
         std::vector<Match> out;
@@ -105,6 +109,8 @@ private:
     MatchIterator(daac_iter *it, std::unique_ptr<std::string> hay) : hay_(std::move(hay)), it_(it) {}
     std::unique_ptr<std::string> hay_;  // the haystack lives (at a stable address) as long as the iterator (the crate's `P`)
     std::unique_ptr<daac_iter, detail::IterDeleter> it_;
+    const daac_match16 *run_ = nullptr;  // what is left of the last run (a view of the iterator's window buffer)
+    size_t run_n_ = 0;
 };
 
 // FindStepper / FindOverlappingStepper (src/bytewise/iter.rs:344-475, src/charwise/iter.rs:403-534), fed a chunk

@@ -6,8 +6,10 @@
 //!   find_overlapping_no_suffix_iter  src/bytewise.rs:410-413  -> FindOverlappingNoSuffixIterator<'_, U8SliceIterator<P>, V>
 //!   leftmost_find_iter               src/bytewise.rs:547-550  -> LeftmostFindIterator<'_, P, V>
 //! with V = u32.  The four iterator structs of src/bytewise/iter.rs keep name and type parameters; under the feature their
-//! private fields are `{ cur: HipCursor<'a>, haystack: I }` (the haystack stays owned/borrowed by the iterator exactly as
-//! `U8SliceIterator<P>` keeps `P`, iter.rs:14-41), and the CPU bodies of these four methods are `#[cfg(not(feature = "hip"))]`.
+//! private fields are `{ cur: HipCursor<'a>, haystack: Box<I> }` (the haystack stays owned/borrowed by the iterator exactly as
+//! `U8SliceIterator<P>` keeps `P`, iter.rs:14-41 — boxed, because the device side reads the bytes lazily through a raw pointer and a `P`
+//! with inline storage would carry them along when the iterator is moved: ffi.rs, HipCursor), and the CPU bodies of these four methods
+//! are `#[cfg(not(feature = "hip"))]`.
 #![cfg(feature = "hip")]
 
 use std::sync::OnceLock;
@@ -17,7 +19,8 @@ use crate::hip::ffi::*;
 use crate::{DoubleArrayAhoCorasick, Match, MatchKind};
 
 // ---- iterator structs under the feature (replace the field lists in src/bytewise/iter.rs:44-57, 117-131, 180-193, 247-258) ----
-pub struct FindIteratorHipFields<'a, I> { pub(crate) cur: HipCursor<'a>, pub(crate) haystack: I }
+// field order = drop order: the cursor (worker thread, raw pointer into the haystack) goes before the haystack
+pub struct FindIteratorHipFields<'a, I> { pub(crate) cur: HipCursor<'a>, pub(crate) haystack: Box<I> }
 // pub struct FindIterator<'a, I, V>                    { f: FindIteratorHipFields<'a, I>, _v: PhantomData<V> }
 // pub struct FindOverlappingIterator<'a, I, V>         { f: FindIteratorHipFields<'a, I>, _v: PhantomData<V> }
 // pub struct FindOverlappingNoSuffixIterator<'a, I, V> { f: FindIteratorHipFields<'a, I>, _v: PhantomData<V> }
@@ -67,8 +70,10 @@ impl DoubleArrayAhoCorasick<u32> {
         P: AsRef<[u8]>,
     {
         assert!(self.match_kind.is_standard(), "Error: match_kind must be standard."); // src/bytewise.rs:194-197
-        let cur = HipCursor::open(self.hip(), DAAC_FIND, haystack.as_ref());
-        FindIterator { f: FindIteratorHipFields { cur, haystack: U8SliceIterator::new(haystack) }, _v: core::marker::PhantomData }
+        // the haystack first, in its final place; THEN the cursor, over the bytes as the box hands them out (`inner`: iter.rs:15)
+        let haystack = Box::new(U8SliceIterator::new(haystack));
+        let cur = HipCursor::open(self.hip(), DAAC_FIND, haystack.inner.as_ref());
+        FindIterator { f: FindIteratorHipFields { cur, haystack }, _v: core::marker::PhantomData }
     }
 
     /// src/bytewise.rs:292-297
@@ -77,8 +82,10 @@ impl DoubleArrayAhoCorasick<u32> {
         P: AsRef<[u8]>,
     {
         assert!(self.match_kind.is_standard(), "Error: match_kind must be standard."); // src/bytewise.rs:299-302
-        let cur = HipCursor::open(self.hip(), DAAC_FIND_OVERLAPPING, haystack.as_ref());
-        FindOverlappingIterator { f: FindIteratorHipFields { cur, haystack: U8SliceIterator::new(haystack) }, _v: core::marker::PhantomData }
+        // the haystack first, in its final place; THEN the cursor, over the bytes as the box hands them out (`inner`: iter.rs:15)
+        let haystack = Box::new(U8SliceIterator::new(haystack));
+        let cur = HipCursor::open(self.hip(), DAAC_FIND_OVERLAPPING, haystack.inner.as_ref());
+        FindOverlappingIterator { f: FindIteratorHipFields { cur, haystack }, _v: core::marker::PhantomData }
     }
 
     /// src/bytewise.rs:410-413
@@ -87,8 +94,10 @@ impl DoubleArrayAhoCorasick<u32> {
         P: AsRef<[u8]>,
     {
         assert!(self.match_kind.is_standard(), "Error: match_kind must be standard."); // src/bytewise.rs:415-418
-        let cur = HipCursor::open(self.hip(), DAAC_FIND_OVERLAPPING_NO_SUFFIX, haystack.as_ref());
-        FindOverlappingNoSuffixIterator { f: FindIteratorHipFields { cur, haystack: U8SliceIterator::new(haystack) }, _v: core::marker::PhantomData }
+        // the haystack first, in its final place; THEN the cursor, over the bytes as the box hands them out (`inner`: iter.rs:15)
+        let haystack = Box::new(U8SliceIterator::new(haystack));
+        let cur = HipCursor::open(self.hip(), DAAC_FIND_OVERLAPPING_NO_SUFFIX, haystack.inner.as_ref());
+        FindOverlappingNoSuffixIterator { f: FindIteratorHipFields { cur, haystack }, _v: core::marker::PhantomData }
     }
 
     /// src/bytewise.rs:547-550
@@ -97,7 +106,8 @@ impl DoubleArrayAhoCorasick<u32> {
         P: AsRef<[u8]>,
     {
         assert!(self.match_kind.is_leftmost(), "Error: match_kind must be leftmost."); // src/bytewise.rs:551-554
-        let cur = HipCursor::open(self.hip(), DAAC_LEFTMOST_FIND, haystack.as_ref());
+        let haystack = Box::new(haystack);
+        let cur = HipCursor::open(self.hip(), DAAC_LEFTMOST_FIND, (*haystack).as_ref());
         LeftmostFindIterator { f: FindIteratorHipFields { cur, haystack }, _v: core::marker::PhantomData }
     }
 

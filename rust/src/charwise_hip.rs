@@ -9,7 +9,9 @@ use crate::charwise::iter::{FindIterator, FindOverlappingIterator, FindOverlappi
 use crate::hip::ffi::*;
 use crate::{CharwiseDoubleArrayAhoCorasick, Match};
 
-pub struct CharIteratorHipFields<'a, P> { pub(crate) cur: HipCursor<'a>, pub(crate) haystack: P }
+// boxed for the reason given at HipCursor (ffi.rs): the device side reads the bytes lazily through a raw pointer, and a haystack that
+// keeps its bytes inline must not carry them along when the iterator is moved; field order = drop order (cursor first)
+pub struct CharIteratorHipFields<'a, P> { pub(crate) cur: HipCursor<'a>, pub(crate) haystack: Box<P> }
 // under the feature: pub struct FindIterator<'a, I, V> { f: CharIteratorHipFields<'a, I>, _v: PhantomData<V> }   (and the other three)
 
 macro_rules! hip_iterator {
@@ -46,25 +48,29 @@ impl CharwiseDoubleArrayAhoCorasick<u32> {
     /// src/charwise.rs:184-187
     pub fn find_iter<P: AsRef<str>>(&self, haystack: P) -> FindIterator<'_, StrIterator<P>, u32> {
         assert!(self.match_kind.is_standard(), "Error: match_kind must be standard."); // src/charwise.rs:104-107
-        let cur = HipCursor::open(self.hip(), DAAC_FIND, haystack.as_ref().as_bytes());
-        FindIterator { f: CharIteratorHipFields { cur, haystack: StrIterator::new(haystack) }, _v: core::marker::PhantomData }
+        let haystack = Box::new(StrIterator::new(haystack));   // in its final place before the cursor takes a pointer into it
+        let cur = HipCursor::open(self.hip(), DAAC_FIND, haystack.inner.as_ref().as_bytes());
+        FindIterator { f: CharIteratorHipFields { cur, haystack }, _v: core::marker::PhantomData }
     }
     /// src/charwise.rs:290-293
     pub fn find_overlapping_iter<P: AsRef<str>>(&self, haystack: P) -> FindOverlappingIterator<'_, StrIterator<P>, u32> {
         assert!(self.match_kind.is_standard(), "Error: match_kind must be standard."); // src/charwise.rs:163-166
-        let cur = HipCursor::open(self.hip(), DAAC_FIND_OVERLAPPING, haystack.as_ref().as_bytes());
-        FindOverlappingIterator { f: CharIteratorHipFields { cur, haystack: StrIterator::new(haystack) }, _v: core::marker::PhantomData }
+        let haystack = Box::new(StrIterator::new(haystack));   // in its final place before the cursor takes a pointer into it
+        let cur = HipCursor::open(self.hip(), DAAC_FIND_OVERLAPPING, haystack.inner.as_ref().as_bytes());
+        FindOverlappingIterator { f: CharIteratorHipFields { cur, haystack }, _v: core::marker::PhantomData }
     }
     /// src/charwise.rs:412-415
     pub fn find_overlapping_no_suffix_iter<P: AsRef<str>>(&self, haystack: P) -> FindOverlappingNoSuffixIterator<'_, StrIterator<P>, u32> {
         assert!(self.match_kind.is_standard(), "Error: match_kind must be standard."); // src/charwise.rs:227-230
-        let cur = HipCursor::open(self.hip(), DAAC_FIND_OVERLAPPING_NO_SUFFIX, haystack.as_ref().as_bytes());
-        FindOverlappingNoSuffixIterator { f: CharIteratorHipFields { cur, haystack: StrIterator::new(haystack) }, _v: core::marker::PhantomData }
+        let haystack = Box::new(StrIterator::new(haystack));   // in its final place before the cursor takes a pointer into it
+        let cur = HipCursor::open(self.hip(), DAAC_FIND_OVERLAPPING_NO_SUFFIX, haystack.inner.as_ref().as_bytes());
+        FindOverlappingNoSuffixIterator { f: CharIteratorHipFields { cur, haystack }, _v: core::marker::PhantomData }
     }
     /// src/charwise.rs:553-556
     pub fn leftmost_find_iter<P: AsRef<str>>(&self, haystack: P) -> LeftmostFindIterator<'_, P, u32> {
         assert!(self.match_kind.is_leftmost(), "Error: match_kind must be leftmost."); // src/charwise.rs:309-312
-        let cur = HipCursor::open(self.hip(), DAAC_LEFTMOST_FIND, haystack.as_ref().as_bytes());
+        let haystack = Box::new(haystack);
+        let cur = HipCursor::open(self.hip(), DAAC_LEFTMOST_FIND, (*haystack).as_ref().as_bytes());
         LeftmostFindIterator { f: CharIteratorHipFields { cur, haystack }, _v: core::marker::PhantomData }
     }
 }

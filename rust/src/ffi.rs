@@ -1,8 +1,8 @@
-//! `extern "C"` mirror of include/daachorse_amd.h (ABI version 3).  Plain pointers and sizes only.
+//! `extern "C"` mirror of include/daachorse_amd.h (ABI version 4).  Plain pointers and sizes only.
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_void};
 
-pub const DAAC_ABI_VERSION: u32 = 3;
+pub const DAAC_ABI_VERSION: u32 = 4;
 
 /// daac_status
 pub const DAAC_OK: i32 = 0;
@@ -54,6 +54,8 @@ extern "C" {
     pub fn daac_iter_open(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,
                           stream: *mut c_void, out: *mut *mut daac_iter) -> i32;
     pub fn daac_iter_next(it: *mut daac_iter, m: *mut daac_match) -> i32; // 1 = Some, 0 = None, < 0 = -daac_status
+    /// the next run of matches as a view of the iterator's own window buffer (valid until the next call): 1 = a run, 0 = exhausted
+    pub fn daac_iter_next_batch(it: *mut daac_iter, batch: *mut *const daac_match16, n: *mut usize) -> i32;
     pub fn daac_iter_close(it: *mut daac_iter);
     pub fn daac_scan_count_only_range(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, begin: usize,
                                       hay_is_device: i32, stream: *mut c_void, count: *mut u64, result_dev: *mut u64) -> i32;
@@ -77,37 +79,53 @@ impl Drop for HipPma {
 }
 
 /// What every iterator of the crate holds under the `hip` feature instead of (state_id, pos, output_pos):
-/// the open `daac_iter` plus what `count()` needs to run as one device pass.
+/// the open `daac_iter`, the run of matches it handed out last, and what `count()` needs to run as one device pass.
+///
+/// SAFETY contract with the iterator structs: `hay_ptr` points into the haystack the iterator owns, and `daac_iter` reads it lazily,
+/// window by window, for as long as the cursor lives.  `P: AsRef<[u8]>` admits haystacks that keep their bytes INLINE (`[u8; N]`,
+/// ArrayVec, SmallVec): moving such a value moves the bytes.  The iterators therefore keep the haystack in a `Box` (made BEFORE the
+/// cursor is opened, see bytewise_hip.rs) — the bytes a boxed `P` hands out do not move when the iterator itself is moved — and declare
+/// the cursor field before the haystack field, so that the cursor (and the worker thread behind it) is gone before the bytes are.
 pub struct HipCursor<'a> {
     pub(crate) it: *mut daac_iter,
     pub(crate) pma: &'a HipPma,
     pub(crate) mode: i32,
     pub(crate) hay_ptr: *const u8,
     pub(crate) hay_len: usize,
+    pub(crate) run: *const daac_match16, // what is left of the last daac_iter_next_batch
+    pub(crate) run_len: usize,
     pub(crate) consumed: bool, // next() has been called: count() must not restart
 }
 impl<'a> HipCursor<'a> {
-    /// Opens the lazy façade.  Panics exactly where the crate panics (wrong MatchKind), with the crate's messages.
+    /// Opens the lazy façade over `hay`, which must stay where it is until the cursor is dropped (see the struct's contract).
+    /// Panics exactly where the crate panics (wrong MatchKind), with the crate's messages.
     pub(crate) fn open(pma: &'a HipPma, mode: i32, hay: &[u8]) -> Self {
         let mut it = core::ptr::null_mut();
         let st = unsafe { daac_iter_open(pma.0, mode, DAAC_ENGINE_AUTO, hay.as_ptr(), hay.len(), 0, core::ptr::null_mut(), &mut it) };
         assert!(!(st == DAAC_ERR_MATCH_KIND && mode != DAAC_LEFTMOST_FIND), "Error: match_kind must be standard.");
         assert!(!(st == DAAC_ERR_MATCH_KIND && mode == DAAC_LEFTMOST_FIND), "Error: match_kind must be leftmost.");
         assert!(st == DAAC_OK, "daachorse_amd: device scan failed (status {st})");
-        Self { it, pma, mode, hay_ptr: hay.as_ptr(), hay_len: hay.len(), consumed: false }
+        Self { it, pma, mode, hay_ptr: hay.as_ptr(), hay_len: hay.len(), run: core::ptr::null(), run_len: 0, consumed: false }
     }
+    /// `Iterator::next`: one 16-byte read from the run at hand; a library call per WINDOW (tens of millions of matches), not per match.
     #[inline]
     pub(crate) fn next(&mut self) -> Option<crate::Match<u32>> {
         self.consumed = true;
-        let mut m = core::mem::MaybeUninit::<daac_match>::uninit();
-        match unsafe { daac_iter_next(self.it, m.as_mut_ptr()) } {
-            1 => {
-                let m = unsafe { m.assume_init() };
-                Some(crate::Match { length: (m.end - m.start) as usize, end: m.end as usize, value: m.value })
+        if self.run_len == 0 {
+            let (mut p, mut n) = (core::ptr::null(), 0usize);
+            match unsafe { daac_iter_next_batch(self.it, &mut p, &mut n) } {
+                1 => {
+                    self.run = p;
+                    self.run_len = n;
+                }
+                0 => return None,
+                e => panic!("daachorse_amd: device scan failed (status {})", -e),
             }
-            0 => None,
-            e => panic!("daachorse_amd: device scan failed (status {})", -e),
         }
+        let t = unsafe { *self.run }; // the crate's own Match fields (src/lib.rs:287-291)
+        self.run = unsafe { self.run.add(1) };
+        self.run_len -= 1;
+        Some(crate::Match { length: t.length as usize, end: t.end as usize, value: t.value })
     }
     /// `Iterator::count()` as ONE device pass (`daac_scan_count_only_range`) when nothing has been pulled yet.
     pub(crate) fn count(mut self) -> usize {

@@ -118,6 +118,9 @@ def test_bench_two_ranks_on_one_gpu_weak_and_strong():
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
     assert strong["match_count"] == one["match_count"] and strong["match_checksum"] == one["match_checksum"]
     assert strong["config"]["haystack_bytes_job"] == 96 << 20 and strong["config"]["engine_used"] == "gram"
+    d = strong["distributed"]   # the self-diagnosis of a multi-rank run: per-rank kernel times, the reduce, the strong-scaling self-check
+    assert d["n_ranks_seen"] == 2 and len(d["per_rank_kernel_ms"]["all"]) == 2 and d["per_rank_kernel_ms"]["max"] >= d["per_rank_kernel_ms"]["min"] > 0
+    assert d["reduce_ms"]["max"] >= 0 and sum(d["per_rank_bytes"]) == 96 << 20 and d["strong_equals_one_rank"] is True
     weak = _run_bench(["--gpus", "2", "--bytes", str(32 << 20)] + common, env)
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["haystack_bytes_job"] == 64 << 20
     assert weak["value"] > 0 and weak["match_count"] > 0
@@ -141,6 +144,8 @@ def test_bench_takes_the_rccl_branch_on_one_gpu():
     env = {"DAAC_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
            "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     rccl = _run_bench(["--gpus", "1"] + common, env)
-    assert rccl["distributed"] == {"backend": "nccl", "world_size": 1, "all_reduces": 4}
+    d = rccl["distributed"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d["all_reduces"] == 4 and d["n_ranks_seen"] == 1
+    assert d["per_rank_kernel_ms"]["min"] > 0 and d["reduce_ms"]["max"] >= 0 and d["rccl_version"]
     assert plain["distributed"] is None
     assert rccl["match_count"] == plain["match_count"] and rccl["match_checksum"] == plain["match_checksum"] and rccl["value"] > 0

@@ -207,3 +207,22 @@ def test_round3_engines_take_host_haystacks_and_streams():
             got = dm.to_numpy()
             dm.free()
             assert np.array_equal(got["end"], ref["end"]) and np.array_equal(got["value"], ref["value"]) and np.array_equal(got["length"], ref["end"] - ref["start"])
+
+
+def test_engines_that_cannot_serve_a_request_say_so():
+    """An engine that only counts (PFX), or a number that is no engine at all, asked for tuples / a lazy iterator / a stepper: status 6 —
+    not a silent scan on the double array with last_engine() = DARRAY (round-3 advisor)."""
+    o = orc.OraclePma.build([b"ab", b"bc", b"abc"])
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    hay = np.frombuffer(b"xxabcabyy" * 50, dtype=np.uint8)
+    want = o.find_overlapping_iter(hay)
+    got = p.scan(ScanMode.FindOverlapping, hay)
+    assert len(got) == len(want)
+    for eng in (int(Engine.Pfx), 77):
+        for call in (lambda: p.scan(ScanMode.FindOverlapping, hay, engine=eng),
+                     lambda: p.scan_device(ScanMode.FindOverlapping, hay, engine=eng),
+                     lambda: list(p.find_overlapping_iter(hay, engine=eng)),
+                     lambda: p.find_overlapping_stepper(engine=eng)):
+            with pytest.raises(da.DaachorseError) as ei:
+                call()
+            assert ei.value.code == 6, eng

@@ -269,36 +269,6 @@ def test_pfx_tables_reproduce_the_match_count(tmp_path):
         blob.write_bytes(orc.OraclePma.build(pats).serialize())
         assert subprocess.check_output([exe, str(blob), "120000", str(h)]).decode().startswith("UNAVAILABLE"), pats
 
-
-def test_jump_tables_reproduce_find_iter(tmp_path):
-    """find_iter without a state chain (jump.hpp): L(s) from the K-gram table and start-anchored walks, the saturating suffix minimum
-    N / D, the chain over them and the h32 tables == the literal FindIterator, duplicates and one-byte patterns included"""
-    exe = str(tmp_path / "jump_check")
-    csrc = os.path.join(ROOT, "daachorse_amd", "csrc")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "jump_check.cpp"),
-                           os.path.join(csrc, "pma.cpp"), os.path.join(csrc, "repack.cpp"), os.path.join(csrc, "jump.cpp")])
-    blob, h = tmp_path / "a.blob", tmp_path / "h.bin"
-    rng = np.random.default_rng(21)
-    pats3 = synth.patterns_cfg3(20000)
-    syms = np.frombuffer(b"abcdefg", dtype=np.uint8)
-    longp = [bytes(syms[rng.integers(0, 7, size=int(rng.integers(4, 100)))]) for _ in range(400)]  # nothing short: every start is a walk
-    dup = [b"ab", b"ab", b"b", b"abab", b"bababab", b"ba", b"b"]
-    cases = [(pats3, synth.uniform_haystack(200000, 3, synth.ALPHA_LOWER_SPACE)),
-             (pats3, synth.wordsoup_haystack(200000, 5, pats3, 20)),
-             (synth.patterns_cfg1(), synth.uniform_haystack(5000, 1, synth.ALPHA_ABCD)),
-             (longp, np.frombuffer(b"".join(longp[i] if k % 2 else bytes(syms[rng.integers(0, 7, size=9)]) for k, i in enumerate(rng.integers(0, 400, size=4000).tolist())), dtype=np.uint8)),
-             (longp, np.frombuffer(b"zzzz" * 300 + longp[3] + b"z" * 700 + longp[5][:-1] + b"q" * 300 + longp[7], dtype=np.uint8)),  # long stretches where nothing starts
-             (dup, np.frombuffer(b"abababbab" * 3000, dtype=np.uint8))]
-    for pats, hay in cases:
-        blob.write_bytes(orc.OraclePma.build(pats).serialize())
-        np.asarray(hay, dtype=np.uint8).tofile(h)
-        out = subprocess.check_output([exe, str(blob), str(h)]).decode()
-        assert out.startswith("OK"), out
-    for pats in (["", "a"], [b"a" * 200, b"b"], [bytes([i]) + b"x" for i in range(40, 80)]):  # "" in the set; a pattern of more than 127 bytes; 41 classes
-        blob.write_bytes(orc.OraclePma.build(pats).serialize())
-        assert subprocess.check_output([exe, str(blob), str(h)]).decode().startswith("UNAVAILABLE"), pats
-
-
 def test_emit_tables_reproduce_the_tuple_stream(tmp_path):
     """the tuple-emission tables (flag bits + value tables for short patterns, ehit / erec for deep ones) walked with the
     emitter's rules give the literal automaton's (start, end, value) list, order included"""

@@ -23,6 +23,9 @@ else:
     synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
 ver = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # emit_version: 0 / 3 = emit3_kernels.hip, 1 = the COUNT + WRITE emitter
 da.set_option("emit_version", ver)
+for k, v in os.environ.items():  # DAAC_OPT_<name>=<value>: tuning options for A/B runs
+    if k.startswith("DAAC_OPT_"):
+        da.set_option(k[len("DAAC_OPT_"):], int(v))
 only16 = len(sys.argv) > 5 and sys.argv[5] == "only16"
 for emit, fmt16 in (((1, True),) if only16 else ((1, True), (1, False), (0, False))):  # the GRAM emitter in both device formats, then the segment scanners
     da.set_option("emit", emit)

@@ -14,9 +14,8 @@ if hk == "sparse":
 else:
     synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
 res = {}
-for name, kind, mode, opts in (("find_iter (jump tables)", da.MatchKind.Standard, ScanMode.Find, {"jump": 1}),
-                               ("find_iter (tier chains)", da.MatchKind.Standard, ScanMode.Find, {"restart_tier": 1, "jump": 0}),
-                               ("find_iter (double array)", da.MatchKind.Standard, ScanMode.Find, {"restart_tier": 0, "jump": 0}),
+for name, kind, mode, opts in (("find_iter (tier chains)", da.MatchKind.Standard, ScanMode.Find, {"restart_tier": 1}),
+                               ("find_iter (double array)", da.MatchKind.Standard, ScanMode.Find, {"restart_tier": 0}),
                                ("leftmost_find_iter LL", da.MatchKind.LeftmostLongest, ScanMode.LeftmostFind, {})):
     for k, v in opts.items():
         da.set_option(k, v)
@@ -35,4 +34,3 @@ for name, kind, mode, opts in (("find_iter (jump tables)", da.MatchKind.Standard
     print(f"{name:40s} {hk} {mib} MiB: {best * 1e3:8.2f} ms  {hay.numel() / best / 1e9:7.1f} GB/s  count={r[0]} checksum={r[1]:016x}", flush=True)
     res[(kind, name.split(' (')[0])] = r
 da.set_option("restart_tier", 0)
-da.set_option("jump", 0)
