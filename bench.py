@@ -234,7 +234,7 @@ def iterator_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha
     from daachorse_amd import ScanMode
     n = 1 << 30
     out = {"bytes": n, "op": "daac_iter_open + daac_iter_next_batch to exhaustion over a page-locked host haystack (zero-copy runs of 16-byte tuples, counted)",
-           "window_bytes": 64 << 20}
+           "window_bytes": "16, 32, then 64 MiB (option iter_window)"}
     host = torch.empty(n, dtype=torch.uint8).pin_memory()
     dev = torch.empty(n, dtype=torch.uint8, device="cuda")
     p2 = da.DoubleArrayAhoCorasick.new(synth.patterns_cfg2())

@@ -34,7 +34,7 @@ struct Options {
     std::atomic<int64_t> rows_share_pct{45};
     std::atomic<int64_t> blocks_per_cu{0};   // 0 = auto
     std::atomic<int64_t> threads{1024};
-    std::atomic<int64_t> iter_window{64ll << 20};
+    std::atomic<int64_t> iter_window{64ll << 20};   // lazy iterator: haystack bytes per window (the first windows are smaller: 16, 32 MiB)
     std::atomic<int64_t> max_result_bytes{8ll << 30};
     std::atomic<int64_t> gram_lds_budget{158 * 1024};
     std::atomic<int64_t> gram_region{0};           // 0 = auto: 16 KiB for the first table set, 64 KiB for the second
@@ -1896,6 +1896,45 @@ struct PinnedPool {
 };
 PinnedPool &pinned_pool() { static PinnedPool *p = new PinnedPool; return *p; }
 
+// What an iterator needs on the device — four streams, its events, two staging buffers — kept per device for the next iterator: creating
+// and destroying them cost ~4 ms per iterator, a sixth of a sparse 1 GiB scan (profiles/r04_iterator.txt).  Never freed at exit.
+struct IterDeviceKit {
+    int device = -1;
+    hipStream_t s_scan = nullptr, s_h2d = nullptr, s_d2h = nullptr, s_d2h2 = nullptr;
+    hipEvent_t staged_ev[2] = {nullptr, nullptr}, half_ev = nullptr;
+    void *stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+};
+struct IterKitPool {
+    std::mutex mu;
+    std::vector<IterDeviceKit *> free_kits;
+    IterDeviceKit *take(int device) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < free_kits.size(); ++i)
+                if (free_kits[i]->device == device) { IterDeviceKit *k = free_kits[i]; free_kits.erase(free_kits.begin() + static_cast<long>(i)); return k; }
+        }
+        std::unique_ptr<IterDeviceKit> k(new IterDeviceKit);
+        k->device = device;
+        bool ok = hipStreamCreateWithFlags(&k->s_scan, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&k->s_h2d, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&k->s_d2h, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&k->s_d2h2, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&k->staged_ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&k->staged_ev[1], hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&k->half_ev, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); return nullptr; }   // (a half-made kit leaks a stream or two: this is an out-of-resources path)
+        return k.release();
+    }
+    void give(IterDeviceKit *k) {
+        if (!k) return;
+        std::lock_guard<std::mutex> g(mu);
+        if (free_kits.size() < 8) { free_kits.push_back(k); return; }
+        // (more than eight idle kits: this one's buffers go back; the streams are few and stay)
+        for (void *&b : k->stage) { if (b) (void)hipFree(b); b = nullptr; }
+        k->stage_bytes = 0;
+        free_kits.push_back(k);
+    }
+};
+IterKitPool &iter_kits() { static IterKitPool *p = new IterKitPool; return *p; }
+
 constexpr int kIterSlots = 3;
 struct IterWindow {
     daac_status st = DAAC_OK;
@@ -1926,7 +1965,8 @@ struct daac_iter {
     IterWindow win[kIterSlots];
     uint64_t produced = 0, consumed = 0;   // windows handed to / taken back from the consumer
     bool stop = false, finished = false;
-    hipStream_t s_scan = nullptr, s_h2d = nullptr, s_d2h = nullptr;
+    IterDeviceKit *kit = nullptr;
+    hipStream_t s_scan = nullptr, s_h2d = nullptr, s_d2h = nullptr, s_d2h2 = nullptr;
     // the consumer's view of the window it is reading
     const daac_match16 *cur = nullptr;
     size_t cur_n = 0, pos = 0;
@@ -1940,24 +1980,26 @@ void daac_iter::run() {
     auto fail_with = [&](IterWindow &w, daac_status st) { w.st = st; w.err = last_error_cstr(); w.n = 0; };
     DeviceTables *t = nullptr;
     const uint64_t window = std::max<uint64_t>(4096, static_cast<uint64_t>(g_opt.iter_window.load()));
+    // windows grow from 16 MiB to the full size: the consumer has its first matches after a small window's scan and copy, not a big one's
+    auto window_of = [&](uint64_t k) -> uint64_t { return std::min<uint64_t>(window, (16ull << 20) << std::min<uint64_t>(k, 16)); };
     const uint64_t halo = pma->halo();
     const bool per_window_copy = !hay_is_device;   // (restart modes were staged whole at open)
-    void *stage[2] = {nullptr, nullptr};
-    size_t stage_bytes = 0;
-    hipEvent_t staged_ev[2] = {nullptr, nullptr};
+    void **stage = kit->stage;
+    hipEvent_t *staged_ev = kit->staged_ev;
     uint64_t begin = 0;
     daac_status st0 = get_tables(pma, &t);
     if (st0 == DAAC_OK && per_window_copy) {
-        stage_bytes = static_cast<size_t>(std::min<uint64_t>(len, window) + halo + 64);
-        for (int i = 0; i < 2 && st0 == DAAC_OK; ++i) {
-            if (hipMalloc(&stage[i], stage_bytes) != hipSuccess || hipEventCreateWithFlags(&staged_ev[i], hipEventDisableTiming) != hipSuccess) {
-                st0 = hip_fail(hipGetLastError(), "iterator staging buffers");
-            }
+        const size_t want = static_cast<size_t>(std::min<uint64_t>(len, window) + halo + 64);
+        if (kit->stage_bytes < want) {
+            for (int i = 0; i < 2; ++i) { if (stage[i]) (void)hipFree(stage[i]); stage[i] = nullptr; }
+            kit->stage_bytes = 0;
+            if (hipMalloc(&stage[0], want) != hipSuccess || hipMalloc(&stage[1], want) != hipSuccess) st0 = hip_fail(hipGetLastError(), "iterator staging buffers");
+            else kit->stage_bytes = want;
         }
     }
     // window k of a host haystack: bytes [from, end) -> stage[k & 1], asynchronously on the copy stream
     auto issue_stage = [&](uint64_t k, uint64_t wb) -> hipError_t {
-        const uint64_t we = std::min<uint64_t>(len, wb + window);
+        const uint64_t we = std::min<uint64_t>(len, wb + window_of(k));
         const uint64_t from = wb > halo ? wb - halo : 0;
         const uint64_t skew = from & 15;  // keep the haystack's 16-byte phase for the vector loop
         if (we > from) {
@@ -1983,7 +2025,7 @@ void daac_iter::run() {
             fail_with(w, st0);
             last = true;
         } else {
-            const uint64_t end = std::min<uint64_t>(len, begin + window);
+            const uint64_t end = std::min<uint64_t>(len, begin + window_of(k));
             const uint8_t *dev_hay = hay;
             if (per_window_copy) {
                 const uint64_t from = begin > halo ? begin - halo : 0;
@@ -2019,8 +2061,12 @@ void daac_iter::run() {
                 if (w.host_bytes < need) {
                     if (w.host) { if (w.host_pinned) pinned_pool().give(w.host, w.host_bytes); else std::free(w.host); }
                     w.host = nullptr; w.host_bytes = 0;
+                    // sized for a FULL window of this density at once (the first windows are small: a buffer that grew with them would be
+                    // pinned four times over, at ~50 ms per GB)
+                    const uint64_t cur_w = std::max<uint64_t>(1, end - begin);
+                    const size_t full = static_cast<size_t>(static_cast<double>(need) * (static_cast<double>(std::max<uint64_t>(window, cur_w)) / static_cast<double>(cur_w)) * 1.15) + 4096;
                     size_t got = 0;
-                    void *q = pinned_pool().take(need + need / 4, &got);
+                    void *q = pinned_pool().take(std::max(full, need + need / 4), &got);
                     w.host_pinned = q != nullptr;
                     if (!q) { q = std::malloc(need); got = need; }
                     if (!q) { set_error("out of host memory for the match list"); st = DAAC_ERR_AUTOMATON_SCALE; }
@@ -2029,7 +2075,14 @@ void daac_iter::run() {
                 }
                 if (st == DAAC_OK) {
                     // (the list is complete: s_scan was waited for above) the copy runs beside the next window's scan
-                    hipError_t e = hipMemcpyAsync(w.host, dm.p, need, hipMemcpyDeviceToHost, s_d2h);
+                    // two halves on two streams: one copy engine alone stayed at 40 GB/s of the link's ~55 (profiles/r04_iterator.txt)
+                    const size_t half = need >= (8u << 20) ? (need / 2) & ~size_t(4095) : need;
+                    hipError_t e = hipMemcpyAsync(w.host, dm.p, half, hipMemcpyDeviceToHost, s_d2h);
+                    if (e == hipSuccess && half != need) {
+                        e = hipMemcpyAsync(reinterpret_cast<char *>(w.host) + half, reinterpret_cast<const char *>(dm.p) + half, need - half, hipMemcpyDeviceToHost, s_d2h2);
+                        if (e == hipSuccess) e = hipEventRecord(kit->half_ev, s_d2h2);
+                        if (e == hipSuccess) e = hipStreamWaitEvent(s_d2h, kit->half_ev, 0);
+                    }
                     if (e == hipSuccess) e = hipEventRecord(w.copied, s_d2h);
                     if (e != hipSuccess) st = hip_fail(e, "iterator: device-to-host copy");
                     dm.s = s_d2h;   // released behind the copy
@@ -2049,8 +2102,9 @@ void daac_iter::run() {
         if (last) break;
     }
     (void)hipStreamSynchronize(s_d2h);
+    (void)hipStreamSynchronize(s_d2h2);
+    (void)hipStreamSynchronize(s_h2d);
     (void)hipStreamSynchronize(s_scan);
-    for (int i = 0; i < 2; ++i) { if (stage[i]) (void)hipFree(stage[i]); if (staged_ev[i]) (void)hipEventDestroy(staged_ev[i]); }
     {
         std::lock_guard<std::mutex> g(mu);
         finished = true;
@@ -2084,9 +2138,9 @@ daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *h
     }
     // whatever the caller queued on its stream (a device haystack being written, the staging copy above) comes first
     HIP_TRY(hipStreamSynchronize(it->user_stream));
-    HIP_TRY(hipStreamCreateWithFlags(&it->s_scan, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&it->s_h2d, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&it->s_d2h, hipStreamNonBlocking));
+    it->kit = iter_kits().take(it->device);
+    if (!it->kit) { if (it->owned_dev) (void)hipFree(it->owned_dev); set_error("iterator: no streams / events to be had"); return DAAC_ERR_DEVICE; }
+    it->s_scan = it->kit->s_scan; it->s_h2d = it->kit->s_h2d; it->s_d2h = it->kit->s_d2h; it->s_d2h2 = it->kit->s_d2h2;
     for (IterWindow &w : it->win) HIP_TRY(hipEventCreateWithFlags(&w.copied, hipEventDisableTiming));
     it->worker = std::thread([p = it.get()] { p->run(); });
     *out = it.release();
@@ -2155,9 +2209,7 @@ void daac_iter_close(daac_iter *it) {
         if (w.host) { if (w.host_pinned) pinned_pool().give(w.host, w.host_bytes); else std::free(w.host); }
         if (w.copied) (void)hipEventDestroy(w.copied);
     }
-    if (it->s_scan) (void)hipStreamDestroy(it->s_scan);
-    if (it->s_h2d) (void)hipStreamDestroy(it->s_h2d);
-    if (it->s_d2h) (void)hipStreamDestroy(it->s_d2h);
+    iter_kits().give(it->kit);   // (the worker has drained its streams)
     if (it->owned_dev) (void)hipFree(it->owned_dev);
     if (switched) (void)hipSetDevice(prev);
     delete it;

@@ -282,7 +282,7 @@ int daac_iter_next(daac_iter *it, daac_match *m); /* 1 = Some(m), 0 = None, <0 =
  * (page-locked) window buffer, as the crate keeps a Match (lib.rs:287-291: end, length, value); valid until the next call on this
  * iterator.  1 = a run, 0 = exhausted, <0 = -daac_status.  May be mixed with daac_iter_next (both advance the same position).
  * Behind both: a worker thread scans the windows (option iter_window, 64 MiB) ahead of the consumer with three stages in flight
- * on three streams — host-to-device copy of window k + 1, scan of window k, device-to-host copy of window k - 1's 16-byte tuples. */
+ * on their own streams — host-to-device copy of window k + 1, scan of window k, device-to-host copy of window k - 1's 16-byte tuples. */
 int daac_iter_next_batch(daac_iter *it, const daac_match16 **batch, size_t *n);
 void daac_iter_close(daac_iter *it);
 
@@ -330,7 +330,7 @@ void daac_stream_close(daac_stream *s);
  *                               charwise automata and the double array, 2 = also in place of the TIERED engine, 0 = the segment scanners
  *   pool (1), pool_keep (0)     scratch and result buffers from the device's stream-ordered pool, which keeps up to pool_keep bytes
  *                               between calls (0 = 1/8 of the device memory, at most 32 GiB); read at the first scan of the process
- *   iter_window (64 MiB)        haystack bytes per window of the lazy iterator
+ *   iter_window (64 MiB)        haystack bytes per window of the lazy iterator (the first windows are 16 and 32 MiB: matches arrive early)
  *   max_result_bytes (8 GiB)    largest match list daac_scan may materialise */
 daac_status daac_set_option(const char *name, int64_t value);
 
