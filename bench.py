@@ -484,6 +484,17 @@ def main():
         "match_count": total_count, "match_checksum": f"{checksum:016x}" if checksum is not None else None,
         "distributed": dist_used,
     }
+    # what the METHOD allows on this chip, measured: the same kernel with everything behind the per-position lookup compiled out
+    # (tools/method_ceiling.sh -> profiles/method_ceiling.json; a figure from a separate run, like `traffic`)
+    try:
+        mc = json.load(open(os.path.join(ROOT, "profiles", "method_ceiling.json")))
+        key = f"{args.workload}_{args.haystack}"
+        if gram and args.op == "count" and key in mc:
+            out["roofline"]["method_ceiling"] = {"value": mc[key]["GB/s"], "unit": "GB/s", "frac": mc[key]["frac"],
+                                                 "achieved_over_ceiling": round(achieved / mc[key]["GB/s"], 3),
+                                                 "what": mc["what"], "source": "profiles/method_ceiling.json (" + str(mc.get("round")) + ", " + str(mc.get("build")) + ")"}
+    except Exception:
+        pass
     tr = hbm_traffic({"cfg3": "cfg3", "cfg2": "cfg2"}[args.workload] + ("_count" if args.workload == "cfg2" else f"_{args.haystack}_{args.op}"),
                      out["roofline"]["kernel"].split("::")[-1])  # the entry of the kernel the roofline names
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr

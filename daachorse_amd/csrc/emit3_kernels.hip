@@ -73,12 +73,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan_x(uint32_t x) {
 // fields, src/lib.rs:287-291: end, length, value) ONE 16-byte store.  Plain stores: it is the L2 that puts the lines together.
 template <bool F16>
 __device__ __forceinline__ void put_tuple_x(void *out, unsigned long long slot, unsigned long long end, uint32_t len, uint32_t value) {
-#ifdef E3X_NO_STORES
-    {   // everything but the store itself (timing only)
-        asm volatile("" ::"v"(static_cast<uint32_t>(end)), "v"(static_cast<uint32_t>(end >> 32)), "v"(len), "v"(value), "v"(static_cast<uint32_t>(slot)));
-        return;
-    }
-#endif
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -157,9 +151,6 @@ __global__ __launch_bounds__(1024) void emit3_detect_kernel(const Gram2EmitDev g
     // device-scope atomics run at ~15 G/s on this chip whatever their addresses, profiles/r04_emit3_experiments.txt)
     auto log_deep = [&](uint32_t p, uint32_t len, uint32_t value, uint32_t copy, bool counted) {
         if (p < a.emit_from) return;
-#ifdef E3X_NO_REC
-        return;
-#endif
         const uint32_t slot = atomicAdd(cursor, 1u);
         if (!counted) atomicAdd(&a.tile_deep[p >> 10], 1u);
         if (slot >= kEmit3Chunk) { atomicOr(a.fail, 2u); return; }
@@ -247,9 +238,6 @@ __global__ __launch_bounds__(1024) void emit3_detect_kernel(const Gram2EmitDev g
             const bool own = (r.x & 1u) != 0 && pend_pos >= a.emit_from;
             const uint32_t my_tile = pend_pos >> 10;
             unsigned long long om = __ballot(own);
-#ifdef E3X_NO_REC
-            om = 0;
-#endif
             while (om != 0) {
                 const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(om));
                 const uint32_t t0 = __builtin_amdgcn_readlane(my_tile, leader);
@@ -445,9 +433,6 @@ __global__ __launch_bounds__(1024) void emit3_detect_kernel(const Gram2EmitDev g
             for (int i = 0; i < P / 4; ++i) nshort += __popc(annw[i] & 0xe0e0e0e0u);
             {
                 uint4 *dst = reinterpret_cast<uint4 *>(a.ann + v);
-#ifdef E3X_NO_ANN
-                if (nshort == 0xdeadbeefu)
-#endif
                 {
                 dst[0] = uint4{annw[0], annw[1], annw[2], annw[3]};
                 dst[1] = uint4{annw[4], annw[5], annw[6], annw[7]};
@@ -868,9 +853,7 @@ __global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gr
                         const uint32_t i2 = __umul24(c1, C) + c0;
                         uint32_t v = v2[i2];
                         if (HAS1) v = kind == 1u ? v1[c0] : v;
-#ifndef E3X_NO_V3
                         if (K == 3 && kind == 3u) v = v3_of(__umul24(annb[14u + p] & 31u, CC) + i2);
-#endif
                         ent[k] = e; val[k] = v;
                     }
                 }
@@ -894,9 +877,7 @@ __global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gr
                         if (k * 64u < wn) {
                             const uint32_t s = k * 64u + lane;
                             const uint2 e = stage[s];
-#ifndef E3X_NO_V3
                             if ((e.y >> 10) == 3u && s < wn) val[k] = v3_of(e.x);
-#endif
                         }
                     }
 #pragma unroll
@@ -929,9 +910,6 @@ __global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gr
                             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                             *reinterpret_cast<u32x2 *>(dst) = u32x2{q.x, q.y};
                         } else {
-#ifdef E3X_NO_STORES
-                            if (q.y == 0xdeadbeefu)
-#endif
                             *reinterpret_cast<u32x4 *>(dst) = q;
                         }
                     }

@@ -24,8 +24,8 @@
 //     the kernel's time (profiles/r03_gram3_decomposition.txt).
 //
 // Roofline: HBM bytes of haystack (1 B read per byte); integer/bit work only, no MFMA.
-// G3X_NO_* : decomposition builds only (tools/ab_libs3.sh, profiles/r03_gram3_decomposition.txt) — they cut a stage out to price it, the counts they give are WRONG, and
-// nothing in the shipped library defines them (_build.py passes no -D).
+// (The timing-only builds that cut one stage out to price it — profiles/r03_gram3_decomposition.txt — are a patch on top of this file:
+// tools/variants/gram3_decomposition.patch, applied by tools/mkvar2.sh.  Nothing of them is in the shipped source.)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -295,11 +295,7 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
             go = false;
         } else {
             cnt32 += r.x & 1u;
-#ifdef G3X_NO_WALKERS
-            go = false;
-#else
             go = k1 != 0 && ((r.x >> k1) & 1u);
-#endif
         }
         const uint32_t child = r.y + __popc(r.x & ((1u << k1) - 2u));
         if (!TAIL) {
@@ -320,9 +316,6 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
         }
     };
     auto process_batch = [&](uint32_t n) {  // n <= 64 entries from the head of the queue
-#ifdef G3X_NO_CONSUMER
-        q_head += n; return;
-#endif
         __builtin_amdgcn_s_setprio(2);
         consume_pending();
         pend = uint4{0u, 0u, 0u, 0u};
@@ -365,16 +358,12 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
                 below += idx > 2 ? __popc(qz & 0x3fffffffu) : 0u;
                 rank = base + below;
             }
-#if defined(G3X_NO_GATHER)
-            pend = uint4{rank & 1u, 0u, 0u, 0u};
-#else
             if (TAIL) {
                 pend = g.dhit_t[rank];
             } else {
                 const uint2 h = g.dhit_c[rank];
                 pend = uint4{h.x, h.y, 0u, 0u};
             }
-#endif
         }
         q_head += n;
         pend_valid = true;
@@ -499,9 +488,6 @@ __device__ __forceinline__ void gram3_body(const Gram2Dev &g, const GramArgs &a,
             }
             cnt32 += ccnt;
 
-#ifdef G3X_NO_PRODUCER
-            H = 0;
-#endif
             // ---- queue the hits, one per lane and turn ----
             bool did_batch = false;
             for (;;) {
