@@ -631,7 +631,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                     }
                 }
                 // (a staged tuple keeps its length in 22 bits)
-                t->emit3_ok = t->emit3_ok && emit3_expand_lds_bytes(e, 4, false, false) <= 64u * 1024u && g2.max_len < (1u << 22);
+                t->emit3_ok = t->emit3_ok && emit3_expand_lds_bytes(e, 4, false, false) <= 64u * 1024u && emit3_expand_lds_bytes(e, 8, true, false) <= 80u * 1024u && g2.max_len < (1u << 22);
                 for (uint32_t w : g2.me) t->emit3_has_len1 = t->emit3_has_len1 || ((w >> 29) & 1u) != 0;
             }
         }
@@ -1089,12 +1089,14 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         a.out = d_out;
         a.pos_base = w.from - w.lead + 1;  // (mod 2^64: a match ends one past its last byte)
         a.has_len1 = t->emit3_has_len1 ? 1u : 0u;
-        // the rank structure goes to LDS when three workgroups per CU still fit with it
-        a.v3_in_lds = (e.v3c != nullptr && g_opt.emit_v3_lds.load() != 0 && emit3_expand_lds_bytes(e, 4, out.f16, true) <= (160u * 1024u) / 3u) ? 1u : 0u;
+        // the rank structure goes to LDS when the workgroups still fit with it: two of eight waves (16-byte tuples), three of four (24-byte)
+        const uint32_t xwaves = out.f16 ? 8u : 4u;
+        a.v3_in_lds = (e.v3c != nullptr && g_opt.emit_v3_lds.load() != 0 &&
+                       emit3_expand_lds_bytes(e, xwaves, out.f16, true) <= (160u * 1024u) / (out.f16 ? 2u : 3u)) ? 1u : 0u;
         a.off_wave = e.v1_bytes + e.v2_bytes + (a.v3_in_lds ? e.v3c_bytes : 0u);
         a.stagger = a.ntiles >= 65536u ? static_cast<uint32_t>(std::max<int64_t>(0, std::min<int64_t>(64, g_opt.emit_stagger.load()))) : 0u;
         a.fail = d_ctl + 1;
-        const uint32_t xblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 4, (a.ntiles + 3) / 4)));
+        const uint32_t xblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * (out.f16 ? 2u : 4u), (a.ntiles + xwaves - 1) / xwaves)));
         HIP_TRY(launch_emit3_expand(e, a, out.f16, xblocks, stream));
     }
     {

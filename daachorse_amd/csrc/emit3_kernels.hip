@@ -530,18 +530,20 @@ __global__ __launch_bounds__(256) void emit3_bin_kernel(const uint4 *__restrict_
 // A tile of more than 1024 tuples (dozens of deep matches per position) takes several passes over a window of slots.
 // HAS1: the dictionary has one-byte patterns (else that flag bit is never set and the walk leaves it out)
 template <int K, bool F16, bool HAS1>
-__global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gram2EmitDev g, const Expand3Args a) {
+__global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_kernel(const Gram2EmitDev g, const Expand3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     e3_copy(smem, g.v1, g.v1_bytes);
     e3_copy(smem + g.v1_bytes, g.v2, g.v2_bytes);
     if (a.v3_in_lds) e3_copy(smem + g.v1_bytes + g.v2_bytes, g.v3c, g.v3c_bytes);
     __syncthreads();
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();   // (tables are also read through absolute LDS addresses)
     const uint32_t *v1 = reinterpret_cast<const uint32_t *>(smem);
     const uint32_t *v2 = reinterpret_cast<const uint32_t *>(smem + g.v1_bytes);
     const uint32_t *v3bm = reinterpret_cast<const uint32_t *>(smem + g.v1_bytes + g.v2_bytes);
     const uint16_t *v3dir = reinterpret_cast<const uint16_t *>(smem + g.v1_bytes + g.v2_bytes + g.v3c_dir);
     const uint32_t *v3val = reinterpret_cast<const uint32_t *>(smem + g.v1_bytes + g.v2_bytes + g.v3c_val);
     const bool v3l = a.v3_in_lds != 0;   // wave-uniform
+    const uint32_t v3_at = g.v1_bytes + g.v2_bytes;   // LDS address of the rank structure (the dynamic segment starts at 0: no static LDS here)
     // value of the 3-byte pattern that is the 3-gram `idx` (the caller knows it is one)
     auto v3_of = [&](uint32_t idx) -> uint32_t {
         if (v3l) {
@@ -573,37 +575,63 @@ __global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gr
     const uint32_t dump = W + lane;
     bool dirty = true;  // wave-uniform: dm holds bits of the previous tile
 
-    // A tile's inputs are asked for one tile ahead (at the top of the tile before it), and everything a tile reads has arrived before its
-    // first tuple is stored: loads retire in order with the stores, and a wave that waited for its next stream bytes behind ten kilobytes
-    // of its own stores spent most of a tile's 14 us waiting (profiles/r04_emit3_experiments.txt).
-    struct TileIn { uint4 annq; uint32_t prev2; unsigned long long tile_base, tile_end, bin0, bin1; };
-    auto ask = [&](uint32_t t) -> TileIn {   // (no branches: a request under a condition is copied, and waited for, where the branches meet)
-        TileIn x;
+    // A tile's inputs are asked for AHEAD, and everything a tile reads has arrived before its first tuple is stored: loads retire in order
+    // with the stores (one vmcnt for both), and a wave that asked for anything after ten kilobytes of its own stores waited for the stores
+    // (profiles/r04_emit3_experiments.txt).  Two levels, because the records of a tile sit where its offsets say: the offsets of tile k + 2
+    // and the stream bytes + first 64 records of tile k + 1 go out at the top of tile k.
+    struct TileOff { unsigned long long tile_base, tile_end, bin0, bin1; };       // as loaded (per lane, all lanes the same)
+    struct TileS { unsigned long long tile_base, bin0; uint32_t tile_n, n; };      // wave-uniform
+    struct TileIn { uint4 annq; uint32_t prev2; uint4 rec0; };
+    auto ask_off = [&](uint32_t t) -> TileOff {   // (no branches: a request under a condition is copied, and waited for, where the branches meet)
         t = t < a.ntiles ? t : a.ntiles - 1u;
-        const uint32_t v0 = t * kEmit3Tile;
-        x.annq = *reinterpret_cast<const uint4 *>(a.ann + v0 + lane * 16u);
-        x.prev2 = *reinterpret_cast<const uint16_t *>(a.ann + (v0 != 0 ? v0 - 2u : 0u));   // the two stream bytes before the tile (tile 0: not used)
+        TileOff x;
         x.tile_base = a.tile_off[t]; x.tile_end = a.tile_off[t + 1];
         x.bin0 = a.bin_off[t]; x.bin1 = a.bin_off[t + 1];
         return x;
     };
+    auto uniform64 = [&](unsigned long long v) -> unsigned long long {
+        return (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32))) << 32) |
+               __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    };
+    auto to_s = [&](const TileOff &o) -> TileS {
+        TileS x;
+        x.tile_base = uniform64(o.tile_base); x.bin0 = uniform64(o.bin0);
+        x.tile_n = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(o.tile_end - o.tile_base));
+        x.n = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(o.bin1 - o.bin0));
+        return x;
+    };
+    auto ask_in = [&](uint32_t t, const TileS &sx) -> TileIn {
+        t = t < a.ntiles ? t : a.ntiles - 1u;
+        const uint32_t v0 = t * kEmit3Tile;
+        TileIn x;
+        x.annq = *reinterpret_cast<const uint4 *>(a.ann + v0 + lane * 16u);
+        x.prev2 = *reinterpret_cast<const uint16_t *>(a.ann + (v0 != 0 ? v0 - 2u : 0u));   // the two stream bytes before the tile (tile 0: not used)
+        x.rec0 = a.binned[sx.bin0 + (lane < sx.n ? lane : 0u)];   // (the list ends with one spare record: n may be 0 at its very end)
+        return x;
+    };
     const uint32_t ctr_at = a.off_wave + wave_in_wg * WAVE_BYTES + SW + 2048 + 256 + 1024 + kEmit3MaxExtras * 16;   // LDS address of `ctr`
-    // (two named sets of input registers, the loop unrolled by hand: with one set the compiler copied the freshly requested registers
-    // at the loop's edge and waited for the request there)
-    auto do_tile = [&](const uint32_t t, const TileIn &in, TileIn &nxt) {
+    // (named sets of input registers, the loop unrolled by hand: with one set the compiler copied the freshly requested registers at the
+    // loop's edge and waited for the request there)
+    // (ts = this tile's offsets, ts1 = the next tile's (in: known; out: those of the tile after it), in / in_next = stream bytes and records)
+    auto do_tile = [&](const uint32_t t, const TileS &ts, TileS &ts1, const TileIn &in, TileIn &in_next) {
         const uint32_t v0 = t * kEmit3Tile;
         const uint4 annq = in.annq;
         const uint32_t prev2 = t > 0 ? in.prev2 : 0u;
-        const unsigned long long tile_base = in.tile_base;
-        const uint32_t tile_n = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(in.tile_end - tile_base));   // wave-uniform
-        const unsigned long long bin0 = in.bin0;
-        const uint32_t n = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(in.bin1 - bin0));   // wave-uniform
+        const unsigned long long tile_base = ts.tile_base;
+        const uint32_t tile_n = ts.tile_n;
+        const unsigned long long bin0 = ts.bin0;
+        const uint32_t n = ts.n;
         const bool deep = n != 0;
-        // this tile's first 64 records are asked for BEFORE the next tile's inputs: loads come back in the order they went out
-        const uint4 rec0 = a.binned[bin0 + (lane < n ? lane : 0u)];   // (the list ends with one spare record: n may be 0 at its very end)
-        asm volatile("" ::: "memory");   // (keeps the two requests in this order)
-        nxt = ask(t + nwaves);
-        if (tile_n == 0) { __builtin_amdgcn_s_waitcnt(0x0f70); return; }
+        const uint4 rec0 = in.rec0;
+        in_next = ask_in(t + nwaves, ts1);
+        const TileOff off2 = ask_off(t + 2u * nwaves);
+        // everything asked for has arrived: the offsets go to scalar registers here, so that no register still counts as "being loaded"
+        // when the stores go out (the compiler would wait for it — and with it for the stores — at the top of the next tile)
+        auto arrived = [&]() {
+            __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+            ts1 = to_s(off2);
+        };
+        if (tile_n == 0) { arrived(); return; }
         char *__restrict__ out = reinterpret_cast<char *>(a.out) + tile_base * (F16 ? 16ull : 24ull);
         const unsigned long long end0 = a.pos_base + v0;   // end of a match whose last byte is the tile's position 0
         const uint32_t aw[4] = {annq.x, annq.y, annq.z, annq.w};
@@ -644,7 +672,7 @@ __global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gr
             xn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile ldsx_u32 *>(static_cast<uintptr_t>(ctr_at)));
             if (xn > kEmit3MaxExtras) {   // left to the other engines (the caller looks at the flag before it hands anything out)
                 if (lane == 0) atomicOr(a.fail, 4u);
-                __builtin_amdgcn_s_waitcnt(0x0f70);
+                arrived();
                 return;
             }
             if (lane < xn) ex = xs[lane];
@@ -674,7 +702,7 @@ __global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gr
         const uint32_t lanebase = incl - cnt;
         if (__builtin_amdgcn_readlane(incl, 63) != tile_n) {   // (DETECT's count of this tile and EXPAND's differ: a bug)
             if (lane == 0) atomicOr(a.fail, 16u);
-            __builtin_amdgcn_s_waitcnt(0x0f70);
+            arrived();
             return;
         }
         if (deep) {
@@ -762,6 +790,9 @@ __global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gr
                     pj += 4u;
                 }
             }
+            // everything this tile asked for at its top has arrived by now; waited for HERE, in front of the first store — the deep
+            // matches below go straight to memory, and a wait behind them would be a wait for them
+            if (wbase == 0) arrived(); else __builtin_amdgcn_s_waitcnt(0x0f70);
             // ---- the deep matches: first slot of the position + the longer ones at the same position ----
             if (deep) {
                 // tuples of lane L that lie before its position j, extras left aside: deep ones (length bits) and short ones (flag bits)
@@ -838,31 +869,51 @@ __global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gr
             // ---- out: 64 consecutive slots per store instruction ----
             const uint32_t wn = tile_n - wbase < W ? tile_n - wbase : W;
             if (F16) {
-                // every slot of the window: its entry, the classes of the position and the two before it (the tile's stream bytes in LDS), the
-                // value from V1 / V2 (LDS) or V3 (L2: all of the window's requests in flight before the first tuple is stored)
-                constexpr uint32_t NIT = W / 64u;
-                uint32_t ent[NIT], val[NIT];
+                // Every slot of the window: its entry, the classes of the position and the two before it (the tile's stream bytes in LDS), the
+                // value from V1 / V2 / the rank structure of V3 (LDS; V3 from L2 when the structure did not fit).  Five store instructions'
+                // worth of slots at a time, each step for all five before the next step (no branch in between: the LDS round trips of the five
+                // overlap; looked up slot by slot, a tile waited for forty round trips in a row).
+                constexpr uint32_t NB = 4;
+#pragma unroll 1
+                for (uint32_t c0 = 0; c0 < wn; c0 += NB * 64u) {
+                    uint32_t ent[NB], b0[NB], b1[NB], b2[NB], val[NB], w3[NB], d3[NB], i3[NB];
 #pragma unroll
-                for (uint32_t k = 0; k < NIT; ++k) {
-                    ent[k] = 0; val[k] = 0;
-                    if (k * 64u < wn) {
-                        const uint32_t s = k * 64u + lane;
-                        const uint32_t e = s < wn ? stage16[s] : 0u;
-                        const uint32_t p = e & 1023u, kind = e >> 10;
-                        const uint32_t c0 = annb[16u + p] & 31u, c1 = annb[15u + p] & 31u;
-                        const uint32_t i2 = __umul24(c1, C) + c0;
-                        uint32_t v = v2[i2];
-                        if (HAS1) v = kind == 1u ? v1[c0] : v;
-                        if (K == 3 && kind == 3u) v = v3_of(__umul24(annb[14u + p] & 31u, CC) + i2);
-                        ent[k] = e; val[k] = v;
+                    for (uint32_t k = 0; k < NB; ++k) ent[k] = stage16[c0 + k * 64u + lane];   // (past the window: stale entries, looked up and dropped)
+#pragma unroll
+                    for (uint32_t k = 0; k < NB; ++k) {
+                        const uint32_t p = ent[k] & 1023u;
+                        b0[k] = annb[16u + p]; b1[k] = annb[15u + p];
+                        b2[k] = K == 3 ? annb[14u + p] : 0u;
                     }
-                }
-                __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): values and the next tile's inputs are in their registers; nothing below waits for memory
 #pragma unroll
-                for (uint32_t k = 0; k < NIT; ++k) {
-                    if (k * 64u < wn) {
-                        const uint32_t s = k * 64u + lane;
-                        if (ent[k] != 0) put_tuple_x<true>(out, wbase + s, end0 + (ent[k] & 1023u), ent[k] >> 10, val[k]);
+                    for (uint32_t k = 0; k < NB; ++k) {
+                        const uint32_t i2 = __umul24(b1[k] & 31u, C) + (b0[k] & 31u);
+                        val[k] = *reinterpret_cast<ldsx_cu32 *>(static_cast<uintptr_t>(g.v1_bytes + i2 * 4u));
+                        if (HAS1) b1[k] = *reinterpret_cast<ldsx_cu32 *>(static_cast<uintptr_t>((b0[k] & 31u) * 4u));
+                        i3[k] = K == 3 ? __umul24(b2[k] & 31u, CC) + i2 : 0u;
+                        if (K == 3 && v3l) {   // (absolute LDS addresses: a pointer that may be LDS or global compiles to flat loads)
+                            w3[k] = *reinterpret_cast<ldsx_cu32 *>(static_cast<uintptr_t>(v3_at + (i3[k] >> 5) * 4u));
+                            d3[k] = *reinterpret_cast<ldsx_cu16 *>(static_cast<uintptr_t>(v3_at + g.v3c_dir + (i3[k] >> 5) * 2u));
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < NB; ++k) {
+                        const uint32_t kind = ent[k] >> 10;
+                        if (HAS1) val[k] = kind == 1u ? b1[k] : val[k];
+                        if (K == 3) {
+                            if (v3l) {
+                                const uint32_t v3v = *reinterpret_cast<ldsx_cu32 *>(static_cast<uintptr_t>(
+                                    v3_at + g.v3c_val + (d3[k] + __popc(w3[k] & ((1u << (i3[k] & 31u)) - 1u))) * 4u));
+                                val[k] = kind == 3u ? v3v : val[k];
+                            } else if (kind == 3u && c0 + k * 64u + lane < wn) {
+                                val[k] = g.v3[i3[k]];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < NB; ++k) {
+                        const uint32_t s = c0 + k * 64u + lane;
+                        if (ent[k] != 0 && s < wn) put_tuple_x<true>(out, wbase + s, end0 + (ent[k] & 1023u), ent[k] >> 10, val[k]);
                     }
                 }
             } else {
@@ -889,7 +940,6 @@ __global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gr
                         }
                     }
                 }
-                __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the next tile's inputs are in their registers; nothing below waits for memory
                 // daac_match is 24 bytes: 128 slots = 192 units of 16 bytes; unit u of a block holds, by u mod 3, {start, end} of tuple 2u/3 |
                 // {value, pad} of that tuple and {start} of the next | {end, value, pad} of tuple (2u + 1) / 3 ... one contiguous kilobyte per store
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -924,11 +974,22 @@ __global__ __launch_bounds__(256, F16 ? 4 : 3) void emit3_expand_kernel(const Gr
     // round against 32 MB of L2 — and the store bursts and the compute phases do not overlap (profiles/r04_emit3_experiments.txt).  The
     // sixteen waves of a CU therefore start a sixteenth of a tile's time apart.
     for (uint32_t d = (wave_global & 15u) * a.stagger; d != 0; --d) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles each
-    in_a = ask(wave_global);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
+    TileS ts0, ts1;
+    {
+        const TileOff o0 = ask_off(wave_global), o1 = ask_off(wave_global + nwaves);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        ts0 = to_s(o0); ts1 = to_s(o1);
+        in_a = ask_in(wave_global, ts0);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
     for (uint32_t t = wave_global; t < a.ntiles; t += 2u * nwaves) {
-        do_tile(t, in_a, in_b);
-        if (t + nwaves < a.ntiles) do_tile(t + nwaves, in_b, in_a);
+        // (do_tile(t, offsets of t, [in] offsets of t + 1 [out] of t + 2, bytes of t, [out] bytes of t + 1))
+        TileS tsa = ts1;
+        do_tile(t, ts0, tsa, in_a, in_b);          // tsa: offsets of t + 2 nwaves
+        if (t + nwaves >= a.ntiles) break;
+        TileS tsb = tsa;
+        do_tile(t + nwaves, ts1, tsb, in_b, in_a);  // tsb: offsets of t + 3 nwaves
+        ts0 = tsa; ts1 = tsb;
     }
 }
 
@@ -976,11 +1037,13 @@ uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves, bool f1
 
 template <int K, bool F16, bool HAS1>
 static hipError_t launch_expand_inst(const Gram2EmitDev &dev, const Expand3Args &a, uint32_t blocks, hipStream_t stream) {
-    const uint32_t lds = emit3_expand_lds_bytes(dev, 4, F16, a.v3_in_lds != 0);
+    // 16-byte format: eight waves share the tables (two workgroups = sixteen waves per CU); 24-byte format: four (its staged tuples are 8 bytes)
+    constexpr uint32_t kWaves = F16 ? 8 : 4;
+    const uint32_t lds = emit3_expand_lds_bytes(dev, kWaves, F16, a.v3_in_lds != 0);
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(emit3_expand_kernel<K, F16, HAS1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((emit3_expand_kernel<K, F16, HAS1>), dim3(blocks), dim3(256), lds, stream, dev, a);
+    hipLaunchKernelGGL((emit3_expand_kernel<K, F16, HAS1>), dim3(blocks), dim3(kWaves * 64), lds, stream, dev, a);
     return hipGetLastError();
 }
 template <int K, bool F16>
