@@ -79,6 +79,18 @@ def hbm_traffic(workload_key, kernel_filter=None):
         return None, None
 
 
+def traffic_stale():
+    """True when the counters in profiles/hbm_traffic.json were collected from other kernel sources than the ones this run was built from
+    (tools/profile_round.sh stamps `_csrc_sha256` = daachorse_amd._build.source_hash()); None when there is no stamp to compare."""
+    path = os.environ.get("DAAC_HBM_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        from daachorse_amd import _build
+        stamp = json.load(open(path)).get("_csrc_sha256")
+        return None if stamp is None else stamp != _build.source_hash()
+    except Exception:
+        return None
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -498,6 +510,7 @@ def main():
     tr = hbm_traffic({"cfg3": "cfg3", "cfg2": "cfg2"}[args.workload] + ("_count" if args.workload == "cfg2" else f"_{args.haystack}_{args.op}"),
                      out["roofline"]["kernel"].split("::")[-1])  # the entry of the kernel the roofline names
     out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr
+    out["roofline"]["traffic_stale"] = traffic_stale()
 
     # ---- tuples (reported, not the metric): device-resident list of a 1 GiB prefix in both device formats, and a list copied to the host ----
     if args.materialize_mib > 0 and world == 1:

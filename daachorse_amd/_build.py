@@ -22,6 +22,20 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
+def source_hash():
+    """sha256 over the sources the library is built from (names + bytes, in SOURCES + HEADERS order): the stamp tools/profile_round.sh
+    writes into profiles/hbm_traffic.json and bench.py compares (`roofline.traffic_stale`) — counters of other kernels than the ones
+    that ran are worth saying so."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        path = os.path.join(CSRC, f)
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True

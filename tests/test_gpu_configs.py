@@ -69,13 +69,13 @@ def test_cfg3_tuples_16mib_and_64_windows():
 def test_cfg5_charwise_leftmost_longest():
     """BASELINE configs[4] as SURVEY 8d states it: 50 000 patterns of 2-8 scalars, Zipf(1.0) over 6 000 symbols,
     LeftmostLongest; text = i.i.d. scalars + 10 % ASCII, generated in HBM by index.  Tuples on 8 MiB, count + checksum
-    on 256 MiB, and the other three charwise iterators on 2 MiB."""
+    on the configuration's full 1 GiB, and the other three charwise iterators on 2 MiB."""
     import torch
     pats = synth.patterns_cfg5()
     assert len(pats) == 50_000
     o = orc.OracleCharwisePma.build(pats, kind=1)
     p, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(o.serialize())
-    n = (256 << 20) - (256 << 20) % synth.CFG5_SLOT
+    n = (1 << 30) - (1 << 30) % synth.CFG5_SLOT
     dev = torch.empty(n, dtype=torch.uint8, device="cuda")
     synth.device_zipf_text(dev)
     small = dev[:(8 << 20) - (8 << 20) % synth.CFG5_SLOT]
@@ -88,7 +88,11 @@ def test_cfg5_charwise_leftmost_longest():
     assert _same(p.scan(ScanMode.LeftmostFind, small), want)
     assert p.scan_count(ScanMode.LeftmostFind, small) == (len(want), orc.matches_checksum(want))
     big = o.leftmost_find_iter(dev.cpu().numpy())
-    assert p.scan_count(ScanMode.LeftmostFind, dev) == (len(big), orc.matches_checksum(big))
+    assert len(big) > 40_000_000
+    want_big = (len(big), orc.matches_checksum(big))
+    del big
+    assert p.scan_count(ScanMode.LeftmostFind, dev) == want_big
+    assert p.count(ScanMode.LeftmostFind, dev) == want_big[0]
     # the Standard-kind iterators of the same dictionary
     o0 = orc.OracleCharwisePma.build(pats, kind=0)
     p0, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(o0.serialize())
@@ -99,6 +103,47 @@ def test_cfg5_charwise_leftmost_longest():
         w = getattr(o0, api)(h2)
         assert _same(p0.scan(mode, two), w), api
         assert p0.scan_count(mode, two) == (len(w), orc.matches_checksum(w)), api
+
+
+def test_product_builder_cfg3_and_cfg5_automata():
+    """The automata every other test here scans come from the ORACLE's builder (deserialize(o.serialize())); this one scans the ones the
+    PRODUCT's own builder makes (daac_bytewise_build / daac_charwise_build, src/bytewise/builder.rs:187-227, src/charwise/builder.rs:148-190)
+    from BASELINE's two dictionaries: same bytes as the oracle's, and count + checksum + tuples against the oracle's scan."""
+    import torch
+    pats = synth.patterns_cfg3()
+    o = orc.OraclePma.build(pats)
+    p = da.DoubleArrayAhoCorasick.new(pats)
+    assert p.serialize() == o.serialize()
+    n = 64 << 20
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+    host = dev.cpu().numpy()
+    want = o.overlapping_count(host, threads=16)
+    assert p.scan_count(ScanMode.FindOverlapping, dev) == want
+    assert da.last_engine() == int(Engine.Gram)
+    assert p.count(ScanMode.FindOverlapping, dev) == want[0]
+    w4 = o.find_overlapping_iter(host[:4 << 20])
+    assert _same(p.scan(ScanMode.FindOverlapping, dev[:4 << 20]), w4)
+    w1 = o.find_iter(host[:4 << 20])
+    assert _same(p.scan(ScanMode.Find, dev[:4 << 20]), w1)
+    pl = da.DoubleArrayAhoCorasickBuilder().match_kind(da.MatchKind.LeftmostLongest).build(pats)
+    ol = orc.OraclePma.build(pats, kind="LeftmostLongest")
+    assert pl.serialize() == ol.serialize()
+    wl = ol.leftmost_find_iter(host[:4 << 20])
+    assert _same(pl.scan(ScanMode.LeftmostFind, dev[:4 << 20]), wl)
+    assert pl.scan_count(ScanMode.LeftmostFind, dev[:4 << 20]) == (len(wl), orc.matches_checksum(wl))
+    # cfg5: the charwise builder, LeftmostLongest
+    cp = synth.patterns_cfg5()
+    co = orc.OracleCharwisePma.build(cp, kind=1)
+    c = da.CharwiseDoubleArrayAhoCorasickBuilder().match_kind(1).build(cp)
+    assert c.serialize() == co.serialize()
+    m = (64 << 20) - (64 << 20) % synth.CFG5_SLOT
+    synth.device_zipf_text(dev[:m])
+    ch = dev[:m].cpu().numpy()
+    cw = co.leftmost_find_iter(ch)
+    assert c.scan_count(ScanMode.LeftmostFind, dev[:m]) == (len(cw), orc.matches_checksum(cw))
+    k = (4 << 20) - (4 << 20) % synth.CFG5_SLOT
+    assert _same(c.scan(ScanMode.LeftmostFind, dev[:k]), co.leftmost_find_iter(ch[:k]))
 
 
 def test_cfg2_full_256_mib():
