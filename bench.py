@@ -659,16 +659,19 @@ def main():
         torch.cuda.empty_cache()
         # ---- dictionaries no byte-class table serves: `.count()` on the PFX engine (any byte alphabet) ------------------
         anyab = {}
-        for name in ("binary256", "utf8jp"):
-            pats_w = synth.patterns_binary256() if name == "binary256" else synth.patterns_cfg5()
+        for name in ("binary256", "utf8jp", "unidic_like", "o200k_like"):
+            pats_w = {"binary256": synth.patterns_binary256, "utf8jp": synth.patterns_cfg5, "unidic_like": synth.patterns_unidic_like,
+                      "o200k_like": synth.patterns_o200k_like}[name]()
             ap = da.DoubleArrayAhoCorasick.new(pats_w)
             ap.upload(local_rank)
             an = 1 << 30
-            if name == "utf8jp":
+            if name in ("utf8jp", "unidic_like"):
                 an -= an % synth.CFG5_SLOT
             ahay = torch.empty(an, dtype=torch.uint8, device="cuda")
             if name == "binary256":
                 synth.device_uniform(ahay, synth.SEEDS["bin_hay"], synth.ALPHA_BYTES)
+            elif name == "o200k_like":
+                synth.device_wordsoup(ahay, synth.SEEDS["o200k_hay"], synth.o200k_soup_words(), 17)
             else:
                 synth.device_zipf_text(ahay)
             fn = lambda: ap.count(ScanMode.FindOverlapping, ahay, stream=stream, result_dev=result.data_ptr())
@@ -695,19 +698,45 @@ def main():
             torch.cuda.synchronize()
             msx = e0.elapsed_time(e1) / 5
             used_x = ENGINE_NAMES.get(da.last_engine(), "?")
-            # parity on a 64 MiB prefix against the oracle (the whole GiB would take the CPU a minute)
-            pn = (64 << 20) - ((64 << 20) % synth.CFG5_SLOT if name == "utf8jp" else 0)
-            ok = None
+            # the tuples (16-byte device format) of the first 256 MiB: wall time of daac_scan_device16
+            tn = (256 << 20) - ((256 << 20) % synth.CFG5_SLOT)
+            da.set_option("max_result_bytes", 64 << 30)
+            dm = ap.scan_device(ScanMode.FindOverlapping, ahay[:tn], fmt16=True)
+            dm.free()
+            torch.cuda.synchronize()
+            t_best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                dm = ap.scan_device(ScanMode.FindOverlapping, ahay[:tn], fmt16=True)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                n_tuples = dm.count
+                dm.free()
+                t_best = dt if t_best is None else min(t_best, dt)
+            used_t = ENGINE_NAMES.get(da.last_engine(), "?")
+            # parity on a 64 MiB prefix against the oracle (the whole GiB would take the CPU a minute); tuples on 8 MiB
+            pn = (64 << 20) - ((64 << 20) % synth.CFG5_SLOT if name in ("utf8jp", "unidic_like") else 0)
+            ok = ok_t = None
             if not args.no_cpu:
                 from oracle import oracle as orc2
                 oo = orc2.OraclePma.deserialize(ap.serialize())
                 want_a = oo.overlapping_count(ahay[:pn].cpu().numpy(), threads=16)
                 ok = bool(ap.count(ScanMode.FindOverlapping, ahay[:pn]) == want_a[0] and ap.scan_count(ScanMode.FindOverlapping, ahay[:pn]) == want_a)
-            anyab[name] = {"dictionary": ("100 000 random patterns of 3-12 bytes over all 256 byte values; haystack: uniform random bytes" if name == "binary256"
-                                          else "cfg5's 50 000 UTF-8 patterns (2-8 three-byte scalars, Zipf) scanned BYTEWISE; haystack: cfg5's Zipf text"),
+                qn = 48 * 174762
+                want_t = oo.find_overlapping_iter(ahay[:qn].cpu().numpy())
+                got_t = ap.scan(ScanMode.FindOverlapping, ahay[:qn])
+                ok_t = bool(len(got_t) == len(want_t) and np.array_equal(got_t["start"], want_t["start"]) and np.array_equal(got_t["end"], want_t["end"]) and
+                            np.array_equal(got_t["value"], want_t["value"]))
+            anyab[name] = {"dictionary": {"binary256": "100 000 random patterns of 3-12 bytes over all 256 byte values; haystack: uniform random bytes",
+                                          "utf8jp": "cfg5's 50 000 UTF-8 patterns (2-8 three-byte scalars, Zipf) scanned BYTEWISE; haystack: cfg5's Zipf text",
+                                          "unidic_like": "look-alike of the crate's Unidic benchmark dictionary: 675 000 UTF-8 patterns of 1-8 three-byte scalars (Zipf); haystack: cfg5's Zipf text",
+                                          "o200k_like": "look-alike of o200k_base: 200 000 byte-level tokens incl. all 256 one-byte patterns; haystack: soup of its base words"}[name],
+                            "patterns": len(pats_w), "automaton_bytes": ap.heap_bytes(),
                             "bytes": an, "value": round(an / ms / 1e6, 2), "unit": "GB/s", "frac": round(an / ms / 1e6 / HBM_PEAK_GBS, 4),
-                            "kernel_ms": round(ms, 4), "engine_used": used, "match_count": gpu_cnt,
+                            "kernel_ms": round(ms, 4), "engine_used": used, "match_count": gpu_cnt, "matches_per_byte": round(gpu_cnt / an, 4),
                             "with_checksum": {"value": round(an / msx / 1e6, 2), "unit": "GB/s", "kernel_ms": round(msx, 4), "engine_used": used_x},
+                            "tuples_device": {"bytes": tn, "matches": int(n_tuples), "GB/s": round(tn / t_best / 1e9, 2), "tuple_GB/s": round(n_tuples * 16 / t_best / 1e9, 1),
+                                              "seconds": round(t_best, 5), "engine_used": used_t, "parity_8mib_prefix_vs_oracle": ok_t},
                             "parity_64mib_prefix_vs_oracle": ok}
             del ahay, ap
             torch.cuda.empty_cache()

@@ -158,6 +158,8 @@ struct DeviceTables {
     bool emit3_ok = false;     // ... with detection done once (emit3_kernels.hip)
     Gram3Lds emit3_lds{};
     bool emit3_has_len1 = false;   // some pattern is a single byte
+    bool pfx_emit_ok = false;      // PFX tuples: pfx_emit_kernel + EXPAND over the raw haystack (no pattern registered twice)
+    Gram2EmitDev pfx_emit{};       // what that EXPAND needs: V1 by byte + the 256 flag bytes (v1, v1_bytes = 1280), K = 1
     std::atomic<uint32_t> emit3_rec_per_kib{0};  // deep-match records per KiB the last scans met (sizes the next scan's list)
     // scans in a row on which an emitter gave up on the TEXT (more deep matches or extras than it places: known only after its detection
     // has run): from the second on the handle stops trying and the plan says so (a served scan resets the count)
@@ -691,6 +693,15 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             { const U32x4 *x; if ((st = t->put(px.slots_x, x)) != DAAC_OK) return st; d.slots_x = reinterpret_cast<const uint4 *>(x); }
             { const U32x4 *x; if ((st = t->put(px.wrec_x, x)) != DAAC_OK) return st; d.wrec_x = reinterpret_cast<const uint4 *>(x); }
             if ((st = t->put(px.hs1, d.hs1)) != DAAC_OK) return st;
+            if (px.emit_ok) {
+                { const U32x4 *x; if ((st = t->put(px.slots_e, x)) != DAAC_OK) return st; d.slots_e = reinterpret_cast<const uint4 *>(x); }
+                std::vector<uint32_t> v1f(320, 0);   // V1 by byte, then the flag bytes
+                std::memcpy(v1f.data(), px.v1.data(), 1024);
+                std::memcpy(v1f.data() + 256, px.has1.data(), 256);
+                if ((st = t->put(v1f, t->pfx_emit.v1)) != DAAC_OK) return st;
+                t->pfx_emit.v1_bytes = 1280;
+                t->pfx_emit.K = 1;
+            }
             d.slots = reinterpret_cast<const uint4 *>(sl);
             d.wrec = reinterpret_cast<const uint2 *>(wr);
             d.G = px.G; d.has_len1 = px.has_len1; d.bloom_words = px.bloom_words; d.buckets = px.buckets; d.n_slots = px.n_slots;
@@ -698,6 +709,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             d.bloom_bytes = p16(px.bloom.size() * 4);
             d.disp_bytes = p16(px.disp.size() * 2);
             t->pfx_ok = pfx_plan(d, 160u * 1024u);
+            t->pfx_emit_ok = t->pfx_ok && px.emit_ok && h.max_pattern_len() < (1u << 22);
         }
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -956,12 +968,14 @@ struct DevMatches {
 // DETECT (annotated class stream, tile counts, deep-match records) -> scans of the tile counts -> BIN (records by tile) -> EXPAND.
 // *served = false when the automaton / request does not qualify or the haystack is of the adversarial kind the kernels give up on
 // (then nothing is returned and the other engines take over).
+// `raw`: the PFX engine's tuples (any byte alphabet): pfx_emit_kernel logs every match of two or more bytes as a record, EXPAND runs over the
+// haystack itself (one-byte patterns by table) — same glue, same record list, no annotated stream.
 daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t end, hipStream_t stream,
-                              DevMatches &out, bool *served) {
+                              DevMatches &out, bool *served, bool raw = false) {
     *served = false;
-    if (!t->emit3_ok || g_opt.emit.load() == 0 || end <= begin) return DAAC_OK;
+    if (!(raw ? t->pfx_emit_ok : t->emit3_ok) || g_opt.emit.load() == 0 || end <= begin) return DAAC_OK;
     if (t->emit3_gave_up.load() >= 2 && end - begin >= (1u << 20)) return DAAC_OK;   // (short scans may still try: they cost little)
-    const Gram2EmitDev &e = t->emit;
+    const Gram2EmitDev &e = raw ? t->pfx_emit : t->emit;
     const Gram3Lds &L = t->emit3_lds;
     const uint64_t halo = pma->halo();
     // windows of at most 1 GiB of end positions: virtual positions inside a window fit 32 bits
@@ -986,25 +1000,26 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         w.tile0 = tiles_total;
         w.ann0 = ann_total;
         tiles_total += w.ntiles;
-        ann_total += static_cast<uint64_t>(w.nsteps) * kStep;
+        if (!raw) ann_total += static_cast<uint64_t>(w.nsteps) * kStep;
         wins.push_back(w);
     }
     if (tiles_total >= (1ull << 32)) return DAAC_OK;
     // DETECT geometry (gram3's): regions of 64 KiB (256 KiB for the large windows), one 16- or 8-wave workgroup per CU
     uint32_t region = (end - begin) >= (1ull << 31) ? 262144u : 65536u;
     if (g_opt.gram_region.load() >= 2048) { region = 2048; while (region * 2 <= static_cast<uint64_t>(g_opt.gram_region.load()) && region < (1u << 20)) region *= 2; }
-    const uint32_t wpb = L.threads / 64;
+    const uint32_t wpb = raw ? t->pfx.threads / 64 : L.threads / 64;
     uint64_t max_regions = 0;
     for (const Win &w : wins) max_regions = std::max<uint64_t>(max_regions, (static_cast<uint64_t>(w.vlen) + region - 1) / region);
     const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (max_regions + wpb - 1) / wpb)));
     const uint64_t nwaves = static_cast<uint64_t>(blocks) * wpb;
     const uint32_t wq_slab = static_cast<uint32_t>(std::max<int64_t>(64 * 32 + 128 + 64, g_opt.gram_slab.load()));
+    const size_t wq_entry = raw ? sizeof(uint4) : sizeof(uint2);
 
     const size_t scan_words = tiles_total + 2 + exclusive_scan_scratch(tiles_total);
     const size_t off_short = 0, off_deep = off_short + ((tiles_total * 4 + 255) & ~size_t(255));
     const size_t off_a = off_deep + ((tiles_total * 4 + 255) & ~size_t(255)), off_b = off_a + ((scan_words * 8 + 255) & ~size_t(255));
     const size_t off_ctl = off_b + ((scan_words * 8 + 255) & ~size_t(255));   // {chunk_next, fail}
-    const size_t off_wq = off_ctl + 256, off_ann = off_wq + ((nwaves * wq_slab * sizeof(uint2) + 255) & ~size_t(255));
+    const size_t off_wq = off_ctl + 256, off_ann = off_wq + ((nwaves * wq_slab * wq_entry + 255) & ~size_t(255));
     DevBuf g1, g_recs, g_bins;
     HIP_TRY(g1.alloc(off_ann + ann_total + 256, stream));
     char *base = static_cast<char *>(g1.p);
@@ -1027,6 +1042,7 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         uint32_t *d_fill = reinterpret_cast<uint32_t *>(d_recs + chunk_cap * kEmit3Chunk);
         HIP_TRY(hipMemsetAsync(d_fill, 0, chunk_cap * 4, stream));
         HIP_TRY(hipMemsetAsync(d_deep, 0, tiles_total * 4, stream));
+        if (raw) HIP_TRY(hipMemsetAsync(d_short, 0, tiles_total * 4, stream));   // (its DETECT writes the tiles it meets one-byte patterns in)
         HIP_TRY(hipMemsetAsync(d_ctl, 0, 256, stream));
         for (const Win &w : wins) {
             Emit3Args a{};
@@ -1037,7 +1053,8 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
             a.wq = reinterpret_cast<uint2 *>(base + off_wq); a.wq_slab = wq_slab;
             a.region_bytes = region; a.nregions = static_cast<uint32_t>((static_cast<uint64_t>(w.vlen) + region - 1) / region);
             a.fail = d_ctl + 1;
-            HIP_TRY(launch_emit3_detect(e, a, L, blocks, stream));
+            if (raw) HIP_TRY(launch_pfx_emit_detect(t->pfx, a, blocks, stream));
+            else HIP_TRY(launch_emit3_detect(e, a, L, blocks, stream));
         }
         HIP_TRY(launch_emit3_combine(d_short, d_deep, d_a, d_b, tiles_total, stream));
         HIP_TRY(launch_exclusive_scan(d_a, tiles_total, d_a + tiles_total, d_a + tiles_total + 2, stream));
@@ -1060,7 +1077,7 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         chunk_cap = static_cast<uint64_t>(ctl[0]) + 2 * nwaves + 16;   // (chunks are closed at least half full: the rerun takes no more of them)
     }
     t->emit3_rec_per_kib.store(static_cast<uint32_t>(std::min<uint64_t>(1u << 20, deep_total * 5 / 4 / ((end - begin) / 1024 + 1) + 1)));
-    g_last_engine = DAAC_ENGINE_GRAM;
+    g_last_engine = raw ? DAAC_ENGINE_PFX : DAAC_ENGINE_GRAM;
     const size_t tuple_bytes = out.f16 ? 16 : sizeof(daac_match);
     if (total == 0) { *served = true; return DAAC_OK; }
     if (total * tuple_bytes > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
@@ -1088,16 +1105,18 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         a.binned = static_cast<const uint4 *>(g_bins.p);
         a.out = d_out;
         a.pos_base = w.from - w.lead + 1;  // (mod 2^64: a match ends one past its last byte)
-        a.has_len1 = t->emit3_has_len1 ? 1u : 0u;
+        a.has_len1 = (raw ? t->pfx.has_len1 != 0 : t->emit3_has_len1) ? 1u : 0u;
+        if (raw) { a.ann = w.hay_al; a.vlen = w.vlen; a.emit_from = w.emit_from; }
         // the rank structure goes to LDS when the workgroups still fit with it: two of eight waves (16-byte tuples), three of four (24-byte)
-        const uint32_t xwaves = out.f16 ? 8u : 4u;
-        a.v3_in_lds = (e.v3c != nullptr && g_opt.emit_v3_lds.load() != 0 &&
+        const uint32_t xwaves = (out.f16 && !raw) ? 8u : 4u;
+        a.v3_in_lds = (!raw && e.v3c != nullptr && g_opt.emit_v3_lds.load() != 0 &&
                        emit3_expand_lds_bytes(e, xwaves, out.f16, true) <= (160u * 1024u) / (out.f16 ? 2u : 3u)) ? 1u : 0u;
         a.off_wave = e.v1_bytes + e.v2_bytes + (a.v3_in_lds ? e.v3c_bytes : 0u);
         a.stagger = a.ntiles >= 65536u ? static_cast<uint32_t>(std::max<int64_t>(0, std::min<int64_t>(64, g_opt.emit_stagger.load()))) : 0u;
         a.fail = d_ctl + 1;
-        const uint32_t xblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * (out.f16 ? 2u : 4u), (a.ntiles + xwaves - 1) / xwaves)));
-        HIP_TRY(launch_emit3_expand(e, a, out.f16, xblocks, stream));
+        const uint32_t xblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * ((out.f16 && !raw) ? 2u : 4u), (a.ntiles + xwaves - 1) / xwaves)));
+        if (raw) HIP_TRY(launch_emit3_expand_raw(e, a, out.f16, xblocks, stream));
+        else HIP_TRY(launch_emit3_expand(e, a, out.f16, xblocks, stream));
     }
     {
         unsigned int fail = 0;
@@ -1235,10 +1254,20 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
                               uint64_t end, uint64_t total_len, hipStream_t stream, DevMatches &out, uint64_t *next_begin) {
     Plan pl;
     bool heads = false;
-    const bool want_gram = engine == DAAC_ENGINE_GRAM;
-    daac_status st = make_plan(pma, t, mode, want_gram ? DAAC_ENGINE_AUTO : engine, begin, end, pl, heads);
+    const bool want_gram = engine == DAAC_ENGINE_GRAM, want_pfx = engine == DAAC_ENGINE_PFX;
+    daac_status st = make_plan(pma, t, mode, (want_gram || want_pfx) ? DAAC_ENGINE_AUTO : engine, begin, end, pl, heads);
     if (st != DAAC_OK) return st;
     if (next_begin) *next_begin = end;
+    if (!pma->charwise && mode == DAAC_FIND_OVERLAPPING && (engine == DAAC_ENGINE_AUTO || want_pfx) && t->pfx_emit_ok) {
+        bool served = false;
+        if (end <= begin && want_pfx) { g_last_engine = DAAC_ENGINE_PFX; return DAAC_OK; }   // (no "" among the patterns: nothing ends at 0)
+        if ((st = emit_overlapping3(pma, t, dev_hay, begin, end, stream, out, &served, true)) != DAAC_OK) return st;
+        if (served) return DAAC_OK;
+    }
+    if (want_pfx) {
+        set_error(std::string("the PFX engine cannot emit tuples for this automaton / request [") + last_error_cstr() + "]");
+        return DAAC_ERR_UNSUPPORTED;
+    }
     if (!pma->charwise && mode == DAAC_FIND_OVERLAPPING && (engine == DAAC_ENGINE_AUTO || want_gram)) {
         bool served = false;
         if (g_opt.emit_version.load() != 1) {
@@ -1470,6 +1499,8 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
     else set(DAAC_REQ_OVERLAPPING_CHECKSUM, micro_engine, micro, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);
     if (((t->emit3_ok && t->emit3_gave_up.load() < 2) || (t->emit_ok && t->emit_gave_up.load() < 2)) && g_opt.emit.load() != 0)
         set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EMIT, DAAC_WHY_FASTEST);
+    else if (t->pfx_emit_ok && t->emit3_gave_up.load() < 2 && g_opt.emit.load() != 0)
+        set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, why_no_gram);
     else set(DAAC_REQ_OVERLAPPING_TUPLES, seg_engine, DAAC_KERNEL_SEGMENT, t->gram2_ok ? DAAC_WHY_DUPLICATES : why_no_gram);
     set(DAAC_REQ_NO_SUFFIX, seg_engine, DAAC_KERNEL_SEGMENT, DAAC_WHY_FASTEST);
     set(DAAC_REQ_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);  // (the restart iterators run on the double array)
@@ -2125,7 +2156,7 @@ daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *h
     if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
     Plan pl;
     bool heads;
-    if ((st = make_plan(pma, t, mode, engine == DAAC_ENGINE_GRAM ? DAAC_ENGINE_AUTO : engine, 0, len, pl, heads)) != DAAC_OK) return st;  // kind / mode checks up front
+    if ((st = make_plan(pma, t, mode, (engine == DAAC_ENGINE_GRAM || engine == DAAC_ENGINE_PFX) ? DAAC_ENGINE_AUTO : engine, 0, len, pl, heads)) != DAAC_OK) return st;  // kind / mode checks up front
     std::unique_ptr<daac_iter> it(new daac_iter);
     it->pma = pma; it->mode = mode; it->engine = engine; it->hay = hay; it->len = len;
     it->hay_is_device = hay_is_device != 0;

@@ -265,6 +265,7 @@ struct Expand3Args {
     uint32_t stagger;                    // start delay per wave of a CU, in units of 1024 cycles x (wave number mod 16)
     uint32_t v3_in_lds;                  // the rank structure of the 3-byte patterns' values is staged behind V2 (else they are read from L2)
     unsigned int *fail;                  // bit 2: more extras in one tile than EXPAND places; bit 3: a slot outside its tile (a bug)
+    uint32_t vlen, emit_from;            // RAW (PFX) only: `ann` is the haystack; positions in [emit_from, vlen) can end a one-byte match
 };
 bool emit3_plan(const Gram2EmitDev &dev, uint32_t waves, uint32_t lds_limit, Gram3Lds &L);
 hipError_t launch_emit3_detect(const Gram2EmitDev &dev, const Emit3Args &a, const Gram3Lds &L, uint32_t blocks, hipStream_t stream);
@@ -273,6 +274,7 @@ hipError_t launch_emit3_combine(const uint32_t *tile_short, const uint32_t *tile
 hipError_t launch_emit3_bin(const uint4 *recs, const uint32_t *chunk_fill, const uint32_t *chunk_next, uint32_t chunk_cap, const unsigned long long *bin_off,
                             uint32_t *cursor, uint4 *binned, uint32_t blocks, hipStream_t stream);
 hipError_t launch_emit3_expand(const Gram2EmitDev &dev, const Expand3Args &a, bool f16, uint32_t blocks, hipStream_t stream);
+hipError_t launch_emit3_expand_raw(const Gram2EmitDev &dev, const Expand3Args &a, bool f16, uint32_t blocks, hipStream_t stream);
 uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves, bool f16, bool v3_in_lds);
 
 // PFX engine (pfx.hpp): `.count()` for bytewise automata over any byte alphabet.  LDS: BLOOM at 0 | DISP | CNT1 | per-wave areas
@@ -285,6 +287,7 @@ struct PfxDev {
     const uint4 *slots_x;    // count + checksum: {key 0-3, key 4-5 | own << 16, BASE, sum of h32 of the patterns that are the key}
     const uint4 *wrec_x;     // count + checksum: {BASE, CHECK | own << 8, sum of h32 of the patterns that end there, 0}
     const uint32_t *hs1;     // 256: sum of h32 of the one-byte patterns (staged behind CNT1)
+    const uint4 *slots_e;    // tuple emission: {key 0-3, key 4-5 | own << 16, BASE, VALUE of the pattern that is the key}; wrec_x[.].w = the value of a state's own pattern
     uint32_t G, has_len1, bloom_words, buckets, n_slots, seed;
     uint32_t bloom_bytes, disp_bytes;                       // multiples of 16
     uint32_t off_disp, off_cnt1, off_wave, wave_stride, lds_bytes, threads;   // pfx_plan
@@ -292,6 +295,8 @@ struct PfxDev {
 };
 bool pfx_plan(PfxDev &d, uint32_t lds_limit);
 hipError_t launch_pfx_scan(const PfxDev &dev, const GramArgs &a, bool exact, uint32_t blocks, hipStream_t stream);
+struct Emit3Args;
+hipError_t launch_pfx_emit_detect(const PfxDev &dev, const Emit3Args &a, uint32_t blocks, hipStream_t stream);
 
 hipError_t launch_overlap_count(const DArrayDev &dev, const ScanArgs &a, bool heads, uint32_t blocks, hipStream_t stream);
 hipError_t launch_char_overlap_count(const CharDev &dev, const ScanArgs &a, bool heads, uint32_t blocks, hipStream_t stream);

@@ -529,8 +529,11 @@ __global__ __launch_bounds__(256) void emit3_bin_kernel(const uint4 *__restrict_
 // lane that holds the record — and the tile is then copied out 64 CONSECUTIVE slots per store instruction: one contiguous kilobyte.
 // A tile of more than 1024 tuples (dozens of deep matches per position) takes several passes over a window of slots.
 // HAS1: the dictionary has one-byte patterns (else that flag bit is never set and the walk leaves it out)
-template <int K, bool F16, bool HAS1>
-__global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_kernel(const Gram2EmitDev g, const Expand3Args a) {
+// RAW (the PFX engine's tuples, K = 1): the "stream" is the haystack itself — a position's only flag is "this byte is a one-byte pattern" (a
+// 256-byte table behind V1, which is indexed by byte), every longer match is a record; tuples are staged as 8-byte entries for both formats.
+template <int K, bool F16, bool HAS1, bool RAW>
+__global__ __launch_bounds__((F16 && !RAW) ? 512 : 256, (F16 && !RAW) ? 4 : 3) void emit3_expand_kernel(const Gram2EmitDev g, const Expand3Args a) {
+    constexpr bool ST16 = F16 && !RAW;   // the staged entries are u16 {position | length} (values looked up when the tile goes out)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     e3_copy(smem, g.v1, g.v1_bytes);
     e3_copy(smem + g.v1_bytes, g.v2, g.v2_bytes);
@@ -560,8 +563,8 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
     constexpr uint32_t W = kEmit3Stage;   // slots per pass
     // F24: W staged tuples of 8 bytes.  F16: W u16 entries {position | length << 10} and the tile's 16 + 1024 stream bytes (the values are
     // looked up when the tile goes out).  Then one dump entry per lane (what a lane has NOT got to write goes there: no branch).
-    constexpr uint32_t SW = F16 ? (W + 64u) * 2u + 1040u : (W + 64u) * 8u;
-    constexpr uint32_t WAVE_BYTES = F16 ? kEmit3ExpandWave16 : kEmit3ExpandWave;
+    constexpr uint32_t SW = ST16 ? (W + 64u) * 2u + 1040u : (W + 64u) * 8u;
+    constexpr uint32_t WAVE_BYTES = ST16 ? kEmit3ExpandWave16 : kEmit3ExpandWave;
     char *wl = smem + a.off_wave + wave_in_wg * WAVE_BYTES;
     uint2 *stage = reinterpret_cast<uint2 *>(wl);                               // F24: W x {value, position in tile | length << 10}
     uint16_t *stage16 = reinterpret_cast<uint16_t *>(wl);                       // F16: W x {position in tile | length << 10} (0: a deep match's slot)
@@ -604,8 +607,14 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
         t = t < a.ntiles ? t : a.ntiles - 1u;
         const uint32_t v0 = t * kEmit3Tile;
         TileIn x;
+        if (RAW) {   // (the haystack ends where it ends: a chunk beyond it is asked for at the last one's address and masked below)
+            const uint32_t va = v0 + lane * 16u, last = (a.vlen - 1u) & ~15u;
+            x.annq = *reinterpret_cast<const uint4 *>(a.ann + (va < last ? va : last));
+            x.prev2 = 0u;
+        } else {
         x.annq = *reinterpret_cast<const uint4 *>(a.ann + v0 + lane * 16u);
         x.prev2 = *reinterpret_cast<const uint16_t *>(a.ann + (v0 != 0 ? v0 - 2u : 0u));   // the two stream bytes before the tile (tile 0: not used)
+        }
         x.rec0 = a.binned[sx.bin0 + (lane < sx.n ? lane : 0u)];   // (the list ends with one spare record: n may be 0 at its very end)
         return x;
     };
@@ -634,10 +643,27 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
         if (tile_n == 0) { arrived(); return; }
         char *__restrict__ out = reinterpret_cast<char *>(a.out) + tile_base * (F16 ? 16ull : 24ull);
         const unsigned long long end0 = a.pos_base + v0;   // end of a match whose last byte is the tile's position 0
-        const uint32_t aw[4] = {annq.x, annq.y, annq.z, annq.w};
+        uint32_t aw[4] = {annq.x, annq.y, annq.z, annq.w};
+        const uint32_t rawq[4] = {annq.x, annq.y, annq.z, annq.w};   // RAW: the haystack bytes themselves
+        if (RAW) {   // flag bytes from the table of one-byte patterns; positions outside [emit_from, vlen) have none
+            const uint32_t p0 = v0 + lane * 16u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t f = 0;
+                if (HAS1) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t p = p0 + 4u * k + b;
+                        const uint32_t fl = *reinterpret_cast<ldsx_cu8 *>(static_cast<uintptr_t>(1024u + ((rawq[k] >> (8 * b)) & 0xffu)));
+                        f |= ((p >= a.emit_from && p < a.vlen) ? fl : 0u) << (8 * b);
+                    }
+                }
+                aw[k] = f;
+            }
+        }
         // classes of positions -2 .. 15 of this lane (5 bits each), flags of positions 0 .. 15 (3 bits each)
         const uint32_t left = wave_shr1_x(annq.w >> 16, prev2);
-        if (F16) {
+        if (ST16) {
             *reinterpret_cast<uint4 *>(annb + 16u + lane * 16u) = annq;
             if (lane == 0) *reinterpret_cast<uint16_t *>(annb + 14u) = static_cast<uint16_t>(prev2);
         }
@@ -718,7 +744,7 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
             // (Four positions — one stream dword — per turn of a loop that is NOT unrolled: unrolled sixteen-fold the compiler hoisted every
             // table lookup to the top and spilled a hundred registers.)
             uint32_t run = lanebase - wbase;
-            if (F16) {
+            if (ST16) {
                 // (F16: an entry is {position | length << 10}; per kind of a position: the flag as a mask (v_bfe_i32), the slot or nothing
                 // (v_bfi), the dump entry for nothing (v_min), the address, the entry, the store, the count)
                 uint32_t q0 = aw[0], q1 = aw[1], q2 = aw[2], q3 = aw[3];
@@ -755,6 +781,7 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
             } else {
                 uint32_t prevw = left << 16;                  // the two classes before the lane's first position, in bytes 2 and 3
                 uint32_t q0 = aw[0], q1 = aw[1], q2 = aw[2], q3 = aw[3];
+                uint32_t r0 = rawq[0], r1 = rawq[1], r2 = rawq[2], r3 = rawq[3];
                 uint32_t e0 = dmw[0], e1 = dmw[1], e2 = dmw[2], e3 = dmw[3], e4 = dmw[4], e5 = dmw[5], e6 = dmw[6], e7 = dmw[7];
                 unsigned long long xq = xin;
                 uint32_t pj = lane * 16u;
@@ -764,7 +791,7 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const uint32_t byte_j = (q0 >> (8 * j)) & 0xffu;
-                        const uint32_t cj = byte_j & 31u;
+                        const uint32_t cj = RAW ? (r0 >> (8 * j)) & 0xffu : byte_j & 31u;
                         const uint32_t cm1 = (j >= 1 ? q0 >> (8 * (j - 1)) : prevw >> 24) & 31u;
                         const uint32_t cm2 = (j >= 2 ? q0 >> (8 * (j - 2)) : prevw >> (8 * (j + 2))) & 31u;
                         if (deep) run += __popc((dd[j >> 1] >> (16 * (j & 1))) & 0xffffu) + static_cast<uint32_t>((xq >> (4 * j)) & 15u);
@@ -773,7 +800,7 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
                             stage[at] = uint2{cm2 * CC + cm1 * C + cj, (pj + j) | (3u << 10)};
                             run += byte_j >> 7;
                         }
-                        {
+                        if (K >= 2) {
                             const uint32_t at = min((byte_j & 0x40u) ? run : 0xffffffffu, dump);
                             stage[at] = uint2{v2[cm1 * C + cj], (pj + j) | (2u << 10)};
                             run += (byte_j >> 6) & 1u;
@@ -785,6 +812,7 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
                         }
                     }
                     prevw = q0; q0 = q1; q1 = q2; q2 = q3;
+                    r0 = r1; r1 = r2; r2 = r3;
                     e0 = e2; e1 = e3; e2 = e4; e3 = e5; e4 = e6; e5 = e7;
                     xq >>= 16;
                     pj += 4u;
@@ -840,7 +868,7 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
                     }
                     if (xn != 0) slot += extras_before(normal ? p : 0xfffffff0u, len, 0u);
                     slot -= wbase;
-                    if (F16) {   // a deep match goes straight to memory (one in fifty tuples of cfg3); its slot stays empty for the copy-out
+                    if (ST16) {   // a deep match goes straight to memory (one in fifty tuples of cfg3); its slot stays empty for the copy-out
                         stage16[min(normal ? slot : 0xffffffffu, dump)] = 0;
                         if (normal && slot < W) put_tuple_x<true>(out, wbase + slot, a.pos_base + r.x, len, r.z);
                     } else {
@@ -858,7 +886,7 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
                     }
                     slot += extras_before(mine ? p : 0xfffffff0u, el, ec);
                     slot -= wbase;
-                    if (F16) {
+                    if (ST16) {
                         stage16[min(mine ? slot : 0xffffffffu, dump)] = 0;
                         if (mine && slot < W) put_tuple_x<true>(out, wbase + slot, end0 + p, el, ex.z);
                     } else {
@@ -868,7 +896,15 @@ __global__ __launch_bounds__(F16 ? 512 : 256, F16 ? 4 : 3) void emit3_expand_ker
             }
             // ---- out: 64 consecutive slots per store instruction ----
             const uint32_t wn = tile_n - wbase < W ? tile_n - wbase : W;
-            if (F16) {
+            if (RAW && F16) {   // 16-byte tuples from the 8-byte entries: 64 consecutive slots per store instruction
+                for (uint32_t c0 = 0; c0 < wn; c0 += 64u) {
+                    const uint32_t s = c0 + lane;
+                    if (s < wn) {
+                        const uint2 e = stage[s];
+                        put_tuple_x<true>(out, wbase + s, end0 + (e.y & 1023u), e.y >> 10, e.x);
+                    }
+                }
+            } else if (ST16) {
                 // Every slot of the window: its entry, the classes of the position and the two before it (the tile's stream bytes in LDS), the
                 // value from V1 / V2 / the rank structure of V3 (LDS; V3 from L2 when the structure did not fit).  Five store instructions'
                 // worth of slots at a time, each step for all five before the next step (no branch in between: the LDS round trips of the five
@@ -1035,24 +1071,30 @@ uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves, bool f1
     return dev.v1_bytes + dev.v2_bytes + (v3_in_lds ? dev.v3c_bytes : 0u) + waves * (f16 ? kEmit3ExpandWave16 : kEmit3ExpandWave);
 }
 
-template <int K, bool F16, bool HAS1>
+template <int K, bool F16, bool HAS1, bool RAW>
 static hipError_t launch_expand_inst(const Gram2EmitDev &dev, const Expand3Args &a, uint32_t blocks, hipStream_t stream) {
-    // 16-byte format: eight waves share the tables (two workgroups = sixteen waves per CU); 24-byte format: four (its staged tuples are 8 bytes)
-    constexpr uint32_t kWaves = F16 ? 8 : 4;
-    const uint32_t lds = emit3_expand_lds_bytes(dev, kWaves, F16, a.v3_in_lds != 0);
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(emit3_expand_kernel<K, F16, HAS1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    // 16-byte format: eight waves share the tables (two workgroups = sixteen waves per CU); 24-byte format and RAW: four (8-byte staged entries)
+    constexpr uint32_t kWaves = (F16 && !RAW) ? 8 : 4;
+    const uint32_t lds = emit3_expand_lds_bytes(dev, kWaves, F16 && !RAW, a.v3_in_lds != 0);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(emit3_expand_kernel<K, F16, HAS1, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((emit3_expand_kernel<K, F16, HAS1>), dim3(blocks), dim3(kWaves * 64), lds, stream, dev, a);
+    hipLaunchKernelGGL((emit3_expand_kernel<K, F16, HAS1, RAW>), dim3(blocks), dim3(kWaves * 64), lds, stream, dev, a);
     return hipGetLastError();
 }
 template <int K, bool F16>
 static hipError_t launch_expand_k(const Gram2EmitDev &dev, const Expand3Args &a, uint32_t blocks, hipStream_t stream) {
-    return a.has_len1 ? launch_expand_inst<K, F16, true>(dev, a, blocks, stream) : launch_expand_inst<K, F16, false>(dev, a, blocks, stream);
+    return a.has_len1 ? launch_expand_inst<K, F16, true, false>(dev, a, blocks, stream) : launch_expand_inst<K, F16, false, false>(dev, a, blocks, stream);
 }
 hipError_t launch_emit3_expand(const Gram2EmitDev &dev, const Expand3Args &a, bool f16, uint32_t blocks, hipStream_t stream) {
     if (dev.K == 3) return f16 ? launch_expand_k<3, true>(dev, a, blocks, stream) : launch_expand_k<3, false>(dev, a, blocks, stream);
     return f16 ? launch_expand_k<2, true>(dev, a, blocks, stream) : launch_expand_k<2, false>(dev, a, blocks, stream);
+}
+// The PFX engine's tuples: the stream is the haystack (a.ann = its 16-byte-aligned address, a.vlen / a.emit_from say which positions count), dev
+// carries only V1 by byte (1024 bytes) and the 256 flag bytes behind it (v1_bytes = 1280, v2_bytes = 0)
+hipError_t launch_emit3_expand_raw(const Gram2EmitDev &dev, const Expand3Args &a, bool f16, uint32_t blocks, hipStream_t stream) {
+    if (f16) return a.has_len1 ? launch_expand_inst<1, true, true, true>(dev, a, blocks, stream) : launch_expand_inst<1, true, false, true>(dev, a, blocks, stream);
+    return a.has_len1 ? launch_expand_inst<1, false, true, true>(dev, a, blocks, stream) : launch_expand_inst<1, false, false, true>(dev, a, blocks, stream);
 }
 
 }  // namespace daac

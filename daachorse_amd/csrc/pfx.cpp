@@ -40,16 +40,18 @@ bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
     }
     for (bool b : seen_byte) out.n_distinct_bytes += b ? 1u : 0u;
     // ---- patterns that END in a state (its own, not those of its suffixes): list entries as long as the state is deep ----
-    std::vector<uint32_t> own(n, 0), own_hs(n, 0);
+    std::vector<uint32_t> own(n, 0), own_hs(n, 0), own_val(n, 0);
     uint32_t min_len2 = kNone;
-    bool has_len1 = false;
+    bool has_len1 = false, no_dups = true;
     for (const uint32_t s : order) {
         uint32_t op = output_pos_of(p.states[s].opos_ch);
         while (op != 0 && p.outputs[op - 1].length == depth[s]) {
+            if (own[s] == 0) own_val[s] = p.outputs[op - 1].value;
             ++own[s];
             own_hs[s] += match_hash32(p.outputs[op - 1].value, p.outputs[op - 1].length);
             op = p.outputs[op - 1].parent;
         }
+        if (own[s] > 1) no_dups = false;
         if (own[s] >= (1u << 24)) return false;
         if (own[s] != 0) {
             if (depth[s] == 1) has_len1 = true; else min_len2 = std::min(min_len2, depth[s]);
@@ -101,11 +103,15 @@ bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
     // ---- CNT1 ----
     out.cnt1.assign(256, 0);
     out.hs1.assign(256, 0);
+    out.v1.assign(256, 0);
+    out.has1.assign(256, 0);
     for (const uint32_t s : order)
         if (depth[s] == 1) {
             if (own[s] > 0xffff) return false;
             out.cnt1[k0[s] & 0xffu] = static_cast<uint16_t>(own[s]);
             out.hs1[k0[s] & 0xffu] = own_hs[s];
+            out.v1[k0[s] & 0xffu] = own_val[s];
+            out.has1[k0[s] & 0xffu] = own[s] ? 0x20 : 0;
         }
 
     // ---- hash and displace ----
@@ -150,10 +156,12 @@ bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
         out.disp = std::move(disp);
         out.slots.assign(M, U32x4{0u, kPfxEmpty, 0u, 0u});
         out.slots_x.assign(M, U32x4{0u, kPfxEmpty, 0u, 0u});
+        out.slots_e.assign(M, U32x4{0u, kPfxEmpty, 0u, 0u});
         for (uint32_t i = 0; i < nk; ++i) {
             const uint32_t s = keys[i].state;
             if (own[s] >= (1u << 14)) return false;
             out.slots_x[slot_of[i]] = U32x4{keys[i].k0, keys[i].k1 | (own[s] << 16), p.states[s].base, own_hs[s]};
+            out.slots_e[slot_of[i]] = U32x4{keys[i].k0, keys[i].k1 | (own[s] << 16), p.states[s].base, own_val[s]};
             if (path_len[s] != 0xff && path_len[s] != 0) {  // one path below the key: the record carries it
                 uint64_t bytes = 0;
                 uint32_t ends = own[s] ? 1u : 0u, cur = s;
@@ -191,8 +199,11 @@ bool build_pfx_tables(const HostPma &p, uint32_t lds_budget, PfxTables &out) {
         // vacant slots keep a CHECK no transition can produce (builder.rs:391-400): they are copied as they are, with nothing ending there
         const uint32_t o = depth[s] != kNone ? own[s] : 0u;
         out.wrec[s] = U32x2{p.states[s].base, static_cast<uint32_t>(check_of(p.states[s].opos_ch)) | (o << 8)};
-        out.wrec_x[s] = U32x4{p.states[s].base, static_cast<uint32_t>(check_of(p.states[s].opos_ch)) | (o << 8), depth[s] != kNone ? own_hs[s] : 0u, 0u};
+        out.wrec_x[s] = U32x4{p.states[s].base, static_cast<uint32_t>(check_of(p.states[s].opos_ch)) | (o << 8), depth[s] != kNone ? own_hs[s] : 0u,
+                              depth[s] != kNone ? own_val[s] : 0u};
     }
+    out.emit_ok = no_dups;
+    if (!no_dups) { out.slots_e.clear(); out.slots_e.shrink_to_fit(); }
     out.available = true;
     return true;
 }

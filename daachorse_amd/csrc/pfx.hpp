@@ -58,8 +58,14 @@ struct PfxTables {
     // count + checksum (the kernel's EXACT variant): no tail records and no path filter — every match has to be met as its own state, because
     // its h32 goes into the sums with its own end position
     std::vector<U32x4> slots_x;      // {k0, k1 | own << 16, base, sum of h32 of the patterns that are the key}
-    std::vector<U32x4> wrec_x;       // per double-array slot {base, check | own << 8, sum of h32 of the patterns that end there, 0}
+    std::vector<U32x4> wrec_x;       // per double-array slot {base, check | own << 8, sum of h32 of the patterns that end there, VALUE of the pattern that ends there (own == 1)}
     std::vector<uint32_t> hs1;       // 256: sum of h32 of the one-byte patterns
+    // tuple emission (pfx_emit_detect_kernel + EXPAND in its raw-haystack mode): every match is logged with its value, so no pattern may be
+    // registered twice (emit_ok).  slots_e = slots_x with the key pattern's VALUE in word 3; wrec_x's word 3; v1 / has1 for the one-byte patterns
+    bool emit_ok = false;
+    std::vector<U32x4> slots_e;
+    std::vector<uint32_t> v1;        // 256: value of the one-byte pattern
+    std::vector<uint8_t> has1;       // 256: 0x20 where the byte is a pattern (the flag bit of EXPAND's stream bytes), else 0
     uint32_t lds_tables = 0;         // BLOOM + CNT1 + DISP bytes
 };
 

@@ -369,6 +369,338 @@ __global__ __launch_bounds__(TPB) void pfx_kernel(const PfxDev g, const GramArgs
     }
 }
 
+// ================================================================================================ tuple emission: DETECT
+// The count + checksum kernel's search (every match met as its own state: slots_e / wrec_x) with every match LOGGED for the tuple emitter
+// of emit3_kernels.hip instead of tallied: a 16-byte record {virtual position of the last byte, length, value, global tile} in the chunked
+// list (a wave appends to its open chunk through an LDS cursor and takes a new chunk when the open one is half full), and one count per
+// tile of 1024 positions the match ENDS in (atomic adds; the matches of a batch go through a four-entry cache in lanes 0 .. 3).  One-byte
+// patterns are not logged: EXPAND meets them in the haystack itself (has1 / v1 by byte); here they are counted per tile — a wave-step is
+// exactly one tile.  Needs a dictionary without duplicate patterns (PfxTables::emit_ok).  Windows of at most 1 GiB: 32-bit positions.
+template <int G, bool LEN1>
+__global__ __launch_bounds__(1024) void pfx_emit_kernel(const PfxDev g, const Emit3Args a) {
+    constexpr int P = 16;
+    constexpr uint32_t SB = 64u * P;          // bytes a wave takes per step = kEmit3Tile
+    constexpr uint32_t SLOT = SB + 32u;       // the step | the first 16 bytes of the next | [SB + 16, SB + 20) of slot 0: the wave's record cursor
+    constexpr uint32_t KMASK0 = G >= 4 ? 0xffffffffu : ((1u << (8 * (G & 3))) - 1u);
+    constexpr uint32_t KMASK1 = G <= 4 ? 0u : ((1u << (8 * ((G - 4) & 3))) - 1u);
+    static_assert(SB == kEmit3Tile, "a wave-step is one tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    px_copy(smem, g.bloom, g.bloom_bytes);
+    px_copy(smem + g.off_disp, g.disp, g.disp_bytes);
+    px_copy(smem + g.off_cnt1, g.cnt1, 512);
+    __syncthreads();
+    if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();  // tables are read through absolute LDS addresses
+    auto lds_u32 = [&](uint32_t addr) -> uint32_t { return *reinterpret_cast<ldsp_cu32 *>(static_cast<uintptr_t>(addr)); };
+    auto lds_u16 = [&](uint32_t addr) -> uint32_t { return *reinterpret_cast<ldsp_cu16 *>(static_cast<uintptr_t>(addr)); };
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint8_t *__restrict__ hay = a.hay_al;
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    const uint32_t tb = g.off_wave + wave_in_wg * g.wave_stride;
+    const uint32_t ringb = tb + 2u * SLOT;
+    const uint32_t cur_at = tb + SB + 16u;    // LDS address of the record cursor
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(smem + cur_at);
+    uint4 *__restrict__ slab = reinterpret_cast<uint4 *>(a.wq) + static_cast<uint64_t>(wave_global) * a.wq_slab;
+    uint32_t wq_n = 0;  // wave-uniform
+
+    // ---- the record list: this wave's open chunk (emit3_kernels.hip, DETECT) ----
+    uint32_t chunk = 0;       // wave-uniform
+    bool chunk_ok = false;    // wave-uniform: the chunk lies inside the list (else the records are only counted: the caller reruns with a longer list)
+    auto take_chunk = [&]() {
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(a.chunk_next, 1u);
+        chunk = __builtin_amdgcn_readfirstlane(c);
+        chunk_ok = chunk < a.chunk_cap;
+    };
+    auto rec_checkpoint = [&]() {   // (wave-uniform places only) the open chunk is closed once it is half full
+        const uint32_t n = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile ldsp_u32 *>(static_cast<uintptr_t>(cur_at)));
+        if (n > kEmit3Chunk / 2u) {
+            if (lane == 0) {
+                if (chunk_ok) a.chunk_fill[chunk] = n < kEmit3Chunk ? n : kEmit3Chunk;
+                *reinterpret_cast<volatile ldsp_u32 *>(static_cast<uintptr_t>(cur_at)) = 0u;
+            }
+            take_chunk();
+        }
+    };
+    if (lane == 0) *reinterpret_cast<volatile ldsp_u32 *>(static_cast<uintptr_t>(cur_at)) = 0u;
+    take_chunk();
+    // `p` = virtual position of the match's last byte; `counted`: the caller has added it to its tile's count already
+    auto log_rec = [&](uint32_t p, uint32_t len, uint32_t value, bool counted) {
+        if (p < a.emit_from) return;
+        const uint32_t slot = atomicAdd(cursor, 1u);
+        if (!counted) atomicAdd(&a.tile_deep[p >> 10], 1u);
+        if (slot >= kEmit3Chunk) { atomicOr(a.fail, 2u); return; }
+        if (chunk_ok) a.recs[static_cast<uint64_t>(chunk) * kEmit3Chunk + slot] = uint4{p, len, value, a.tile0 + (p >> 10)};
+    };
+
+    auto load_chunk = [&](uint32_t v) -> uint4 {
+        if (v >= a.vlen) return uint4{0u, 0u, 0u, 0u};
+        const px_u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const px_u32x4_t *>(hay + v));
+        return uint4{q.x, q.y, q.z, q.w};  // (bytes outside [lead, vlen) are whatever memory holds: starts there are masked out)
+    };
+    auto read_ahead = [&](uint32_t v) -> unsigned long long {
+        unsigned long long x;
+        if (v + 8 <= a.vlen) {
+            __builtin_memcpy(&x, hay + v, 8);
+        } else {
+            x = 0;
+            for (int b = 7; b >= 0; --b) x = (x << 8) | ((v + b < a.vlen) ? hay[v + b] : 0u);
+        }
+        return x;
+    };
+
+    // the queued branches: goto-only over the double array, W side by side per lane; every state that ends a pattern logs it
+    auto drain = [&]() {
+        constexpr int W = 4;
+        if (wq_n != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (what one lane stored to the slab another lane reads back)
+        for (uint32_t base_i = 0; base_i < wq_n; base_i += 64u * W) {
+            uint32_t vn[W], st[W], b[W], n_ahead[W];
+            unsigned long long ah[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t i = base_i + 64u * w + lane;
+                uint4 e = uint4{0u, 0u, 0u, 0u};
+                if (i < wq_n) e = slab[i];
+                st[w] = e.x;
+                vn[w] = e.x + G;  // the next byte to take
+                b[w] = e.y;
+                n_ahead[w] = 8;
+                ah[w] = (static_cast<unsigned long long>(e.w) << 32) | e.z;
+                if (vn[w] >= a.vlen) b[w] = 0;
+            }
+            for (;;) {
+                rec_checkpoint();   // (at most 64 W records per turn: the open chunk has room for 512)
+                uint4 r[W];
+                bool any = false;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    r[w] = uint4{0u, 0u, 0u, 0u};
+                    if (b[w] != 0) {
+                        if (n_ahead[w] == 0) { ah[w] = read_ahead(vn[w]); n_ahead[w] = 8; }
+                        r[w] = g.wrec_x[b[w] ^ (static_cast<uint32_t>(ah[w]) & 0xffu)];
+                        any = true;
+                    }
+                }
+                if (!__any(any)) break;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    if (b[w] == 0) continue;
+                    const uint32_t c = static_cast<uint32_t>(ah[w]) & 0xffu;
+                    if ((r[w].y & 0xffu) != c) { b[w] = 0; continue; }
+                    b[w] = r[w].x;
+                    ++vn[w];
+                    if (r[w].y >> 8) log_rec(vn[w] - 1u, vn[w] - st[w], r[w].w, false);   // the match ends with the byte just taken
+                    ah[w] >>= 8;
+                    --n_ahead[w];
+                    if (vn[w] >= a.vlen) b[w] = 0;
+                }
+            }
+        }
+        wq_n = 0;
+    };
+
+    uint32_t q_head = 0, q_tail = 0;   // wave-uniform, free running
+    uint32_t posbias0 = 0, posbias1 = 0;  // per slot: (virtual position of a byte) - (its LDS address)
+    uint4 pend = uint4{0u, kPfxEmpty, 0u, 0u};
+    uint32_t pend_pos = 0, pend_k0 = 0, pend_k1 = 0, pend_t0 = 0, pend_t1 = 0;
+    bool pend_valid = false;           // wave-uniform
+    uint32_t acc_tile = 0xffffffffu, acc_cnt = 0;   // lanes 0 .. 3: a direct-mapped cache of tile counts
+    auto consume_pending = [&]() {
+        if (!pend_valid) return;
+        pend_valid = false;
+        const uint4 r = pend;
+        const bool match = r.x == pend_k0 && (r.y & 0x8000ffffu) == pend_k1;
+        const uint32_t p = pend_pos + (G - 1u);
+        const bool own = match && ((r.y >> 16) & 0x3fffu) != 0 && p >= a.emit_from;
+        {
+            const uint32_t my_tile = p >> 10;
+            unsigned long long om = __ballot(own);
+            while (om != 0) {
+                const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(om));
+                const uint32_t t0 = __builtin_amdgcn_readlane(my_tile, leader);
+                const unsigned long long same = __ballot(own && my_tile == t0);
+                if (lane == (t0 & 3u)) {
+                    if (acc_tile != t0) {
+                        if (acc_cnt != 0) atomicAdd(&a.tile_deep[acc_tile], acc_cnt);
+                        acc_tile = t0;
+                        acc_cnt = 0;
+                    }
+                    acc_cnt += static_cast<uint32_t>(__popcll(same));
+                }
+                om &= ~same;
+            }
+        }
+        if (own) log_rec(p, G, r.w, true);
+        const bool go = match && r.z != 0;
+        const unsigned long long m = __ballot(go);
+        if (m != 0) {
+            if (go) {
+                const uint32_t at = wq_n + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+                slab[at] = uint4{pend_pos, r.z, pend_t0, pend_t1};
+            }
+            wq_n += static_cast<uint32_t>(__popcll(m));
+        }
+    };
+    auto process_batch = [&](uint32_t n) {  // n <= 64 entries from the head of the queue
+        __builtin_amdgcn_s_setprio(2);
+        rec_checkpoint();
+        consume_pending();
+        pend = uint4{0u, kPfxEmpty, 0u, 0u};
+        if (lane < n) {
+            const uint32_t e = lds_u32(ringb + (((q_head + lane) & (kRingP - 1u)) << 2));
+            pend_pos = e + ((e - tb) >= SLOT ? posbias1 : posbias0);
+            const uint32_t a0 = e & ~3u, sh = e & 3u;
+            const uint32_t d0 = lds_u32(a0), d1 = lds_u32(a0 + 4u), d2 = lds_u32(a0 + 8u), d3 = lds_u32(a0 + 12u);
+            const uint32_t x0 = __builtin_amdgcn_alignbyte(d1, d0, sh), x1 = __builtin_amdgcn_alignbyte(d2, d1, sh), x2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            const uint32_t key0 = x0 & KMASK0, key1 = x1 & KMASK1;
+            pend_k0 = key0;
+            pend_k1 = key1;
+            if (G == 4) { pend_t0 = x1; pend_t1 = x2; }
+            else if (G < 4) { pend_t0 = __builtin_amdgcn_alignbyte(x1, x0, G & 3); pend_t1 = __builtin_amdgcn_alignbyte(x2, x1, G & 3); }
+            else {
+                const uint32_t d4 = lds_u32(a0 + 16u);
+                const uint32_t x3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+                pend_t0 = __builtin_amdgcn_alignbyte(x2, x1, G & 3);
+                pend_t1 = __builtin_amdgcn_alignbyte(x3, x2, G & 3);
+            }
+            const uint32_t mb = key0 * kPfxMulBucket0 + (key1 ^ g.seed) * kPfxMulBucket1;
+            const uint32_t ms = key0 * kPfxMulSlot0 + (key1 ^ g.seed) * kPfxMulSlot1;
+            const uint32_t bucket = __umulhi(mb, g.buckets);
+            const uint32_t d = lds_u16(g.off_disp + (bucket << 1));
+            pend = g.slots_e[pfx_slot(ms, d, g.n_slots)];
+        }
+        q_head += n;
+        pend_valid = true;
+    };
+
+    uint32_t sl = 0;          // slot of the current step (wave-uniform)
+    uint32_t carry_in = 0;    // queued entries that belong to the step before the current one
+    const uint32_t start_end = a.vlen >= static_cast<uint32_t>(G) ? a.vlen - G + 1 : 0;   // starts are valid in [lead, vlen - G]
+    for (uint32_t region = wave_global; region < a.nregions; region += nwaves) {
+        const uint32_t rbase = region * a.region_bytes;
+        const uint32_t rend = rbase + a.region_bytes < a.vlen ? rbase + a.region_bytes : a.vlen;
+        auto fetch = [&](uint32_t s0) -> uint4 {
+            if (s0 < rend) return load_chunk(s0 + lane * P);
+            if (lane == 0 && s0 < rend + SB) return load_chunk(s0);
+            return uint4{0u, 0u, 0u, 0u};
+        };
+        uint4 pf0 = fetch(rbase), pf1 = fetch(rbase + SB);
+        for (uint32_t sb = rbase; sb < rend; sb += SB) {
+            if (wq_n + 64u * P + 128u > a.wq_slab) drain();
+            const uint32_t v = sb + lane * P;
+            const uint4 cur = pf0;
+            pf0 = pf1;
+            rec_checkpoint();
+            consume_pending();  // before the next chunk is requested: loads retire in order
+            __builtin_amdgcn_s_setprio(0);
+            pf1 = fetch(sb + 2u * SB);
+
+            const uint32_t slot = tb + sl * SLOT;                 // wave-uniform
+            const uint32_t my_text = slot + lane * P;
+            {
+                const uint32_t bias = sb - slot;
+                if (sl) posbias1 = bias; else posbias0 = bias;
+            }
+            *reinterpret_cast<ldsp_u32x4 *>(static_cast<uintptr_t>(my_text)) = px_u32x4_t{cur.x, cur.y, cur.z, cur.w};
+            if (lane == 0) *reinterpret_cast<ldsp_u32x4 *>(static_cast<uintptr_t>(slot + SB)) = px_u32x4_t{pf0.x, pf0.y, pf0.z, pf0.w};
+
+            uint32_t W[6] = {cur.x, cur.y, cur.z, cur.w, 0u, 0u};
+            W[4] = wave_shl1_p(cur.x, __builtin_amdgcn_readfirstlane(pf0.x));
+            W[5] = wave_shl1_p(cur.y, __builtin_amdgcn_readfirstlane(pf0.y));
+            uint32_t H = 0, H1 = 0;
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int q = j >> 2, r = j & 3;
+                uint32_t k0 = r == 0 ? W[q] : __builtin_amdgcn_alignbyte(W[q + 1], W[q], static_cast<uint32_t>(r));
+                if (G < 4) k0 &= KMASK0;
+                uint32_t m = k0 * kPfxMulBloom0;
+                if (G > 4) {
+                    uint32_t k1 = r == 0 ? W[q + 1] : __builtin_amdgcn_alignbyte(W[q + 2], W[q + 1], static_cast<uint32_t>(r));
+                    k1 &= KMASK1;
+                    m += k1 * kPfxMulBloom1;
+                }
+                const uint32_t word = lds_u32(__umulhi(m, g.bloom_words) << 2);   // BLOOM sits at LDS offset 0
+                const uint32_t m2 = m * kPfxMulBits;
+                H |= (__builtin_amdgcn_ubfe(word, m2 >> kPfxBit1, 1) & __builtin_amdgcn_ubfe(word, m2 >> kPfxBit2, 1)) << j;
+                if (LEN1) {
+                    const uint32_t byte = (W[q] >> (8 * r)) & 0xffu;
+                    H1 |= (lds_u16(g.off_cnt1 + (byte << 1)) != 0 ? 1u : 0u) << j;
+                }
+            }
+            // starts before the haystack's first byte or too close to its end do not count (first / last step only)
+            if (v < a.lead || sb + SB + G > a.vlen + 1) {
+                const uint32_t lo = a.lead > v ? a.lead - v : 0, hi = start_end > v ? start_end - v : 0;
+                uint32_t keep = hi >= 16 ? 0xffffu : ((1u << hi) - 1u);
+                keep &= lo >= 16 ? 0u : ~((1u << lo) - 1u);
+                H &= keep;
+            }
+            if (LEN1) {   // one-byte matches of this tile: positions in [emit_from, vlen)
+                if (sb < a.emit_from || sb + SB > a.vlen) {
+                    const uint32_t lo = a.emit_from > v ? a.emit_from - v : 0, hi = a.vlen > v ? a.vlen - v : 0;
+                    uint32_t keep = hi >= 16 ? 0xffffu : ((1u << hi) - 1u);
+                    keep &= lo >= 16 ? 0u : ~((1u << lo) - 1u);
+                    H1 &= keep;
+                }
+                uint32_t c1 = __popc(H1);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) c1 += __shfl_down(c1, off, 64);
+                if (lane == 0) a.tile_short[sb >> 10] = c1;
+            }
+
+            bool did_batch = false;
+            for (;;) {
+                const bool has = H != 0;
+                const unsigned long long m = __ballot(has);
+                if (m == 0) break;
+                if (has) {
+                    const uint32_t b = static_cast<uint32_t>(__builtin_ctz(H));
+                    H &= H - 1u;
+                    const uint32_t at = q_tail + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+                    *reinterpret_cast<ldsp_u32 *>(static_cast<uintptr_t>(ringb + ((at & (kRingP - 1u)) << 2))) = my_text + b;
+                }
+                q_tail += static_cast<uint32_t>(__popcll(m));
+                if (q_tail - q_head >= 64u) { process_batch(64u); did_batch = true; }
+            }
+            if (carry_in != 0 && !did_batch) process_batch(q_tail - q_head);
+            carry_in = q_tail - q_head;
+            sl ^= 1u;
+        }
+    }
+    if (q_tail != q_head) process_batch(q_tail - q_head);
+    rec_checkpoint();
+    consume_pending();
+    drain();
+    if (lane < 4u && acc_cnt != 0) atomicAdd(&a.tile_deep[acc_tile], acc_cnt);
+    {   // close the open chunk
+        const uint32_t n = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile ldsp_u32 *>(static_cast<uintptr_t>(cur_at)));
+        if (lane == 0 && chunk_ok) a.chunk_fill[chunk] = n < kEmit3Chunk ? n : kEmit3Chunk;
+    }
+}
+
+template <int G, bool LEN1>
+static hipError_t launch_pfx_emit_inst(const PfxDev &dev, const Emit3Args &a, uint32_t blocks, hipStream_t stream) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfx_emit_kernel<G, LEN1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(dev.lds_bytes));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((pfx_emit_kernel<G, LEN1>), dim3(blocks), dim3(1024), dev.lds_bytes, stream, dev, a);
+    return hipGetLastError();
+}
+template <int G>
+static hipError_t launch_pfx_emit_g(const PfxDev &dev, const Emit3Args &a, uint32_t blocks, hipStream_t stream) {
+    return dev.has_len1 ? launch_pfx_emit_inst<G, true>(dev, a, blocks, stream) : launch_pfx_emit_inst<G, false>(dev, a, blocks, stream);
+}
+hipError_t launch_pfx_emit_detect(const PfxDev &dev, const Emit3Args &a, uint32_t blocks, hipStream_t stream) {
+    switch (dev.G) {
+        case 2: return launch_pfx_emit_g<2>(dev, a, blocks, stream);
+        case 3: return launch_pfx_emit_g<3>(dev, a, blocks, stream);
+        case 4: return launch_pfx_emit_g<4>(dev, a, blocks, stream);
+        case 5: return launch_pfx_emit_g<5>(dev, a, blocks, stream);
+        default: return launch_pfx_emit_g<6>(dev, a, blocks, stream);
+    }
+}
+
 template <int G, bool LEN1, bool EXACT>
 static hipError_t launch_pfx_inst(const PfxDev &dev, const GramArgs &a, uint32_t blocks, hipStream_t stream) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pfx_kernel<G, LEN1, EXACT, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,

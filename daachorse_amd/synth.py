@@ -196,12 +196,13 @@ _CFG5_LENGTHS = [(2, 27), (3, 30), (4, 22), (5, 12), (6, 6), (7, 2), (8, 1)]  # 
 SEEDS["cfg5_hay"] = 0xDAAC0015
 
 
-def patterns_cfg5(n=50_000, seed=SEEDS["cfg5_pat"]):
+def patterns_cfg5(n=50_000, seed=SEEDS["cfg5_pat"], lengths=None):
     """n distinct UTF-8 patterns (bytes) of 2..8 three-byte scalars, Zipf(1.0) over CFG5_CODEPOINTS, value = index"""
     assert len(CFG5_CODEPOINTS) == 6000
+    lengths = _CFG5_LENGTHS if lengths is None else lengths
     total = np.uint64(CFG5_CUM[-1])
-    cum_len = np.cumsum([w for _, w in _CFG5_LENGTHS])
-    len_of = np.array([l for l, _ in _CFG5_LENGTHS])
+    cum_len = np.cumsum([w for _, w in lengths])
+    len_of = np.array([l for l, _ in lengths])
     enc = [chr(int(c)).encode("utf-8") for c in CFG5_CODEPOINTS]
     seen, out, j = set(), [], 0
     batch = 1 << 15
@@ -223,6 +224,78 @@ def patterns_cfg5(n=50_000, seed=SEEDS["cfg5_pat"]):
                 if len(out) == n:
                     break
     return out
+
+
+# Look-alikes of the two WIDE dictionaries the crate publishes numbers for (figures/overlapping.txt:1-5, figures/memory.txt:4) — the real
+# ones are not in the repository (and there is no network): same number of patterns, same kind of bytes, same kind of automaton.
+#   unidic_like: 675 000 UTF-8 patterns of 1-8 three-byte scalars (single characters included), Zipf(1.0) over the cfg5 alphabet; scanned
+#                bytewise the automaton has ~250 distinct bytes on its edges; text: zipf_text / device_zipf_text (cfg5's).
+#   o200k_like:  200 000 byte-level tokens, ALL 256 one-byte patterns among them: words in four spellings ("word", " word", "Word", " Word",
+#                "WORD"), numbers, punctuation runs, UTF-8 pieces (lead + continuation bytes, whole CJK characters and pairs), short random
+#                ASCII; text: word soup of the same base words (wordsoup_haystack / device_wordsoup with o200k_soup_words()).
+SEEDS["unidic_pat"], SEEDS["o200k_pat"], SEEDS["o200k_hay"] = 0xDAAC0007, 0xDAAC0008, 0xDAAC0018
+_UNIDIC_LENGTHS = [(1, 6), (2, 26), (3, 28), (4, 20), (5, 11), (6, 6), (7, 2), (8, 1)]  # scalars, percent
+
+
+def patterns_unidic_like(n=675_000, seed=SEEDS["unidic_pat"]):
+    return patterns_cfg5(n, seed, _UNIDIC_LENGTHS)
+
+
+def o200k_soup_words(n=60_000):
+    return patterns_cfg3(n)
+
+
+def patterns_o200k_like(n=200_000, seed=SEEDS["o200k_pat"]):
+    out, seen = [], set()
+
+    def add(w):
+        if w and w not in seen and len(w) <= 24:
+            seen.add(w)
+            out.append(w)
+
+    for b in range(256):
+        add(bytes([b]))
+    words = o200k_soup_words()
+    z = zstream(seed, np.arange(len(words), dtype=np.uint64)).tolist()
+    for w, zi in zip(words, z):          # every word plain and with its leading space, a third also capitalised / upper
+        add(w)
+        add(b" " + w)
+        if zi % 3 == 0:
+            add(w[:1].upper() + w[1:])
+            add(b" " + w[:1].upper() + w[1:])
+        if zi % 11 == 0:
+            add(w.upper())
+        if len(out) >= n * 3 // 4:
+            break
+    for i in range(1000):
+        add(str(i).encode())
+        add(b" " + str(i).encode())
+    for c in b".,;:!?-_=*#/\\()[]{}<>\"'\n\t":
+        for k in range(2, 9):
+            add(bytes([c]) * k)
+    for lead in range(0xC2, 0xE0):       # two-byte UTF-8 characters
+        for cont in range(0x80, 0xC0, 2):
+            add(bytes([lead, cont]))
+    enc = [chr(int(c)).encode("utf-8") for c in CFG5_CODEPOINTS]
+    for e in enc:                        # three-byte characters and their two-byte heads
+        add(e)
+        add(e[:2])
+    total = np.uint64(CFG5_CUM[-1])
+    j = 0
+    while len(out) < n:                  # the rest: CJK pairs (Zipf) and short random printable ASCII, alternating
+        zz = zstream(seed ^ 0x77, np.arange(j, j + 4096, dtype=np.uint64))
+        j += 4096
+        a = np.searchsorted(CFG5_CUM, (((zz & np.uint64(0xFFFFFFFF)) * total) >> np.uint64(32)).astype(np.uint32), side="right")
+        b = np.searchsorted(CFG5_CUM, (((zz >> np.uint64(32)) * total) >> np.uint64(32)).astype(np.uint32), side="right")
+        for k, (x, y, zi) in enumerate(zip(a.tolist(), b.tolist(), zz.tolist())):
+            if k & 1:
+                add(enc[x] + enc[y])
+            else:
+                ln = 2 + zi % 3
+                add(bytes(0x20 + ((zi >> (8 * (t + 1))) & 0xFF) % 95 for t in range(ln)))
+            if len(out) >= n:
+                break
+    return out[:n]
 
 
 def zipf_text(n, seed=SEEDS["cfg5_hay"], offset=0, codepoints=CFG5_CODEPOINTS, cum=CFG5_CUM, ascii_256=CFG5_ASCII_256,

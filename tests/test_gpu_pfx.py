@@ -210,12 +210,21 @@ def test_round3_engines_take_host_haystacks_and_streams():
 
 
 def test_engines_that_cannot_serve_a_request_say_so():
-    """An engine that only counts (PFX), or a number that is no engine at all, asked for tuples / a lazy iterator / a stepper: status 6 —
-    not a silent scan on the double array with last_engine() = DARRAY (round-3 advisor)."""
+    """An engine whose tables a handle does not have (PFX where the GRAM tables serve), or a number that is no engine at all, asked for
+    tuples / a lazy iterator / a stepper: status 6 — not a silent scan on the double array with last_engine() = DARRAY (round-3 advisor).
+    With its tables built PFX serves tuples and the lazy iterator (round 4); steppers it does not."""
     o = orc.OraclePma.build([b"ab", b"bc", b"abc"])
-    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
     hay = np.frombuffer(b"xxabcabyy" * 50, dtype=np.uint8)
     want = o.find_overlapping_iter(hay)
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())   # (the fixture's pfx = 2: PFX tables built)
+    assert _same(p.scan(ScanMode.FindOverlapping, hay, engine=Engine.Pfx), want)
+    assert da.last_engine() == int(Engine.Pfx)
+    assert [(m.start(), m.end(), m.value()) for m in p.find_overlapping_iter(hay, engine=Engine.Pfx)] == orc.triples_sev(want)
+    with pytest.raises(da.DaachorseError) as ei:
+        p.find_overlapping_stepper(engine=Engine.Pfx)
+    assert ei.value.code == 6
+    da.set_option("pfx", 1)
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
     got = p.scan(ScanMode.FindOverlapping, hay)
     assert len(got) == len(want)
     for eng in (int(Engine.Pfx), 77):
@@ -226,3 +235,131 @@ def test_engines_that_cannot_serve_a_request_say_so():
             with pytest.raises(da.DaachorseError) as ei:
                 call()
             assert ei.value.code == 6, eng
+
+
+def _same(a, b):
+    return len(a) == len(b) and np.array_equal(a["start"], b["start"]) and np.array_equal(a["end"], b["end"]) and \
+        np.array_equal(a["value"], b["value"])
+
+
+def _tuples16(p, dev, **kw):
+    dm = p.scan_device(ScanMode.FindOverlapping, dev, engine=Engine.Pfx, fmt16=True, **kw)
+    assert da.last_engine() == int(Engine.Pfx)
+    t = dm.to_numpy()
+    dm.free()
+    return t
+
+
+def _same16(t, want):
+    return len(t) == len(want) and np.array_equal(t["end"], want["end"]) and np.array_equal(t["length"], (want["end"] - want["start"]).astype(np.uint32)) and \
+        np.array_equal(t["value"], want["value"])
+
+
+def test_pfx_tuples_against_the_oracle():
+    """The find_overlapping tuples of dictionaries over ANY byte alphabet through pfx_emit_kernel + EXPAND over the raw haystack
+    (bytewise/iter.rs:133-176: by end, longest first), both device formats: a 256-byte-alphabet dictionary, UTF-8 Japanese scanned
+    bytewise, one-byte patterns (all 256 of them in one case), patterns beyond the 17 bytes a tile's length bits carry (extras),
+    several patterns ending on one byte, every key length G, unaligned haystacks, a shard, text shorter than a key."""
+    import torch
+    rng = np.random.default_rng(77)
+    binp = synth.patterns_binary256(20000)
+    jp = synth.patterns_cfg5(5000)
+    mixed = list(dict.fromkeys([bytes(rng.integers(0, 256, size=int(rng.integers(1, 9))).astype(np.uint8)) for _ in range(3000)]))
+    nested = [b"a", b"ab", b"abc", b"bc", b"c", b"abcabcabcabcabcabcabc", b"cabcabcabcabcabcabcabca", b"bcabcabcabcabcabcabcabcabcabc", b"\xff\x00", b"\x00\xff\x00\xff"]
+    all1 = [bytes([b]) for b in range(256)] + [b"th", b"the", b"he", b" the ", b"\xe3\x81\x82", b"\xe3\x81"]
+    by_len = {g: list(dict.fromkeys(bytes(rng.integers(0, 256, size=int(rng.integers(g, g + 6))).astype(np.uint8)) for _ in range(4000))) for g in (2, 3, 4, 5, 6, 9)}
+    cases = [(binp, rng.integers(0, 256, size=1 << 20).astype(np.uint8)),
+             (binp, np.frombuffer(b"".join(binp[i] for i in rng.integers(0, len(binp), size=100000).tolist()), dtype=np.uint8)),
+             (jp, synth.zipf_text(48 * 20000)),
+             (mixed, rng.integers(0, 256, size=1 << 19).astype(np.uint8)),
+             (nested, np.frombuffer(((b"abcabcabcabcabcabcabcabcabcabcab\xff\x00\xff\x00xx" + b"q" * 300 + b"abcab" * 9) * 1500), dtype=np.uint8)),
+             (all1, np.frombuffer(b"the cat and the \xe3\x81\x82 other " * 3000, dtype=np.uint8)),
+             (all1, rng.integers(0, 256, size=70000).astype(np.uint8))]
+    for g, pats in by_len.items():
+        soup = b"".join(pats[i] if rng.integers(0, 3) else bytes(rng.integers(0, 256, size=5).astype(np.uint8)) for i in rng.integers(0, len(pats), size=30000).tolist())
+        cases.append((pats, np.frombuffer(soup, dtype=np.uint8)))
+    for pats, hay in cases:
+        o, p = _pma(pats)
+        p.upload()
+        want = o.find_overlapping_iter(hay)
+        dev = torch.from_numpy(np.concatenate([np.zeros(5, dtype=np.uint8), hay])).cuda()[5:]  # not 16-byte aligned
+        got = p.scan(ScanMode.FindOverlapping, dev, engine=Engine.Pfx)
+        assert da.last_engine() == int(Engine.Pfx)
+        assert _same(got, want), (len(pats), len(hay), len(got), len(want))
+        assert _same16(_tuples16(p, dev), want), (len(pats), len(hay))
+        # a prefix, and the automatic engine choice on a dictionary no GRAM table serves
+        cut = int(rng.integers(1, min(len(hay), 5000)))
+        assert _same(p.scan(ScanMode.FindOverlapping, dev[:cut], engine=Engine.Pfx), o.find_overlapping_iter(hay[:cut])), cut
+        da.set_option("gram_region", 2048)
+        assert _same(p.scan(ScanMode.FindOverlapping, dev, engine=Engine.Pfx), want)
+        da.set_option("gram_region", 0)
+        # the lazy iterator over the same bytes (windows with begin > 0)
+        da.set_option("iter_window", 1 << 16)
+        try:
+            it = p.find_overlapping_iter(hay[:200000], engine=Engine.Pfx)
+            runs = []
+            while True:
+                r = it.next_batch()
+                if r is None:
+                    break
+                runs.append(r.copy())
+            it.close()
+            got16 = np.concatenate(runs) if runs else np.zeros(0, dtype=bytewise_match16())
+            assert _same16(got16, o.find_overlapping_iter(hay[:200000])), len(pats)
+        finally:
+            da.set_option("iter_window", 64 << 20)
+    # text shorter than a key, an empty text
+    o, p = _pma([b"abcd", b"abcde", b"x"])
+    for text in (b"", b"ab", b"x", b"abc", b"abcd", b"xabcdex"):
+        h = np.frombuffer(text, dtype=np.uint8)
+        assert _same(p.scan(ScanMode.FindOverlapping, h, engine=Engine.Pfx), o.find_overlapping_iter(h)), text
+    # more long matches (beyond the 17 bytes a position's length bits carry) in one tile than EXPAND places: PFX says so, the default engine answers
+    o, p = _pma(nested)
+    h = np.frombuffer(b"abcabcabcabcabcabcabcabcabcabcab" * 3000, dtype=np.uint8)
+    with pytest.raises(da.DaachorseError):
+        p.scan(ScanMode.FindOverlapping, h, engine=Engine.Pfx)
+    assert _same(p.scan(ScanMode.FindOverlapping, h), o.find_overlapping_iter(h))
+    # a pattern registered twice: no PFX tuples (the engine says so), the default engine still answers
+    o, p = _pma([b"ab\xff", b"ab\xff", b"b\xffq"])
+    h = np.frombuffer(b"xab\xffqab\xff" * 100, dtype=np.uint8)
+    with pytest.raises(da.DaachorseError):
+        p.scan(ScanMode.FindOverlapping, h, engine=Engine.Pfx)
+    assert _same(p.scan(ScanMode.FindOverlapping, h), o.find_overlapping_iter(h))
+
+
+def bytewise_match16():
+    from daachorse_amd.bytewise import MATCH16_DTYPE
+    return MATCH16_DTYPE
+
+
+def test_wide_dictionary_look_alikes():
+    """Look-alikes of the two wide dictionaries of the crate's own benchmark (figures/overlapping.txt:1-5): Unidic-like (675 000 UTF-8
+    patterns) and o200k-like (200 000 byte-level tokens, all 256 one-byte patterns among them), built by the PRODUCT's builder: count,
+    count + checksum and tuples against the oracle on 8 MiB of their text."""
+    import torch
+    da.set_option("pfx", 1)
+    for name in ("unidic_like", "o200k_like"):
+        if name == "unidic_like":
+            pats = synth.patterns_unidic_like()
+            n = (8 << 20) - (8 << 20) % synth.CFG5_SLOT
+            dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+            synth.device_zipf_text(dev)
+        else:
+            pats = synth.patterns_o200k_like()
+            n = 8 << 20
+            dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+            synth.device_wordsoup(dev, synth.SEEDS["o200k_hay"], synth.o200k_soup_words(), 17)
+        p = da.DoubleArrayAhoCorasick.new(pats)
+        o = orc.OraclePma.deserialize(p.serialize())
+        host = dev.cpu().numpy()
+        want = o.find_overlapping_iter(host)
+        assert len(want) > n // 8, name
+        assert p.count(ScanMode.FindOverlapping, dev) == len(want), name
+        assert da.last_engine() == int(Engine.Pfx), name
+        assert p.scan_count(ScanMode.FindOverlapping, dev) == (len(want), orc.matches_checksum(want)), name
+        got = p.scan(ScanMode.FindOverlapping, dev)
+        assert da.last_engine() == int(Engine.Pfx), name
+        assert _same(got, want), name
+        dm = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
+        assert _same16(dm.to_numpy(), want), name
+        dm.free()
