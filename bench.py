@@ -675,6 +675,7 @@ def main():
             else:
                 synth.device_zipf_text(ahay)
             fn = lambda: ap.count(ScanMode.FindOverlapping, ahay, stream=stream, result_dev=result.data_ptr())
+            ap.count(ScanMode.FindOverlapping, ahay)   # a synchronous call samples the text and leaves the engine choice (PFX / walker) in the handle
             fn()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

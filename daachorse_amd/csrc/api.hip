@@ -45,6 +45,8 @@ struct Options {
     std::atomic<int64_t> gram_version{0};       // 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram3 on the v2 tables), 1 = v1 only,
                                                 // 2 = v2 tables with gram2_kernels.hip, 3 = v2 tables with gram3_kernels.hip for `.count()`
     std::atomic<int64_t> gram2_dpp{1};
+    std::atomic<int64_t> pfx_probe{16384};      // AUTO, `.count()` / count + checksum of a dictionary PFX serves: the micro-step walker takes over where more than
+                                                // this many of 65 536 sampled positions survive PFX's filter (0 = never ask, always PFX)
     std::atomic<int64_t> pfx{1};                // PFX engine: 1 = built for automata the GRAM tables do not serve, 2 = always, 0 = never (read at upload)
     std::atomic<int64_t> gram3_tail{-1};        // gram3: tail records from the hit record on (-1 = decide per launch)
     std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
@@ -158,6 +160,8 @@ struct DeviceTables {
     bool emit3_ok = false;     // ... with detection done once (emit3_kernels.hip)
     Gram3Lds emit3_lds{};
     bool emit3_has_len1 = false;   // some pattern is a single byte
+    const uint32_t *pfx_probe_word = nullptr;   // device word the probe kernel leaves its count in
+    std::atomic<int> pfx_dense{-1};  // the last probe's verdict on the text (scan_count_impl): 1 = most positions survive the filter
     bool pfx_emit_ok = false;      // PFX tuples: pfx_emit_kernel + EXPAND over the raw haystack (no pattern registered twice)
     Gram2EmitDev pfx_emit{};       // what that EXPAND needs: V1 by byte + the 256 flag bytes (v1, v1_bytes = 1280), K = 1
     std::atomic<uint32_t> emit3_rec_per_kib{0};  // deep-match records per KiB the last scans met (sizes the next scan's list)
@@ -693,6 +697,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             { const U32x4 *x; if ((st = t->put(px.slots_x, x)) != DAAC_OK) return st; d.slots_x = reinterpret_cast<const uint4 *>(x); }
             { const U32x4 *x; if ((st = t->put(px.wrec_x, x)) != DAAC_OK) return st; d.wrec_x = reinterpret_cast<const uint4 *>(x); }
             if ((st = t->put(px.hs1, d.hs1)) != DAAC_OK) return st;
+            { const std::vector<uint32_t> z(4, 0); if ((st = t->put(z, t->pfx_probe_word)) != DAAC_OK) return st; }
             if (px.emit_ok) {
                 { const U32x4 *x; if ((st = t->put(px.slots_e, x)) != DAAC_OK) return st; d.slots_e = reinterpret_cast<const uint4 *>(x); }
                 std::vector<uint32_t> v1f(320, 0);   // V1 by byte, then the flag bytes
@@ -1635,8 +1640,26 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len - begin < (1ull << 35) &&
                           (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (g2_can || g1_can || gw_can)));
     // PFX: `.count()` for automata over any byte alphabet — what AUTO takes where the GRAM tables do not apply
-    const bool use_pfx = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && t->pfx_ok &&
-                         len - begin < (1ull << 35) && (engine == DAAC_ENGINE_PFX || (engine == DAAC_ENGINE_AUTO && !use_gram));
+    bool use_pfx = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && t->pfx_ok &&
+                   len - begin < (1ull << 35) && (engine == DAAC_ENGINE_PFX || (engine == DAAC_ENGINE_AUTO && !use_gram));
+    if (use_pfx && engine == DAAC_ENGINE_AUTO && g_opt.pfx_probe.load() != 0) {
+        // PFX is a filter: where the text's G-grams are mostly trie prefixes the micro-step walker over the double array is faster.  A
+        // synchronous scan of a device haystack of 32 MiB or more samples the text (one small kernel + a read-back) and leaves its
+        // verdict in the handle; every other call goes by the last verdict (none yet: PFX).
+        int dense = t->pfx_dense.load();
+        if (hay_is_device && !result_dev && len - begin >= (32ull << 20) && t->pfx_probe_word) {
+            unsigned int *pin = pinned_words();
+            unsigned int got = 0;
+            unsigned int *tmp = const_cast<unsigned int *>(t->pfx_probe_word);   // (concurrent scans of one handle may read each other's sample: any of them is a sample)
+            HIP_TRY(launch_pfx_probe(t->pfx, hay + begin, len - begin, tmp, stream));
+            HIP_TRY(hipMemcpyAsync(pin ? pin : &got, tmp, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (pin) got = *pin;
+            dense = got > static_cast<unsigned int>(std::max<int64_t>(0, g_opt.pfx_probe.load())) ? 1 : 0;
+            t->pfx_dense.store(dense);
+        }
+        if (dense > 0) use_pfx = false;   // (no verdict yet: PFX, as the handle's plan says)
+    }
     if (engine == DAAC_ENGINE_PFX && !use_pfx) {
         set_error("PFX engine not available for this automaton / request (bytewise Standard automata without \"\", count (+ checksum) of find_overlapping)");
         return DAAC_ERR_UNSUPPORTED;
@@ -2402,6 +2425,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
     else if (n == "gram3_tail") g_opt.gram3_tail = value;
     else if (n == "pfx") g_opt.pfx = value;
+    else if (n == "pfx_probe") g_opt.pfx_probe = value;
     else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles") g_opt.emit_tiles = value;

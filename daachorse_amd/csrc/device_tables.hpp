@@ -295,6 +295,7 @@ struct PfxDev {
 };
 bool pfx_plan(PfxDev &d, uint32_t lds_limit);
 hipError_t launch_pfx_scan(const PfxDev &dev, const GramArgs &a, bool exact, uint32_t blocks, hipStream_t stream);
+hipError_t launch_pfx_probe(const PfxDev &dev, const uint8_t *hay, uint64_t len, unsigned int *out, hipStream_t stream);
 struct Emit3Args;
 hipError_t launch_pfx_emit_detect(const PfxDev &dev, const Emit3Args &a, uint32_t blocks, hipStream_t stream);
 

@@ -715,6 +715,40 @@ static hipError_t launch_pfx_g(const PfxDev &dev, const GramArgs &a, bool exact,
     return dev.has_len1 ? launch_pfx_inst<G, true, false>(dev, a, blocks, stream) : launch_pfx_inst<G, false, false>(dev, a, blocks, stream);
 }
 
+// How many positions of a text survive the filter: 64 samples of 1 KiB, evenly spaced, one workgroup.  The engine is a FILTER: on text
+// whose G-grams are mostly trie prefixes (a tokenizer vocabulary over its own language, a dictionary with every character as a pattern)
+// every position is a survivor with a gather and a walk of its own, and the chain walker over the double array — one transition per
+// byte whatever the text — is faster (tools/ab_wide.py: o200k-like 46 against 129 GB/s).  scan_count_impl asks before it chooses.
+__global__ __launch_bounds__(1024) void pfx_probe_kernel(const PfxDev g, const uint8_t *__restrict__ hay, uint64_t len, unsigned int *__restrict__ out) {
+    __shared__ unsigned int tot;
+    if (threadIdx.x == 0) tot = 0;
+    __syncthreads();
+    const uint64_t stride = len / 64u;
+    const uint64_t base = static_cast<uint64_t>(threadIdx.x >> 4) * stride + (threadIdx.x & 15u) * 64u;
+    unsigned int c = 0;
+    for (uint32_t j = 0; j < 64u; ++j) {
+        const uint64_t v = base + j;
+        if (v + g.G > len) break;
+        uint32_t k0 = 0, k1 = 0;
+        for (uint32_t b = 0; b < g.G; ++b) {
+            const uint32_t x = hay[v + b];
+            if (b < 4) k0 |= x << (8u * b); else k1 |= x << (8u * (b - 4u));
+        }
+        const uint32_t m = k0 * kPfxMulBloom0 + k1 * kPfxMulBloom1;
+        const uint32_t word = g.bloom[__umulhi(m, g.bloom_words)];
+        const uint32_t m2 = m * kPfxMulBits;
+        c += (word >> (m2 >> kPfxBit1)) & (word >> ((m2 >> kPfxBit2) & 31u)) & 1u;
+    }
+    atomicAdd(&tot, c);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = tot;
+}
+// survivors among 65 536 sampled positions of hay[0, len) (len >= 128 KiB), left in *out (device or page-locked memory)
+hipError_t launch_pfx_probe(const PfxDev &dev, const uint8_t *hay, uint64_t len, unsigned int *out, hipStream_t stream) {
+    hipLaunchKernelGGL(pfx_probe_kernel, dim3(1), dim3(1024), 0, stream, dev, hay, len, out);
+    return hipGetLastError();
+}
+
 // LDS plan: BLOOM at 0, DISP, CNT1, then 16 waves x (two text slots + the survivor queue)
 bool pfx_plan(PfxDev &d, uint32_t lds_limit) {
     d.off_disp = d.bloom_bytes;

@@ -66,8 +66,9 @@ typedef enum {
     DAAC_ENGINE_TIERED = 1, /* re-packed bitmap-rank trie, top levels dense in LDS */
     DAAC_ENGINE_DARRAY = 2, /* the reference's own double array, hot/cold split   */
     DAAC_ENGINE_GRAM = 3,   /* k-gram context tables in LDS, no state chain: count / checksum, and tuples of FIND_OVERLAPPING */
-    DAAC_ENGINE_PFX = 4     /* hashed prefix filter in LDS + goto-only walks from the start of an occurrence: `.count()` of
-                             * FIND_OVERLAPPING for dictionaries over any byte alphabet (what AUTO takes where GRAM's byte classes run out) */
+    DAAC_ENGINE_PFX = 4     /* hashed prefix filter in LDS + goto-only walks from the start of an occurrence: `.count()`, count + checksum
+                             * and (round 4, dictionaries without duplicate patterns) the tuples of FIND_OVERLAPPING for dictionaries over
+                             * any byte alphabet (what AUTO takes where GRAM's byte classes run out) */
 } daac_engine;
 
 /* Match<u32> (src/lib.rs:286-320): start() = end - length, end(), value() */
@@ -103,8 +104,9 @@ typedef enum {
     DAAC_KERNEL_GRAM_COUNT = 1,  /* gram3_kernels.hip: one LDS lookup per byte, lane-local hit masks           (cfg3: 1.3 TB/s) */
     DAAC_KERNEL_GRAM_EXACT = 2,  /* gram_kernels.hip / gram2_kernels.hip with the checksum                      (cfg3: 1.0 TB/s) */
     DAAC_KERNEL_GRAM_WIDE = 3,   /* gram2w_kernels.hip: 31 .. 62 byte classes                                   (1.0 / 0.9 TB/s) */
-    DAAC_KERNEL_GRAM_EMIT = 4,   /* gram2_emit_kernels.hip: tuples in reference order                           (cfg3: 0.12 TB/s of haystack) */
-    DAAC_KERNEL_PFX = 5,         /* pfx_kernels.hip: any byte alphabet, `.count()`                              (0.6 - 1.3 TB/s) */
+    DAAC_KERNEL_GRAM_EMIT = 4,   /* emit3_kernels.hip (gram2_emit_kernels.hip behind it): tuples in reference order (cfg3: 0.22 TB/s of haystack) */
+    DAAC_KERNEL_PFX = 5,         /* pfx_kernels.hip: any byte alphabet; `.count()` 0.6 - 1.3 TB/s on sparse dictionaries, 0.05 - 0.1 on the
+                                  * wide look-alikes; tuples through pfx_emit_kernel + EXPAND: 0.02 - 0.36 TB/s of haystack */
     DAAC_KERNEL_SEGMENT = 6,     /* scan_kernels.hip: one lane per segment, TIERED or DARRAY tables             (0.03 - 0.4 TB/s) */
     DAAC_KERNEL_MICRO = 7,       /* chain_scan.hpp overlap_count_body: micro-step walker over the double array  (0.08 - 0.4 TB/s) */
     DAAC_KERNEL_CHAIN = 8        /* chain_scan.hpp: speculate / reconcile / emit for the restart iterators      (0.1 - 0.3 TB/s) */
@@ -147,7 +149,7 @@ typedef struct {
     uint32_t gram2_lds_count;    /* LDS bytes per workgroup, count only / with checksum */
     uint32_t gram2_lds_exact;
     uint8_t gram_wide;           /* 31 .. 62 byte classes: the GRAM engine runs on 64-bit words with K = 2 (gram2w.hpp) */
-    uint8_t pfx_available;       /* the PFX tables were built (any byte alphabet, `.count()`) */
+    uint8_t pfx_available;       /* the PFX tables were built (any byte alphabet: `.count()`, count + checksum, tuples) */
     uint32_t pfx_key_bytes;      /* G: bytes of a PFX filter key */
     uint32_t pfx_lds_bytes;
     /* the engine plan, indexed by daac_request; valid after upload, for engine AUTO */
@@ -312,6 +314,9 @@ void daac_stream_close(daac_stream *s);
  *                 1 = first table set only, 2 = gram2 kernels only, 3 = gram3 for `.count()`), gram2_dpp (1: DPP wave shifts),
  *   gram2_rfull (1)             rank directory with one entry per M word when LDS allows (0: one per four words)
  *   gram3_tail (-1 = every workgroup samples its text and picks; 0 / 1: the plain / the tail-record body of the gram3 kernel)
+ *   pfx_probe (16384)           AUTO, count (+ checksum) of a dictionary PFX serves: a synchronous scan of a device haystack >= 32 MiB samples
+ *                               65 536 positions; where more than this many survive PFX's filter the micro-step walker over the double array
+ *                               takes the scan (the verdict stays in the handle for the asynchronous calls); 0 = never ask, always PFX
  *   pfx (1)                     PFX tables (any byte alphabet): 1 = built where no GRAM table set applies, 2 = for every automaton they can
  *                               serve (DAAC_ENGINE_PFX then selects them explicitly), 0 = never; read at upload
  *   emit (1)                    materialising overlapping scans through the GRAM tuple emitter where it applies (0: segment scanners);

@@ -354,12 +354,43 @@ def test_wide_dictionary_look_alikes():
         host = dev.cpu().numpy()
         want = o.find_overlapping_iter(host)
         assert len(want) > n // 8, name
-        assert p.count(ScanMode.FindOverlapping, dev) == len(want), name
-        assert da.last_engine() == int(Engine.Pfx), name
-        assert p.scan_count(ScanMode.FindOverlapping, dev) == (len(want), orc.matches_checksum(want)), name
+        # (`.count()`: PFX, or the micro-step walker where most positions of the text survive PFX's filter — both against the oracle)
+        for eng in (Engine.Auto, Engine.Pfx, Engine.DArray):
+            assert p.count(ScanMode.FindOverlapping, dev, engine=eng) == len(want), (name, eng)
+            assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == (len(want), orc.matches_checksum(want)), (name, eng)
         got = p.scan(ScanMode.FindOverlapping, dev)
         assert da.last_engine() == int(Engine.Pfx), name
         assert _same(got, want), name
         dm = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
         assert _same16(dm.to_numpy(), want), name
         dm.free()
+
+
+def test_the_probe_sends_dense_text_to_the_walker():
+    """AUTO on a dictionary PFX serves: a synchronous `.count()` of 32 MiB or more samples the text; where more than a quarter of the
+    positions survive the filter (every character of the text is a pattern) the micro-step walker over the double array takes the scan, on
+    text the filter thins out PFX does — the counts agree with each other and with a shard sum either way."""
+    import torch
+    da.set_option("pfx", 1)
+    pats = synth.patterns_unidic_like(60_000)
+    p = da.DoubleArrayAhoCorasick.new(pats)
+    n = (48 << 20) - (48 << 20) % synth.CFG5_SLOT
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    synth.device_zipf_text(dev)
+    want = p.count(ScanMode.FindOverlapping, dev, engine=Engine.Pfx)
+    assert p.count(ScanMode.FindOverlapping, dev) == want
+    assert da.last_engine() == int(Engine.DArray)
+    res = torch.zeros(3, dtype=torch.int64, device="cuda")
+    p.count(ScanMode.FindOverlapping, dev, result_dev=res.data_ptr())      # asynchronous: goes by the verdict in the handle
+    assert int(res[0].item()) == want and da.last_engine() == int(Engine.DArray)
+    synth.device_uniform(dev, synth.SEEDS["bin_hay"], synth.ALPHA_BYTES)  # random bytes: next to nothing survives
+    want = p.count(ScanMode.FindOverlapping, dev, engine=Engine.DArray)
+    assert p.count(ScanMode.FindOverlapping, dev) == want
+    assert da.last_engine() == int(Engine.Pfx)
+    da.set_option("pfx_probe", 0)
+    try:
+        synth.device_zipf_text(dev)
+        p.count(ScanMode.FindOverlapping, dev)
+        assert da.last_engine() == int(Engine.Pfx)
+    finally:
+        da.set_option("pfx_probe", 16384)
