@@ -51,9 +51,6 @@ struct Options {
     std::atomic<int64_t> gram3_tail{-1};        // gram3: tail records from the hit record on (-1 = decide per launch)
     std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
     std::atomic<int64_t> emit{1};               // materialising overlapping scans: GRAM tuple emission where it applies (0: segment scanners)
-    std::atomic<int64_t> emit_tiles{64};        // tiles of 1024 positions a wave takes at a time
-    std::atomic<int64_t> emit_rec_cap{256};     // deep-match records per wave and tile before the scan falls back
-    std::atomic<int64_t> emit_version{0};       // 0 = auto (emit3_kernels.hip: detection once, then expansion), 1 = gram2_emit_kernels.hip (COUNT + WRITE)
     std::atomic<int64_t> emit_v3_lds{1};        // emit3 EXPAND: values of the 3-byte patterns from a rank structure in LDS when it fits (0: from L2)
     std::atomic<int64_t> emit_stagger{0};       // emit3 EXPAND: the waves of a CU start this many x 1024 cycles apart (0: together)
     std::atomic<int64_t> emit_rec_per_kib{32};  // emit3: deep-match records the list is first sized for, per KiB of haystack (a rerun sizes it exactly)
@@ -155,7 +152,6 @@ struct DeviceTables {
     uint32_t n_distinct_bytes = 0;  // distinct pattern bytes (known when the PFX builder ran)
     PfxDev pfx{};
     Gram2WDev gramw{};
-    bool emit_ok = false;      // tuple emission on the second table set (gram2_emit_kernels.hip)
     Gram2EmitDev emit{};
     bool emit3_ok = false;     // ... with detection done once (emit3_kernels.hip)
     Gram3Lds emit3_lds{};
@@ -167,7 +163,7 @@ struct DeviceTables {
     std::atomic<uint32_t> emit3_rec_per_kib{0};  // deep-match records per KiB the last scans met (sizes the next scan's list)
     // scans in a row on which an emitter gave up on the TEXT (more deep matches or extras than it places: known only after its detection
     // has run): from the second on the handle stops trying and the plan says so (a served scan resets the count)
-    std::atomic<uint32_t> emit3_gave_up{0}, emit_gave_up{0};
+    std::atomic<uint32_t> emit3_gave_up{0};
     CharDev chr{};  // charwise automata only
 
     ~DeviceTables() {
@@ -610,9 +606,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 e.off_v2 = e.off_v1 + e.v1_bytes;
                 e.off_ring = e.off_v2 + e.v2_bytes;
                 e.off_wave = e.off_ring + ring_bytes;
-                e.lds_bytes = e.off_wave + 16u * (2048u + 256u + 256u + 64u * 8u + 32u);  // kWaveLds of gram2_emit_kernels.hip
                 e.K = g2.K; e.C = g2.C; e.s16 = g2.s16; e.unused_byte = g2.unused_byte;
-                t->emit_ok = e.lds_bytes <= 160u * 1024u;
                 // emit3: DETECT as a 16-wave workgroup when the tables leave room for the text slots, else 8 waves
                 t->emit3_ok = emit3_plan(e, 16, 160u * 1024u, t->emit3_lds) || emit3_plan(e, 8, 160u * 1024u, t->emit3_lds);
                 // the values of the 3-byte patterns as a rank structure for EXPAND's LDS (device_tables.hpp: v3c)
@@ -1142,113 +1136,6 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
     return DAAC_OK;
 }
 
-// FindOverlappingIterator of a bytewise Standard automaton through the GRAM tuple emitter (gram2_emit_kernels.hip):
-// COUNT pass -> exclusive scan of the per-tile counts -> WRITE pass.  *served = false when the automaton / request does
-// not qualify or a wave ran out of record space (then nothing is returned and the segment scanners take over).
-daac_status emit_overlapping(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t end, hipStream_t stream,
-                             DevMatches &out, bool *served) {
-    *served = false;
-    if (!t->emit_ok || g_opt.emit.load() == 0 || end <= begin) return DAAC_OK;
-    if (t->emit_gave_up.load() >= 2 && end - begin >= (1u << 20)) return DAAC_OK;
-    const Gram2EmitDev &e = t->emit;
-    const uint64_t halo = pma->halo();
-    // windows of at most 1 GiB of end positions: virtual positions inside a window fit 32 bits
-    const uint64_t kWin = 1ull << 30;
-    struct Win { uint64_t wb, we, from; uint32_t lead, vlen, emit_from, ntiles; uint64_t tile0; const uint8_t *hay_al; };
-    std::vector<Win> wins;
-    uint64_t tiles_total = 0;
-    for (uint64_t wb = begin; wb < end; wb += kWin) {
-        Win w{};
-        w.wb = wb; w.we = std::min(end, wb + kWin);
-        w.from = wb > halo ? wb - halo : 0;
-        const uint8_t *first = dev_hay + w.from;
-        w.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(first) & 15u);
-        w.hay_al = first - w.lead;
-        w.vlen = static_cast<uint32_t>(w.lead + (w.we - w.from));
-        w.emit_from = static_cast<uint32_t>(w.lead + (wb - w.from));
-        w.ntiles = (w.vlen + 1023u) / 1024u;
-        w.tile0 = tiles_total;
-        tiles_total += w.ntiles;
-        wins.push_back(w);
-    }
-    const uint32_t tpr = static_cast<uint32_t>(std::max<int64_t>(1, g_opt.emit_tiles.load()));
-    const uint32_t rec_cap = static_cast<uint32_t>(std::max<int64_t>(16, g_opt.emit_rec_cap.load()));
-    const uint32_t wq_slab = 2048;
-    // one launch geometry for all windows
-    uint64_t max_regions = 0;
-    for (const Win &w : wins) max_regions = std::max<uint64_t>(max_regions, (w.ntiles + tpr - 1) / tpr);
-    const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (max_regions + 15) / 16)));
-    const uint64_t nwaves = static_cast<uint64_t>(blocks) * 16;
-    unsigned long long *d_tiles = nullptr;
-    void *d_scratch = nullptr;
-    const size_t wq_bytes = nwaves * wq_slab * sizeof(uint2), rec_bytes = nwaves * 2ull * rec_cap * sizeof(uint4);
-    DevBuf g1, g2;
-    HIP_TRY(g1.alloc((tiles_total + 2 + exclusive_scan_scratch(tiles_total)) * sizeof(unsigned long long), stream));
-    d_tiles = static_cast<unsigned long long *>(g1.p);
-    HIP_TRY(g2.alloc(wq_bytes + rec_bytes + 16, stream));
-    d_scratch = g2.p;
-    unsigned int *d_fail = reinterpret_cast<unsigned int *>(static_cast<char *>(d_scratch) + wq_bytes + rec_bytes);
-    HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(unsigned int), stream));
-    auto args_of = [&](const Win &w) {
-        EmitArgs a{};
-        a.hay_al = w.hay_al; a.lead = w.lead; a.vlen = w.vlen; a.emit_from = w.emit_from;
-        a.pos_base = w.from - w.lead + 1;  // (mod 2^64: a match ends one past its last byte)
-        a.tile_cnt = d_tiles + w.tile0;
-        a.wq = static_cast<uint2 *>(d_scratch); a.wq_slab = wq_slab;
-        a.recs = reinterpret_cast<uint4 *>(static_cast<char *>(d_scratch) + wq_bytes); a.rec_cap = rec_cap;
-        a.ntiles = w.ntiles; a.tiles_per_region = tpr; a.nregions = (w.ntiles + tpr - 1) / tpr;
-        a.fail = d_fail;
-        return a;
-    };
-    for (const Win &w : wins) HIP_TRY(launch_gram2_emit(e, args_of(w), 0, false, blocks, stream));
-    HIP_TRY(launch_exclusive_scan(d_tiles, tiles_total, d_tiles + tiles_total, d_tiles + tiles_total + 2, stream));
-    unsigned long long total = 0;
-    unsigned int fail = 0;
-    {
-        // the total and the COUNT pass's verdict on the record lists (a wave that met more deep matches in one tile than it has room
-        // for): known before anything is allocated or written
-        unsigned long long *pin = reinterpret_cast<unsigned long long *>(pinned_words());
-        HIP_TRY(hipMemcpyAsync(pin ? pin : &total, d_tiles + tiles_total, sizeof(total), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(pin ? reinterpret_cast<unsigned int *>(pin + 1) : &fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (pin) { total = pin[0]; fail = *reinterpret_cast<unsigned int *>(pin + 1); }
-    }
-    if (fail != 0) { t->emit_gave_up.fetch_add(1); set_error("GRAM emitter: record lists overflowed in the count pass (code " + std::to_string(fail) + ")"); return DAAC_OK; }  // left to the segment scanners
-    g_last_engine = DAAC_ENGINE_GRAM;
-    const size_t tuple_bytes = out.f16 ? 16 : sizeof(daac_match);
-    if (total == 0) { *served = true; return DAAC_OK; }
-    if (total * tuple_bytes > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
-        set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
-        return DAAC_ERR_AUTOMATON_SCALE;
-    }
-    daac_match *d_out = nullptr;
-    HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_out), total * tuple_bytes, stream));
-    out.p = d_out;
-    out.s = stream;
-    out.n = total;
-    for (const Win &w : wins) {
-        EmitArgs a = args_of(w);
-        a.out = d_out;
-        HIP_TRY(launch_gram2_emit(e, a, 1, out.f16, blocks, stream));
-    }
-    {
-        unsigned int *pin = pinned_words();
-        HIP_TRY(hipMemcpyAsync(pin ? pin : &fail, d_fail, sizeof(fail), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (pin) fail = *pin;
-    }
-    if (fail != 0) {  // more extras in one tile than the write pass places (the COUNT pass cannot know): leave it to the segment scanners
-        t->emit_gave_up.fetch_add(1);
-        set_error("GRAM emitter: the write pass gave up (code " + std::to_string(fail) + ")");
-        dev_free(out.release(), stream);
-        return DAAC_OK;
-    }
-    out.f16_done = out.f16;
-    t->emit_gave_up.store(0);
-    *served = true;
-    return DAAC_OK;
-}
-
 // Scans [begin, end) of a haystack whose byte 0 is at `dev_hay` (device pointer; only bytes
 // >= begin - halo are dereferenced) and leaves the matches with end in (begin, end] — plus
 // ROOT's list at end = 0 when begin == 0 — in device memory, in reference order.
@@ -1275,14 +1162,8 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
     }
     if (!pma->charwise && mode == DAAC_FIND_OVERLAPPING && (engine == DAAC_ENGINE_AUTO || want_gram)) {
         bool served = false;
-        if (g_opt.emit_version.load() != 1) {
-            if ((st = emit_overlapping3(pma, t, dev_hay, begin, end, stream, out, &served)) != DAAC_OK) return st;
-            if (served) return DAAC_OK;
-        }
-        if (g_opt.emit_version.load() != 3) {   // (3: the new emitter or nothing — tests)
-            if ((st = emit_overlapping(pma, t, dev_hay, begin, end, stream, out, &served)) != DAAC_OK) return st;
-            if (served) return DAAC_OK;
-        }
+        if ((st = emit_overlapping3(pma, t, dev_hay, begin, end, stream, out, &served)) != DAAC_OK) return st;
+        if (served) return DAAC_OK;
     }
     if (want_gram) {
         set_error(std::string("the GRAM engine cannot emit tuples for this automaton / request [") + last_error_cstr() + "]");
@@ -1502,7 +1383,7 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
     else if (t->gramw_ok && t->gramw.exact_ok) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_WIDE, DAAC_WHY_FASTEST);
     else if (t->pfx_ok) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);  // (as scan_count_impl: PFX wherever no GRAM table set serves the request)
     else set(DAAC_REQ_OVERLAPPING_CHECKSUM, micro_engine, micro, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);
-    if (((t->emit3_ok && t->emit3_gave_up.load() < 2) || (t->emit_ok && t->emit_gave_up.load() < 2)) && g_opt.emit.load() != 0)
+    if (t->emit3_ok && t->emit3_gave_up.load() < 2 && g_opt.emit.load() != 0)
         set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EMIT, DAAC_WHY_FASTEST);
     else if (t->pfx_emit_ok && t->emit3_gave_up.load() < 2 && g_opt.emit.load() != 0)
         set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, why_no_gram);
@@ -1683,6 +1564,10 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
             g3_ppl = 16;
             use_g3 = gram3_plan(t->gram2, 16, 16, want_rfull, 160u * 1024u, g3l);
         }
+    }
+    if (use_g2 && !use_g3 && !t->gram2.exact_ok) {   // (`.count()` alone lives on gram3_kernels.hip; what is left of gram2_kernels.hip computes the checksum too)
+        set_error("GRAM second table set: `.count()` runs on the gram3 kernel (gram_version 0 or 3); the count + checksum kernel needs tables this dictionary has no room for");
+        return DAAC_ERR_UNSUPPORTED;
     }
     const bool use_gw = use_gram && !g2_can && !g1_can && gw_can;
     Plan pl;
@@ -2428,9 +2313,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "pfx_probe") g_opt.pfx_probe = value;
     else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
-    else if (n == "emit_tiles") g_opt.emit_tiles = value;
-    else if (n == "emit_rec_cap") g_opt.emit_rec_cap = value;
-    else if (n == "emit_version") g_opt.emit_version = value;
+    else if (n == "emit_tiles" || n == "emit_rec_cap" || n == "emit_version") {}   // (options of the round-3 COUNT + WRITE emitter: accepted, nothing left to steer)
     else if (n == "emit_stagger") g_opt.emit_stagger = value;
     else if (n == "emit_v3_lds") g_opt.emit_v3_lds = value;
     else if (n == "emit_rec_per_kib") g_opt.emit_rec_per_kib = value;

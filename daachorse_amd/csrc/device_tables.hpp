@@ -192,23 +192,6 @@ struct Gram2EmitDev {
     const uint32_t *v3c;      // [bitmap words | directory (u16 per word, padded to 4 bytes) | values]
     uint32_t v3c_bytes, v3c_dir, v3c_val;   // size of the whole (multiple of 16), byte offsets of directory and values
 };
-struct EmitArgs {
-    const uint8_t *hay_al;        // window address rounded down to 16 bytes ("virtual" positions count from here)
-    uint32_t lead;                // bytes between hay_al and the first byte of the window
-    uint32_t vlen;                // lead + window length
-    uint32_t emit_from;           // matches whose last byte lies at a virtual position >= this are reported
-    unsigned long long pos_base;  // end (in haystack coordinates) of a match whose last byte is at virtual position v = pos_base + v
-    unsigned long long *tile_cnt; // per tile of 1024 positions: tuple count (COUNT pass out) / exclusive offset (WRITE pass in)
-    void *out;                    // daac_match (24 bytes) or {end u64, length u32, value u32} (16 bytes) tuples
-    uint4 *recs;                  // per wave two lists of rec_cap deep-match records {byte, length, value, 1 << 31 | copy for an extra}
-    uint32_t rec_cap;
-    uint2 *wq;                    // per-wave walker slabs
-    uint32_t wq_slab;
-    uint32_t ntiles, tiles_per_region, nregions;
-    unsigned int *fail;           // set when a record list overflowed (the caller falls back to the segment scanners)
-};
-hipError_t launch_gram2_emit(const Gram2EmitDev &dev, const EmitArgs &a, int em, bool f16, uint32_t blocks, hipStream_t stream);
-
 hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool exact, uint32_t blocks, uint32_t threads, hipStream_t stream);
 
 // `.count()` with lane-local hit masks and the step's text staged in LDS (gram3_kernels.hip); tables of Gram2Dev.

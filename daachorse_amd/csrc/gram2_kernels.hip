@@ -7,7 +7,8 @@
 //     against four SIMDs: lookups per position are what the step is priced in.  v1: class (u32), CID (u16), COMBO (b64),
 //     B word (b32) = 3 random + 1 table read, two index chains (K-gram and (K+1)-gram).  Here: class (u8), M word (b32) —
 //     continuation bits AND the number of short patterns in one word, one index chain; CID/H are read only when the
-//     caller wants the checksum (EXACT), so `.count()` runs on one random lookup per position;
+//     caller wants the checksum — which is what this kernel serves since round 4: `.count()` alone runs on gram3_kernels.hip (one
+//     random lookup per position), and the count-only variants of this kernel, which AUTO never selected, are gone;
 //   * the neighbour exchange goes through DPP wave shifts (VALU) instead of ds_bpermute (6.4 LDS cycles each);
 //   * the byte address of the M word comes straight out of the mad chain: the class is scaled and the table base added
 //     by one v_lshl_add, so neither lookup needs address arithmetic of its own.
@@ -82,22 +83,19 @@ __device__ __forceinline__ void g2_reduce(unsigned long long cnt, uint32_t s1, u
 
 }  // namespace
 
-// K = context length; EXACT = count + checksum (CID/H staged and read), else count only; S16 = directory entries are u16;
-// DENSE = queue the hits position by position without testing the group of four first; RFULL = the directory has one u16
-// entry per M word (count-only launches have the LDS for it: a hit's rank is then one entry + one popcount)
-template <int K, bool EXACT, bool S16, bool DENSE, bool RFULL, int TPB>
+// Count + checksum (CID/H staged and read).  K = context length; S16 = directory entries are u16;
+// DENSE = queue the hits position by position without testing the group of four first
+template <int K, bool S16, bool DENSE, int TPB>
 __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const GramArgs a) {
     constexpr int P = 16;  // positions (bytes) a lane takes per step
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t offM = EXACT ? g.off_m_exact : g.off_m_count, offS = EXACT ? g.off_s_exact : g.off_s_count;
-    const uint32_t offRing = EXACT ? g.off_ring_exact : RFULL ? g.off_ring_rfull : g.off_ring_count;
+    const uint32_t offM = g.off_m_exact, offS = g.off_s_exact;
+    const uint32_t offRing = g.off_ring_exact;
     g2_copy(smem, g.cls, 256);
     g2_copy(smem + offM, g.m, g.m_bytes);
-    if (RFULL) g2_copy(smem + offS, g.rfull, g.rfull_bytes); else g2_copy(smem + offS, g.sdir, g.s_bytes);
-    if (EXACT) {
-        g2_copy(smem + kGram2OffH, g.hsum, g.h_bytes);
-        g2_copy(smem + g.off_cid, g.cid4, g.cid_bytes);
-    }
+    g2_copy(smem + offS, g.sdir, g.s_bytes);
+    g2_copy(smem + kGram2OffH, g.hsum, g.h_bytes);
+    g2_copy(smem + g.off_cid, g.cid4, g.cid_bytes);
     __syncthreads();
     // tables are read through absolute LDS addresses (this kernel has no static LDS: the dynamic segment starts at 0)
     if (__builtin_amdgcn_groupstaticsize() != 0) __builtin_trap();
@@ -141,7 +139,7 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
     // takes the next entry at once, one record per lane and turn, was no faster on word-soup text and 11 % slower on uniform
     // text: the drain is not where the time goes, profiles/r02_emit_experiments.txt.)
     auto drain = [&]() {
-        const uint4 *__restrict__ recs = (EXACT || !DAAC_G2_TAILS) ? g.drec : g.drec_c;
+        const uint4 *__restrict__ recs = g.drec;
         // W branches per lane at a time, each taken through its first record and first step (where, with the single paths folded
         // into tail records, nearly every branch ends); what is left of a branch walks on by itself.  (W = 1, 2, 4, 6 measured
         // the same: the drain is not bound by the latency of a round.)
@@ -178,10 +176,8 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 cnt32 += r[w].z;
-                if (EXACT) {
-                    tot_s1 += r[w].w;
-                    tot_s2 += r[w].w * static_cast<uint32_t>(vnext[w] - a.lead);
-                }
+                tot_s1 += r[w].w;
+                tot_s2 += r[w].w * static_cast<uint32_t>(vnext[w] - a.lead);
                 go[w] = ((r[w].x >> kn[w]) & 1u) != 0;
                 ahead[w] = 0;
                 if (go[w]) {
@@ -199,22 +195,10 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
                 unsigned long long ah = ahead[w];
                 uint32_t n_ahead = 8, k = 0;
                 for (;;) {
-                    if (!EXACT && DAAC_G2_TAILS && (rr.x >> 31)) {  // the rest of the subtree is one path: compare it with the text in one go
-                        const uint32_t edges = rr.x & 15u;
-                        if (n_ahead < edges) { ah = read_ahead(vn); n_ahead = 8; }
-                        const unsigned long long path = (static_cast<unsigned long long>(rr.w) << 32) | rr.z;
-                        const unsigned long long diff = path ^ ah;
-                        uint32_t same = diff ? static_cast<uint32_t>(__builtin_ctzll(diff)) >> 3 : 8u;
-                        same = same < edges ? same : edges;
-                        cnt32 += __popc((rr.x >> 4) & ((2u << same) - 1u) & 0x1ffu);
-                        break;
-                    }
                     k = cls_of(static_cast<uint32_t>(ah) & 0xffu);
                     cnt32 += rr.z;
-                    if (EXACT) {
-                        tot_s1 += rr.w;
-                        tot_s2 += rr.w * static_cast<uint32_t>(vn - a.lead);
-                    }
+                    tot_s1 += rr.w;
+                    tot_s2 += rr.w * static_cast<uint32_t>(vn - a.lead);
                     if (((rr.x >> k) & 1u) == 0) break;
                     rr = recs[rr.y + __popc(rr.x & ((1u << k) - 1u))];
                     ++vn;
@@ -236,31 +220,22 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
     auto consume_pending = [&]() {
         if (!pend_valid) return;
         pend_valid = false;
-        const uint4 r = pend;     // EXACT: {cmap, own h32 sum, first_child, -}, else {cmap | ends-a-pattern, first_child, -, -}; zero for idle lanes
-        if (EXACT) {
-            cnt32 += r.y != 0;
-            tot_s1 += r.y;
-            tot_s2 += r.y * (pend_pos - a.lead + 1u);  // end = position - lead + 1 (mod 2^32)
-        } else {
-            cnt32 += r.x & 1u;
-        }
+        const uint4 r = pend;     // {cmap, own h32 sum, first_child, -}; zero for idle lanes
+        cnt32 += r.y != 0;
+        tot_s1 += r.y;
+        tot_s2 += r.y * (pend_pos - a.lead + 1u);  // end = position - lead + 1 (mod 2^32)
         const uint32_t k1 = (pend_item >> 22) & 31u;  // (a class >= 1 where there is an edge to follow; class 0: bit 0 is not an edge)
         const bool go = k1 != 0 && ((r.x >> k1) & 1u);
         const unsigned long long m = __ballot(go);
         if (m != 0) {  // the branch goes on past depth K+1 -> queue a walker
             if (go)
                 (slab + wq_n)[__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0))] =
-                    uint2{pend_pos, ((EXACT ? r.z : r.y) + __popc(r.x & ((1u << k1) - 2u))) | ((pend_item >> 27) << 27)};
+                    uint2{pend_pos, (r.z + __popc(r.x & ((1u << k1) - 2u))) | ((pend_item >> 27) << 27)};
             wq_n += __popcll(m);
         }
     };
     // rank of continuation bit d of the M word at LDS address `am` among all set bits = offset of the depth-(K+1) state
     auto deep_rank = [&](uint32_t am, uint32_t d) -> uint32_t {
-        if (RFULL) {  // one directory entry per word
-            const uint32_t own = lds_u32(am);
-            const uint32_t base = *reinterpret_cast<lds2_cu16 *>(static_cast<uintptr_t>(offS + ((am - offM) >> 1)));
-            return base + __popc(own & kMaskBits & ((1u << d) - 1u));
-        }
         const uint32_t rel = am - offM;
         // one 16-byte read of the group (left to itself the compiler splits it into b96 + b32: two LDS instructions)
         g2_u32x4_t q;
@@ -287,12 +262,7 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
             pend_item = it.x;
             pend_pos = it.y;
             pend_rank = deep_rank(it.x & 0x1ffffu, (it.x >> 17) & 31u);
-            if (EXACT) {
-                pend = g.dhit4[pend_rank];
-            } else {
-                const uint2 h = g.dhit_c[pend_rank];
-                pend = uint4{h.x, h.y, 0u, 0u};
-            }
+            pend = g.dhit4[pend_rank];
         }
         pend_valid = true;
     };
@@ -396,17 +366,16 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
                 for (int jj = 0; jj < kGroup2; ++jj) {
                     const int j = grp * kGroup2 + jj;
                     mw[jj] = lds_u32(am[j + 1]);
-                    if (EXACT) id4[jj] = *reinterpret_cast<lds2_cu16 *>(static_cast<uintptr_t>((am[j + 1] >> 1) + cid_bias));
+                    id4[jj] = *reinterpret_cast<lds2_cu16 *>(static_cast<uintptr_t>((am[j + 1] >> 1) + cid_bias));
                 }
-                if (EXACT) {
 #pragma unroll
-                    for (int jj = 0; jj < kGroup2; ++jj) hs[jj] = lds_u32(id4[jj]);  // H sits at a fixed offset that the ids include
-                }
+                for (int jj = 0; jj < kGroup2; ++jj) hs[jj] = lds_u32(id4[jj]);  // H sits at a fixed offset that the ids include
 #pragma unroll
                 for (int jj = 0; jj < kGroup2; ++jj) {
                     mb[jj] = jj == 0 ? mprev : mw[jj - 1];  // the word whose continuation bits the byte at j is tested against
                     ccnt += mw[jj] >> 30;
-                    if (EXACT) { A += hs[jj]; T += A; }
+                    A += hs[jj];
+                    T += A;
                 }
                 mprev = mw[kGroup2 - 1];
                 auto queue_hit = [&](int jj, bool hit) {
@@ -464,10 +433,8 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
                 }
             }
             cnt32 += ccnt;
-            if (EXACT) {
-                tot_s1 += A;
-                tot_s2 += A * (e0 + static_cast<uint32_t>(P)) - T;  // sum_j hs_j * (e0 + j)
-            }
+            tot_s1 += A;
+            tot_s2 += A * (e0 + static_cast<uint32_t>(P)) - T;  // sum_j hs_j * (e0 + j)
         }
         tot_cnt += cnt32;  // per region: 32 bits cannot overflow within one
         cnt32 = 0;
@@ -481,38 +448,36 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
     g2_reduce(tot_cnt, tot_s1, tot_s2, reinterpret_cast<unsigned long long *>(smem), a.result);
 }
 
-template <int K, bool EXACT, bool S16, bool DENSE, bool RFULL>
+template <int K, bool S16, bool DENSE>
 static hipError_t launch2_tpb(const Gram2Dev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t stream) {
     // two register budgets: 1024-thread workgroups (128 VGPRs) and <= 512 (256 VGPRs)
     if (threads > 512) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_kernel<K, EXACT, S16, DENSE, RFULL, 1024>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_kernel<K, S16, DENSE, 1024>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((gram2_kernel<K, EXACT, S16, DENSE, RFULL, 1024>), dim3(blocks), dim3(threads), lds, stream, dev, a);
+        hipLaunchKernelGGL((gram2_kernel<K, S16, DENSE, 1024>), dim3(blocks), dim3(threads), lds, stream, dev, a);
     } else {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_kernel<K, EXACT, S16, DENSE, RFULL, 512>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram2_kernel<K, S16, DENSE, 512>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((gram2_kernel<K, EXACT, S16, DENSE, RFULL, 512>), dim3(blocks), dim3(threads), lds, stream, dev, a);
+        hipLaunchKernelGGL((gram2_kernel<K, S16, DENSE, 512>), dim3(blocks), dim3(threads), lds, stream, dev, a);
     }
     return hipGetLastError();
 }
-template <int K, bool EXACT, bool RFULL>
+template <int K>
 static hipError_t launch2_k(const Gram2Dev &dev, const GramArgs &a, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t stream) {
-    if (dev.s16 || RFULL)
-        return a.dense ? launch2_tpb<K, EXACT, true, true, RFULL>(dev, a, blocks, threads, lds, stream)
-                       : launch2_tpb<K, EXACT, true, false, RFULL>(dev, a, blocks, threads, lds, stream);
-    return a.dense ? launch2_tpb<K, EXACT, false, true, false>(dev, a, blocks, threads, lds, stream)
-                   : launch2_tpb<K, EXACT, false, false, false>(dev, a, blocks, threads, lds, stream);
+    if (dev.s16)
+        return a.dense ? launch2_tpb<K, true, true>(dev, a, blocks, threads, lds, stream) : launch2_tpb<K, true, false>(dev, a, blocks, threads, lds, stream);
+    return a.dense ? launch2_tpb<K, false, true>(dev, a, blocks, threads, lds, stream) : launch2_tpb<K, false, false>(dev, a, blocks, threads, lds, stream);
 }
 
-uint32_t gram2_lds_bytes(const Gram2Dev &dev, bool exact) { return exact ? dev.lds_exact : dev.rfull_ok ? dev.lds_rfull : dev.lds_count; }
+uint32_t gram2_lds_bytes(const Gram2Dev &dev, bool) { return dev.lds_exact; }
 
-hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool exact, uint32_t blocks, uint32_t threads, hipStream_t stream) {
-    const uint32_t lds = gram2_lds_bytes(dev, exact);
-    if (exact) return dev.K == 3 ? launch2_k<3, true, false>(dev, a, blocks, threads, lds, stream) : launch2_k<2, true, false>(dev, a, blocks, threads, lds, stream);
-    if (dev.rfull_ok) return dev.K == 3 ? launch2_k<3, false, true>(dev, a, blocks, threads, lds, stream) : launch2_k<2, false, true>(dev, a, blocks, threads, lds, stream);
-    return dev.K == 3 ? launch2_k<3, false, false>(dev, a, blocks, threads, lds, stream) : launch2_k<2, false, false>(dev, a, blocks, threads, lds, stream);
+// count + checksum over the second table set (`.count()` alone: launch_gram3_scan); needs dev.exact_ok
+hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool, uint32_t blocks, uint32_t threads, hipStream_t stream) {
+    if (!dev.exact_ok) return hipErrorInvalidValue;
+    const uint32_t lds = dev.lds_exact;
+    return dev.K == 3 ? launch2_k<3>(dev, a, blocks, threads, lds, stream) : launch2_k<2>(dev, a, blocks, threads, lds, stream);
 }
 
 }  // namespace daac

@@ -319,12 +319,11 @@ void daac_stream_close(daac_stream *s);
  *                               takes the scan (the verdict stays in the handle for the asynchronous calls); 0 = never ask, always PFX
  *   pfx (1)                     PFX tables (any byte alphabet): 1 = built where no GRAM table set applies, 2 = for every automaton they can
  *                               serve (DAAC_ENGINE_PFX then selects them explicitly), 0 = never; read at upload
- *   emit (1)                    materialising overlapping scans through the GRAM tuple emitter where it applies (0: segment scanners);
- *   emit_version (0)            0 = emit3_kernels.hip (detection once, then expansion) with the COUNT + WRITE emitter behind it, 1 = COUNT + WRITE only,
- *                               3 = emit3 or nothing
- *   emit_rec_per_kib (32)       emit3: deep-match records per KiB of haystack the record list is first sized for (a handle remembers what its
+ *   emit (1)                    materialising overlapping scans through the tuple emitter (emit3_kernels.hip: detection once, then expansion;
+ *                               GRAM tables, or PFX's for any byte alphabet) where it applies (0: segment scanners);
+ *   emit_rec_per_kib (32)       deep-match records per KiB of haystack the record list is first sized for (a handle remembers what its
  *                               last scan met; a list that proves too short is sized exactly and the detection is rerun once)
- *   emit_tiles (64), emit_rec_cap (256)   COUNT + WRITE emitter: tiles of 1024 positions per wave region / deep-match records per wave and tile
+ *   emit_version, emit_tiles, emit_rec_cap   options of the round-3 COUNT + WRITE emitter (now tools/experiments/emit_v1): accepted, without effect
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
  *   restart_tier (0)            1: find_iter of Standard bytewise automata runs its chains over the TIERED tables instead of the double array
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners

@@ -351,10 +351,8 @@ def _same16(got16, want):
         np.array_equal(got16["length"].astype(np.uint64), want["end"] - want["start"])
 
 
-@pytest.mark.parametrize("emit_version", [3, 1])
-def test_gram_tuple_emitter(emit_version):
-    """(emit_version 3: emit3_kernels.hip — detection once, then expansion — and nothing else; 1: the COUNT + WRITE emitter it replaces.)
-    daac_scan_device / daac_scan_device16 / daac_scan through the GRAM tuple emitter (gram2_emit_kernels.hip): bit-exact tuples in
+def test_gram_tuple_emitter():
+    """daac_scan_device / daac_scan_device16 / daac_scan through the GRAM tuple emitter (emit3_kernels.hip: detection once, then expansion): bit-exact tuples in
     the reference's order, in both device formats, on texts that stress its seams — matches that straddle tile (1024 B) and region
     boundaries, lazy windows that begin inside matches, unaligned device haystacks, both K, patterns longer than K + 16 bytes and
     duplicate patterns (placed as extras), record-list overflow (falls back) — and the list left in device memory equals the one
@@ -378,14 +376,12 @@ def test_gram_tuple_emitter(emit_version):
              (pats3, synth.wordsoup_haystack(1 << 20, synth.SEEDS["cfg3_dense"], pats3, 20)),
              (extra_pats, np.frombuffer(extra_text, dtype=np.uint8))]
     try:
-        da.set_option("emit_version", emit_version)
         for pats, hay in cases:
             o, _ = _pma(pats)
             want = o.find_overlapping_iter(hay)
             for tiles, budget, shift in ((64, 158 * 1024, 0), (1, 158 * 1024, 3), (2, 24 * 1024, 9), (3, 158 * 1024, 5)):
-                da.set_option("emit_tiles", tiles)
+                da.set_option("gram_region", 2048 * tiles if tiles < 64 else 0)   # regions of one to three DETECT steps: every seam between waves
                 da.set_option("gram_lds_budget", budget)
-                da.set_option("emit_rec_cap", 2048 if pats is extra_pats else 256)
                 p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
                 dev = torch.from_numpy(np.concatenate([np.zeros(shift, dtype=np.uint8), hay])).cuda()[shift:]
                 got = p.scan(ScanMode.FindOverlapping, dev, engine=Engine.Gram)  # Engine.Gram: no silent fallback
@@ -402,7 +398,7 @@ def test_gram_tuple_emitter(emit_version):
                 d16 = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
                 assert da.last_engine() == int(Engine.Gram) and d16.count == len(want) and _same16(d16.to_numpy(), want)
                 d16.free()
-            da.set_option("emit_tiles", 64)
+            da.set_option("gram_region", 0)
             da.set_option("gram_lds_budget", 158 * 1024)
             # lazy windows begin wherever the previous one ended: inside matches, off the tile grid
             p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
@@ -412,36 +408,28 @@ def test_gram_tuple_emitter(emit_version):
             lazy = [(m.start(), m.end(), m.value()) for m in p.find_overlapping_iter(sub)]
             assert lazy == [(int(x["start"]), int(x["end"]), int(x["value"])) for x in wsub]
             da.set_option("iter_window", 64 << 20)
-        da.set_option("emit_rec_cap", 256)
-        # more deep matches in one tile than a wave has record space for: the scan falls back and stays exact
+        # more deep matches between two checkpoints than a chunk holds: the scan falls back and stays exact
         pats = [b"a" * k for k in range(1, 17)]
         hay = np.frombuffer(b"a" * 5000 + b"b" + b"a" * 3000, dtype=np.uint8)
         o, p = _pma(pats)
         want = o.find_overlapping_iter(hay)
         got = p.scan(ScanMode.FindOverlapping, hay)
-        # (both emitters give this text up — thirteen deep matches per position: version 1 runs out of record space per tile, version 3
-        # logs more records between two checkpoints than a chunk holds — and the segment scanners serve it)
+        # (thirteen deep matches per position: the emitter gives this text up and the segment scanners serve it)
         assert _same(got, want) and da.last_engine() != int(Engine.Gram)
         d16 = p.scan_device(ScanMode.FindOverlapping, hay, fmt16=True)  # another engine's list, repacked on the device
         assert da.last_engine() != int(Engine.Gram) and _same16(d16.to_numpy(), want)
         d16.free()
-        if emit_version == 1:
-            da.set_option("emit_rec_cap", 1 << 14)
-            q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
-            assert _same(q.scan(ScanMode.FindOverlapping, hay, engine=Engine.Gram), want)
-        # more extras in one tile than the write pass places (every prefix of a long run a pattern): falls back too
-        da.set_option("emit_rec_cap", 1 << 14)
+        # more extras in one tile than the expansion places (every prefix of a long run a pattern): falls back too
         o, p = _pma([b"z" * k for k in range(1, 60)])
         hay = np.frombuffer(b"z" * 4000, dtype=np.uint8)
         assert _same(p.scan(ScanMode.FindOverlapping, hay), o.find_overlapping_iter(hay)) and da.last_engine() != int(Engine.Gram)
         # a record list sized too small: DETECT counts what it cannot store and the scan is rerun with the exact size
-        if emit_version == 3:
-            da.set_option("emit_rec_per_kib", 1)
-            o, p = _pma(pats3)
-            hay = synth.wordsoup_haystack(3 << 20, 5, pats3, 20)
-            got = p.scan(ScanMode.FindOverlapping, hay, engine=Engine.Gram)
-            assert _same(got, o.find_overlapping_iter(hay))
-            da.set_option("emit_rec_per_kib", 32)
+        da.set_option("emit_rec_per_kib", 1)
+        o, p = _pma(pats3)
+        hay = synth.wordsoup_haystack(3 << 20, 5, pats3, 20)
+        got = p.scan(ScanMode.FindOverlapping, hay, engine=Engine.Gram)
+        assert _same(got, o.find_overlapping_iter(hay))
+        da.set_option("emit_rec_per_kib", 32)
         # the other iterators in the 16-byte format (repacked)
         o, p = _pma(pats3[:2000])
         hay = synth.wordsoup_haystack(50000, 3, pats3[:2000], 20)
@@ -454,8 +442,7 @@ def test_gram_tuple_emitter(emit_version):
             p.scan(ScanMode.FindOverlapping, b"xabcabab", engine=Engine.Gram)
         assert ei.value.code == 6
     finally:
-        for k, v in (("emit_tiles", 64), ("gram_lds_budget", 158 * 1024), ("iter_window", 64 << 20), ("emit_rec_cap", 256), ("emit_version", 0),
-                     ("emit_rec_per_kib", 32)):
+        for k, v in (("gram_region", 0), ("gram_lds_budget", 158 * 1024), ("iter_window", 64 << 20), ("emit_rec_per_kib", 32)):
             da.set_option(k, v)
 
 

@@ -21,7 +21,7 @@ if hk == "sparse":
     synth.device_uniform(hay, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
 else:
     synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
-ver = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # emit_version: 0 / 3 = emit3_kernels.hip, 1 = the COUNT + WRITE emitter
+ver = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # (emit_version: an option of the round-3 emitter, ignored since)
 da.set_option("emit_version", ver)
 for k, v in os.environ.items():  # DAAC_OPT_<name>=<value>: tuning options for A/B runs
     if k.startswith("DAAC_OPT_"):
