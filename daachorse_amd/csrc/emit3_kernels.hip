@@ -486,33 +486,51 @@ __global__ __launch_bounds__(256) void emit3_combine_kernel(const uint32_t *__re
         deep[i] = d;
     }
 }
-// records -> the bin of the tile they end in; `cursor` = the per-tile record counts, counted down.  A chunk holds one wave's records
-// in the order it met them: runs of the same tile, for which one lane takes the slots of the whole run (one atomic per run).
+// records -> the bin of the tile they end in; `cursor` = the per-tile record counts, counted down.  One workgroup per chunk: the chunk's
+// records are grouped by tile in LDS (a hash of the tile numbers: a chunk holds one wave's records, a few dozen tiles), so that one
+// device-scope atomic per TILE AND CHUNK takes the slots — those atomics run at ~15-30 G/s whatever their addresses, and one per run of
+// equal tiles in meeting order (8 M per GiB of cfg3) was all of this kernel's 0.26 ms (profiles/r04_emit3_experiments.txt).
 __global__ __launch_bounds__(256) void emit3_bin_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__ chunk_fill, const uint32_t *__restrict__ chunk_next,
                                                         uint32_t chunk_cap, const unsigned long long *__restrict__ bin_off, uint32_t *__restrict__ cursor,
                                                         uint4 *__restrict__ binned) {
+    constexpr uint32_t H = 2048, kEmptyKey = 0xffffffffu;   // slots of the hash (a chunk holds at most 1024 records)
+    constexpr uint32_t PER = kEmit3Chunk / 256;
+    __shared__ uint32_t keys[H], cnt[H], base[H];
     const uint32_t used = *chunk_next < chunk_cap ? *chunk_next : chunk_cap;
-    const uint32_t lane = threadIdx.x & 63;
     for (uint32_t c = blockIdx.x; c < used; c += gridDim.x) {
         const uint32_t fill = chunk_fill[c];
-        for (uint32_t i0 = (threadIdx.x >> 6) * 64u; i0 < fill; i0 += blockDim.x) {   // (wave-uniform bounds)
-            const uint32_t i = i0 + lane;
-            const bool valid = i < fill;
-            uint4 r = uint4{0u, 0u, 0u, 0xffffffffu};
-            if (valid) r = recs[static_cast<uint64_t>(c) * kEmit3Chunk + i];
-            const uint32_t prev = __shfl_up(r.w, 1, 64);
-            const bool head = valid && (lane == 0 || r.w != prev);
-            const unsigned long long hm = __ballot(head), vm = __ballot(valid);
-            const uint32_t nvalid = static_cast<uint32_t>(__popcll(vm));   // valid lanes are 0 .. nvalid - 1
-            const unsigned long long at_or_below = hm & (~0ull >> (63u - lane));
-            const uint32_t start = at_or_below ? 63u - static_cast<uint32_t>(__builtin_clzll(at_or_below)) : 0u;
-            const unsigned long long above = lane < 63u ? hm & (~0ull << (lane + 1u)) : 0ull;
-            const uint32_t next = above ? static_cast<uint32_t>(__builtin_ctzll(above)) : nvalid;
-            uint32_t base = 0;
-            if (head) base = atomicSub(&cursor[r.w], next - lane) - (next - lane);
-            base = __shfl(base, start, 64);
-            if (valid) binned[bin_off[r.w] + base + (lane - start)] = r;
+        for (uint32_t h = threadIdx.x; h < H; h += 256) { keys[h] = kEmptyKey; cnt[h] = 0; }
+        __syncthreads();
+        uint4 r[PER];
+        uint32_t slot[PER], rank[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * 256u + threadIdx.x;
+            slot[k] = 0; rank[k] = 0;
+            if (i < fill) {
+                r[k] = recs[static_cast<uint64_t>(c) * kEmit3Chunk + i];
+                uint32_t h = (r[k].w * 0x9E3779B1u) >> 21;
+                for (;;) {
+                    const uint32_t old = atomicCAS(&keys[h], kEmptyKey, r[k].w);
+                    if (old == kEmptyKey || old == r[k].w) break;
+                    h = (h + 1u) & (H - 1u);
+                }
+                slot[k] = h;
+                rank[k] = atomicAdd(&cnt[h], 1u);
+            }
         }
+        __syncthreads();
+        for (uint32_t h = threadIdx.x; h < H; h += 256) {
+            const uint32_t n = cnt[h];
+            if (n != 0) base[h] = atomicSub(&cursor[keys[h]], n) - n;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t i = k * 256u + threadIdx.x;
+            if (i < fill) binned[bin_off[r[k].w] + base[slot[k]] + rank[k]] = r[k];
+        }
+        __syncthreads();
     }
 }
 
