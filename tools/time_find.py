@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""find_iter / leftmost_find_iter count + checksum throughput on cfg3 (bytewise) — tools/time_find.py [mib] [sparse|dense]"""
+"""find_iter / leftmost_find_iter count + checksum throughput on cfg3 (bytewise) — tools/time_find.py [mib] [sparse|dense] [find|leftmost]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,9 +14,12 @@ if hk == "sparse":
 else:
     synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
 res = {}
+only = sys.argv[3] if len(sys.argv) > 3 else ""   # "find" / "leftmost": that iterator alone (one kernel family per profile)
 for name, kind, mode, opts in (("find_iter (tier chains)", da.MatchKind.Standard, ScanMode.Find, {"restart_tier": 1}),
                                ("find_iter (double array)", da.MatchKind.Standard, ScanMode.Find, {"restart_tier": 0}),
                                ("leftmost_find_iter LL", da.MatchKind.LeftmostLongest, ScanMode.LeftmostFind, {})):
+    if (only == "find" and "double array" not in name) or (only == "leftmost" and "leftmost" not in name):
+        continue
     for k, v in opts.items():
         da.set_option(k, v)
     pma = da.DoubleArrayAhoCorasickBuilder().match_kind(kind).build(pats)
