@@ -725,6 +725,8 @@ static daac_status get_tables(daac_pma *pma, DeviceTables **out) {
 }
 
 // ---------------------------------------------------------------------------------- scan driver
+static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin, int hay_is_device,
+                                   void *stream_, uint64_t *count, uint64_t *checksum, uint64_t *result_dev, bool want_checksum);
 namespace {
 
 // The reference panics when a query does not fit the automaton's MatchKind (bytewise.rs:194-197,
@@ -967,10 +969,11 @@ struct DevMatches {
 // DETECT (annotated class stream, tile counts, deep-match records) -> scans of the tile counts -> BIN (records by tile) -> EXPAND.
 // *served = false when the automaton / request does not qualify or the haystack is of the adversarial kind the kernels give up on
 // (then nothing is returned and the other engines take over).
+// `dest`: the tuples go to this place (room for dest_cap of them) instead of a buffer of the call's own: out.n says how many, out.p stays null.
 // `raw`: the PFX engine's tuples (any byte alphabet): pfx_emit_kernel logs every match of two or more bytes as a record, EXPAND runs over the
 // haystack itself (one-byte patterns by table) — same glue, same record list, no annotated stream.
 daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t end, hipStream_t stream,
-                              DevMatches &out, bool *served, bool raw = false) {
+                              DevMatches &out, bool *served, bool raw = false, void *dest = nullptr, uint64_t dest_cap = 0) {
     *served = false;
     if (!(raw ? t->pfx_emit_ok : t->emit3_ok) || g_opt.emit.load() == 0 || end <= begin) return DAAC_OK;
     if (t->emit3_gave_up.load() >= 2 && end - begin >= (1u << 20)) return DAAC_OK;   // (short scans may still try: they cost little)
@@ -1079,10 +1082,11 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
     g_last_engine = raw ? DAAC_ENGINE_PFX : DAAC_ENGINE_GRAM;
     const size_t tuple_bytes = out.f16 ? 16 : sizeof(daac_match);
     if (total == 0) { *served = true; return DAAC_OK; }
-    if (total * tuple_bytes > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+    if (!dest && total * tuple_bytes > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
         set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
         return DAAC_ERR_AUTOMATON_SCALE;
     }
+    if (dest && total > dest_cap) { set_error("tuple emitter: more tuples than the count pass announced"); return DAAC_ERR_DEVICE; }
     HIP_TRY(g_bins.alloc(static_cast<size_t>(deep_total + 1) * sizeof(uint4), stream));
     if (deep_total != 0) {
         uint4 *d_recs = static_cast<uint4 *>(g_recs.p);
@@ -1090,9 +1094,11 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         HIP_TRY(launch_emit3_bin(d_recs, d_fill, d_ctl, static_cast<uint32_t>(chunk_cap), d_b, d_deep, static_cast<uint4 *>(g_bins.p),
                                  static_cast<uint32_t>(std::min<uint64_t>(ctl[0], static_cast<uint64_t>(t->num_cu) * 16)), stream));
     }
-    daac_match *d_out = nullptr;
-    HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_out), total * tuple_bytes, stream));
-    out.p = d_out;
+    daac_match *d_out = static_cast<daac_match *>(dest);
+    if (!dest) {
+        HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_out), total * tuple_bytes, stream));
+        out.p = d_out;
+    }
     out.s = stream;
     out.n = total;
     HIP_TRY(hipMemsetAsync(d_ctl + 1, 0, 4, stream));
@@ -1153,8 +1159,43 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
     if (!pma->charwise && mode == DAAC_FIND_OVERLAPPING && (engine == DAAC_ENGINE_AUTO || want_pfx) && t->pfx_emit_ok) {
         bool served = false;
         if (end <= begin && want_pfx) { g_last_engine = DAAC_ENGINE_PFX; return DAAC_OK; }   // (no "" among the patterns: nothing ends at 0)
-        if ((st = emit_overlapping3(pma, t, dev_hay, begin, end, stream, out, &served, true)) != DAAC_OK) return st;
-        if (served) return DAAC_OK;
+        // Every tuple of this path is first a record, then a binned record, then a tuple: three and a half times the list's size in flight
+        // (1 GiB of the Unidic-like text in one piece asked the driver for 30 GB per call and took 1.2 s for it).  A range whose scratch
+        // would pass 8 GB — by what the handle's last scan met; a first scan beyond 256 MiB counts as such — is therefore COUNTED first
+        // (`.count()`, one pass), the list allocated once, and emitted piece by piece straight into its place.
+        const uint64_t kPiece = 256ull << 20;
+        const uint64_t hint = t->emit3_rec_per_kib.load();
+        const uint64_t est = hint ? (end - begin) / 1024 * hint * 58 : ~0ull;   // 16 B per record x 3.6
+        if (end - begin <= kPiece || est <= (8ull << 30)) {
+            if ((st = emit_overlapping3(pma, t, dev_hay, begin, end, stream, out, &served, true)) != DAAC_OK) return st;
+            if (served) return DAAC_OK;
+        } else {
+            uint64_t total = 0;
+            if ((st = scan_count_impl(pma, DAAC_FIND_OVERLAPPING, DAAC_ENGINE_AUTO, dev_hay, end, begin, 1, stream, &total, nullptr, nullptr, false)) != DAAC_OK) return st;
+            const size_t tb = out.f16 ? 16 : sizeof(daac_match);
+            if (total * tb > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+                set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
+                return DAAC_ERR_AUTOMATON_SCALE;
+            }
+            daac_match *d_out = nullptr;
+            HIP_TRY(dev_malloc(reinterpret_cast<void **>(&d_out), std::max<size_t>(16, total * tb), stream));
+            uint64_t at = 0;
+            served = true;
+            for (uint64_t b = begin; b < end && served; b += kPiece) {
+                DevMatches part;
+                part.f16 = out.f16;
+                if ((st = emit_overlapping3(pma, t, dev_hay, b, std::min(end, b + kPiece), stream, part, &served, true,
+                                            reinterpret_cast<char *>(d_out) + at * tb, total - at)) != DAAC_OK) { dev_free(d_out, stream); return st; }
+                at += part.n;
+            }
+            if (served && at == total) {
+                out.p = d_out; out.s = stream; out.n = total; out.f16_done = out.f16;
+                g_last_engine = DAAC_ENGINE_PFX;
+                return DAAC_OK;
+            }
+            dev_free(d_out, stream);   // (a piece was given up: the other engines take the whole range)
+            served = false;
+        }
     }
     if (want_pfx) {
         set_error(std::string("the PFX engine cannot emit tuples for this automaton / request [") + last_error_cstr() + "]");

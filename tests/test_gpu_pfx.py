@@ -394,3 +394,38 @@ def test_the_probe_sends_dense_text_to_the_walker():
         assert da.last_engine() == int(Engine.Pfx)
     finally:
         da.set_option("pfx_probe", 16384)
+
+
+def test_pfx_tuples_piece_by_piece():
+    """daac_scan_device16 of a range beyond 256 MiB on the PFX engine goes piece by piece (every tuple is a record first: the scratch of a
+    whole GiB of match-dense text would be tens of GB per call); the pieces' lists, put together, are the oracle's list — matches that
+    straddle a piece boundary included."""
+    import torch
+    da.set_option("pfx", 1)
+    pats = synth.patterns_cfg5(20_000)
+    p = da.DoubleArrayAhoCorasick.new(pats)
+    o = orc.OraclePma.deserialize(p.serialize())
+    n = (300 << 20) - (300 << 20) % synth.CFG5_SLOT
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    synth.device_zipf_text(dev)
+    host = dev.cpu().numpy()
+    want = o.find_overlapping_iter(host)
+    assert len(want) > 5_000_000
+    for rep in range(2):   # (the first scan of a handle counts as match-dense; the second goes by what the first met)
+        dm = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
+        assert da.last_engine() == int(Engine.Pfx)
+        got = dm.to_numpy()
+        dm.free()
+        assert _same16(got, want), rep
+    # the same text cut so that a match straddles the first piece boundary (256 MiB), on a fresh handle
+    cut = 256 << 20
+    j = int(np.searchsorted(want["start"], cut))
+    shift = int(want["start"][j]) + 1 - cut
+    assert 0 < shift < (1 << 20)
+    want2 = o.find_overlapping_iter(host[shift:])
+    assert np.any((want2["start"] < cut) & (want2["end"] > cut))
+    q = da.DoubleArrayAhoCorasick.new(pats)
+    dm = q.scan_device(ScanMode.FindOverlapping, dev[shift:])
+    assert da.last_engine() == int(Engine.Pfx)
+    assert _same(dm.to_numpy(), want2)
+    dm.free()
