@@ -264,7 +264,7 @@ def iterator_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha
     (bound by the haystack's way to the device)."""
     from daachorse_amd import ScanMode
     n = 1 << 30
-    out = {"bytes": n, "op": "daac_iter_open + daac_iter_next_batch to exhaustion over a page-locked host haystack (zero-copy runs of 16-byte tuples, counted)",
+    out = {"bytes": n, "op": "daac_iter_open_compact + daac_iter_next_batch12 to exhaustion over a page-locked host haystack (zero-copy runs of 12-byte tuples, counted)",
            "window_bytes": "16, 32, then 64 MiB (option iter_window)"}
     host = torch.empty(n, dtype=torch.uint8).pin_memory()
     dev = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -276,27 +276,42 @@ def iterator_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha
         host.copy_(dev)
         torch.cuda.synchronize()
         h = host.numpy()
-        best, cnt, best_sum, ends = None, 0, None, 0
+        best, cnt, best_sum, ends, best16, cnt16 = None, 0, None, 0, None, 0
         for rep in range(3):   # the first pass also pays for pinning the window buffers; the last one reads every tuple on the host
             t0 = time.perf_counter()
-            it = pma.find_overlapping_iter(h)
+            it = pma.find_overlapping_iter(h, compact=True)
             cnt, ends = 0, 0
             while True:
-                run = it.next_batch()
-                if run is None:
+                got = it.next_batch12()
+                if got is None:
                     break
+                run, base = got
                 cnt += len(run)
                 if rep == 2:
-                    ends += int(run["end"].sum(dtype=np.uint64))
+                    ends += int(run["end_lo"].sum(dtype=np.uint64)) + base * len(run)
             it.close()
             dt = time.perf_counter() - t0
             if rep == 2:
                 best_sum = dt
             else:
                 best = dt if best is None else min(best, dt)
+        for rep in range(2):   # the 16-byte runs (daac_iter_open / daac_iter_next_batch) beside it
+            t0 = time.perf_counter()
+            it = pma.find_overlapping_iter(h)
+            cnt16 = 0
+            while True:
+                run = it.next_batch()
+                if run is None:
+                    break
+                cnt16 += len(run)
+            it.close()
+            dt = time.perf_counter() - t0
+            best16 = dt if best16 is None else min(best16, dt)
         want = pma.count(ScanMode.FindOverlapping, dev)
         out[name] = {"GB/s": round(n / best / 1e9, 2), "seconds": round(best, 4), "matches": cnt, "matches_per_byte": round(cnt / n, 4),
-                     "tuple_GB/s_over_pcie": round(cnt * 16 / best / 1e9, 2), "count_agrees_with_count_kernel": bool(cnt == want),
+                     "wire": "12-byte tuples (daac_iter_open_compact / daac_iter_next_batch12: end relative to the window)",
+                     "tuple_GB/s_over_pcie": round(cnt * 12 / best / 1e9, 2), "count_agrees_with_count_kernel": bool(cnt == want and cnt16 == want),
+                     "GB/s_16_byte_runs": round(n / best16 / 1e9, 2),
                      "GB/s_with_a_numpy_pass_over_every_tuple": round(n / best_sum / 1e9, 2),
                      "engine_used": ENGINE_NAMES.get(da.last_engine(), "?")}
     del host, dev, p2

@@ -86,6 +86,9 @@ def lib():
     L.daac_iter_next.restype = C.c_int
     L.daac_iter_next_batch.argtypes = [vp, P(vp), P(sz)]
     L.daac_iter_next_batch.restype = C.c_int
+    L.daac_iter_open_compact.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp)]
+    L.daac_iter_next_batch12.argtypes = [vp, P(vp), P(sz), P(C.c_uint64)]
+    L.daac_iter_next_batch12.restype = C.c_int
     L.daac_iter_close.argtypes = [vp]
     L.daac_stream_open.argtypes = [vp, C.c_int, C.c_int, vp, P(vp)]
     L.daac_stream_feed.argtypes = [vp, u8p, sz, C.c_int, P(vp)]
@@ -109,7 +112,7 @@ def lib():
                                        C.c_uint64, vp]
     for name in ("daac_bytewise_from_serialized", "daac_bytewise_from_parts", "daac_bytewise_build", "daac_charwise_from_serialized",
                  "daac_charwise_build", "daac_pma_serialize",
-                 "daac_pma_info", "daac_pma_upload", "daac_scan", "daac_scan_count", "daac_scan_count_range", "daac_iter_open", "daac_stream_open", "daac_stream_feed", "daac_set_option",
+                 "daac_pma_info", "daac_pma_upload", "daac_scan", "daac_scan_count", "daac_scan_count_range", "daac_iter_open", "daac_iter_open_compact", "daac_stream_open", "daac_stream_feed", "daac_set_option",
                  "daac_synth_uniform", "daac_synth_wordsoup", "daac_synth_zipf_text"):
         getattr(L, name).restype = C.c_int
     _lib = L

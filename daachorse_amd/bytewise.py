@@ -113,6 +113,7 @@ class _MatchList:
 
 
 MATCH16_DTYPE = np.dtype([("end", "<u8"), ("length", "<u4"), ("value", "<u4")])  # daac_match16 = the crate's own Match fields
+MATCH12_DTYPE = np.dtype([("end_lo", "<u4"), ("length", "<u4"), ("value", "<u4")])  # daac_match12: end relative to the run's base
 
 
 class DeviceMatches:
@@ -148,12 +149,13 @@ class DeviceMatches:
 class _LazyIter:
     """Iterator<Item = Match<u32>> over daac_iter_* (bytewise/iter.rs next())."""
 
-    def __init__(self, pma, mode, haystack, engine, stream):
+    def __init__(self, pma, mode, haystack, engine, stream, compact=False):
         self._pma = pma
         self._h = _Haystack(haystack)
         self._it = C.c_void_p()
-        _ffi.check(_ffi.lib().daac_iter_open(pma._h, int(mode), int(engine), self._h.ptr, self._h.len, self._h.is_device,
-                                             stream, C.byref(self._it)))
+        self._compact = bool(compact)
+        opener = _ffi.lib().daac_iter_open_compact if compact else _ffi.lib().daac_iter_open
+        _ffi.check(opener(pma._h, int(mode), int(engine), self._h.ptr, self._h.len, self._h.is_device, stream, C.byref(self._it)))
 
     def __iter__(self):
         return self
@@ -179,6 +181,19 @@ class _LazyIter:
             _ffi.check(-r)
         buf = (C.c_char * (n.value * 16)).from_address(p.value)
         return np.frombuffer(buf, dtype=MATCH16_DTYPE)
+
+    def next_batch12(self):
+        """daac_iter_next_batch12 (iterators opened with compact=True): the next run as (view {end_lo u32, length u32, value u32}, end_base) —
+        end = end_base + end_lo — or None when the iterator is exhausted."""
+        import numpy as np
+        p, n, base = C.c_void_p(), C.c_size_t(), C.c_uint64()
+        r = _ffi.lib().daac_iter_next_batch12(self._it, C.byref(p), C.byref(n), C.byref(base))
+        if r == 0:
+            return None
+        if r < 0:
+            _ffi.check(-r)
+        buf = (C.c_char * (n.value * 12)).from_address(p.value)
+        return np.frombuffer(buf, dtype=MATCH12_DTYPE), base.value
 
     def close(self):
         if self._it:
@@ -309,17 +324,18 @@ class DoubleArrayAhoCorasick:
         return self
 
     # ---- lazy iterators, crate names (bytewise.rs:190-203, 292-314, 410-428, 547-566) --------------------
-    def find_iter(self, haystack, engine=Engine.Auto, stream=None):
-        return _LazyIter(self, ScanMode.Find, haystack, engine, stream)
+    # (compact=True: daac_iter_open_compact — 12-byte tuples over PCIe, read with next_batch12(); iterating match by match works on either)
+    def find_iter(self, haystack, engine=Engine.Auto, stream=None, compact=False):
+        return _LazyIter(self, ScanMode.Find, haystack, engine, stream, compact)
 
-    def find_overlapping_iter(self, haystack, engine=Engine.Auto, stream=None):
-        return _LazyIter(self, ScanMode.FindOverlapping, haystack, engine, stream)
+    def find_overlapping_iter(self, haystack, engine=Engine.Auto, stream=None, compact=False):
+        return _LazyIter(self, ScanMode.FindOverlapping, haystack, engine, stream, compact)
 
-    def find_overlapping_no_suffix_iter(self, haystack, engine=Engine.Auto, stream=None):
-        return _LazyIter(self, ScanMode.FindOverlappingNoSuffix, haystack, engine, stream)
+    def find_overlapping_no_suffix_iter(self, haystack, engine=Engine.Auto, stream=None, compact=False):
+        return _LazyIter(self, ScanMode.FindOverlappingNoSuffix, haystack, engine, stream, compact)
 
-    def leftmost_find_iter(self, haystack, engine=Engine.Auto, stream=None):
-        return _LazyIter(self, ScanMode.LeftmostFind, haystack, engine, stream)
+    def leftmost_find_iter(self, haystack, engine=Engine.Auto, stream=None, compact=False):
+        return _LazyIter(self, ScanMode.LeftmostFind, haystack, engine, stream, compact)
 
     # ---- steppers for haystacks that arrive in pieces (bytewise.rs:238-251, 353-375; iter.rs:344-475) ------------------
     def find_stepper(self, engine=Engine.Auto, stream=None):

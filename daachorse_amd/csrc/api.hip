@@ -930,6 +930,16 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
 
 // {count, S1, S2} of a shard scanned with shard-relative ends -> absolute ends, plus tuples counted on the host
 // daac_match {start, end, value} -> {end u64, length u32, value u32}
+// daac_match16 -> daac_match12 {end - base (32 bits), length, value}: what the compact lazy iterator sends over PCIe (a quarter less)
+__global__ void repack12_kernel(const uint4 *in, uint32_t *out, unsigned long long n, unsigned long long base) {
+    for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
+        const uint4 t = in[i];
+        const unsigned long long end = (static_cast<unsigned long long>(t.y) << 32) | t.x;
+        out[3 * i] = static_cast<uint32_t>(end - base);
+        out[3 * i + 1] = t.z;
+        out[3 * i + 2] = t.w;
+    }
+}
 __global__ void repack16_kernel(const daac_match *in, uint4 *out, unsigned long long n) {
     for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
         const daac_match m = in[i];
@@ -1922,7 +1932,8 @@ struct IterWindow {
     daac_status st = DAAC_OK;
     std::string err;
     uint64_t n = 0;                 // tuples of the window
-    daac_match16 *host = nullptr;   // page-locked (pageable if pinning failed)
+    uint64_t base = 0;              // compact: ends count from here (the window's first byte)
+    daac_match16 *host = nullptr;   // page-locked (pageable if pinning failed); compact: daac_match12 tuples
     size_t host_bytes = 0;
     bool host_pinned = false;
     hipEvent_t copied = nullptr;    // the tuples are in `host`
@@ -1938,6 +1949,7 @@ struct daac_iter {
     uint64_t len = 0;
     bool hay_is_device = false;
     bool restart = false;          // find_iter / leftmost_find_iter: windows end at sync points
+    bool compact = false;          // daac_iter_open_compact: 12-byte tuples over PCIe (end relative to the window), daac_iter_next_batch12
     void *owned_dev = nullptr;     // host haystack staged once (restart modes read past a window's nominal end)
     hipStream_t user_stream = nullptr;
     // the worker and its three streams
@@ -1950,7 +1962,8 @@ struct daac_iter {
     IterDeviceKit *kit = nullptr;
     hipStream_t s_scan = nullptr, s_h2d = nullptr, s_d2h = nullptr, s_d2h2 = nullptr;
     // the consumer's view of the window it is reading
-    const daac_match16 *cur = nullptr;
+    const daac_match16 *cur = nullptr;   // (compact: daac_match12 tuples behind this pointer)
+    uint64_t cur_base = 0;
     size_t cur_n = 0, pos = 0;
     bool holding = false;
 
@@ -2036,10 +2049,23 @@ void daac_iter::run() {
                     dm.p = static_cast<daac_match *>(d16);
                 }
             }
+            if (st == DAAC_OK && compact && dm.n != 0) {   // ends relative to the window's first byte: 12 bytes per tuple over the link
+                void *d12 = nullptr;
+                if (next_begin - begin >= (1ull << 32)) { set_error("iterator: a window of 4 GiB or more has no compact form"); st = DAAC_ERR_UNSUPPORTED; }
+                else if (dev_malloc(&d12, dm.n * 12, s_scan) != hipSuccess) { st = hip_fail(hipGetLastError(), "iterator: repack buffer"); }
+                else {
+                    hipLaunchKernelGGL(repack12_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>(65535, (dm.n + 255) / 256))), dim3(256), 0, s_scan,
+                                       reinterpret_cast<const uint4 *>(dm.p), static_cast<uint32_t *>(d12), static_cast<unsigned long long>(dm.n),
+                                       static_cast<unsigned long long>(begin));
+                    dev_free(dm.release_keep_n(), s_scan);
+                    dm.p = static_cast<daac_match *>(d12);
+                }
+            }
+            w.base = begin;
             // the list (repacked or not) is complete before another stream copies it, and before the staging buffer is written again
             if (st == DAAC_OK && hipStreamSynchronize(s_scan) != hipSuccess) st = hip_fail(hipGetLastError(), "iterator: scan");
             if (st == DAAC_OK && dm.n != 0) {
-                const size_t need = dm.n * sizeof(daac_match16);
+                const size_t need = dm.n * (compact ? 12 : sizeof(daac_match16));
                 if (w.host_bytes < need) {
                     if (w.host) { if (w.host_pinned) pinned_pool().give(w.host, w.host_bytes); else std::free(w.host); }
                     w.host = nullptr; w.host_bytes = 0;
@@ -2096,8 +2122,18 @@ void daac_iter::run() {
 
 extern "C" {
 
+static daac_status iter_open_impl(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream,
+                                  bool compact, daac_iter **out);
 daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream,
                            daac_iter **out) {
+    return iter_open_impl(pma, mode, engine, hay, len, hay_is_device, stream, false, out);
+}
+daac_status daac_iter_open_compact(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream,
+                                   daac_iter **out) {
+    return iter_open_impl(pma, mode, engine, hay, len, hay_is_device, stream, true, out);
+}
+static daac_status iter_open_impl(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream,
+                                  bool compact, daac_iter **out) {
     if (!pma || !out || (len && !hay)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     DeviceTables *t = nullptr;
     daac_status st = check_mode_kind(pma, mode);
@@ -2108,6 +2144,7 @@ daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *h
     if ((st = make_plan(pma, t, mode, (engine == DAAC_ENGINE_GRAM || engine == DAAC_ENGINE_PFX) ? DAAC_ENGINE_AUTO : engine, 0, len, pl, heads)) != DAAC_OK) return st;  // kind / mode checks up front
     std::unique_ptr<daac_iter> it(new daac_iter);
     it->pma = pma; it->mode = mode; it->engine = engine; it->hay = hay; it->len = len;
+    it->compact = compact;
     it->hay_is_device = hay_is_device != 0;
     it->user_stream = static_cast<hipStream_t>(stream);
     it->restart = pl.restart;
@@ -2149,7 +2186,7 @@ static int iter_advance(daac_iter *it) {
         g_last_engine = w.engine;
         if (w.n == 0) continue;
         if (hipEventSynchronize(w.copied) != hipSuccess) return -static_cast<int>(hip_fail(hipGetLastError(), "iterator: waiting for the tuples"));
-        it->cur = w.host; it->cur_n = static_cast<size_t>(w.n); it->pos = 0;
+        it->cur = w.host; it->cur_n = static_cast<size_t>(w.n); it->pos = 0; it->cur_base = w.base;
         return 1;
     }
 }
@@ -2160,13 +2197,33 @@ int daac_iter_next(daac_iter *it, daac_match *m) {
         const int r = iter_advance(it);
         if (r <= 0) return r;
     }
+    if (it->compact) {
+        const daac_match12 &t = reinterpret_cast<const daac_match12 *>(it->cur)[it->pos++];
+        m->end = it->cur_base + t.end_lo; m->start = m->end - t.length; m->value = t.value; m->_pad = 0;
+        return 1;
+    }
     const daac_match16 &t = it->cur[it->pos++];
     m->start = t.end - t.length; m->end = t.end; m->value = t.value; m->_pad = 0;
     return 1;
 }
 
+int daac_iter_next_batch12(daac_iter *it, const daac_match12 **batch, size_t *n, uint64_t *end_base) {
+    if (!it || !batch || !n || !end_base) return -DAAC_ERR_INVALID_ARGUMENT;
+    if (!it->compact) { set_error("daac_iter_next_batch12 serves iterators opened with daac_iter_open_compact"); return -DAAC_ERR_UNSUPPORTED; }
+    if (it->pos >= it->cur_n) {
+        const int r = iter_advance(it);
+        if (r <= 0) { *batch = nullptr; *n = 0; return r; }
+    }
+    *batch = reinterpret_cast<const daac_match12 *>(it->cur) + it->pos;
+    *n = it->cur_n - it->pos;
+    *end_base = it->cur_base;
+    it->pos = it->cur_n;
+    return 1;
+}
+
 int daac_iter_next_batch(daac_iter *it, const daac_match16 **batch, size_t *n) {
     if (!it || !batch || !n) return -DAAC_ERR_INVALID_ARGUMENT;
+    if (it->compact) { set_error("daac_iter_next_batch serves iterators opened with daac_iter_open (this one is compact: daac_iter_next_batch12)"); return -DAAC_ERR_UNSUPPORTED; }
     if (it->pos >= it->cur_n) {
         const int r = iter_advance(it);
         if (r <= 0) { *batch = nullptr; *n = 0; return r; }

@@ -86,16 +86,18 @@ struct IterDeleter { void operator()(daac_iter *p) const { daac_iter_close(p); }
 // LeftmostFindIterator of src/bytewise/iter.rs, one type here because the device engine sits behind them.
 class MatchIterator {
 public:
-    // one 16-byte read from the run at hand; a library call per window of the haystack (daac_iter_next_batch), not per match
+    // one 12-byte read from the run at hand (the compact iterator: ends relative to the run's base, a quarter less over PCIe); a library
+    // call per window of the haystack (daac_iter_next_batch12), not per match
     std::optional<Match> next() {
         if (run_n_ == 0) {
-            const int r = daac_iter_next_batch(it_.get(), &run_, &run_n_);
+            const int r = daac_iter_next_batch12(it_.get(), &run_, &run_n_, &base_);
             if (r == 0) return std::nullopt;
             if (r < 0) throw PanicError(std::string("device scan failed: ") + daac_last_error());
         }
-        const daac_match16 t = *run_++;
+        const daac_match12 t = *run_++;
         --run_n_;
-        return Match(t.end - t.length, t.end, t.value);
+        const uint64_t end = base_ + t.end_lo;
+        return Match(end - t.length, end, t.value);
     }
     std::vector<Match> collect() {
         std::vector<Match> out;
@@ -109,8 +111,9 @@ private:
     MatchIterator(daac_iter *it, std::unique_ptr<std::string> hay) : hay_(std::move(hay)), it_(it) {}
     std::unique_ptr<std::string> hay_;  // the haystack lives (at a stable address) as long as the iterator (the crate's `P`)
     std::unique_ptr<daac_iter, detail::IterDeleter> it_;
-    const daac_match16 *run_ = nullptr;  // what is left of the last run (a view of the iterator's window buffer)
+    const daac_match12 *run_ = nullptr;  // what is left of the last run (a view of the iterator's window buffer)
     size_t run_n_ = 0;
+    uint64_t base_ = 0;
 };
 
 // FindStepper / FindOverlappingStepper (src/bytewise/iter.rs:344-475, src/charwise/iter.rs:403-534), fed a chunk
@@ -283,8 +286,8 @@ private:
     MatchIterator open(int mode, std::string hay, const char *panic_msg) const {
         auto keep = std::make_unique<std::string>(std::move(hay));
         daac_iter *it = nullptr;
-        const daac_status st = daac_iter_open(h_.get(), mode, DAAC_ENGINE_AUTO, reinterpret_cast<const uint8_t *>(keep->data()), keep->size(),
-                                              0, nullptr, &it);
+        const daac_status st = daac_iter_open_compact(h_.get(), mode, DAAC_ENGINE_AUTO, reinterpret_cast<const uint8_t *>(keep->data()), keep->size(),
+                                                      0, nullptr, &it);
         if (st == DAAC_ERR_MATCH_KIND) throw PanicError(panic_msg);
         if (st != DAAC_OK) throw PanicError(std::string("device scan failed: ") + daac_last_error());
         return MatchIterator(it, std::move(keep));

@@ -792,3 +792,55 @@ def test_engine_options_do_not_change_answers():
     finally:
         for k, v in {"pool": 1, "overlap_micro": 1, "char_map_lds": 1, "char_row_lds": 1, "restart_chain": 1, "restart_tier": 0, "seg_bytes": 0}.items():
             da.set_option(k, v)
+
+
+def test_compact_lazy_iterator():
+    """daac_iter_open_compact / daac_iter_next_batch12: the same match stream with 12 bytes per tuple over PCIe (end relative to the
+    run's base) — every iterator of the crate, bytewise and charwise, windows small enough for many runs, matches that straddle windows;
+    the two run formats refuse each other's iterators."""
+    rng = np.random.default_rng(12)
+    pats = synth.patterns_cfg3(5000)
+    hay = synth.wordsoup_haystack(400_000, 9, pats, 20)
+    cpats = synth.patterns_cfg5(3000)
+    chay = synth.zipf_text(48 * 6000)
+    da.set_option("iter_window", 50_000)
+    try:
+        for kind, mode, api in ((0, ScanMode.FindOverlapping, "find_overlapping_iter"), (0, ScanMode.Find, "find_iter"),
+                                (0, ScanMode.FindOverlappingNoSuffix, "find_overlapping_no_suffix_iter"), (1, ScanMode.LeftmostFind, "leftmost_find_iter")):
+            for charwise in (False, True):
+                if charwise:
+                    o = orc.OracleCharwisePma.build(cpats, kind=kind)
+                    p, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(o.serialize())
+                    h = chay
+                else:
+                    o = orc.OraclePma.build(pats, kind=kind)
+                    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+                    h = hay
+                want = getattr(o, api)(h)
+                it = getattr(p, api)(h, compact=True)
+                ends, lens, vals, nruns = [], [], [], 0
+                while True:
+                    got = it.next_batch12()
+                    if got is None:
+                        break
+                    run, base = got
+                    nruns += 1
+                    ends.append(run["end_lo"].astype(np.uint64) + np.uint64(base)); lens.append(run["length"].copy()); vals.append(run["value"].copy())
+                it.close()
+                assert nruns > 3, (api, charwise)
+                e, l, v = np.concatenate(ends), np.concatenate(lens), np.concatenate(vals)
+                assert len(e) == len(want) and np.array_equal(e, want["end"]) and np.array_equal(l, (want["end"] - want["start"]).astype(np.uint32)) and \
+                    np.array_equal(v, want["value"]), (api, charwise)
+                # match by match on a compact iterator, and the 16-byte runs on an ordinary one
+                k = int(rng.integers(1000, 3000))
+                got = [(m.start(), m.end(), m.value()) for _, m in zip(range(k), getattr(p, api)(h, compact=True))]
+                assert got == orc.triples_sev(want[:k]), (api, charwise)
+        p, _ = da.DoubleArrayAhoCorasick.deserialize(orc.OraclePma.build(pats).serialize())
+        with pytest.raises(da.DaachorseError) as ei:
+            p.find_overlapping_iter(hay, compact=True).next_batch()
+        assert ei.value.code == 6
+        with pytest.raises(da.DaachorseError) as ei:
+            p.find_overlapping_iter(hay).next_batch12()
+        assert ei.value.code == 6
+    finally:
+        da.set_option("iter_window", 64 << 20)

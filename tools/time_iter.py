@@ -29,20 +29,21 @@ for name, pats, fill in (("cfg3", synth.patterns_cfg3(), lambda: synth.device_un
     want = pma.count(ScanMode.FindOverlapping, dev)
     for w in windows:
         da.set_option("iter_window", w << 20)
-        best = None
-        for rep in range(3):
-            t0 = time.perf_counter()
-            it = pma.find_overlapping_iter(h)
-            cnt = 0
-            while True:
-                run = it.next_batch()
-                if run is None:
-                    break
-                cnt += len(run)
-            it.close()
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        assert cnt == want, (cnt, want)
-        print(f"{name:12s} window {w:4d} MiB: {best * 1e3:8.2f} ms  {n / best / 1e9:6.2f} GB/s of haystack, {cnt * 16 / best / 1e9:6.2f} GB/s of tuples over PCIe ({cnt} matches)", flush=True)
+        for compact, tb in ((True, 12), (False, 16)):
+            best = None
+            for rep in range(3):
+                t0 = time.perf_counter()
+                it = pma.find_overlapping_iter(h, compact=compact)
+                cnt = 0
+                while True:
+                    run = it.next_batch12() if compact else it.next_batch()
+                    if run is None:
+                        break
+                    cnt += len(run[0]) if compact else len(run)
+                it.close()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            assert cnt == want, (cnt, want)
+            print(f"{name:12s} window {w:4d} MiB, {tb}-byte tuples: {best * 1e3:8.2f} ms  {n / best / 1e9:6.2f} GB/s of haystack, {cnt * tb / best / 1e9:6.2f} GB/s of tuples over PCIe ({cnt} matches)", flush=True)
     # Iterator::next one match at a time through ctypes is a Python number, not the library's: a C++ caller's loop is tests/native/cpp_facade_test.cpp
 da.set_option("iter_window", 64 << 20)
