@@ -264,7 +264,7 @@ def iterator_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha
     (bound by the haystack's way to the device)."""
     from daachorse_amd import ScanMode
     n = 1 << 30
-    out = {"bytes": n, "op": "daac_iter_open_compact + daac_iter_next_batch12 to exhaustion over a page-locked host haystack (zero-copy runs of 12-byte tuples, counted)",
+    out = {"bytes": n, "op": "daac_iter_open_compact + daac_iter_next_batch8 to exhaustion over a page-locked host haystack (zero-copy runs of 8-byte tuples, counted)",
            "window_bytes": "16, 32, then 64 MiB (option iter_window)"}
     host = torch.empty(n, dtype=torch.uint8).pin_memory()
     dev = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -282,13 +282,13 @@ def iterator_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha
             it = pma.find_overlapping_iter(h, compact=True)
             cnt, ends = 0, 0
             while True:
-                got = it.next_batch12()
+                got = it.next_batch8()
                 if got is None:
                     break
-                run, base = got
+                run, base, eb = got
                 cnt += len(run)
                 if rep == 2:
-                    ends += int(run["end_lo"].sum(dtype=np.uint64)) + base * len(run)
+                    ends += int((run["end_len"] & np.uint32((1 << eb) - 1)).sum(dtype=np.uint64)) + base * len(run)
             it.close()
             dt = time.perf_counter() - t0
             if rep == 2:
@@ -309,8 +309,8 @@ def iterator_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha
             best16 = dt if best16 is None else min(best16, dt)
         want = pma.count(ScanMode.FindOverlapping, dev)
         out[name] = {"GB/s": round(n / best / 1e9, 2), "seconds": round(best, 4), "matches": cnt, "matches_per_byte": round(cnt / n, 4),
-                     "wire": "12-byte tuples (daac_iter_open_compact / daac_iter_next_batch12: end relative to the window)",
-                     "tuple_GB/s_over_pcie": round(cnt * 12 / best / 1e9, 2), "count_agrees_with_count_kernel": bool(cnt == want and cnt16 == want),
+                     "wire": "8-byte tuples (daac_iter_open_compact / daac_iter_next_batch8: {value, end relative to the window | length << end_bits})",
+                     "tuple_GB/s_over_pcie": round(cnt * 8 / best / 1e9, 2), "count_agrees_with_count_kernel": bool(cnt == want and cnt16 == want),
                      "GB/s_16_byte_runs": round(n / best16 / 1e9, 2),
                      "GB/s_with_a_numpy_pass_over_every_tuple": round(n / best_sum / 1e9, 2),
                      "engine_used": ENGINE_NAMES.get(da.last_engine(), "?")}

@@ -87,8 +87,8 @@ def lib():
     L.daac_iter_next_batch.argtypes = [vp, P(vp), P(sz)]
     L.daac_iter_next_batch.restype = C.c_int
     L.daac_iter_open_compact.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp)]
-    L.daac_iter_next_batch12.argtypes = [vp, P(vp), P(sz), P(C.c_uint64)]
-    L.daac_iter_next_batch12.restype = C.c_int
+    L.daac_iter_next_batch8.argtypes = [vp, P(vp), P(sz), P(C.c_uint64), P(C.c_uint32)]
+    L.daac_iter_next_batch8.restype = C.c_int
     L.daac_iter_close.argtypes = [vp]
     L.daac_stream_open.argtypes = [vp, C.c_int, C.c_int, vp, P(vp)]
     L.daac_stream_feed.argtypes = [vp, u8p, sz, C.c_int, P(vp)]

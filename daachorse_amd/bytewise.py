@@ -113,7 +113,7 @@ class _MatchList:
 
 
 MATCH16_DTYPE = np.dtype([("end", "<u8"), ("length", "<u4"), ("value", "<u4")])  # daac_match16 = the crate's own Match fields
-MATCH12_DTYPE = np.dtype([("end_lo", "<u4"), ("length", "<u4"), ("value", "<u4")])  # daac_match12: end relative to the run's base
+MATCH8_DTYPE = np.dtype([("value", "<u4"), ("end_len", "<u4")])  # daac_match8: end relative to the run's base | length << end_bits
 
 
 class DeviceMatches:
@@ -182,18 +182,18 @@ class _LazyIter:
         buf = (C.c_char * (n.value * 16)).from_address(p.value)
         return np.frombuffer(buf, dtype=MATCH16_DTYPE)
 
-    def next_batch12(self):
-        """daac_iter_next_batch12 (iterators opened with compact=True): the next run as (view {end_lo u32, length u32, value u32}, end_base) —
-        end = end_base + end_lo — or None when the iterator is exhausted."""
+    def next_batch8(self):
+        """daac_iter_next_batch8 (iterators opened with compact=True): the next run as (view {value u32, end_len u32}, end_base, end_bits) —
+        end = end_base + (end_len & ((1 << end_bits) - 1)), length = end_len >> end_bits — or None when the iterator is exhausted."""
         import numpy as np
-        p, n, base = C.c_void_p(), C.c_size_t(), C.c_uint64()
-        r = _ffi.lib().daac_iter_next_batch12(self._it, C.byref(p), C.byref(n), C.byref(base))
+        p, n, base, eb = C.c_void_p(), C.c_size_t(), C.c_uint64(), C.c_uint32()
+        r = _ffi.lib().daac_iter_next_batch8(self._it, C.byref(p), C.byref(n), C.byref(base), C.byref(eb))
         if r == 0:
             return None
         if r < 0:
             _ffi.check(-r)
-        buf = (C.c_char * (n.value * 12)).from_address(p.value)
-        return np.frombuffer(buf, dtype=MATCH12_DTYPE), base.value
+        buf = (C.c_char * (n.value * 8)).from_address(p.value)
+        return np.frombuffer(buf, dtype=MATCH8_DTYPE), base.value, eb.value
 
     def close(self):
         if self._it:
@@ -324,7 +324,7 @@ class DoubleArrayAhoCorasick:
         return self
 
     # ---- lazy iterators, crate names (bytewise.rs:190-203, 292-314, 410-428, 547-566) --------------------
-    # (compact=True: daac_iter_open_compact — 12-byte tuples over PCIe, read with next_batch12(); iterating match by match works on either)
+    # (compact=True: daac_iter_open_compact — 8-byte tuples over PCIe, read with next_batch8(); iterating match by match works on either)
     def find_iter(self, haystack, engine=Engine.Auto, stream=None, compact=False):
         return _LazyIter(self, ScanMode.Find, haystack, engine, stream, compact)
 

@@ -930,14 +930,12 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
 
 // {count, S1, S2} of a shard scanned with shard-relative ends -> absolute ends, plus tuples counted on the host
 // daac_match {start, end, value} -> {end u64, length u32, value u32}
-// daac_match16 -> daac_match12 {end - base (32 bits), length, value}: what the compact lazy iterator sends over PCIe (a quarter less)
-__global__ void repack12_kernel(const uint4 *in, uint32_t *out, unsigned long long n, unsigned long long base) {
+// daac_match16 -> daac_match8 {value, (end - base) | length << end_bits}: what the compact lazy iterator sends over PCIe (half)
+__global__ void repack8_kernel(const uint4 *in, uint2 *out, unsigned long long n, unsigned long long base, uint32_t end_bits) {
     for (unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<unsigned long long>(gridDim.x) * blockDim.x) {
         const uint4 t = in[i];
         const unsigned long long end = (static_cast<unsigned long long>(t.y) << 32) | t.x;
-        out[3 * i] = static_cast<uint32_t>(end - base);
-        out[3 * i + 1] = t.z;
-        out[3 * i + 2] = t.w;
+        out[i] = uint2{t.w, static_cast<uint32_t>(end - base) | (t.z << end_bits)};
     }
 }
 __global__ void repack16_kernel(const daac_match *in, uint4 *out, unsigned long long n) {
@@ -1933,7 +1931,7 @@ struct IterWindow {
     std::string err;
     uint64_t n = 0;                 // tuples of the window
     uint64_t base = 0;              // compact: ends count from here (the window's first byte)
-    daac_match16 *host = nullptr;   // page-locked (pageable if pinning failed); compact: daac_match12 tuples
+    daac_match16 *host = nullptr;   // page-locked (pageable if pinning failed); compact: daac_match8 tuples
     size_t host_bytes = 0;
     bool host_pinned = false;
     hipEvent_t copied = nullptr;    // the tuples are in `host`
@@ -1949,7 +1947,8 @@ struct daac_iter {
     uint64_t len = 0;
     bool hay_is_device = false;
     bool restart = false;          // find_iter / leftmost_find_iter: windows end at sync points
-    bool compact = false;          // daac_iter_open_compact: 12-byte tuples over PCIe (end relative to the window), daac_iter_next_batch12
+    bool compact = false;          // daac_iter_open_compact: 8-byte tuples over PCIe {value, end relative to the window | length << end_bits}
+    uint32_t end_bits = 32;        // ... 32 - bits of the longest pattern's length; a window spans less than 2^end_bits bytes
     void *owned_dev = nullptr;     // host haystack staged once (restart modes read past a window's nominal end)
     hipStream_t user_stream = nullptr;
     // the worker and its three streams
@@ -1962,7 +1961,7 @@ struct daac_iter {
     IterDeviceKit *kit = nullptr;
     hipStream_t s_scan = nullptr, s_h2d = nullptr, s_d2h = nullptr, s_d2h2 = nullptr;
     // the consumer's view of the window it is reading
-    const daac_match16 *cur = nullptr;   // (compact: daac_match12 tuples behind this pointer)
+    const daac_match16 *cur = nullptr;   // (compact: daac_match8 tuples behind this pointer)
     uint64_t cur_base = 0;
     size_t cur_n = 0, pos = 0;
     bool holding = false;
@@ -1974,7 +1973,8 @@ void daac_iter::run() {
     (void)hipSetDevice(device);
     auto fail_with = [&](IterWindow &w, daac_status st) { w.st = st; w.err = last_error_cstr(); w.n = 0; };
     DeviceTables *t = nullptr;
-    const uint64_t window = std::max<uint64_t>(4096, static_cast<uint64_t>(g_opt.iter_window.load()));
+    uint64_t window = std::max<uint64_t>(4096, static_cast<uint64_t>(g_opt.iter_window.load()));
+    if (compact) window = std::min<uint64_t>(window, (1ull << end_bits) - pma->halo() - 4096);   // (a restart window runs on to a sync point: less than a pattern further)
     // windows grow from 16 MiB to the full size: the consumer has its first matches after a small window's scan and copy, not a big one's
     auto window_of = [&](uint64_t k) -> uint64_t { return std::min<uint64_t>(window, (16ull << 20) << std::min<uint64_t>(k, 16)); };
     const uint64_t halo = pma->halo();
@@ -2049,23 +2049,23 @@ void daac_iter::run() {
                     dm.p = static_cast<daac_match *>(d16);
                 }
             }
-            if (st == DAAC_OK && compact && dm.n != 0) {   // ends relative to the window's first byte: 12 bytes per tuple over the link
-                void *d12 = nullptr;
-                if (next_begin - begin >= (1ull << 32)) { set_error("iterator: a window of 4 GiB or more has no compact form"); st = DAAC_ERR_UNSUPPORTED; }
-                else if (dev_malloc(&d12, dm.n * 12, s_scan) != hipSuccess) { st = hip_fail(hipGetLastError(), "iterator: repack buffer"); }
+            if (st == DAAC_OK && compact && dm.n != 0) {   // ends relative to the window's first byte, the length above them: 8 bytes per tuple over the link
+                void *d8 = nullptr;
+                if (next_begin - begin >= (1ull << end_bits)) { set_error("iterator: a window ran past what its compact form can say"); st = DAAC_ERR_UNSUPPORTED; }
+                else if (dev_malloc(&d8, dm.n * 8, s_scan) != hipSuccess) { st = hip_fail(hipGetLastError(), "iterator: repack buffer"); }
                 else {
-                    hipLaunchKernelGGL(repack12_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>(65535, (dm.n + 255) / 256))), dim3(256), 0, s_scan,
-                                       reinterpret_cast<const uint4 *>(dm.p), static_cast<uint32_t *>(d12), static_cast<unsigned long long>(dm.n),
-                                       static_cast<unsigned long long>(begin));
+                    hipLaunchKernelGGL(repack8_kernel, dim3(static_cast<uint32_t>(std::min<uint64_t>(65535, (dm.n + 255) / 256))), dim3(256), 0, s_scan,
+                                       reinterpret_cast<const uint4 *>(dm.p), static_cast<uint2 *>(d8), static_cast<unsigned long long>(dm.n),
+                                       static_cast<unsigned long long>(begin), end_bits);
                     dev_free(dm.release_keep_n(), s_scan);
-                    dm.p = static_cast<daac_match *>(d12);
+                    dm.p = static_cast<daac_match *>(d8);
                 }
             }
             w.base = begin;
             // the list (repacked or not) is complete before another stream copies it, and before the staging buffer is written again
             if (st == DAAC_OK && hipStreamSynchronize(s_scan) != hipSuccess) st = hip_fail(hipGetLastError(), "iterator: scan");
             if (st == DAAC_OK && dm.n != 0) {
-                const size_t need = dm.n * (compact ? 12 : sizeof(daac_match16));
+                const size_t need = dm.n * (compact ? 8 : sizeof(daac_match16));
                 if (w.host_bytes < need) {
                     if (w.host) { if (w.host_pinned) pinned_pool().give(w.host, w.host_bytes); else std::free(w.host); }
                     w.host = nullptr; w.host_bytes = 0;
@@ -2145,6 +2145,15 @@ static daac_status iter_open_impl(daac_pma *pma, int mode, int engine, const uin
     std::unique_ptr<daac_iter> it(new daac_iter);
     it->pma = pma; it->mode = mode; it->engine = engine; it->hay = hay; it->len = len;
     it->compact = compact;
+    if (compact) {   // length bits above the end: the longest pattern decides the split, and with it the largest window
+        uint32_t lb = 1;
+        while ((1ull << lb) <= pma->max_pattern_len()) ++lb;
+        it->end_bits = 32 - lb;
+        if ((1ull << it->end_bits) < 4ull * pma->halo() + (1ull << 20)) {
+            set_error("patterns of " + std::to_string(pma->max_pattern_len()) + " bytes leave no room for a window in the compact tuple; use daac_iter_open");
+            return DAAC_ERR_UNSUPPORTED;
+        }
+    }
     it->hay_is_device = hay_is_device != 0;
     it->user_stream = static_cast<hipStream_t>(stream);
     it->restart = pl.restart;
@@ -2198,8 +2207,8 @@ int daac_iter_next(daac_iter *it, daac_match *m) {
         if (r <= 0) return r;
     }
     if (it->compact) {
-        const daac_match12 &t = reinterpret_cast<const daac_match12 *>(it->cur)[it->pos++];
-        m->end = it->cur_base + t.end_lo; m->start = m->end - t.length; m->value = t.value; m->_pad = 0;
+        const daac_match8 &t = reinterpret_cast<const daac_match8 *>(it->cur)[it->pos++];
+        m->end = it->cur_base + (t.end_len & ((1u << it->end_bits) - 1u)); m->start = m->end - (t.end_len >> it->end_bits); m->value = t.value; m->_pad = 0;
         return 1;
     }
     const daac_match16 &t = it->cur[it->pos++];
@@ -2207,14 +2216,15 @@ int daac_iter_next(daac_iter *it, daac_match *m) {
     return 1;
 }
 
-int daac_iter_next_batch12(daac_iter *it, const daac_match12 **batch, size_t *n, uint64_t *end_base) {
-    if (!it || !batch || !n || !end_base) return -DAAC_ERR_INVALID_ARGUMENT;
-    if (!it->compact) { set_error("daac_iter_next_batch12 serves iterators opened with daac_iter_open_compact"); return -DAAC_ERR_UNSUPPORTED; }
+int daac_iter_next_batch8(daac_iter *it, const daac_match8 **batch, size_t *n, uint64_t *end_base, uint32_t *end_bits) {
+    if (!it || !batch || !n || !end_base || !end_bits) return -DAAC_ERR_INVALID_ARGUMENT;
+    if (!it->compact) { set_error("daac_iter_next_batch8 serves iterators opened with daac_iter_open_compact"); return -DAAC_ERR_UNSUPPORTED; }
+    *end_bits = it->end_bits;
     if (it->pos >= it->cur_n) {
         const int r = iter_advance(it);
         if (r <= 0) { *batch = nullptr; *n = 0; return r; }
     }
-    *batch = reinterpret_cast<const daac_match12 *>(it->cur) + it->pos;
+    *batch = reinterpret_cast<const daac_match8 *>(it->cur) + it->pos;
     *n = it->cur_n - it->pos;
     *end_base = it->cur_base;
     it->pos = it->cur_n;
@@ -2223,7 +2233,7 @@ int daac_iter_next_batch12(daac_iter *it, const daac_match12 **batch, size_t *n,
 
 int daac_iter_next_batch(daac_iter *it, const daac_match16 **batch, size_t *n) {
     if (!it || !batch || !n) return -DAAC_ERR_INVALID_ARGUMENT;
-    if (it->compact) { set_error("daac_iter_next_batch serves iterators opened with daac_iter_open (this one is compact: daac_iter_next_batch12)"); return -DAAC_ERR_UNSUPPORTED; }
+    if (it->compact) { set_error("daac_iter_next_batch serves iterators opened with daac_iter_open (this one is compact: daac_iter_next_batch8)"); return -DAAC_ERR_UNSUPPORTED; }
     if (it->pos >= it->cur_n) {
         const int r = iter_advance(it);
         if (r <= 0) { *batch = nullptr; *n = 0; return r; }

@@ -287,18 +287,19 @@ int daac_iter_next(daac_iter *it, daac_match *m); /* 1 = Some(m), 0 = None, <0 =
  * on their own streams — host-to-device copy of window k + 1, scan of window k, device-to-host copy of window k - 1's 16-byte tuples. */
 int daac_iter_next_batch(daac_iter *it, const daac_match16 **batch, size_t *n);
 /* The compact form of the same iterator.  On match-dense text `next()` is bound by the tuples' way back over PCIe (cfg3: 10 GB of
- * 16-byte tuples per GiB of haystack at the link's ~50 GB/s), so an iterator opened with daac_iter_open_compact sends 12 bytes per tuple:
- * the end as 32 bits relative to the window's first byte.  daac_iter_next_batch12 hands out runs of them with that base:
- * end = *end_base + batch[i].end_lo, start = end - length.  daac_iter_next works on either kind; daac_iter_next_batch only on
- * the 16-byte kind and daac_iter_next_batch12 only on the compact one (status 6 otherwise). */
-typedef struct daac_match12 {
-    uint32_t end_lo;
-    uint32_t length;
+ * 16-byte tuples per GiB of haystack at the link's ~50 GB/s), so an iterator opened with daac_iter_open_compact sends 8 bytes per tuple:
+ * the value, and one word that holds the end relative to the window's first byte in its low `end_bits` bits and the length above them
+ * (end_bits = 32 - the bits of the longest pattern's length; windows are kept below 2^end_bits bytes).  daac_iter_next_batch8 hands out
+ * runs of them:  end = *end_base + (t.end_len & ((1 << *end_bits) - 1)),  length = t.end_len >> *end_bits,  start = end - length.
+ * daac_iter_next works on either kind; daac_iter_next_batch only on the 16-byte kind and daac_iter_next_batch8 only on the compact one
+ * (status 6 otherwise); daac_iter_open_compact itself answers 6 for dictionaries with patterns of several KB (no room for a window). */
+typedef struct daac_match8 {
     uint32_t value;
-} daac_match12;
+    uint32_t end_len;
+} daac_match8;
 daac_status daac_iter_open_compact(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len,
                                    int hay_is_device, void *stream, daac_iter **out);
-int daac_iter_next_batch12(daac_iter *it, const daac_match12 **batch, size_t *n, uint64_t *end_base);
+int daac_iter_next_batch8(daac_iter *it, const daac_match8 **batch, size_t *n, uint64_t *end_base, uint32_t *end_bits);
 void daac_iter_close(daac_iter *it);
 
 /* Chunk-fed steppers = FindOverlappingStepper / FindStepper (bytewise/iter.rs:344-475, charwise/iter.rs:403-534)

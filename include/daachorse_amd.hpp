@@ -86,18 +86,23 @@ struct IterDeleter { void operator()(daac_iter *p) const { daac_iter_close(p); }
 // LeftmostFindIterator of src/bytewise/iter.rs, one type here because the device engine sits behind them.
 class MatchIterator {
 public:
-    // one 12-byte read from the run at hand (the compact iterator: ends relative to the run's base, a quarter less over PCIe); a library
-    // call per window of the haystack (daac_iter_next_batch12), not per match
+    // one 8-byte read from the run at hand (the compact iterator: {value, end relative to the run's base | length << end_bits}: half the
+    // bytes over PCIe); a library call per window of the haystack (daac_iter_next_batch8), not per match.  Dictionaries with patterns of
+    // several KB have no compact form: 16-byte runs then.
     std::optional<Match> next() {
         if (run_n_ == 0) {
-            const int r = daac_iter_next_batch12(it_.get(), &run_, &run_n_, &base_);
+            const int r = compact_ ? daac_iter_next_batch8(it_.get(), &run8_, &run_n_, &base_, &end_bits_) : daac_iter_next_batch(it_.get(), &run16_, &run_n_);
             if (r == 0) return std::nullopt;
             if (r < 0) throw PanicError(std::string("device scan failed: ") + daac_last_error());
         }
-        const daac_match12 t = *run_++;
         --run_n_;
-        const uint64_t end = base_ + t.end_lo;
-        return Match(end - t.length, end, t.value);
+        if (!compact_) {
+            const daac_match16 t = *run16_++;
+            return Match(t.end - t.length, t.end, t.value);
+        }
+        const daac_match8 t = *run8_++;
+        const uint64_t end = base_ + (t.end_len & ((1u << end_bits_) - 1u));
+        return Match(end - (t.end_len >> end_bits_), end, t.value);
     }
     std::vector<Match> collect() {
         std::vector<Match> out;
@@ -108,12 +113,15 @@ public:
 private:
     template <class F>
     friend class BasicAhoCorasick;
-    MatchIterator(daac_iter *it, std::unique_ptr<std::string> hay) : hay_(std::move(hay)), it_(it) {}
+    MatchIterator(daac_iter *it, std::unique_ptr<std::string> hay, bool compact) : hay_(std::move(hay)), it_(it), compact_(compact) {}
     std::unique_ptr<std::string> hay_;  // the haystack lives (at a stable address) as long as the iterator (the crate's `P`)
     std::unique_ptr<daac_iter, detail::IterDeleter> it_;
-    const daac_match12 *run_ = nullptr;  // what is left of the last run (a view of the iterator's window buffer)
+    bool compact_ = true;
+    const daac_match8 *run8_ = nullptr;    // what is left of the last run (a view of the iterator's window buffer)
+    const daac_match16 *run16_ = nullptr;
     size_t run_n_ = 0;
     uint64_t base_ = 0;
+    uint32_t end_bits_ = 32;
 };
 
 // FindStepper / FindOverlappingStepper (src/bytewise/iter.rs:344-475, src/charwise/iter.rs:403-534), fed a chunk
@@ -286,11 +294,16 @@ private:
     MatchIterator open(int mode, std::string hay, const char *panic_msg) const {
         auto keep = std::make_unique<std::string>(std::move(hay));
         daac_iter *it = nullptr;
-        const daac_status st = daac_iter_open_compact(h_.get(), mode, DAAC_ENGINE_AUTO, reinterpret_cast<const uint8_t *>(keep->data()), keep->size(),
-                                                      0, nullptr, &it);
+        bool compact = true;
+        daac_status st = daac_iter_open_compact(h_.get(), mode, DAAC_ENGINE_AUTO, reinterpret_cast<const uint8_t *>(keep->data()), keep->size(),
+                                                0, nullptr, &it);
+        if (st == DAAC_ERR_UNSUPPORTED) {   // (patterns of several KB: the 16-byte runs)
+            compact = false;
+            st = daac_iter_open(h_.get(), mode, DAAC_ENGINE_AUTO, reinterpret_cast<const uint8_t *>(keep->data()), keep->size(), 0, nullptr, &it);
+        }
         if (st == DAAC_ERR_MATCH_KIND) throw PanicError(panic_msg);
         if (st != DAAC_OK) throw PanicError(std::string("device scan failed: ") + daac_last_error());
-        return MatchIterator(it, std::move(keep));
+        return MatchIterator(it, std::move(keep), compact);
     }
     std::unique_ptr<daac_pma, detail::PmaDeleter> h_;
 };

@@ -32,13 +32,13 @@ pub struct daac_match16 {
     pub length: u32,
     pub value: u32,
 }
-/// the 12-byte tuple of the compact lazy iterator (daac_iter_open_compact): end = run base + end_lo
+/// the 8-byte tuple of the compact lazy iterator (daac_iter_open_compact): end = run base + (end_len & ((1 << end_bits) - 1)),
+/// length = end_len >> end_bits
 #[repr(C)]
 #[derive(Clone, Copy)]
-pub struct daac_match12 {
-    pub end_lo: u32,
-    pub length: u32,
+pub struct daac_match8 {
     pub value: u32,
+    pub end_len: u32,
 }
 #[repr(C)]
 pub struct daac_pma {
@@ -61,10 +61,11 @@ extern "C" {
     pub fn daac_pma_free(pma: *mut daac_pma);
     pub fn daac_iter_open(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,
                           stream: *mut c_void, out: *mut *mut daac_iter) -> i32;
-    /// the same iterator with 12 bytes per tuple over PCIe (what bounds `next()` on match-dense text); read with daac_iter_next_batch12
+    /// the same iterator with 8 bytes per tuple over PCIe (what bounds `next()` on match-dense text); read with daac_iter_next_batch8.
+    /// DAAC_ERR_UNSUPPORTED for dictionaries with patterns of several KB (no room for a window in the packed word).
     pub fn daac_iter_open_compact(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,
                                   stream: *mut c_void, out: *mut *mut daac_iter) -> i32;
-    pub fn daac_iter_next_batch12(it: *mut daac_iter, batch: *mut *const daac_match12, n: *mut usize, end_base: *mut u64) -> i32;
+    pub fn daac_iter_next_batch8(it: *mut daac_iter, batch: *mut *const daac_match8, n: *mut usize, end_base: *mut u64, end_bits: *mut u32) -> i32;
     pub fn daac_iter_next(it: *mut daac_iter, m: *mut daac_match) -> i32; // 1 = Some, 0 = None, < 0 = -daac_status
     /// the next run of matches as a view of the iterator's own window buffer (valid until the next call): 1 = a run, 0 = exhausted
     pub fn daac_iter_next_batch(it: *mut daac_iter, batch: *mut *const daac_match16, n: *mut usize) -> i32;
@@ -104,9 +105,12 @@ pub struct HipCursor<'a> {
     pub(crate) mode: i32,
     pub(crate) hay_ptr: *const u8,
     pub(crate) hay_len: usize,
-    pub(crate) run: *const daac_match12, // what is left of the last daac_iter_next_batch12
+    pub(crate) compact: bool,            // 8-byte runs (else: the dictionary's patterns are too long for them, 16-byte runs)
+    pub(crate) run: *const daac_match8,  // what is left of the last daac_iter_next_batch8 ...
+    pub(crate) run16: *const daac_match16, // ... or daac_iter_next_batch
     pub(crate) run_len: usize,
     pub(crate) run_base: u64, // ends of the run count from here
+    pub(crate) end_bits: u32,
     pub(crate) consumed: bool, // next() has been called: count() must not restart
 }
 impl<'a> HipCursor<'a> {
@@ -114,32 +118,55 @@ impl<'a> HipCursor<'a> {
     /// Panics exactly where the crate panics (wrong MatchKind), with the crate's messages.
     pub(crate) fn open(pma: &'a HipPma, mode: i32, hay: &[u8]) -> Self {
         let mut it = core::ptr::null_mut();
-        let st = unsafe { daac_iter_open_compact(pma.0, mode, DAAC_ENGINE_AUTO, hay.as_ptr(), hay.len(), 0, core::ptr::null_mut(), &mut it) };
+        let mut compact = true;
+        let mut st = unsafe { daac_iter_open_compact(pma.0, mode, DAAC_ENGINE_AUTO, hay.as_ptr(), hay.len(), 0, core::ptr::null_mut(), &mut it) };
+        if st == DAAC_ERR_UNSUPPORTED {
+            compact = false;
+            st = unsafe { daac_iter_open(pma.0, mode, DAAC_ENGINE_AUTO, hay.as_ptr(), hay.len(), 0, core::ptr::null_mut(), &mut it) };
+        }
         assert!(!(st == DAAC_ERR_MATCH_KIND && mode != DAAC_LEFTMOST_FIND), "Error: match_kind must be standard.");
         assert!(!(st == DAAC_ERR_MATCH_KIND && mode == DAAC_LEFTMOST_FIND), "Error: match_kind must be leftmost.");
         assert!(st == DAAC_OK, "daachorse_amd: device scan failed (status {st})");
-        Self { it, pma, mode, hay_ptr: hay.as_ptr(), hay_len: hay.len(), run: core::ptr::null(), run_len: 0, run_base: 0, consumed: false }
+        Self { it, pma, mode, hay_ptr: hay.as_ptr(), hay_len: hay.len(), compact, run: core::ptr::null(), run16: core::ptr::null(), run_len: 0,
+               run_base: 0, end_bits: 32, consumed: false }
     }
-    /// `Iterator::next`: one 12-byte read from the run at hand; a library call per WINDOW (tens of millions of matches), not per match.
+    /// `Iterator::next`: one 8-byte read from the run at hand; a library call per WINDOW (tens of millions of matches), not per match.
     #[inline]
     pub(crate) fn next(&mut self) -> Option<crate::Match<u32>> {
         self.consumed = true;
         if self.run_len == 0 {
-            let (mut p, mut n, mut base) = (core::ptr::null(), 0usize, 0u64);
-            match unsafe { daac_iter_next_batch12(self.it, &mut p, &mut n, &mut base) } {
+            let (mut n, mut base, mut eb) = (0usize, 0u64, 32u32);
+            let r = if self.compact {
+                let mut p = core::ptr::null();
+                let r = unsafe { daac_iter_next_batch8(self.it, &mut p, &mut n, &mut base, &mut eb) };
+                self.run = p;
+                r
+            } else {
+                let mut p = core::ptr::null();
+                let r = unsafe { daac_iter_next_batch(self.it, &mut p, &mut n) };
+                self.run16 = p;
+                r
+            };
+            match r {
                 1 => {
-                    self.run = p;
                     self.run_len = n;
                     self.run_base = base;
+                    self.end_bits = eb;
                 }
                 0 => return None,
                 e => panic!("daachorse_amd: device scan failed (status {})", -e),
             }
         }
-        let t = unsafe { *self.run }; // the crate's own Match fields (src/lib.rs:287-291), the end relative to the run's base
-        self.run = unsafe { self.run.add(1) };
         self.run_len -= 1;
-        Some(crate::Match { length: t.length as usize, end: (self.run_base + t.end_lo as u64) as usize, value: t.value })
+        if !self.compact {
+            let t = unsafe { *self.run16 }; // the crate's own Match fields (src/lib.rs:287-291)
+            self.run16 = unsafe { self.run16.add(1) };
+            return Some(crate::Match { length: t.length as usize, end: t.end as usize, value: t.value });
+        }
+        let t = unsafe { *self.run };
+        self.run = unsafe { self.run.add(1) };
+        let end = self.run_base + (t.end_len & ((1u32 << self.end_bits) - 1)) as u64;
+        Some(crate::Match { length: (t.end_len >> self.end_bits) as usize, end: end as usize, value: t.value })
     }
     /// `Iterator::count()` as ONE device pass (`daac_scan_count_only_range`) when nothing has been pulled yet.
     pub(crate) fn count(mut self) -> usize {

@@ -795,8 +795,8 @@ def test_engine_options_do_not_change_answers():
 
 
 def test_compact_lazy_iterator():
-    """daac_iter_open_compact / daac_iter_next_batch12: the same match stream with 12 bytes per tuple over PCIe (end relative to the
-    run's base) — every iterator of the crate, bytewise and charwise, windows small enough for many runs, matches that straddle windows;
+    """daac_iter_open_compact / daac_iter_next_batch8: the same match stream with 8 bytes per tuple over PCIe ({value, end relative to the
+    run's base | length << end_bits}) — every iterator of the crate, bytewise and charwise, windows small enough for many runs, matches that straddle windows;
     the two run formats refuse each other's iterators."""
     rng = np.random.default_rng(12)
     pats = synth.patterns_cfg3(5000)
@@ -820,12 +820,13 @@ def test_compact_lazy_iterator():
                 it = getattr(p, api)(h, compact=True)
                 ends, lens, vals, nruns = [], [], [], 0
                 while True:
-                    got = it.next_batch12()
+                    got = it.next_batch8()
                     if got is None:
                         break
-                    run, base = got
+                    run, base, eb = got
                     nruns += 1
-                    ends.append(run["end_lo"].astype(np.uint64) + np.uint64(base)); lens.append(run["length"].copy()); vals.append(run["value"].copy())
+                    ends.append((run["end_len"] & np.uint32((1 << eb) - 1)).astype(np.uint64) + np.uint64(base))
+                    lens.append(run["end_len"] >> np.uint32(eb)); vals.append(run["value"].copy())
                 it.close()
                 assert nruns > 3, (api, charwise)
                 e, l, v = np.concatenate(ends), np.concatenate(lens), np.concatenate(vals)
@@ -840,7 +841,14 @@ def test_compact_lazy_iterator():
             p.find_overlapping_iter(hay, compact=True).next_batch()
         assert ei.value.code == 6
         with pytest.raises(da.DaachorseError) as ei:
-            p.find_overlapping_iter(hay).next_batch12()
+            p.find_overlapping_iter(hay).next_batch8()
         assert ei.value.code == 6
+        # a dictionary with a pattern of several KB has no compact form (the 16-byte iterator serves it)
+        o = orc.OraclePma.build([b"ab", b"x" * 5000])
+        q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+        with pytest.raises(da.DaachorseError) as ei:
+            q.find_overlapping_iter(hay, compact=True)
+        assert ei.value.code == 6
+        assert [(m.start(), m.end(), m.value()) for m in q.find_overlapping_iter(b"zabab" + b"x" * 5001)] == orc.triples_sev(o.find_overlapping_iter(b"zabab" + b"x" * 5001))
     finally:
         da.set_option("iter_window", 64 << 20)

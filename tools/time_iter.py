@@ -29,14 +29,14 @@ for name, pats, fill in (("cfg3", synth.patterns_cfg3(), lambda: synth.device_un
     want = pma.count(ScanMode.FindOverlapping, dev)
     for w in windows:
         da.set_option("iter_window", w << 20)
-        for compact, tb in ((True, 12), (False, 16)):
+        for compact, tb in ((True, 8), (False, 16)):
             best = None
             for rep in range(3):
                 t0 = time.perf_counter()
                 it = pma.find_overlapping_iter(h, compact=compact)
                 cnt = 0
                 while True:
-                    run = it.next_batch12() if compact else it.next_batch()
+                    run = it.next_batch8() if compact else it.next_batch()
                     if run is None:
                         break
                     cnt += len(run[0]) if compact else len(run)
