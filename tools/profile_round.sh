@@ -75,7 +75,7 @@ for pass in "$PASS1" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT
   rm -rf $d
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $d -o p -- python $R/tools/time_emit.py 1024 sparse 3 0 only16 > $d.log 2>&1
   echo "== tuple emitter, cfg3 sparse, 1 GiB, 16-byte tuples" >> $OUT/${TAG}_pmc_sq.txt
-  python $R/tools/pmc_summary.py $d >> $OUT/${TAG}_pmc_sq.txt 2>&1
+  DAAC_PMC_FILTER=emit3_detect,emit3_bin,emit3_expand python $R/tools/pmc_summary.py $d | grep -v duration_us >> $OUT/${TAG}_pmc_sq.txt 2>&1
 done
 
 # the bench lines themselves (they read the traffic file given here; in the repository: profiles/hbm_traffic.json)
