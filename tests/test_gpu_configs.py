@@ -222,3 +222,70 @@ def test_cfg3_count_kernel_on_a_vector_of_window_counts():
     finally:
         da.set_option("gram_version", 0)
     assert np.array_equal(got3, want[::8])
+
+
+class _DeviceWords:
+    """a device buffer of n int64 words as a __cuda_array_interface__ object (torch.as_tensor takes it without a copy)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+
+def _checksum_of_device_tuples16(dm):
+    """(count, checksum) of a device list of daac_match16 {end u64, length u32, value u32}, computed on the device with torch's wrapping
+    int64 arithmetic: h = low32(mix64(value << 32 | length)), S1 = sum h, S2 = sum h * low32(end) (include/daachorse_amd.h)"""
+    import torch
+    n = dm.count
+    w = torch.as_tensor(_DeviceWords(dm.ptr, 2 * n), device="cuda").view(n, 2)
+    M1, M2 = -4658895280553007687, -7723592293110705685   # 0xBF58476D1CE4E5B9, 0x94D049BB133111EB as int64
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+    s1 = s2 = 0
+    for lo in range(0, n, 1 << 27):   # (in pieces: a few temporaries of the piece's size at a time)
+        end, z = w[lo:lo + (1 << 27), 0], w[lo:lo + (1 << 27), 1].clone()   # value << 32 | length is the tuple's second word as it stands
+        z = (z ^ lsr(z, 30)) * M1
+        z = (z ^ lsr(z, 27)) * M2
+        h = (z ^ lsr(z, 31)) & 0xFFFFFFFF
+        s1 += int(h.sum().item())
+        s2 += int(((h * (end & 0xFFFFFFFF)) & 0xFFFFFFFF).sum().item())
+    return n, ((s1 & 0xFFFFFFFF) << 32) | (s2 & 0xFFFFFFFF)
+
+
+def test_cfg3_tuples_at_size_checksum_of_the_list():
+    """Full-size property of the tuple emitter: the (count, checksum) of the LIST daac_scan_device16 leaves in HBM — computed from the
+    tuples themselves on the device — equals what the count + checksum kernel says of the same haystack (which the 4 GiB test pins to the
+    oracle).  2.5 GiB of cfg3 = three emitter windows, 1.6 G tuples, ends beyond 2^32; ends ascend; and the same for 1 GiB of word soup."""
+    import torch
+    pats = synth.patterns_cfg3()
+    p = da.DoubleArrayAhoCorasick.new(pats)
+    da.set_option("max_result_bytes", 64 << 30)
+    try:
+        for kind, n in (("sparse", (5 << 29) + 12345), ("dense", 1 << 30)):
+            dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+            if kind == "sparse":
+                synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+            else:
+                synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20)
+            want = p.scan_count(ScanMode.FindOverlapping, dev)
+            dm = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
+            assert da.last_engine() == int(Engine.Gram)
+            assert _checksum_of_device_tuples16(dm) == want, kind
+            ends = torch.as_tensor(_DeviceWords(dm.ptr, 2 * dm.count), device="cuda").view(dm.count, 2)[:, 0]
+            assert bool((ends[1:] >= ends[:-1]).all()), kind      # by end (as unsigned they are below 2^63: the comparison holds)
+            assert int(ends[-1].item()) <= n and int(ends[0].item()) >= 1
+            dm.free()
+            del dev, ends
+            torch.cuda.empty_cache()
+        # the PFX engine's list likewise (utf8jp scanned bytewise, 1 GiB: counted first, emitted piece by piece)
+        q = da.DoubleArrayAhoCorasick.new(synth.patterns_cfg5())
+        m = (1 << 30) - (1 << 30) % synth.CFG5_SLOT
+        dev = torch.empty(m, dtype=torch.uint8, device="cuda")
+        synth.device_zipf_text(dev)
+        want = q.scan_count(ScanMode.FindOverlapping, dev)
+        dm = q.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
+        assert da.last_engine() == int(Engine.Pfx)
+        assert _checksum_of_device_tuples16(dm) == want
+        dm.free()
+    finally:
+        da.set_option("max_result_bytes", 8 << 30)
