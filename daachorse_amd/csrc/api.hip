@@ -1164,6 +1164,16 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
     daac_status st = make_plan(pma, t, mode, (want_gram || want_pfx) ? DAAC_ENGINE_AUTO : engine, begin, end, pl, heads);
     if (st != DAAC_OK) return st;
     if (next_begin) *next_begin = end;
+    // (AUTO: the GRAM tables' emitter where the dictionary has them — option pfx = 2 builds both —, then PFX's)
+    if (!pma->charwise && mode == DAAC_FIND_OVERLAPPING && (engine == DAAC_ENGINE_AUTO || want_gram)) {
+        bool served = false;
+        if ((st = emit_overlapping3(pma, t, dev_hay, begin, end, stream, out, &served)) != DAAC_OK) return st;
+        if (served) return DAAC_OK;
+    }
+    if (want_gram) {
+        set_error(std::string("the GRAM engine cannot emit tuples for this automaton / request [") + last_error_cstr() + "]");
+        return DAAC_ERR_UNSUPPORTED;
+    }
     if (!pma->charwise && mode == DAAC_FIND_OVERLAPPING && (engine == DAAC_ENGINE_AUTO || want_pfx) && t->pfx_emit_ok) {
         bool served = false;
         if (end <= begin && want_pfx) { g_last_engine = DAAC_ENGINE_PFX; return DAAC_OK; }   // (no "" among the patterns: nothing ends at 0)
@@ -1207,15 +1217,6 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
     }
     if (want_pfx) {
         set_error(std::string("the PFX engine cannot emit tuples for this automaton / request [") + last_error_cstr() + "]");
-        return DAAC_ERR_UNSUPPORTED;
-    }
-    if (!pma->charwise && mode == DAAC_FIND_OVERLAPPING && (engine == DAAC_ENGINE_AUTO || want_gram)) {
-        bool served = false;
-        if ((st = emit_overlapping3(pma, t, dev_hay, begin, end, stream, out, &served)) != DAAC_OK) return st;
-        if (served) return DAAC_OK;
-    }
-    if (want_gram) {
-        set_error(std::string("the GRAM engine cannot emit tuples for this automaton / request [") + last_error_cstr() + "]");
         return DAAC_ERR_UNSUPPORTED;
     }
     g_last_engine = pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY;

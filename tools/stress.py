@@ -172,7 +172,7 @@ def engines_soak(seconds, seed, max_cases=None):
     from daachorse_amd import Engine
     rng = np.random.default_rng(seed)
     t0 = time.time()
-    n_auto = n_g3 = n_pfx = n_emit = 0
+    n_auto = n_g3 = n_pfx = n_emit = n_pfx_emit = 0
     da.set_option("pfx", 2)
     while (n_auto < max_cases) if max_cases is not None else (time.time() - t0 < seconds):
         nsym = int(rng.choice([2, 5, 12, 26, 29, 31, 60, 256]))
@@ -234,10 +234,36 @@ def engines_soak(seconds, seed, max_cases=None):
                 ok = all(np.array_equal(got[f], ref[f]) for f in ("start", "end", "value"))
             assert ok, ("tuples", fmt16, ctx)
         n_emit += da.last_engine() == int(Engine.Gram)
+        # round 4: the same list from the PFX engine's emitter where it applies (no duplicate patterns; a tile's extras may make it say no),
+        # and through the compact lazy iterator (8-byte tuples, windows of 4-64 KiB)
+        if info.pfx_available:
+            try:
+                dm = p.scan_device(ScanMode.FindOverlapping, dev[:m], engine=Engine.Pfx, fmt16=True)
+                got = dm.to_numpy()
+                dm.free()
+                assert len(got) == len(ref) and np.array_equal(got["end"], ref["end"]) and np.array_equal(got["length"], ref["end"] - ref["start"]) and \
+                    np.array_equal(got["value"], ref["value"]), ("pfx tuples", ctx)
+                n_pfx_emit += 1
+            except da.DaachorseError as e:
+                assert e.code == 6, (str(e), ctx)
+        if max(len(w) for w in pats) < 2000:
+            da.set_option("iter_window", int(rng.choice([4096, 20000, 65536])))
+            it = p.find_overlapping_iter(host[:m], compact=True)
+            e_, l_, v_ = [np.zeros(0, dtype=np.uint64)], [np.zeros(0, dtype=np.uint32)], [np.zeros(0, dtype=np.uint32)]
+            while True:
+                got = it.next_batch8()
+                if got is None:
+                    break
+                run, base, eb = got
+                e_.append((run["end_len"] & np.uint32((1 << eb) - 1)).astype(np.uint64) + np.uint64(base)); l_.append(run["end_len"] >> np.uint32(eb)); v_.append(run["value"].copy())
+            it.close()
+            da.set_option("iter_window", 64 << 20)
+            assert np.array_equal(np.concatenate(e_), ref["end"]) and np.array_equal(np.concatenate(l_), (ref["end"] - ref["start"]).astype(np.uint32)) and \
+                np.array_equal(np.concatenate(v_), ref["value"]), ("compact iterator", ctx)
     for k, v in (("gram_lds_budget", 158 * 1024), ("gram_region", 0), ("gram_ppl", 0), ("gram3_tail", -1), ("gram_version", 0), ("gram2_rfull", 1), ("threads", 1024),
                  ("pfx", 1)):
         da.set_option(k, v)
-    print(f"engines soak ok: {n_auto} automata ({n_g3} with GRAM tables, {n_pfx} with PFX tables, {n_emit} tuple lists from the GRAM emitter) in {time.time() - t0:.0f} s (seed {seed})")
+    print(f"engines soak ok: {n_auto} automata ({n_g3} with GRAM tables, {n_pfx} with PFX tables, {n_emit} tuple lists from the GRAM emitter, {n_pfx_emit} from PFX's) in {time.time() - t0:.0f} s (seed {seed})")
 
 
 if __name__ == "__main__":
