@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -45,6 +46,8 @@ struct Options {
     std::atomic<int64_t> gram_version{0};       // 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram3 on the v2 tables), 1 = v1 only,
                                                 // 2 = v2 tables with gram2_kernels.hip, 3 = v2 tables with gram3_kernels.hip for `.count()`
     std::atomic<int64_t> gram2_dpp{1};
+    std::atomic<int64_t> find3{1};              // find_iter's count (+ checksum) of a whole haystack of at most 1 GiB through find3_kernels.hip (selection over the
+                                                // emitter's per-position flags, no state chain) where the dictionary allows; 0: the chain walkers always
     std::atomic<int64_t> pfx_probe{16384};      // AUTO, `.count()` / count + checksum of a dictionary PFX serves: the micro-step walker takes over where more than
                                                 // this many of 65 536 sampled positions survive PFX's filter (0 = never ask, always PFX)
     std::atomic<int64_t> pfx{1};                // PFX engine: 1 = built for automata the GRAM tables do not serve, 2 = always, 0 = never (read at upload)
@@ -158,6 +161,12 @@ struct DeviceTables {
     bool emit3_has_len1 = false;   // some pattern is a single byte
     const uint32_t *pfx_probe_word = nullptr;   // device word the probe kernel leaves its count in
     std::atomic<int> pfx_dense{-1};  // the last probe's verdict on the text (scan_count_impl): 1 = most positions survive the filter
+    bool find3_ok = false;         // find_iter's count / checksum without a state chain (find3_kernels.hip): K = 3, no pattern beyond 19 bytes
+    Find3Dev find3{};
+    std::atomic<uint32_t> find3_gave_up{0};
+    std::atomic<uint32_t> find3_skips{0};
+    std::atomic<uint32_t> find3_rec_per_kib{0};   // deep matches per KiB the last find3 request met, + 1 (0: none yet): text made of the dictionary's
+                                                   // own words keeps DETECT's walkers busy (3.4 ms per GiB against 1.4) and the chain walkers are faster there
     bool pfx_emit_ok = false;      // PFX tuples: pfx_emit_kernel + EXPAND over the raw haystack (no pattern registered twice)
     Gram2EmitDev pfx_emit{};       // what that EXPAND needs: V1 by byte + the 256 flag bytes (v1, v1_bytes = 1280), K = 1
     std::atomic<uint32_t> emit3_rec_per_kib{0};  // deep-match records per KiB the last scans met (sizes the next scan's list)
@@ -628,11 +637,27 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                         while (blob.size() & 3) blob.push_back(0);
                         e.v3c_bytes = static_cast<uint32_t>(blob.size() * 4);
                         if ((st = t->put(blob, e.v3c)) != DAAC_OK) return st;
+                        // find3: the same three tables with h32 of the pattern in place of its value
+                        if (g2.max_len <= 19) {   // (duplicates: find_iter reports a state's FIRST output, which is the record's own value)
+                            std::vector<uint32_t> h1(g2.v1.size()), h2(g2.v2.size()), hb(blob);
+                            for (size_t i = 0; i < h1.size(); ++i) h1[i] = match_hash32(g2.v1[i], 1);
+                            for (size_t i = 0; i < h2.size(); ++i) h2[i] = match_hash32(g2.v2[i], 2);
+                            for (size_t i = 0; i < vals.size(); ++i) hb[e.v3c_val / 4 + i] = match_hash32(vals[i], 3);
+                            h1.resize(e.v1_bytes / 4, 0);
+                            h2.resize(e.v2_bytes / 4, 0);
+                            Find3Dev &f = t->find3;
+                            if ((st = t->put(h1, f.h1)) != DAAC_OK) return st;
+                            if ((st = t->put(h2, f.h2)) != DAAC_OK) return st;
+                            if ((st = t->put(hb, f.h3c)) != DAAC_OK) return st;
+                            f.h1_bytes = e.v1_bytes; f.h2_bytes = e.v2_bytes; f.h3c_bytes = e.v3c_bytes; f.h3c_dir = e.v3c_dir; f.h3c_val = e.v3c_val; f.C = g2.C;
+                            t->find3_ok = true;   // (&& emit3_ok, decided below)
+                        }
                     }
                 }
                 // (a staged tuple keeps its length in 22 bits)
                 t->emit3_ok = t->emit3_ok && emit3_expand_lds_bytes(e, 4, false, false) <= 64u * 1024u && emit3_expand_lds_bytes(e, 8, true, false) <= 80u * 1024u && g2.max_len < (1u << 22);
                 for (uint32_t w : g2.me) t->emit3_has_len1 = t->emit3_has_len1 || ((w >> 29) & 1u) != 0;
+                t->find3_ok = t->find3_ok && t->emit3_ok && find3_lds_bytes(t->find3, true) <= 160u * 1024u;
             }
         }
     }
@@ -1150,6 +1175,147 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
     return DAAC_OK;
 }
 
+// FindIterator's count (+ checksum) over [begin, len) of a haystack that ends at `len`, without a state chain (find3_kernels.hip): DETECT and
+// BIN of the tuple emitter, then SELECT passes over tiles of 2 048 positions until no tile's last word moves.  The result is left in
+// d_res {count, S1, S2}.  *served = false: the dictionary / request does not qualify, or the text is of the kind the relaxation gives up
+// on (then d_res holds nothing of value and the chain walkers take the request).
+daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t len, hipStream_t stream,
+                        unsigned long long *d_res, bool want_checksum, bool *served) {
+    *served = false;
+    const bool dbg = std::getenv("DAAC_DEBUG_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t_0 = tnow();
+    auto lap = [&](const char *what) { if (dbg) { (void)hipStreamSynchronize(stream); auto t1 = tnow(); fprintf(stderr, "[find3] %-18s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t_0).count()); t_0 = t1; } };
+    if (!t->find3_ok || g_opt.find3.load() == 0 || len <= begin || len - begin > (1ull << 30)) return DAAC_OK;
+    if (t->find3_gave_up.load() >= 2 && len - begin >= (1u << 20)) return DAAC_OK;
+    // (option find3 = 2: whatever the text)
+    const uint32_t kDenseRecPerKib = 26;
+    if (g_opt.find3.load() < 2 && t->find3_rec_per_kib.load() > kDenseRecPerKib + 1 && len - begin >= (1u << 20) &&
+        (t->find3_skips.fetch_add(1) & 7u) != 7u)   // (every eighth such request looks again: the text may have changed)
+        return DAAC_OK;
+    const Gram2EmitDev &e = t->emit;
+    const Gram3Lds &L = t->emit3_lds;
+    const uint64_t halo = pma->halo();
+    constexpr uint32_t kStep = 2048;
+    const uint64_t from = begin > halo ? begin - halo : 0;
+    const uint8_t *first = dev_hay + from;
+    const uint32_t lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(first) & 15u);
+    const uint8_t *hay_al = first - lead;
+    const uint64_t vlen64 = lead + (len - from);
+    if (vlen64 >= (1ull << 31)) return DAAC_OK;
+    const uint32_t vlen = static_cast<uint32_t>(vlen64), emit_from = static_cast<uint32_t>(lead + (begin - from));
+    const uint32_t nsteps = (vlen + kStep - 1) / kStep, n1k = nsteps * (kStep / kEmit3Tile);
+    const uint32_t region = 65536u;
+    const uint32_t wpb = L.threads / 64;
+    const uint64_t nregions = (static_cast<uint64_t>(vlen) + region - 1) / region;
+    const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (nregions + wpb - 1) / wpb)));
+    const uint64_t nwaves = static_cast<uint64_t>(blocks) * wpb;
+    const uint32_t wq_slab = static_cast<uint32_t>(std::max<int64_t>(64 * 32 + 128 + 64, g_opt.gram_slab.load()));
+    const size_t scan_words = n1k + 2 + exclusive_scan_scratch(n1k);
+    const size_t off_short = 0, off_deep = off_short + ((static_cast<size_t>(n1k) * 4 + 255) & ~size_t(255));
+    const size_t off_a = off_deep + ((static_cast<size_t>(n1k) * 4 + 255) & ~size_t(255)), off_b = off_a + ((scan_words * 8 + 255) & ~size_t(255));
+    const size_t off_ctl = off_b + ((scan_words * 8 + 255) & ~size_t(255));
+    const size_t off_ex = off_ctl + 256, off_wq = off_ex + 2 * ((static_cast<size_t>(nsteps) * 4 + 255) & ~size_t(255));
+    const size_t off_ann = off_wq + ((nwaves * wq_slab * sizeof(uint2) + 255) & ~size_t(255));
+    DevBuf g1, g_recs, g_bins;
+    HIP_TRY(g1.alloc(off_ann + static_cast<size_t>(nsteps) * kStep + 256, stream));
+    char *base = static_cast<char *>(g1.p);
+    lap("alloc g1");
+    uint32_t *d_short = reinterpret_cast<uint32_t *>(base + off_short), *d_deep = reinterpret_cast<uint32_t *>(base + off_deep);
+    unsigned long long *d_a = reinterpret_cast<unsigned long long *>(base + off_a), *d_b = reinterpret_cast<unsigned long long *>(base + off_b);
+    uint32_t *d_ctl = reinterpret_cast<uint32_t *>(base + off_ctl);
+    uint32_t *d_ex[2] = {reinterpret_cast<uint32_t *>(base + off_ex), reinterpret_cast<uint32_t *>(base + off_ex + ((static_cast<size_t>(nsteps) * 4 + 255) & ~size_t(255)))};
+    uint8_t *d_ann = reinterpret_cast<uint8_t *>(base + off_ann);
+    // ---- DETECT (emit3_kernels.hip) with its record list, sized from what the handle's last scans met, rerun once if too short ----
+    uint32_t per_kib = t->emit3_rec_per_kib.load();
+    if (per_kib == 0) per_kib = static_cast<uint32_t>(std::max<int64_t>(1, g_opt.emit_rec_per_kib.load()));
+    uint64_t chunk_cap = ((len - begin) / 1024 + 1) * per_kib / kEmit3Chunk * 2 + 2 * nwaves + 16;
+    unsigned long long deep_total = 0;
+    uint32_t ctl[2] = {0, 0};
+    for (int attempt = 0;; ++attempt) {
+        if (chunk_cap >= (1ull << 32) / kEmit3Chunk) return DAAC_OK;
+        dev_free(g_recs.p, g_recs.s); g_recs.p = nullptr;
+        HIP_TRY(g_recs.alloc(chunk_cap * (static_cast<size_t>(kEmit3Chunk) * sizeof(uint4) + 4), stream));
+        uint4 *d_recs = static_cast<uint4 *>(g_recs.p);
+        uint32_t *d_fill = reinterpret_cast<uint32_t *>(d_recs + chunk_cap * kEmit3Chunk);
+        HIP_TRY(hipMemsetAsync(d_fill, 0, chunk_cap * 4, stream));
+        HIP_TRY(hipMemsetAsync(d_deep, 0, static_cast<size_t>(n1k) * 4, stream));
+        HIP_TRY(hipMemsetAsync(d_ctl, 0, 256, stream));
+        Emit3Args a{};
+        a.hay_al = hay_al; a.lead = lead; a.vlen = vlen; a.emit_from = emit_from;
+        a.ann = d_ann;
+        a.tile_short = d_short; a.tile_deep = d_deep; a.tile0 = 0;
+        a.recs = d_recs; a.chunk_fill = d_fill; a.chunk_next = d_ctl; a.chunk_cap = static_cast<uint32_t>(chunk_cap);
+        a.wq = reinterpret_cast<uint2 *>(base + off_wq); a.wq_slab = wq_slab;
+        a.region_bytes = region; a.nregions = static_cast<uint32_t>(nregions);
+        a.fail = d_ctl + 1;
+        lap("recs alloc+memsets");
+        HIP_TRY(launch_emit3_detect(e, a, L, blocks, stream));
+        lap("DETECT");
+        HIP_TRY(launch_emit3_combine(d_short, d_deep, d_a, d_b, n1k, stream));
+        HIP_TRY(launch_exclusive_scan(d_b, n1k, d_b + n1k, d_b + n1k + 2, stream));
+        {
+            unsigned long long *pin = reinterpret_cast<unsigned long long *>(pinned_words());
+            HIP_TRY(hipMemcpyAsync(pin ? pin : &deep_total, d_b + n1k, 8, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(pin ? reinterpret_cast<uint32_t *>(pin + 1) : ctl, d_ctl, 8, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (pin) { deep_total = pin[0]; std::memcpy(ctl, pin + 1, 8); }
+        }
+        lap("combine+scan+read");
+        if (ctl[1] != 0) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }
+        if (ctl[0] <= chunk_cap) break;
+        if (attempt != 0) return DAAC_OK;
+        chunk_cap = static_cast<uint64_t>(ctl[0]) + 2 * nwaves + 16;
+    }
+    t->emit3_rec_per_kib.store(static_cast<uint32_t>(std::min<uint64_t>(1u << 20, deep_total * 5 / 4 / ((len - begin) / 1024 + 1) + 1)));
+    {   // text that is mostly dictionary words: this detection has cost more than the chain walkers' whole scan — theirs from here on
+        const uint64_t rk = deep_total / ((len - begin) / 1024 + 1);
+        t->find3_rec_per_kib.store(static_cast<uint32_t>(std::min<uint64_t>(1u << 20, rk + 1)));
+        if (g_opt.find3.load() < 2 && rk > kDenseRecPerKib && len - begin >= (1u << 20)) return DAAC_OK;
+    }
+    HIP_TRY(g_bins.alloc(static_cast<size_t>(deep_total + 1) * sizeof(uint4), stream));
+    if (deep_total != 0) {
+        uint4 *d_recs = static_cast<uint4 *>(g_recs.p);
+        const uint32_t *d_fill = reinterpret_cast<const uint32_t *>(d_recs + chunk_cap * kEmit3Chunk);
+        HIP_TRY(launch_emit3_bin(d_recs, d_fill, d_ctl, static_cast<uint32_t>(chunk_cap), d_b, d_deep, static_cast<uint4 *>(g_bins.p),
+                                 static_cast<uint32_t>(std::min<uint64_t>(ctl[0], static_cast<uint64_t>(t->num_cu) * 16)), stream));
+    }
+    lap("bins alloc + BIN");
+    // ---- SELECT: pass A leaves every tile's last word; the tallying passes enter with the words of the pass before ----
+    Find3Args f{};
+    f.ann = d_ann; f.ntiles = nsteps; f.n1k = n1k;
+    f.bin_off = d_b; f.binned = static_cast<const uint4 *>(g_bins.p);
+    f.force_pos = emit_from == 0 ? 0xffffffffu : emit_from - 1u;
+    f.pos_base = from - lead + 1;  // (mod 2^64: a match ends one past its last byte)
+    f.result = d_res;
+    f.flag = d_ctl + 2;
+    const uint32_t sblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (nsteps + 15) / 16)));
+    f.count_only = want_checksum ? 0u : 1u;
+    f.entry_in = nullptr; f.exit_out = d_ex[0]; f.off_wave = 0;
+    HIP_TRY(hipMemsetAsync(d_ctl + 2, 0, 4, stream));
+    HIP_TRY(launch_find3_tail(f, t->emit3_has_len1, static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 8, (nsteps + 63) / 64))), stream));
+    f.off_wave = t->find3.h1_bytes + t->find3.h2_bytes + t->find3.h3c_bytes;
+    for (int pass = 0;; ++pass) {
+        HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
+        if (pass != 0) HIP_TRY(hipMemsetAsync(d_ctl + 2, 0, 4, stream));   // (pass 0 also sees what pass A flagged: a pattern beyond 19 bytes, a tail that would not settle)
+        f.entry_in = d_ex[pass & 1]; f.exit_out = d_ex[(pass & 1) ^ 1];
+        HIP_TRY(launch_find3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
+        unsigned int flag = 0;
+        unsigned int *pin = pinned_words();
+        HIP_TRY(hipMemcpyAsync(pin ? pin : &flag, d_ctl + 2, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (pin) flag = *pin;
+        lap("tail+select+read");
+        if (flag & 6u) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }
+        if ((flag & 1u) == 0) break;
+        if (pass == 5) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }   // (chains that will not fall in step: the walkers' business)
+    }
+    t->find3_gave_up.store(0);
+    g_last_engine = DAAC_ENGINE_GRAM;
+    *served = true;
+    return DAAC_OK;
+}
+
 // Scans [begin, end) of a haystack whose byte 0 is at `dev_hay` (device pointer; only bytes
 // >= begin - halo are dereferenced) and leaves the matches with end in (begin, end] — plus
 // ROOT's list at end = 0 when begin == 0 — in device memory, in reference order.
@@ -1637,9 +1803,14 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     if (!d_res) { HIP_TRY(hipMalloc(&own, 3 * sizeof(unsigned long long))); d_res = static_cast<unsigned long long *>(own); }
     std::unique_ptr<void, void (*)(void *)> g2(own, [](void *p) { if (p) (void)hipFree(p); });
     pl.a.result = d_res;
+    // find_iter over a whole haystack of a dictionary the emitter serves: selection over per-position flags instead of a walk (find3_kernels.hip)
+    bool find3_served = false;
+    if (mode == DAAC_FIND && !pma->charwise && pma->host.is_standard() && engine == DAAC_ENGINE_AUTO && !pma->root_has_output() && len != begin) {
+        if ((st = find_count3(pma, t, dev_hay, begin, len, stream, d_res, want_checksum, &find3_served)) != DAAC_OK) return st;
+    }
     ChainBuffers chain_buffers;
-    if (pl.a.nseg != 0 && (st = chain_resolve(pma, t, pl, stream, chain_buffers)) != DAAC_OK) return st;
-    HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
+    if (!find3_served && pl.a.nseg != 0 && (st = chain_resolve(pma, t, pl, stream, chain_buffers)) != DAAC_OK) return st;
+    if (!find3_served) HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
     void *flagbuf = nullptr;
     if (pl.leftmost && pma->root_has_output()) {  // the one scan that can hit the non-terminating corner
         HIP_TRY(hipMalloc(&flagbuf, sizeof(unsigned long long)));
@@ -1647,8 +1818,9 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         pl.a.flags = static_cast<unsigned long long *>(flagbuf);
     }
     std::unique_ptr<void, void (*)(void *)> g3(flagbuf, [](void *p) { if (p) (void)hipFree(p); });
-    g_last_engine = use_pfx ? DAAC_ENGINE_PFX : use_gram ? DAAC_ENGINE_GRAM : (pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY);
-    if ((use_gram || use_pfx) && len != begin) {
+    if (!find3_served) g_last_engine = use_pfx ? DAAC_ENGINE_PFX : use_gram ? DAAC_ENGINE_GRAM : (pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY);
+    if (find3_served) {
+    } else if ((use_gram || use_pfx) && len != begin) {
         // A shard [begin, len) is scanned as a haystack of its own: that counts every occurrence lying inside it,
         // with ends relative to `begin`.  What is missing are the occurrences that start before `begin` and end
         // after it (at most Lmax - 1 bytes in); they are added below from a materialising scan of that sliver.
@@ -2420,6 +2592,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram3_tail") g_opt.gram3_tail = value;
     else if (n == "pfx") g_opt.pfx = value;
     else if (n == "pfx_probe") g_opt.pfx_probe = value;
+    else if (n == "find3") g_opt.find3 = value;
     else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles" || n == "emit_rec_cap" || n == "emit_version") {}   // (options of the round-3 COUNT + WRITE emitter: accepted, nothing left to steer)

@@ -261,6 +261,35 @@ hipError_t launch_emit3_expand_raw(const Gram2EmitDev &dev, const Expand3Args &a
 uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves, bool f16, bool v3_in_lds);
 
 // PFX engine (pfx.hpp): `.count()` for bytewise automata over any byte alphabet.  LDS: BLOOM at 0 | DISP | CNT1 | per-wave areas
+// find_iter without a state chain (find3_kernels.hip): SELECT over the emitter's annotated stream and binned records.
+constexpr uint32_t kFind3Tile = 2048;                  // positions a wave takes at a time (32 per lane)
+constexpr uint32_t kFind3Deep = 255;                   // deep selections a tile's list holds
+constexpr uint32_t kFind3Wave = 2064 + 4096 + 1024 + 256;   // per wave in LDS: 16 + 2048 stream bytes | 2048 x u16 length bits (then the staged positions) | the list of deep selections | per lane: positions with deep matches
+struct Find3Dev {
+    const uint32_t *h1, *h2;  // h32 of the pattern that IS the 1- / 2-gram of classes (layout of Gram2EmitDev::v1 / v2)
+    const uint32_t *h3c;      // h32 of the 3-byte patterns as a rank structure (layout of Gram2EmitDev::v3c)
+    uint32_t h1_bytes, h2_bytes, h3c_bytes, h3c_dir, h3c_val, C;
+};
+struct Find3Args {
+    const uint8_t *ann;                  // the annotated stream of DETECT (one window)
+    uint32_t ntiles;                     // tiles of kFind3Tile positions
+    uint32_t n1k;                        // tiles of 1024 positions (bin_off has n1k + 1 entries)
+    const unsigned long long *bin_off;   // exclusive record offsets per tile of 1024 positions
+    const uint4 *binned;                 // the deep matches, grouped by that tile
+    const uint32_t *entry_in;            // per tile: its last word of the pass before (a tile enters with the word of the tile before it); null: first pass
+    uint32_t *exit_out;                  // per tile: its last word of this pass
+    uint32_t force_pos;                  // virtual position just before the first byte that counts (the restart point); 0xffffffff: before position 0
+    unsigned long long pos_base;         // end (haystack coordinates) of a match whose last byte is at virtual position v = pos_base + v
+    uint32_t off_wave;                   // LDS: the h tables at 0 (tallying passes), the per-wave areas from here
+    uint32_t count_only;                 // `.count()`: the selections are counted, their h not looked up
+    unsigned long long *result;          // {count, S1, S2} (tallying passes; zeroed by the caller)
+    unsigned int *flag;                  // bit 0: some tile's last word differs from the pass before (one more pass); bit 1: a match this engine
+                                         // cannot place (longer than 19 bytes, a duplicate's copy); bit 2: a tile that would not settle
+};
+uint32_t find3_lds_bytes(const Find3Dev &dev, bool tally);
+hipError_t launch_find3_select(const Find3Dev &dev, const Find3Args &a, bool has_len1, bool tally, uint32_t blocks, hipStream_t stream);
+hipError_t launch_find3_tail(const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream);
+
 struct PfxDev {
     const uint32_t *bloom;   // bloom_words words
     const uint16_t *cnt1;    // 256: patterns that are this one byte
