@@ -65,6 +65,7 @@ struct Options {
     std::atomic<int64_t> overlap_micro{1};      // counts of overlapping scans outside GRAM: 1 micro-step walker (charwise, DARRAY), 2 also instead of TIERED, 0 off
     std::atomic<int64_t> pool{1};               // scratch / result buffers from the stream-ordered pool
     std::atomic<int64_t> pool_keep{0};          // bytes the pool keeps between calls (0 = auto)
+    std::atomic<int64_t> workspace_keep{8ll << 30};   // bytes of scratch a handle may keep for its emitter / find3 calls (0: none)
     std::atomic<int64_t> char_map_lds{1};
     std::atomic<int64_t> char_row_lds{1};       // ... and ROOT's row of children beside it       // charwise chain scans: stage the populated stretch of the code mapper in LDS
                                                 // (off: measured slower on cfg5, 88 vs 104 GB/s — the stretch is L1-resident anyway)
@@ -111,6 +112,15 @@ static int pool_mode_of_current_device() {
     }
     g_pool_mode[dev].store(mode);
     return mode;
+}
+// DAAC_DEBUG_TIMING=1: host wall time between marks of one call, to stderr
+static void dbg_mark(const char *what) {
+    static const bool on = std::getenv("DAAC_DEBUG_TIMING") != nullptr;
+    if (!on) return;
+    static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mark] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - last).count());
+    last = now;
 }
 static hipError_t dev_malloc(void **p, size_t bytes, hipStream_t s) {
     if (bytes == 0) bytes = 16;
@@ -174,9 +184,18 @@ struct DeviceTables {
     // has run): from the second on the handle stops trying and the plan says so (a served scan resets the count)
     std::atomic<uint32_t> emit3_gave_up{0};
     CharDev chr{};  // charwise automata only
+    // The emitter's and find3's scratch (annotated stream, record list, scan arrays: ~2 bytes per haystack byte), kept by the handle from
+    // one call to the next — the stream-ordered pool's calls cost host time in proportion to the bytes asked for, and what a call frees is
+    // handed back at the next synchronisation (tools/micro/pool_ops.hip: 0.3 + 0.45 ms per GiB).  One call at a time borrows it
+    // (Scratch below); a second concurrent call on the handle goes to the pool.  Option workspace_keep bounds it; 0 = none.
+    std::atomic<bool> ws_busy{false};
+    void *ws_p = nullptr;
+    size_t ws_bytes = 0;
+    std::atomic<uint64_t> ws_want{0};   // what the largest call so far needed
 
     ~DeviceTables() {
         for (void *p : allocs) (void)hipFree(p);
+        if (ws_p) (void)hipFree(ws_p);
     }
     template <class T>
     daac_status put(const std::vector<T> &v, const T *&out) {
@@ -998,6 +1017,48 @@ struct DevMatches {
     daac_match *release_keep_n() { daac_match *q = p; p = nullptr; return q; }
 };
 
+// A call's scratch, carved from the handle's kept workspace when nobody else is using it (DeviceTables::ws_*), from the pool otherwise.
+// The borrower gives it back only when its stream has drained (every caller below has read its results back by then: the wait is a formality).
+struct Scratch {
+    DeviceTables *t;
+    hipStream_t s;
+    bool borrowed = false;
+    size_t used = 0, pool_bytes = 0;
+    std::vector<void *> pool_allocs;
+    Scratch(DeviceTables *t_, hipStream_t s_, size_t expect) : t(t_), s(s_) {
+        const uint64_t keep = static_cast<uint64_t>(g_opt.workspace_keep.load());
+        const uint64_t want = std::max<uint64_t>(expect, t->ws_want.load());
+        if (keep == 0 || expect > keep || t->ws_busy.exchange(true)) return;
+        borrowed = true;
+        const uint64_t target = std::min<uint64_t>(keep, want + want / 8);
+        if (t->ws_bytes < expect || (t->ws_bytes < want && target > t->ws_bytes)) {
+            if (t->ws_p) (void)hipFree(t->ws_p);
+            t->ws_p = nullptr; t->ws_bytes = 0;
+            if (hipMalloc(&t->ws_p, target) == hipSuccess) t->ws_bytes = target;
+            else { (void)hipGetLastError(); t->ws_p = nullptr; }
+        }
+    }
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    ~Scratch() {
+        for (void *p : pool_allocs) dev_free(p, s);
+        if (!borrowed) return;
+        if (used != 0) (void)hipStreamSynchronize(s);
+        uint64_t need = used + pool_bytes, seen = t->ws_want.load();
+        while (need > seen && !t->ws_want.compare_exchange_weak(seen, need)) {}
+        t->ws_busy.store(false);
+    }
+    hipError_t alloc(void **p, size_t bytes) {
+        bytes = (std::max<size_t>(bytes, 16) + 255) & ~size_t(255);
+        if (borrowed && used + bytes <= t->ws_bytes) { *p = static_cast<char *>(t->ws_p) + used; used += bytes; return hipSuccess; }
+        const hipError_t e = dev_malloc(p, bytes, s);
+        if (e == hipSuccess) { pool_allocs.push_back(*p); pool_bytes += bytes; }
+        return e;
+    }
+    size_t mark() const { return used; }
+    void rewind(size_t m) { used = m; }   // (what went to the pool after the mark stays until the call ends: the rare rerun's business)
+};
+
 // FindOverlappingIterator of a bytewise Standard automaton through the one-detection tuple emitter (emit3_kernels.hip):
 // DETECT (annotated class stream, tile counts, deep-match records) -> scans of the tile counts -> BIN (records by tile) -> EXPAND.
 // *served = false when the automaton / request does not qualify or the haystack is of the adversarial kind the kernels give up on
@@ -1055,25 +1116,28 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
     const size_t off_a = off_deep + ((tiles_total * 4 + 255) & ~size_t(255)), off_b = off_a + ((scan_words * 8 + 255) & ~size_t(255));
     const size_t off_ctl = off_b + ((scan_words * 8 + 255) & ~size_t(255));   // {chunk_next, fail}
     const size_t off_wq = off_ctl + 256, off_ann = off_wq + ((nwaves * wq_slab * wq_entry + 255) & ~size_t(255));
-    DevBuf g1, g_recs, g_bins;
-    HIP_TRY(g1.alloc(off_ann + ann_total + 256, stream));
-    char *base = static_cast<char *>(g1.p);
-    uint32_t *d_short = reinterpret_cast<uint32_t *>(base + off_short), *d_deep = reinterpret_cast<uint32_t *>(base + off_deep);
-    unsigned long long *d_a = reinterpret_cast<unsigned long long *>(base + off_a), *d_b = reinterpret_cast<unsigned long long *>(base + off_b);
-    uint32_t *d_ctl = reinterpret_cast<uint32_t *>(base + off_ctl);
-    uint8_t *d_ann = reinterpret_cast<uint8_t *>(base + off_ann);
-
     // the record list: sized for what the last scans of this automaton met (or the option's guess), rerun once with the exact number
     uint32_t per_kib = t->emit3_rec_per_kib.load();
     if (per_kib == 0) per_kib = static_cast<uint32_t>(std::max<int64_t>(1, g_opt.emit_rec_per_kib.load()));
     uint64_t chunk_cap = ((end - begin) / 1024 + 1) * per_kib / kEmit3Chunk * 2 + 2 * nwaves + 16;
+    const size_t g1_bytes = off_ann + ann_total + 256;
+    Scratch sc(t, stream, g1_bytes + chunk_cap * (static_cast<size_t>(kEmit3Chunk) * sizeof(uint4) * 3 / 2 + 4) + 4096);   // (+ the binned copy: the list is at most half empty)
+    void *g1_p = nullptr, *g_recs_p = nullptr, *g_bins_p = nullptr;
+    HIP_TRY(sc.alloc(&g1_p, g1_bytes));
+    char *base = static_cast<char *>(g1_p);
+    uint32_t *d_short = reinterpret_cast<uint32_t *>(base + off_short), *d_deep = reinterpret_cast<uint32_t *>(base + off_deep);
+    unsigned long long *d_a = reinterpret_cast<unsigned long long *>(base + off_a), *d_b = reinterpret_cast<unsigned long long *>(base + off_b);
+    uint32_t *d_ctl = reinterpret_cast<uint32_t *>(base + off_ctl);
+    uint8_t *d_ann = reinterpret_cast<uint8_t *>(base + off_ann);
+    const size_t sc_mark = sc.mark();
+    dbg_mark("emit: scratch");
     unsigned long long total = 0, deep_total = 0;
     uint32_t ctl[2] = {0, 0};
     for (int attempt = 0;; ++attempt) {
         if (chunk_cap >= (1ull << 32) / kEmit3Chunk) return DAAC_OK;
-        dev_free(g_recs.p, g_recs.s); g_recs.p = nullptr;
-        HIP_TRY(g_recs.alloc(chunk_cap * (static_cast<size_t>(kEmit3Chunk) * sizeof(uint4) + 4), stream));
-        uint4 *d_recs = static_cast<uint4 *>(g_recs.p);
+        sc.rewind(sc_mark);
+        HIP_TRY(sc.alloc(&g_recs_p, chunk_cap * (static_cast<size_t>(kEmit3Chunk) * sizeof(uint4) + 4)));
+        uint4 *d_recs = static_cast<uint4 *>(g_recs_p);
         uint32_t *d_fill = reinterpret_cast<uint32_t *>(d_recs + chunk_cap * kEmit3Chunk);
         HIP_TRY(hipMemsetAsync(d_fill, 0, chunk_cap * 4, stream));
         HIP_TRY(hipMemsetAsync(d_deep, 0, tiles_total * 4, stream));
@@ -1120,11 +1184,12 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         return DAAC_ERR_AUTOMATON_SCALE;
     }
     if (dest && total > dest_cap) { set_error("tuple emitter: more tuples than the count pass announced"); return DAAC_ERR_DEVICE; }
-    HIP_TRY(g_bins.alloc(static_cast<size_t>(deep_total + 1) * sizeof(uint4), stream));
+    dbg_mark("emit: DETECT + scans read");
+    HIP_TRY(sc.alloc(&g_bins_p, static_cast<size_t>(deep_total + 1) * sizeof(uint4)));
     if (deep_total != 0) {
-        uint4 *d_recs = static_cast<uint4 *>(g_recs.p);
+        uint4 *d_recs = static_cast<uint4 *>(g_recs_p);
         const uint32_t *d_fill = reinterpret_cast<const uint32_t *>(d_recs + chunk_cap * kEmit3Chunk);
-        HIP_TRY(launch_emit3_bin(d_recs, d_fill, d_ctl, static_cast<uint32_t>(chunk_cap), d_b, d_deep, static_cast<uint4 *>(g_bins.p),
+        HIP_TRY(launch_emit3_bin(d_recs, d_fill, d_ctl, static_cast<uint32_t>(chunk_cap), d_b, d_deep, static_cast<uint4 *>(g_bins_p), tiles_total, deep_total,
                                  static_cast<uint32_t>(std::min<uint64_t>(ctl[0], static_cast<uint64_t>(t->num_cu) * 16)), stream));
     }
     daac_match *d_out = static_cast<daac_match *>(dest);
@@ -1134,13 +1199,17 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
     }
     out.s = stream;
     out.n = total;
+    dbg_mark("emit: BIN asked + out alloc");
+    const char *dbg_env = std::getenv("DAAC_DEBUG_TIMING");
+    const bool dbg_sync = dbg_env && dbg_env[0] == '1';
+    if (dbg_sync) { fprintf(stderr, "[emit] BIN sync: %s  total=%llu deep=%llu chunks=%u cap=%llu\n", hipGetErrorString(hipStreamSynchronize(stream)), total, deep_total, ctl[0], (unsigned long long)chunk_cap); }
     HIP_TRY(hipMemsetAsync(d_ctl + 1, 0, 4, stream));
     for (const Win &w : wins) {
         Expand3Args a{};
         a.ann = d_ann + w.ann0;
         a.ntiles = (w.vlen + kEmit3Tile - 1) / kEmit3Tile;
         a.tile_off = d_a + w.tile0; a.bin_off = d_b + w.tile0;
-        a.binned = static_cast<const uint4 *>(g_bins.p);
+        a.binned = static_cast<const uint4 *>(g_bins_p);
         a.out = d_out;
         a.pos_base = w.from - w.lead + 1;  // (mod 2^64: a match ends one past its last byte)
         a.has_len1 = (raw ? t->pfx.has_len1 != 0 : t->emit3_has_len1) ? 1u : 0u;
@@ -1155,6 +1224,7 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         const uint32_t xblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * ((out.f16 && !raw) ? 2u : 4u), (a.ntiles + xwaves - 1) / xwaves)));
         if (raw) HIP_TRY(launch_emit3_expand_raw(e, a, out.f16, xblocks, stream));
         else HIP_TRY(launch_emit3_expand(e, a, out.f16, xblocks, stream));
+        if (dbg_sync) fprintf(stderr, "[emit] EXPAND window at %llu sync: %s\n", (unsigned long long)w.wb, hipGetErrorString(hipStreamSynchronize(stream)));
     }
     {
         unsigned int fail = 0;
@@ -1172,6 +1242,7 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
     out.f16_done = out.f16;
     t->emit3_gave_up.store(0);
     *served = true;
+    dbg_mark("emit: EXPAND read");
     return DAAC_OK;
 }
 
@@ -1182,16 +1253,16 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
 daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t len, hipStream_t stream,
                         unsigned long long *d_res, bool want_checksum, bool *served) {
     *served = false;
-    const bool dbg = std::getenv("DAAC_DEBUG_TIMING") != nullptr;
-    auto tnow = [] { return std::chrono::steady_clock::now(); };
-    auto t_0 = tnow();
-    auto lap = [&](const char *what) { if (dbg) { (void)hipStreamSynchronize(stream); auto t1 = tnow(); fprintf(stderr, "[find3] %-18s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t_0).count()); t_0 = t1; } };
+    // (DAAC_DEBUG_TIMING=1: the stream is waited for at every lap — kernel times; =2: host time between the laps as the call really runs)
+    const char *dbg_env = std::getenv("DAAC_DEBUG_TIMING");
+    const bool dbg_sync = dbg_env && dbg_env[0] == '1';
+    auto lap = [&](const char *what) { if (dbg_env) { if (dbg_sync) (void)hipStreamSynchronize(stream); dbg_mark(what); } };
     if (!t->find3_ok || g_opt.find3.load() == 0 || len <= begin || len - begin > (1ull << 30)) return DAAC_OK;
     if (t->find3_gave_up.load() >= 2 && len - begin >= (1u << 20)) return DAAC_OK;
     // (option find3 = 2: whatever the text)
     const uint32_t kDenseRecPerKib = 26;
     if (g_opt.find3.load() < 2 && t->find3_rec_per_kib.load() > kDenseRecPerKib + 1 && len - begin >= (1u << 20) &&
-        (t->find3_skips.fetch_add(1) & 7u) != 7u)   // (every eighth such request looks again: the text may have changed)
+        (t->find3_skips.fetch_add(1) & 15u) != 15u)   // (every sixteenth such request looks again: the text may have changed)
         return DAAC_OK;
     const Gram2EmitDev &e = t->emit;
     const Gram3Lds &L = t->emit3_lds;
@@ -1217,30 +1288,53 @@ daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, 
     const size_t off_ctl = off_b + ((scan_words * 8 + 255) & ~size_t(255));
     const size_t off_ex = off_ctl + 256, off_wq = off_ex + 2 * ((static_cast<size_t>(nsteps) * 4 + 255) & ~size_t(255));
     const size_t off_ann = off_wq + ((nwaves * wq_slab * sizeof(uint2) + 255) & ~size_t(255));
-    DevBuf g1, g_recs, g_bins;
-    HIP_TRY(g1.alloc(off_ann + static_cast<size_t>(nsteps) * kStep + 256, stream));
-    char *base = static_cast<char *>(g1.p);
-    lap("alloc g1");
+    uint32_t per_kib = t->emit3_rec_per_kib.load();
+    if (per_kib == 0) per_kib = static_cast<uint32_t>(std::max<int64_t>(1, g_opt.emit_rec_per_kib.load()));
+    uint64_t chunk_cap = ((len - begin) / 1024 + 1) * per_kib / kEmit3Chunk * 2 + 2 * nwaves + 16;
+    const size_t g1_bytes = off_ann + static_cast<size_t>(nsteps) * kStep + 256;
+    Scratch sc(t, stream, g1_bytes + chunk_cap * (static_cast<size_t>(kEmit3Chunk) * sizeof(uint4) * 2 + 4) + 4096);
+    void *g1_p = nullptr, *g_recs_p = nullptr, *g_bins_p = nullptr;
+    HIP_TRY(sc.alloc(&g1_p, g1_bytes));
+    const size_t sc_mark = sc.mark();
+    char *base = static_cast<char *>(g1_p);
+    lap("scratch");
     uint32_t *d_short = reinterpret_cast<uint32_t *>(base + off_short), *d_deep = reinterpret_cast<uint32_t *>(base + off_deep);
     unsigned long long *d_a = reinterpret_cast<unsigned long long *>(base + off_a), *d_b = reinterpret_cast<unsigned long long *>(base + off_b);
     uint32_t *d_ctl = reinterpret_cast<uint32_t *>(base + off_ctl);
     uint32_t *d_ex[2] = {reinterpret_cast<uint32_t *>(base + off_ex), reinterpret_cast<uint32_t *>(base + off_ex + ((static_cast<size_t>(nsteps) * 4 + 255) & ~size_t(255)))};
     uint8_t *d_ann = reinterpret_cast<uint8_t *>(base + off_ann);
-    // ---- DETECT (emit3_kernels.hip) with its record list, sized from what the handle's last scans met, rerun once if too short ----
-    uint32_t per_kib = t->emit3_rec_per_kib.load();
-    if (per_kib == 0) per_kib = static_cast<uint32_t>(std::max<int64_t>(1, g_opt.emit_rec_per_kib.load()));
-    uint64_t chunk_cap = ((len - begin) / 1024 + 1) * per_kib / kEmit3Chunk * 2 + 2 * nwaves + 16;
+    // ---- DETECT (emit3_kernels.hip) with its record list, sized from what the handle's last scans met (rerun once if too short), and
+    // behind it — without the host looking in between — BIN, the tiles' tails and the first SELECT pass; those do nothing when the list
+    // overflowed or holds more than the chain walkers' text would (find3_detect_usable) ----
+    const uint64_t kib = (len - begin) / 1024 + 1;
+    const bool gate = g_opt.find3.load() < 2 && len - begin >= (1u << 20);
+    const unsigned long long rec_gate = gate ? static_cast<unsigned long long>(kib) * (kDenseRecPerKib + 1) : ~0ull;
+    Find3Args f{};
+    f.ann = d_ann; f.ntiles = nsteps; f.n1k = n1k;
+    f.bin_off = d_b;
+    f.force_pos = emit_from == 0 ? 0xffffffffu : emit_from - 1u;
+    f.pos_base = from - lead + 1;  // (mod 2^64: a match ends one past its last byte)
+    f.result = d_res;
+    f.flag = d_ctl + 2;
+    f.ctl = d_ctl;
+    f.count_only = want_checksum ? 0u : 1u;
+    const uint32_t sblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (nsteps + 15) / 16)));
+    const uint32_t tblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 8, (nsteps + 63) / 64)));
+    const uint32_t lds_tables = t->find3.h1_bytes + t->find3.h2_bytes + t->find3.h3c_bytes;
     unsigned long long deep_total = 0;
-    uint32_t ctl[2] = {0, 0};
+    uint32_t ctl[3] = {0, 0, 0};
     for (int attempt = 0;; ++attempt) {
         if (chunk_cap >= (1ull << 32) / kEmit3Chunk) return DAAC_OK;
-        dev_free(g_recs.p, g_recs.s); g_recs.p = nullptr;
-        HIP_TRY(g_recs.alloc(chunk_cap * (static_cast<size_t>(kEmit3Chunk) * sizeof(uint4) + 4), stream));
-        uint4 *d_recs = static_cast<uint4 *>(g_recs.p);
+        sc.rewind(sc_mark);
+        HIP_TRY(sc.alloc(&g_recs_p, chunk_cap * (static_cast<size_t>(kEmit3Chunk) * sizeof(uint4) + 4)));
+        const unsigned long long rec_limit = std::min<unsigned long long>(rec_gate, chunk_cap * kEmit3Chunk);
+        HIP_TRY(sc.alloc(&g_bins_p, static_cast<size_t>(rec_limit + 1) * sizeof(uint4)));
+        uint4 *d_recs = static_cast<uint4 *>(g_recs_p);
         uint32_t *d_fill = reinterpret_cast<uint32_t *>(d_recs + chunk_cap * kEmit3Chunk);
         HIP_TRY(hipMemsetAsync(d_fill, 0, chunk_cap * 4, stream));
         HIP_TRY(hipMemsetAsync(d_deep, 0, static_cast<size_t>(n1k) * 4, stream));
         HIP_TRY(hipMemsetAsync(d_ctl, 0, 256, stream));
+        HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
         Emit3Args a{};
         a.hay_al = hay_al; a.lead = lead; a.vlen = vlen; a.emit_from = emit_from;
         a.ann = d_ann;
@@ -1249,67 +1343,58 @@ daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, 
         a.wq = reinterpret_cast<uint2 *>(base + off_wq); a.wq_slab = wq_slab;
         a.region_bytes = region; a.nregions = static_cast<uint32_t>(nregions);
         a.fail = d_ctl + 1;
-        lap("recs alloc+memsets");
+        lap("allocs + memsets");
         HIP_TRY(launch_emit3_detect(e, a, L, blocks, stream));
         lap("DETECT");
         HIP_TRY(launch_emit3_combine(d_short, d_deep, d_a, d_b, n1k, stream));
         HIP_TRY(launch_exclusive_scan(d_b, n1k, d_b + n1k, d_b + n1k + 2, stream));
+        HIP_TRY(launch_emit3_bin(d_recs, d_fill, d_ctl, static_cast<uint32_t>(chunk_cap), d_b, d_deep, static_cast<uint4 *>(g_bins_p), n1k, rec_limit,
+                                 static_cast<uint32_t>(std::min<uint64_t>(chunk_cap, static_cast<uint64_t>(t->num_cu) * 16)), stream));
+        lap("combine + scan + BIN");
+        // SELECT: the tails' kernel leaves every tile's last word; a tallying pass enters with the words of the pass before
+        f.binned = static_cast<const uint4 *>(g_bins_p);
+        f.chunk_cap = static_cast<uint32_t>(chunk_cap); f.rec_limit = rec_limit;
+        f.entry_in = nullptr; f.exit_out = d_ex[0]; f.off_wave = 0;
+        HIP_TRY(launch_find3_tail(f, t->emit3_has_len1, tblocks, stream));
+        f.off_wave = lds_tables;
+        f.entry_in = d_ex[0]; f.exit_out = d_ex[1];
+        HIP_TRY(launch_find3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
         {
             unsigned long long *pin = reinterpret_cast<unsigned long long *>(pinned_words());
             HIP_TRY(hipMemcpyAsync(pin ? pin : &deep_total, d_b + n1k, 8, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipMemcpyAsync(pin ? reinterpret_cast<uint32_t *>(pin + 1) : ctl, d_ctl, 8, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(pin ? reinterpret_cast<uint32_t *>(pin + 1) : ctl, d_ctl, 12, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            if (pin) { deep_total = pin[0]; std::memcpy(ctl, pin + 1, 8); }
+            if (pin) { deep_total = pin[0]; std::memcpy(ctl, pin + 1, 12); }
         }
-        lap("combine+scan+read");
+        lap("tails + SELECT + read");
         if (ctl[1] != 0) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }
         if (ctl[0] <= chunk_cap) break;
         if (attempt != 0) return DAAC_OK;
         chunk_cap = static_cast<uint64_t>(ctl[0]) + 2 * nwaves + 16;
     }
-    t->emit3_rec_per_kib.store(static_cast<uint32_t>(std::min<uint64_t>(1u << 20, deep_total * 5 / 4 / ((len - begin) / 1024 + 1) + 1)));
+    t->emit3_rec_per_kib.store(static_cast<uint32_t>(std::min<uint64_t>(1u << 20, deep_total * 5 / 4 / kib + 1)));
     {   // text that is mostly dictionary words: this detection has cost more than the chain walkers' whole scan — theirs from here on
-        const uint64_t rk = deep_total / ((len - begin) / 1024 + 1);
+        const uint64_t rk = deep_total / kib;
         t->find3_rec_per_kib.store(static_cast<uint32_t>(std::min<uint64_t>(1u << 20, rk + 1)));
-        if (g_opt.find3.load() < 2 && rk > kDenseRecPerKib && len - begin >= (1u << 20)) return DAAC_OK;
+        if (gate && rk > kDenseRecPerKib) return DAAC_OK;
     }
-    HIP_TRY(g_bins.alloc(static_cast<size_t>(deep_total + 1) * sizeof(uint4), stream));
-    if (deep_total != 0) {
-        uint4 *d_recs = static_cast<uint4 *>(g_recs.p);
-        const uint32_t *d_fill = reinterpret_cast<const uint32_t *>(d_recs + chunk_cap * kEmit3Chunk);
-        HIP_TRY(launch_emit3_bin(d_recs, d_fill, d_ctl, static_cast<uint32_t>(chunk_cap), d_b, d_deep, static_cast<uint4 *>(g_bins.p),
-                                 static_cast<uint32_t>(std::min<uint64_t>(ctl[0], static_cast<uint64_t>(t->num_cu) * 16)), stream));
-    }
-    lap("bins alloc + BIN");
-    // ---- SELECT: pass A leaves every tile's last word; the tallying passes enter with the words of the pass before ----
-    Find3Args f{};
-    f.ann = d_ann; f.ntiles = nsteps; f.n1k = n1k;
-    f.bin_off = d_b; f.binned = static_cast<const uint4 *>(g_bins.p);
-    f.force_pos = emit_from == 0 ? 0xffffffffu : emit_from - 1u;
-    f.pos_base = from - lead + 1;  // (mod 2^64: a match ends one past its last byte)
-    f.result = d_res;
-    f.flag = d_ctl + 2;
-    const uint32_t sblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (nsteps + 15) / 16)));
-    f.count_only = want_checksum ? 0u : 1u;
-    f.entry_in = nullptr; f.exit_out = d_ex[0]; f.off_wave = 0;
-    HIP_TRY(hipMemsetAsync(d_ctl + 2, 0, 4, stream));
-    HIP_TRY(launch_find3_tail(f, t->emit3_has_len1, static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 8, (nsteps + 63) / 64))), stream));
-    f.off_wave = t->find3.h1_bytes + t->find3.h2_bytes + t->find3.h3c_bytes;
+    if (deep_total > std::min<unsigned long long>(rec_gate, chunk_cap * kEmit3Chunk)) return DAAC_OK;   // (the kernels behind DETECT did nothing)
     for (int pass = 0;; ++pass) {
-        HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
-        if (pass != 0) HIP_TRY(hipMemsetAsync(d_ctl + 2, 0, 4, stream));   // (pass 0 also sees what pass A flagged: a pattern beyond 19 bytes, a tail that would not settle)
-        f.entry_in = d_ex[pass & 1]; f.exit_out = d_ex[(pass & 1) ^ 1];
-        HIP_TRY(launch_find3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
-        unsigned int flag = 0;
-        unsigned int *pin = pinned_words();
-        HIP_TRY(hipMemcpyAsync(pin ? pin : &flag, d_ctl + 2, 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (pin) flag = *pin;
-        lap("tail+select+read");
+        const unsigned int flag = ctl[2];
         if (flag & 6u) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }
         if ((flag & 1u) == 0) break;
         if (pass == 5) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }   // (chains that will not fall in step: the walkers' business)
+        HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(d_ctl + 2, 0, 4, stream));
+        f.entry_in = d_ex[(pass & 1) ^ 1]; f.exit_out = d_ex[pass & 1];
+        HIP_TRY(launch_find3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
+        unsigned int *pin = pinned_words();
+        HIP_TRY(hipMemcpyAsync(pin ? pin : &ctl[2], d_ctl + 2, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (pin) ctl[2] = *pin;
+        lap("one more SELECT");
     }
+    dbg_mark("find3: before frees");
     t->find3_gave_up.store(0);
     g_last_engine = DAAC_ENGINE_GRAM;
     *served = true;
@@ -1723,6 +1808,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceTables *t = nullptr;
+    dbg_mark("count: entry");
     daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
     if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
@@ -1799,15 +1885,16 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     std::unique_ptr<void, void (*)(void *)> g1(staged, [](void *p) { if (p) (void)hipFree(p); });
     pl.a.hay = dev_hay;
     unsigned long long *d_res = reinterpret_cast<unsigned long long *>(result_dev);
-    void *own = nullptr;
-    if (!d_res) { HIP_TRY(hipMalloc(&own, 3 * sizeof(unsigned long long))); d_res = static_cast<unsigned long long *>(own); }
-    std::unique_ptr<void, void (*)(void *)> g2(own, [](void *p) { if (p) (void)hipFree(p); });
+    DevBuf own;
+    if (!d_res) { HIP_TRY(own.alloc(3 * sizeof(unsigned long long), stream)); d_res = static_cast<unsigned long long *>(own.p); }
     pl.a.result = d_res;
     // find_iter over a whole haystack of a dictionary the emitter serves: selection over per-position flags instead of a walk (find3_kernels.hip)
     bool find3_served = false;
+    dbg_mark("count: plan made");
     if (mode == DAAC_FIND && !pma->charwise && pma->host.is_standard() && engine == DAAC_ENGINE_AUTO && !pma->root_has_output() && len != begin) {
         if ((st = find_count3(pma, t, dev_hay, begin, len, stream, d_res, want_checksum, &find3_served)) != DAAC_OK) return st;
     }
+    dbg_mark("count: find3 back");
     ChainBuffers chain_buffers;
     if (!find3_served && pl.a.nseg != 0 && (st = chain_resolve(pma, t, pl, stream, chain_buffers)) != DAAC_OK) return st;
     if (!find3_served) HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
@@ -1907,6 +1994,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     unsigned long long r[3];
     HIP_TRY(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    dbg_mark("count: result read");
     if (flagv & 1ull) return diverged();
     if (count) *count = r[0];
     if (checksum) *checksum = ((r[1] & 0xffffffffull) << 32) | (r[2] & 0xffffffffull);
@@ -1965,6 +2053,7 @@ static daac_status scan_device_impl(daac_pma *pma, int mode, int engine, const u
     if (!pma || !dev_out || !count || (len && !hay)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceTables *t = nullptr;
+    dbg_mark("scan_device: entry");
     daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
     if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
@@ -2606,6 +2695,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "overlap_micro") g_opt.overlap_micro = value;
     else if (n == "pool") g_opt.pool = value;
     else if (n == "pool_keep") g_opt.pool_keep = value;
+    else if (n == "workspace_keep") g_opt.workspace_keep = std::max<int64_t>(0, value);
     else if (n == "char_map_lds") g_opt.char_map_lds = value;
     else if (n == "char_row_lds") g_opt.char_row_lds = value;
     else { set_error("unknown option: " + n); return DAAC_ERR_INVALID_ARGUMENT; }

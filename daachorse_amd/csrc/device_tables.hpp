@@ -255,7 +255,7 @@ hipError_t launch_emit3_detect(const Gram2EmitDev &dev, const Emit3Args &a, cons
 hipError_t launch_emit3_combine(const uint32_t *tile_short, const uint32_t *tile_deep, unsigned long long *total, unsigned long long *deep, uint64_t n,
                                 hipStream_t stream);
 hipError_t launch_emit3_bin(const uint4 *recs, const uint32_t *chunk_fill, const uint32_t *chunk_next, uint32_t chunk_cap, const unsigned long long *bin_off,
-                            uint32_t *cursor, uint4 *binned, uint32_t blocks, hipStream_t stream);
+                            uint32_t *cursor, uint4 *binned, uint32_t n1k, unsigned long long rec_limit, uint32_t blocks, hipStream_t stream);
 hipError_t launch_emit3_expand(const Gram2EmitDev &dev, const Expand3Args &a, bool f16, uint32_t blocks, hipStream_t stream);
 hipError_t launch_emit3_expand_raw(const Gram2EmitDev &dev, const Expand3Args &a, bool f16, uint32_t blocks, hipStream_t stream);
 uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves, bool f16, bool v3_in_lds);
@@ -285,7 +285,15 @@ struct Find3Args {
     unsigned long long *result;          // {count, S1, S2} (tallying passes; zeroed by the caller)
     unsigned int *flag;                  // bit 0: some tile's last word differs from the pass before (one more pass); bit 1: a match this engine
                                          // cannot place (longer than 19 bytes, a duplicate's copy); bit 2: a tile that would not settle
+    // launched behind DETECT without the host having looked: nothing is done when DETECT's record list overflowed (ctl[0] > chunk_cap),
+    // its queue failed (ctl[1] != 0) or the records are more than rec_limit (text for the chain walkers)
+    const uint32_t *ctl;
+    uint32_t chunk_cap;
+    unsigned long long rec_limit;
 };
+__device__ __forceinline__ bool find3_detect_usable(const Find3Args &a) {
+    return a.ctl[0] <= a.chunk_cap && a.ctl[1] == 0u && a.bin_off[a.n1k] <= a.rec_limit;
+}
 uint32_t find3_lds_bytes(const Find3Dev &dev, bool tally);
 hipError_t launch_find3_select(const Find3Dev &dev, const Find3Args &a, bool has_len1, bool tally, uint32_t blocks, hipStream_t stream);
 hipError_t launch_find3_tail(const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream);

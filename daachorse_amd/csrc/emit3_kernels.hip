@@ -492,11 +492,12 @@ __global__ __launch_bounds__(256) void emit3_combine_kernel(const uint32_t *__re
 // equal tiles in meeting order (8 M per GiB of cfg3) was all of this kernel's 0.26 ms (profiles/r04_emit3_experiments.txt).
 __global__ __launch_bounds__(256) void emit3_bin_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__ chunk_fill, const uint32_t *__restrict__ chunk_next,
                                                         uint32_t chunk_cap, const unsigned long long *__restrict__ bin_off, uint32_t *__restrict__ cursor,
-                                                        uint4 *__restrict__ binned) {
+                                                        uint4 *__restrict__ binned, uint32_t n1k, unsigned long long rec_limit) {
     constexpr uint32_t H = 2048, kEmptyKey = 0xffffffffu;   // slots of the hash (a chunk holds at most 1024 records)
     constexpr uint32_t PER = kEmit3Chunk / 256;
     __shared__ uint32_t keys[H], cnt[H], base[H];
-    const uint32_t used = *chunk_next < chunk_cap ? *chunk_next : chunk_cap;
+    if (*chunk_next > chunk_cap || bin_off[n1k] > rec_limit) return;   // (a list that overflowed, or one the caller has no room / use for: launched without the host having looked)
+    const uint32_t used = *chunk_next;
     for (uint32_t c = blockIdx.x; c < used; c += gridDim.x) {
         const uint32_t fill = chunk_fill[c];
         for (uint32_t h = threadIdx.x; h < H; h += 256) { keys[h] = kEmptyKey; cnt[h] = 0; }
@@ -611,8 +612,9 @@ __global__ __launch_bounds__((F16 && !RAW) ? 512 : 256, (F16 && !RAW) ? 4 : 3) v
         return x;
     };
     auto uniform64 = [&](unsigned long long v) -> unsigned long long {
-        return (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32))) << 32) |
-               __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+        // (the builtin returns int: the low half goes through uint32_t, or a tuple index of 2^31 and more arrives sign-extended)
+        return (static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32)))) << 32) |
+               static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v))));
     };
     auto to_s = [&](const TileOff &o) -> TileS {
         TileS x;
@@ -1080,8 +1082,8 @@ hipError_t launch_emit3_combine(const uint32_t *tile_short, const uint32_t *tile
     return hipGetLastError();
 }
 hipError_t launch_emit3_bin(const uint4 *recs, const uint32_t *chunk_fill, const uint32_t *chunk_next, uint32_t chunk_cap, const unsigned long long *bin_off,
-                            uint32_t *cursor, uint4 *binned, uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(emit3_bin_kernel, dim3(blocks), dim3(256), 0, stream, recs, chunk_fill, chunk_next, chunk_cap, bin_off, cursor, binned);
+                            uint32_t *cursor, uint4 *binned, uint32_t n1k, unsigned long long rec_limit, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(emit3_bin_kernel, dim3(blocks), dim3(256), 0, stream, recs, chunk_fill, chunk_next, chunk_cap, bin_off, cursor, binned, n1k, rec_limit);
     return hipGetLastError();
 }
 

@@ -85,6 +85,7 @@ __device__ __forceinline__ uint32_t q_nib(uint32_t x) { return ((x & 0x01010101u
 template <bool HAS1, bool TALLY>
 __global__ __launch_bounds__(1024) void find3_select_kernel(const Find3Dev g, const Find3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (!find3_detect_usable(a)) return;
     if (TALLY) {
         q_copy(smem, g.h1, g.h1_bytes);
         q_copy(smem + g.h1_bytes, g.h2, g.h2_bytes);
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(1024) void find3_select_kernel(const Find3Dev g, co
 template <bool HAS1>
 __global__ __launch_bounds__(256) void find3_tail_kernel(const Find3Args a) {
     __shared__ __attribute__((aligned(16))) uint32_t dm_all[4][16 * 64];   // per wave, per group of four lanes: 128 x u16 length bits
+    if (!find3_detect_usable(a)) return;
     const uint32_t lane = threadIdx.x & 63, li = lane & 3u, grp = lane >> 2;
     const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);

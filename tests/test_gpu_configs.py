@@ -255,13 +255,14 @@ def _checksum_of_device_tuples16(dm):
 def test_cfg3_tuples_at_size_checksum_of_the_list():
     """Full-size property of the tuple emitter: the (count, checksum) of the LIST daac_scan_device16 leaves in HBM — computed from the
     tuples themselves on the device — equals what the count + checksum kernel says of the same haystack (which the 4 GiB test pins to the
-    oracle).  2.5 GiB of cfg3 = three emitter windows, 1.6 G tuples, ends beyond 2^32; ends ascend; and the same for 1 GiB of word soup."""
+    oracle).  3.5 GiB of cfg3 = four emitter windows, 2.24 G tuples (tuple indices beyond 2^31 — a sign-extended tile offset faulted there
+    until round 4 — and 34 GB of list), ends beyond 2^32; ends ascend; and the same for 1 GiB of word soup."""
     import torch
     pats = synth.patterns_cfg3()
     p = da.DoubleArrayAhoCorasick.new(pats)
     da.set_option("max_result_bytes", 64 << 30)
     try:
-        for kind, n in (("sparse", (5 << 29) + 12345), ("dense", 1 << 30)):
+        for kind, n in (("sparse", (7 << 29) + 12345), ("dense", 1 << 30)):
             dev = torch.empty(n, dtype=torch.uint8, device="cuda")
             if kind == "sparse":
                 synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
@@ -271,6 +272,7 @@ def test_cfg3_tuples_at_size_checksum_of_the_list():
             dm = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
             assert da.last_engine() == int(Engine.Gram)
             assert _checksum_of_device_tuples16(dm) == want, kind
+            assert kind != "sparse" or dm.count > (1 << 31)
             ends = torch.as_tensor(_DeviceWords(dm.ptr, 2 * dm.count), device="cuda").view(dm.count, 2)[:, 0]
             assert bool((ends[1:] >= ends[:-1]).all()), kind      # by end (as unsigned they are below 2^63: the comparison holds)
             assert int(ends[-1].item()) <= n and int(ends[0].item()) >= 1
