@@ -65,6 +65,7 @@ struct Options {
     std::atomic<int64_t> overlap_micro{1};      // counts of overlapping scans outside GRAM: 1 micro-step walker (charwise, DARRAY), 2 also instead of TIERED, 0 off
     std::atomic<int64_t> pool{1};               // scratch / result buffers from the stream-ordered pool
     std::atomic<int64_t> pool_keep{0};          // bytes the pool keeps between calls (0 = auto)
+    std::atomic<int64_t> find3_window{1ll << 30};     // find3: end positions per window (tests: small windows = many restarts)
     std::atomic<int64_t> workspace_keep{8ll << 30};   // bytes of scratch a handle may keep for its emitter / find3 calls (0: none)
     std::atomic<int64_t> char_map_lds{1};
     std::atomic<int64_t> char_row_lds{1};       // ... and ROOT's row of children beside it       // charwise chain scans: stage the populated stretch of the code mapper in LDS
@@ -1250,8 +1251,12 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
 // BIN of the tuple emitter, then SELECT passes over tiles of 2 048 positions until no tile's last word moves.  The result is left in
 // d_res {count, S1, S2}.  *served = false: the dictionary / request does not qualify, or the text is of the kind the relaxation gives up
 // on (then d_res holds nothing of value and the chain walkers take the request).
-daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t len, hipStream_t stream,
-                        unsigned long long *d_res, bool want_checksum, bool *served) {
+// One window: matches with end in (begin, len], len - begin <= 1 GiB; begin is a restart point (0, or the end of a match the iterator
+// returned).  r = {count, S1, S2} of the window; *next_begin = where a window behind this one restarts: the end of the last match
+// selected here, or — none within the last two tiles — 64 bytes before the end (no match ends in between, and the longest pattern is
+// shorter: the restart changes nothing).
+static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t len, hipStream_t stream,
+                                      bool want_checksum, unsigned long long r[3], uint64_t *next_begin, bool *served) {
     *served = false;
     // (DAAC_DEBUG_TIMING=1: the stream is waited for at every lap — kernel times; =2: host time between the laps as the call really runs)
     const char *dbg_env = std::getenv("DAAC_DEBUG_TIMING");
@@ -1314,15 +1319,16 @@ daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, 
     f.bin_off = d_b;
     f.force_pos = emit_from == 0 ? 0xffffffffu : emit_from - 1u;
     f.pos_base = from - lead + 1;  // (mod 2^64: a match ends one past its last byte)
-    f.result = d_res;
+    f.result = reinterpret_cast<unsigned long long *>(d_ctl + 4);   // d_ctl: {chunks, DETECT's failure, flag, last selection + 1, - count, S1, S2 -}
     f.flag = d_ctl + 2;
+    f.last_sel = d_ctl + 3;
     f.ctl = d_ctl;
     f.count_only = want_checksum ? 0u : 1u;
     const uint32_t sblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (nsteps + 15) / 16)));
     const uint32_t tblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 8, (nsteps + 63) / 64)));
     const uint32_t lds_tables = t->find3.h1_bytes + t->find3.h2_bytes + t->find3.h3c_bytes;
     unsigned long long deep_total = 0;
-    uint32_t ctl[3] = {0, 0, 0};
+    uint32_t ctl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int attempt = 0;; ++attempt) {
         if (chunk_cap >= (1ull << 32) / kEmit3Chunk) return DAAC_OK;
         sc.rewind(sc_mark);
@@ -1334,7 +1340,6 @@ daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, 
         HIP_TRY(hipMemsetAsync(d_fill, 0, chunk_cap * 4, stream));
         HIP_TRY(hipMemsetAsync(d_deep, 0, static_cast<size_t>(n1k) * 4, stream));
         HIP_TRY(hipMemsetAsync(d_ctl, 0, 256, stream));
-        HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
         Emit3Args a{};
         a.hay_al = hay_al; a.lead = lead; a.vlen = vlen; a.emit_from = emit_from;
         a.ann = d_ann;
@@ -1362,9 +1367,9 @@ daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, 
         {
             unsigned long long *pin = reinterpret_cast<unsigned long long *>(pinned_words());
             HIP_TRY(hipMemcpyAsync(pin ? pin : &deep_total, d_b + n1k, 8, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipMemcpyAsync(pin ? reinterpret_cast<uint32_t *>(pin + 1) : ctl, d_ctl, 12, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(pin ? reinterpret_cast<uint32_t *>(pin + 1) : ctl, d_ctl, 40, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            if (pin) { deep_total = pin[0]; std::memcpy(ctl, pin + 1, 12); }
+            if (pin) { deep_total = pin[0]; std::memcpy(ctl, pin + 1, 40); }
         }
         lap("tails + SELECT + read");
         if (ctl[1] != 0) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }
@@ -1384,17 +1389,44 @@ daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, 
         if (flag & 6u) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }
         if ((flag & 1u) == 0) break;
         if (pass == 5) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }   // (chains that will not fall in step: the walkers' business)
-        HIP_TRY(hipMemsetAsync(d_res, 0, 3 * sizeof(unsigned long long), stream));
-        HIP_TRY(hipMemsetAsync(d_ctl + 2, 0, 4, stream));
+        HIP_TRY(hipMemsetAsync(d_ctl + 2, 0, 32, stream));   // flag, last selection, the three sums
         f.entry_in = d_ex[(pass & 1) ^ 1]; f.exit_out = d_ex[pass & 1];
         HIP_TRY(launch_find3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
         unsigned int *pin = pinned_words();
-        HIP_TRY(hipMemcpyAsync(pin ? pin : &ctl[2], d_ctl + 2, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(pin ? pin : &ctl[2], d_ctl + 2, 32, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (pin) ctl[2] = *pin;
+        if (pin) std::memcpy(&ctl[2], pin, 32);
         lap("one more SELECT");
     }
-    dbg_mark("find3: before frees");
+    std::memcpy(r, &ctl[4], 24);
+    *next_begin = ctl[3] != 0 ? f.pos_base + (ctl[3] - 1u) : (len > 64 ? len - 64 : 0);
+    *served = true;
+    return DAAC_OK;
+}
+
+__global__ void set_result_kernel(unsigned long long *res, unsigned long long c, unsigned long long s1, unsigned long long s2) { res[0] = c; res[1] = s1; res[2] = s2; }
+
+// The request in windows of 1 GiB of end positions, each restarting where the one before it selected its last match; the sums are left in
+// d_res {count, S1, S2} (stream order) and in acc.
+daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t len, hipStream_t stream,
+                        unsigned long long *d_res, bool want_checksum, unsigned long long acc[3], bool *served) {
+    *served = false;
+    acc[0] = acc[1] = acc[2] = 0;
+    const uint64_t kWin = static_cast<uint64_t>(g_opt.find3_window.load());
+    for (uint64_t cur = begin;;) {
+        const uint64_t wend = std::min<uint64_t>(len, cur + kWin);
+        unsigned long long r[3] = {0, 0, 0};
+        uint64_t next = wend;
+        bool ok = false;
+        const daac_status st = find_count3_window(pma, t, dev_hay, cur, wend, stream, want_checksum, r, &next, &ok);
+        if (st != DAAC_OK || !ok) return st;
+        for (int k = 0; k < 3; ++k) acc[k] += r[k];
+        if (wend >= len) break;
+        if (next <= cur || next > wend) return DAAC_OK;   // (cannot happen; the walkers then)
+        cur = next;
+    }
+    hipLaunchKernelGGL(set_result_kernel, dim3(1), dim3(1), 0, stream, d_res, acc[0], acc[1], acc[2]);
+    HIP_TRY(hipGetLastError());
     t->find3_gave_up.store(0);
     g_last_engine = DAAC_ENGINE_GRAM;
     *served = true;
@@ -1890,9 +1922,10 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     pl.a.result = d_res;
     // find_iter over a whole haystack of a dictionary the emitter serves: selection over per-position flags instead of a walk (find3_kernels.hip)
     bool find3_served = false;
+    unsigned long long find3_sums[3] = {0, 0, 0};
     dbg_mark("count: plan made");
     if (mode == DAAC_FIND && !pma->charwise && pma->host.is_standard() && engine == DAAC_ENGINE_AUTO && !pma->root_has_output() && len != begin) {
-        if ((st = find_count3(pma, t, dev_hay, begin, len, stream, d_res, want_checksum, &find3_served)) != DAAC_OK) return st;
+        if ((st = find_count3(pma, t, dev_hay, begin, len, stream, d_res, want_checksum, find3_sums, &find3_served)) != DAAC_OK) return st;
     }
     dbg_mark("count: find3 back");
     ChainBuffers chain_buffers;
@@ -1992,8 +2025,12 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         return (flagv & 1ull) ? diverged() : DAAC_OK;
     }
     unsigned long long r[3];
-    HIP_TRY(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    if (find3_served) {   // (its windows were read back one by one)
+        std::memcpy(r, find3_sums, sizeof(r));
+    } else {
+        HIP_TRY(hipMemcpyAsync(r, d_res, sizeof(r), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
     dbg_mark("count: result read");
     if (flagv & 1ull) return diverged();
     if (count) *count = r[0];
@@ -2695,6 +2732,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "overlap_micro") g_opt.overlap_micro = value;
     else if (n == "pool") g_opt.pool = value;
     else if (n == "pool_keep") g_opt.pool_keep = value;
+    else if (n == "find3_window") g_opt.find3_window = std::min<int64_t>(1ll << 30, std::max<int64_t>(8192, value));
     else if (n == "workspace_keep") g_opt.workspace_keep = std::max<int64_t>(0, value);
     else if (n == "char_map_lds") g_opt.char_map_lds = value;
     else if (n == "char_row_lds") g_opt.char_row_lds = value;

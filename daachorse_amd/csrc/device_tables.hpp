@@ -283,6 +283,7 @@ struct Find3Args {
     uint32_t off_wave;                   // LDS: the h tables at 0 (tallying passes), the per-wave areas from here
     uint32_t count_only;                 // `.count()`: the selections are counted, their h not looked up
     unsigned long long *result;          // {count, S1, S2} (tallying passes; zeroed by the caller)
+    uint32_t *last_sel;                  // max over the last two tiles of (virtual position of a selection, the restart point included) + 1
     unsigned int *flag;                  // bit 0: some tile's last word differs from the pass before (one more pass); bit 1: a match this engine
                                          // cannot place (longer than 19 bytes, a duplicate's copy); bit 2: a tile that would not settle
     // launched behind DETECT without the host having looked: nothing is done when DETECT's record list overflowed (ctl[0] > chunk_cap),

@@ -54,6 +54,11 @@ __device__ __forceinline__ unsigned long long q_wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
+__device__ __forceinline__ uint32_t q_wave_max(uint32_t v) {   // (all lanes get it)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
 __device__ __forceinline__ void q_copy(void *dst, const void *src, uint32_t bytes) {
     const uint4 *s = reinterpret_cast<const uint4 *>(src);
     uint4 *d = reinterpret_cast<uint4 *>(dst);
@@ -232,6 +237,11 @@ __global__ __launch_bounds__(1024) void find3_select_kernel(const Find3Dev g, co
             }
         }
         if (!TALLY) continue;
+        if (t + 2u >= a.ntiles) {   // where a window behind this one restarts
+            const uint32_t hi = S != 0 ? v0 + lane * 32u + (31u - static_cast<uint32_t>(__builtin_clz(S))) + 1u : 0u;
+            const uint32_t top = q_wave_max(hi);
+            if (lane == 0 && top != 0) atomicMax(a.last_sel, top);
+        }
         // ---- the selected matches ----
         Sp = wave_shr1_q(S, entry);
         const uint32_t A1 = __builtin_amdgcn_alignbit(S, Sp, 31), A2 = __builtin_amdgcn_alignbit(S, Sp, 30);

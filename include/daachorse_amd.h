@@ -328,9 +328,12 @@ void daac_stream_close(daac_stream *s);
  *                 1 = first table set only, 2 = gram2 kernels only, 3 = gram3 for `.count()`), gram2_dpp (1: DPP wave shifts),
  *   gram2_rfull (1)             rank directory with one entry per M word when LDS allows (0: one per four words)
  *   gram3_tail (-1 = every workgroup samples its text and picks; 0 / 1: the plain / the tail-record body of the gram3 kernel)
- *   find3 (1)                   find_iter's count (+ checksum) over a whole haystack of at most 1 GiB by selection over the tuple emitter's per-position
- *                               flags (find3_kernels.hip; Standard bytewise dictionaries with K = 3 tables and no pattern beyond 19 bytes) instead of the
- *                               chain walkers; a handle whose last such request met text made of dictionary words goes back to the walkers (2: never), 0: off
+ *   find3 (1)                   find_iter's count (+ checksum) by selection over the tuple emitter's per-position flags (find3_kernels.hip;
+ *                               Standard bytewise dictionaries with K = 3 tables and no pattern beyond 19 bytes) instead of the chain walkers,
+ *                               in windows of find3_window (2^30) end positions, each restarting at the last match of the one before; a handle
+ *                               whose last such request met text made of dictionary words goes back to the walkers (2: never), 0: off
+ *   workspace_keep (8 GiB)      bytes of scratch (annotated stream, record list: ~2 per haystack byte) a handle keeps between its tuple-emitter
+ *                               and find3 calls instead of asking the pool every time (tools/micro/pool_ops.hip); 0: none
  *   pfx_probe (16384)           AUTO, count (+ checksum) of a dictionary PFX serves: a synchronous scan of a device haystack >= 32 MiB samples
  *                               65 536 positions; where more than this many survive PFX's filter the micro-step walker over the double array
  *                               takes the scan (the verdict stays in the handle for the asynchronous calls); 0 = never ask, always PFX

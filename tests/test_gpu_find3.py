@@ -102,3 +102,50 @@ def test_find3_one_gib_of_cfg3():
         assert got == ref, kind
         pre = dev[:64 << 20]
         assert p.scan_count(ScanMode.Find, pre) == _want(o, pre.cpu().numpy()), kind
+
+
+def test_find3_windows_restart_where_the_last_match_ended():
+    """A haystack beyond one window is scanned window by window, each restarting at the end of the last match the one before selected (or,
+    none near its end, 64 bytes before it).  Windows of 8 KiB .. 1 MiB over texts whose matches straddle every boundary, against the
+    oracle; then 2.5 GiB of cfg3 in the real windows of 1 GiB against the chain walkers."""
+    import torch
+    pats3 = synth.patterns_cfg3(30000)
+    with1 = synth.patterns_cfg3(5000) + [b"a", b"e", b"q"]
+    deepish = [b"abcd", b"bcdefg", b"cdefghijklmnopqrs", b"defg", b"ghij", b"xy", b"yz", b"zab", b"nopqrstuvwxyzabcdef"]
+    cases = [(pats3, synth.uniform_haystack((3 << 20) + 7, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)),
+             (pats3, synth.wordsoup_haystack(2 << 20, synth.SEEDS["cfg3_dense"], pats3, 20)),
+             (with1, synth.wordsoup_haystack(1 << 20, 6, with1, 20)),
+             (deepish, np.frombuffer((b"abcdefghijklmnopqrstuvwxyz" * 40000)[:1000003], dtype=np.uint8)),
+             (deepish, np.frombuffer((b"abcdefghijklmnopqrstuvwxyz" + b"-" * 4000) * 200, dtype=np.uint8)),   # stretches without any match: the 64-byte rule
+             (deepish, synth.uniform_haystack(1 << 20, 9, b"abcdefghijklmnopqrstuvwxyz"))]
+    try:
+        da.set_option("find3", 2)
+        for pats, hay in cases:
+            o, p = _pma(pats)
+            want = _want(o, hay)
+            dev = torch.from_numpy(hay.copy()).cuda()
+            for win in (8192, 8192 + 4096 + 17, 65536, 1 << 20):
+                da.set_option("find3_window", win)
+                assert p.scan_count(ScanMode.Find, dev) == want, (len(pats), len(hay), win)
+                assert da.last_engine() == int(Engine.Gram)
+                assert p.count(ScanMode.Find, dev) == want[0]
+            b = len(hay) // 3
+            da.set_option("find3", 0)
+            ref = p.scan_count(ScanMode.Find, dev, begin=b)
+            da.set_option("find3", 2)
+            da.set_option("find3_window", 100000)
+            assert p.scan_count(ScanMode.Find, dev, begin=b) == ref
+    finally:
+        da.set_option("find3", 1)
+        da.set_option("find3_window", 1 << 30)
+    pats = synth.patterns_cfg3()
+    p = da.DoubleArrayAhoCorasick.new(pats)
+    dev = torch.empty((5 << 29) + 4321, dtype=torch.uint8, device="cuda")
+    synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+    got = p.scan_count(ScanMode.Find, dev)
+    assert da.last_engine() == int(Engine.Gram)
+    da.set_option("find3", 0)
+    try:
+        assert p.scan_count(ScanMode.Find, dev) == got
+    finally:
+        da.set_option("find3", 1)
