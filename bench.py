@@ -79,6 +79,18 @@ def hbm_traffic(workload_key, kernel_filter=None):
         return None, None
 
 
+def hbm_traffic_sum(workload_key, kernel_filters):
+    """A workload served by several kernels in a row (find3: DETECT, BIN, the tails, SELECT): the sum of their bytes per launch.
+    -> (bytes or None, {kernel: bytes})"""
+    path = os.environ.get("DAAC_HBM_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        kernels = json.load(open(path))[workload_key]
+        parts = {k[:48]: v["bytes_per_launch"] for k, v in kernels.items() if any(f in k for f in kernel_filters)}
+        return (sum(parts.values()) if parts else None), parts
+    except Exception:
+        return None, None
+
+
 def emitter_write_ratio(n_tuples, hay_bytes, tuple_bytes=16):
     """HBM bytes the three kernels of the tuple emitter WRITE per launch (WRITE_SIZE of the committed PMC pass over tools/time_emit.py 1024
     sparse: DETECT's annotated stream and records, BIN's bins, EXPAND's tuples) over (tuples + one byte per haystack byte): the bound the
@@ -212,10 +224,15 @@ def restart_legs(da, synth, torch, patterns, local_rank, stream, result, no_cpu,
                 sample = hay[:pn].cpu().numpy()
                 want = getattr(oo, api)(sample)
                 ok = bool(pma.scan_count(mode, sample) == (len(want), orc.matches_checksum(want)))
+            eng = ENGINE_NAMES.get(da.last_engine(), "?")
             tr = hbm_traffic(f"{'find' if kind_name == 'find_iter' else 'leftmost'}_{hk}", "chain")
+            if eng == "gram":   # find3 (find3_kernels.hip): DETECT + BIN of the tuple emitter, the tiles' tails, SELECT — one launch each per GiB
+                tr = hbm_traffic_sum(f"find_{hk}", ("find3_", "emit3_detect", "emit3_bin"))
             out[f"{kind_name}_{hk}"] = {"value": round(n / ms / 1e6, 2), "unit": "GB/s", "frac": round(n / ms / 1e6 / HBM_PEAK_GBS, 4), "kernel_ms": round(ms, 3),
-                                        "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"), "match_count": int(r[0]),
+                                        "engine_used": eng, "match_count": int(r[0]),
                                         "matches_per_byte": round(int(r[0]) / n, 4), "traffic": tr[0], "parity_16mib_prefix_vs_oracle": ok}
+            if eng == "gram":
+                out[f"{kind_name}_{hk}"]["method"] = "find3: selection over the emitter's per-position flags, no state chain (the chain walkers serve text made of dictionary words)"
         del pma
     del hay
     torch.cuda.empty_cache()

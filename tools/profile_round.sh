@@ -47,7 +47,7 @@ profile cfg3_dense_count     "gram3_kernel" 2 $B --haystack dense
 profile cfg2_count           "gram3_kernel" 2 $B --workload cfg2 --bytes 1073741824
 profile emit                 "emit3_detect_kernel,emit3_bin_kernel,emit3_expand_kernel" 2 python $R/tools/time_emit.py 1024 sparse 3
 profile emit_dense           "emit3_detect_kernel,emit3_bin_kernel,emit3_expand_kernel" 2 python $R/tools/time_emit.py 512 dense 3
-profile find_sparse          "chain,restart" 0 python $R/tools/time_find.py 1024 sparse find
+profile find_sparse          "find3_,emit3_detect,emit3_bin,chain,restart" 0 python $R/tools/time_find.py 1024 sparse find
 profile find_dense           "chain,restart" 0 python $R/tools/time_find.py 1024 dense find
 profile leftmost_sparse      "chain,restart" 0 python $R/tools/time_find.py 1024 sparse leftmost
 profile leftmost_dense       "chain,restart" 0 python $R/tools/time_find.py 1024 dense leftmost
