@@ -65,6 +65,7 @@ struct Options {
     std::atomic<int64_t> overlap_micro{1};      // counts of overlapping scans outside GRAM: 1 micro-step walker (charwise, DARRAY), 2 also instead of TIERED, 0 off
     std::atomic<int64_t> pool{1};               // scratch / result buffers from the stream-ordered pool
     std::atomic<int64_t> pool_keep{0};          // bytes the pool keeps between calls (0 = auto)
+    std::atomic<int64_t> left3{1};                    // leftmost_find_iter's count (+ checksum) through left3_kernels.hip (as find3: 2 = whatever the text, 0 = off)
     std::atomic<int64_t> find3_window{1ll << 30};     // find3: end positions per window (tests: small windows = many restarts)
     std::atomic<int64_t> workspace_keep{8ll << 30};   // bytes of scratch a handle may keep for its emitter / find3 calls (0: none)
     std::atomic<int64_t> char_map_lds{1};
@@ -141,6 +142,49 @@ struct DevBuf {  // scratch that lives as long as the call
     hipError_t alloc(size_t bytes, hipStream_t stream) { s = stream; return dev_malloc(&p, bytes, stream); }
 };
 
+// The patterns a bytewise automaton of either kind was built from, read back from its trie (goto edges of the double array, bytewise.rs:1070-1077)
+// with their values: a state's own pattern is the output as long as the state is deep.  (LeftmostFirst: the builder never inserted what lies
+// below an earlier-registered pattern, nfa_builder.rs:60-66 — what is read back is what can be reported.)  false: not a tree / "" / too large.
+static bool recover_patterns(const HostPma &p, std::vector<uint8_t> &blob, std::vector<uint64_t> &offs, std::vector<uint32_t> &vals) {
+    const uint32_t n = static_cast<uint32_t>(p.states_len());
+    if (n == 0 || output_pos_of(p.opos_ch(kRoot)) != 0) return false;
+    constexpr uint32_t kNone = 0xffffffffu;
+    std::vector<uint32_t> depth(n, kNone), parent(n, kNone), order{kRoot};
+    std::vector<uint8_t> label(n, 0);
+    depth[kRoot] = 0;
+    for (size_t qi = 0; qi < order.size(); ++qi) {
+        const uint32_t s = order[qi], base = p.base(s);
+        if (base == 0) continue;
+        for (uint32_t c = 0; c < 256; ++c) {
+            const uint32_t t = base ^ c;
+            if (t >= n || t == kRoot || t == kDead || check_of(p.opos_ch(t)) != c) continue;
+            if (depth[t] != kNone) return false;
+            depth[t] = depth[s] + 1; parent[t] = s; label[t] = static_cast<uint8_t>(c);
+            order.push_back(t);
+        }
+    }
+    blob.clear(); offs.assign(1, 0); vals.clear();
+    std::vector<uint8_t> tmp;
+    for (const uint32_t s : order) {
+        if (s == kRoot) continue;
+        uint32_t op = output_pos_of(p.opos_ch(s));
+        bool own = false; uint32_t value = 0;
+        for (int hops = 0; op != 0 && hops < 4 && op - 1 < p.outputs.size(); ++hops) {
+            if (p.outputs[op - 1].length == depth[s]) { own = true; value = p.outputs[op - 1].value; break; }
+            if (p.outputs[op - 1].length < depth[s]) break;
+            op = p.outputs[op - 1].parent;
+        }
+        if (!own) continue;
+        tmp.clear();
+        for (uint32_t x = s; x != kRoot; x = parent[x]) tmp.push_back(label[x]);
+        blob.insert(blob.end(), tmp.rbegin(), tmp.rend());
+        offs.push_back(blob.size());
+        vals.push_back(value);
+        if (blob.size() >= (1ull << 31)) return false;
+    }
+    return !vals.empty();
+}
+
 // hit records with the first child beside them: one request instead of a dependent second one
 static std::vector<U32x4> zip_first_child(const std::vector<U32x2> &hit, const std::vector<uint32_t> &first) {
     std::vector<U32x4> out(hit.size());
@@ -174,6 +218,7 @@ struct DeviceTables {
     std::atomic<int> pfx_dense{-1};  // the last probe's verdict on the text (scan_count_impl): 1 = most positions survive the filter
     bool find3_ok = false;         // find_iter's count / checksum without a state chain (find3_kernels.hip): K = 3, no pattern beyond 19 bytes
     Find3Dev find3{};
+    bool left3_ok = false;         // a leftmost handle whose patterns, as a Standard automaton, got the emitter's and find3's tables: left3_kernels.hip serves leftmost_find_iter
     std::atomic<uint32_t> find3_gave_up{0};
     std::atomic<uint32_t> find3_skips{0};
     std::atomic<uint32_t> find3_rec_per_kib{0};   // deep matches per KiB the last find3 request met, + 1 (0: none yet): text made of the dictionary's
@@ -534,12 +579,24 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             t->tier_host_meta = tt;
         }
     }
-    // GRAM engine, second table set: built from the automaton itself
+    // GRAM engine, second table set: built from the automaton itself.  A leftmost handle gets the tables of a Standard automaton of ITS
+    // patterns (read back from its trie) — not for any Standard scan (its kind forbids them) but for left3_kernels.hip, which selects
+    // leftmost_find_iter's matches among the ones the emitter's detection finds.
+    HostPma shadow;
+    bool have_shadow = false;
+    if (!h.is_standard() && g_opt.left3.load() != 0 && !pma->root_has_output()) {
+        std::vector<uint8_t> blob; std::vector<uint64_t> offs; std::vector<uint32_t> vals;
+        if (recover_patterns(h, blob, offs, vals) &&
+            build_bytewise(blob.data(), offs.data(), vals.data(), vals.size(), DAAC_STANDARD, 16, shadow) == DAAC_OK) {
+            have_shadow = true;
+        }
+    }
+    const HostPma &hg2 = have_shadow ? shadow : h;
     {
         Gram2Tables g2;
         const uint32_t ring_bytes = 16u * 128u * 8u;  // one 128-entry x 8-byte hit ring per wave of a 1024-thread workgroup
         const int64_t budget = g_opt.gram_lds_budget.load() - static_cast<int64_t>(ring_bytes);
-        if (budget > 0 && build_gram2_tables(h, static_cast<uint32_t>(budget), g2)) {
+        if (budget > 0 && build_gram2_tables(hg2, static_cast<uint32_t>(budget), g2)) {
             Gram2Dev &d = t->gram2;
             auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
             const U32x4 *drec; const U32x2 *dhit;
@@ -678,6 +735,10 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 t->emit3_ok = t->emit3_ok && emit3_expand_lds_bytes(e, 4, false, false) <= 64u * 1024u && emit3_expand_lds_bytes(e, 8, true, false) <= 80u * 1024u && g2.max_len < (1u << 22);
                 for (uint32_t w : g2.me) t->emit3_has_len1 = t->emit3_has_len1 || ((w >> 29) & 1u) != 0;
                 t->find3_ok = t->find3_ok && t->emit3_ok && find3_lds_bytes(t->find3, true) <= 160u * 1024u;
+                if (have_shadow) {   // (nothing Standard is ever asked of a leftmost handle; said explicitly all the same)
+                    t->left3_ok = t->find3_ok && left3_lds_bytes(t->find3, true) <= 160u * 1024u;
+                    t->find3_ok = false;
+                }
             }
         }
     }
@@ -1255,18 +1316,20 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
 // returned).  r = {count, S1, S2} of the window; *next_begin = where a window behind this one restarts: the end of the last match
 // selected here, or — none within the last two tiles — 64 bytes before the end (no match ends in between, and the longest pattern is
 // shorter: the restart changes nothing).
+// `leftmost`: the handle is a leftmost one and the selection is left3_kernels.hip's (by starts; begin = the first start that counts).
 static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t len, hipStream_t stream,
-                                      bool want_checksum, unsigned long long r[3], uint64_t *next_begin, bool *served) {
+                                      bool want_checksum, bool leftmost, unsigned long long r[3], uint64_t *next_begin, bool *served) {
     *served = false;
+    const int64_t optv = leftmost ? g_opt.left3.load() : g_opt.find3.load();
     // (DAAC_DEBUG_TIMING=1: the stream is waited for at every lap — kernel times; =2: host time between the laps as the call really runs)
     const char *dbg_env = std::getenv("DAAC_DEBUG_TIMING");
     const bool dbg_sync = dbg_env && dbg_env[0] == '1';
     auto lap = [&](const char *what) { if (dbg_env) { if (dbg_sync) (void)hipStreamSynchronize(stream); dbg_mark(what); } };
-    if (!t->find3_ok || g_opt.find3.load() == 0 || len <= begin || len - begin > (1ull << 30)) return DAAC_OK;
+    if (!(leftmost ? t->left3_ok : t->find3_ok) || optv == 0 || len <= begin || len - begin > (1ull << 30)) return DAAC_OK;
     if (t->find3_gave_up.load() >= 2 && len - begin >= (1u << 20)) return DAAC_OK;
     // (option find3 = 2: whatever the text)
     const uint32_t kDenseRecPerKib = 26;
-    if (g_opt.find3.load() < 2 && t->find3_rec_per_kib.load() > kDenseRecPerKib + 1 && len - begin >= (1u << 20) &&
+    if (optv < 2 && t->find3_rec_per_kib.load() > kDenseRecPerKib + 1 && len - begin >= (1u << 20) &&
         (t->find3_skips.fetch_add(1) & 15u) != 15u)   // (every sixteenth such request looks again: the text may have changed)
         return DAAC_OK;
     const Gram2EmitDev &e = t->emit;
@@ -1312,7 +1375,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
     // behind it — without the host looking in between — BIN, the tiles' tails and the first SELECT pass; those do nothing when the list
     // overflowed or holds more than the chain walkers' text would (find3_detect_usable) ----
     const uint64_t kib = (len - begin) / 1024 + 1;
-    const bool gate = g_opt.find3.load() < 2 && len - begin >= (1u << 20);
+    const bool gate = optv < 2 && len - begin >= (1u << 20);
     const unsigned long long rec_gate = gate ? static_cast<unsigned long long>(kib) * (kDenseRecPerKib + 1) : ~0ull;
     Find3Args f{};
     f.ann = d_ann; f.ntiles = nsteps; f.n1k = n1k;
@@ -1322,6 +1385,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
     f.result = reinterpret_cast<unsigned long long *>(d_ctl + 4);   // d_ctl: {chunks, DETECT's failure, flag, last selection + 1, - count, S1, S2 -}
     f.flag = d_ctl + 2;
     f.last_sel = d_ctl + 3;
+    f.first_start = emit_from;
     f.ctl = d_ctl;
     f.count_only = want_checksum ? 0u : 1u;
     const uint32_t sblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (nsteps + 15) / 16)));
@@ -1360,10 +1424,12 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
         f.binned = static_cast<const uint4 *>(g_bins_p);
         f.chunk_cap = static_cast<uint32_t>(chunk_cap); f.rec_limit = rec_limit;
         f.entry_in = nullptr; f.exit_out = d_ex[0]; f.off_wave = 0;
-        HIP_TRY(launch_find3_tail(f, t->emit3_has_len1, tblocks, stream));
+        if (leftmost) HIP_TRY(launch_left3_select(t->find3, f, t->emit3_has_len1, false, sblocks, stream));   // pass A: every tile as if nothing reached into it
+        else HIP_TRY(launch_find3_tail(f, t->emit3_has_len1, tblocks, stream));
         f.off_wave = lds_tables;
         f.entry_in = d_ex[0]; f.exit_out = d_ex[1];
-        HIP_TRY(launch_find3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
+        if (leftmost) HIP_TRY(launch_left3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
+        else HIP_TRY(launch_find3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
         {
             unsigned long long *pin = reinterpret_cast<unsigned long long *>(pinned_words());
             HIP_TRY(hipMemcpyAsync(pin ? pin : &deep_total, d_b + n1k, 8, hipMemcpyDeviceToHost, stream));
@@ -1391,7 +1457,8 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
         if (pass == 5) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }   // (chains that will not fall in step: the walkers' business)
         HIP_TRY(hipMemsetAsync(d_ctl + 2, 0, 32, stream));   // flag, last selection, the three sums
         f.entry_in = d_ex[(pass & 1) ^ 1]; f.exit_out = d_ex[pass & 1];
-        HIP_TRY(launch_find3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
+        if (leftmost) HIP_TRY(launch_left3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
+        else HIP_TRY(launch_find3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
         unsigned int *pin = pinned_words();
         HIP_TRY(hipMemcpyAsync(pin ? pin : &ctl[2], d_ctl + 2, 32, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1409,16 +1476,17 @@ __global__ void set_result_kernel(unsigned long long *res, unsigned long long c,
 // The request in windows of 1 GiB of end positions, each restarting where the one before it selected its last match; the sums are left in
 // d_res {count, S1, S2} (stream order) and in acc.
 daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t len, hipStream_t stream,
-                        unsigned long long *d_res, bool want_checksum, unsigned long long acc[3], bool *served) {
+                        unsigned long long *d_res, bool want_checksum, bool leftmost, unsigned long long acc[3], bool *served) {
     *served = false;
     acc[0] = acc[1] = acc[2] = 0;
-    const uint64_t kWin = static_cast<uint64_t>(g_opt.find3_window.load());
+    const uint64_t kWin = leftmost ? (1ull << 30) : static_cast<uint64_t>(g_opt.find3_window.load());
+    if (leftmost && len - begin > kWin) return DAAC_OK;   // (one window: the leftmost iterators' windows are not chained yet)
     for (uint64_t cur = begin;;) {
         const uint64_t wend = std::min<uint64_t>(len, cur + kWin);
         unsigned long long r[3] = {0, 0, 0};
         uint64_t next = wend;
         bool ok = false;
-        const daac_status st = find_count3_window(pma, t, dev_hay, cur, wend, stream, want_checksum, r, &next, &ok);
+        const daac_status st = find_count3_window(pma, t, dev_hay, cur, wend, stream, want_checksum, leftmost, r, &next, &ok);
         if (st != DAAC_OK || !ok) return st;
         for (int k = 0; k < 3; ++k) acc[k] += r[k];
         if (wend >= len) break;
@@ -1924,8 +1992,9 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     bool find3_served = false;
     unsigned long long find3_sums[3] = {0, 0, 0};
     dbg_mark("count: plan made");
-    if (mode == DAAC_FIND && !pma->charwise && pma->host.is_standard() && engine == DAAC_ENGINE_AUTO && !pma->root_has_output() && len != begin) {
-        if ((st = find_count3(pma, t, dev_hay, begin, len, stream, d_res, want_checksum, find3_sums, &find3_served)) != DAAC_OK) return st;
+    if (!pma->charwise && engine == DAAC_ENGINE_AUTO && !pma->root_has_output() && len != begin &&
+        ((mode == DAAC_FIND && pma->host.is_standard()) || (mode == DAAC_LEFTMOST_FIND && !pma->host.is_standard()))) {
+        if ((st = find_count3(pma, t, dev_hay, begin, len, stream, d_res, want_checksum, mode == DAAC_LEFTMOST_FIND, find3_sums, &find3_served)) != DAAC_OK) return st;
     }
     dbg_mark("count: find3 back");
     ChainBuffers chain_buffers;
@@ -2719,6 +2788,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "pfx") g_opt.pfx = value;
     else if (n == "pfx_probe") g_opt.pfx_probe = value;
     else if (n == "find3") g_opt.find3 = value;
+    else if (n == "left3") g_opt.left3 = value;
     else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles" || n == "emit_rec_cap" || n == "emit_version") {}   // (options of the round-3 COUNT + WRITE emitter: accepted, nothing left to steer)

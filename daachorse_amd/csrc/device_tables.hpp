@@ -264,6 +264,7 @@ uint32_t emit3_expand_lds_bytes(const Gram2EmitDev &dev, uint32_t waves, bool f1
 // find_iter without a state chain (find3_kernels.hip): SELECT over the emitter's annotated stream and binned records.
 constexpr uint32_t kFind3Tile = 2048;                  // positions a wave takes at a time (32 per lane)
 constexpr uint32_t kFind3Deep = 255;                   // deep selections a tile's list holds
+constexpr uint32_t kLeft3Wave = 2080 + 4096 + 1024 + 256 + 288;   // left3_kernels.hip: 16 more stream bytes (the tile after), 65 words of cover bits
 constexpr uint32_t kFind3Wave = 2064 + 4096 + 1024 + 256;   // per wave in LDS: 16 + 2048 stream bytes | 2048 x u16 length bits (then the staged positions) | the list of deep selections | per lane: positions with deep matches
 struct Find3Dev {
     const uint32_t *h1, *h2;  // h32 of the pattern that IS the 1- / 2-gram of classes (layout of Gram2EmitDev::v1 / v2)
@@ -283,6 +284,7 @@ struct Find3Args {
     uint32_t off_wave;                   // LDS: the h tables at 0 (tallying passes), the per-wave areas from here
     uint32_t count_only;                 // `.count()`: the selections are counted, their h not looked up
     unsigned long long *result;          // {count, S1, S2} (tallying passes; zeroed by the caller)
+    uint32_t first_start;                // left3: virtual position of the first START that counts (the restart point)
     uint32_t *last_sel;                  // max over the last two tiles of (virtual position of a selection, the restart point included) + 1
     unsigned int *flag;                  // bit 0: some tile's last word differs from the pass before (one more pass); bit 1: a match this engine
                                          // cannot place (longer than 19 bytes, a duplicate's copy); bit 2: a tile that would not settle
@@ -298,6 +300,9 @@ __device__ __forceinline__ bool find3_detect_usable(const Find3Args &a) {
 uint32_t find3_lds_bytes(const Find3Dev &dev, bool tally);
 hipError_t launch_find3_select(const Find3Dev &dev, const Find3Args &a, bool has_len1, bool tally, uint32_t blocks, hipStream_t stream);
 hipError_t launch_find3_tail(const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream);
+// leftmost_find_iter likewise (left3_kernels.hip): exit_out / entry_in hold, per tile, how many positions of the NEXT tile lie under its last match
+uint32_t left3_lds_bytes(const Find3Dev &dev, bool tally);
+hipError_t launch_left3_select(const Find3Dev &dev, const Find3Args &a, bool has_len1, bool tally, uint32_t blocks, hipStream_t stream);
 
 struct PfxDev {
     const uint32_t *bloom;   // bloom_words words
