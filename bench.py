@@ -226,13 +226,13 @@ def restart_legs(da, synth, torch, patterns, local_rank, stream, result, no_cpu,
                 ok = bool(pma.scan_count(mode, sample) == (len(want), orc.matches_checksum(want)))
             eng = ENGINE_NAMES.get(da.last_engine(), "?")
             tr = hbm_traffic(f"{'find' if kind_name == 'find_iter' else 'leftmost'}_{hk}", "chain")
-            if eng == "gram":   # find3 (find3_kernels.hip): DETECT + BIN of the tuple emitter, the tiles' tails, SELECT — one launch each per GiB
-                tr = hbm_traffic_sum(f"find_{hk}", ("find3_", "emit3_detect", "emit3_bin"))
+            if eng == "gram":   # find3 / left3: DETECT + BIN of the tuple emitter, the tiles' tails, SELECT — one launch each per GiB
+                tr = hbm_traffic_sum(f"{'find' if kind_name == 'find_iter' else 'leftmost'}_{hk}", ("find3_", "left3_", "emit3_detect", "emit3_bin"))
             out[f"{kind_name}_{hk}"] = {"value": round(n / ms / 1e6, 2), "unit": "GB/s", "frac": round(n / ms / 1e6 / HBM_PEAK_GBS, 4), "kernel_ms": round(ms, 3),
                                         "engine_used": eng, "match_count": int(r[0]),
                                         "matches_per_byte": round(int(r[0]) / n, 4), "traffic": tr[0], "parity_16mib_prefix_vs_oracle": ok}
             if eng == "gram":
-                out[f"{kind_name}_{hk}"]["method"] = "find3: selection over the emitter's per-position flags, no state chain (the chain walkers serve text made of dictionary words)"
+                out[f"{kind_name}_{hk}"]["method"] = ("find3" if kind_name == "find_iter" else "left3") + ": selection over the emitter's per-position flags, no state chain (the chain walkers serve text made of dictionary words)"
         del pma
     del hay
     torch.cuda.empty_cache()

@@ -1317,7 +1317,9 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
 // selected here, or — none within the last two tiles — 64 bytes before the end (no match ends in between, and the longest pattern is
 // shorter: the restart changes nothing).
 // `leftmost`: the handle is a leftmost one and the selection is left3_kernels.hip's (by starts; begin = the first start that counts).
-static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t len, hipStream_t stream,
+// There the window's matches START in [begin, sel_end) and the detection runs on to `len` (a match may end behind sel_end); *next_begin = the
+// end of the window's last match, at least sel_end.
+static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t len, uint64_t sel_end, hipStream_t stream,
                                       bool want_checksum, bool leftmost, unsigned long long r[3], uint64_t *next_begin, bool *served) {
     *served = false;
     const int64_t optv = leftmost ? g_opt.left3.load() : g_opt.find3.load();
@@ -1386,6 +1388,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
     f.flag = d_ctl + 2;
     f.last_sel = d_ctl + 3;
     f.first_start = emit_from;
+    f.last_start = (leftmost && sel_end < len) ? static_cast<uint32_t>(emit_from + (sel_end - begin)) : 0xffffffffu;
     f.ctl = d_ctl;
     f.count_only = want_checksum ? 0u : 1u;
     const uint32_t sblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (nsteps + 15) / 16)));
@@ -1424,7 +1427,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
         f.binned = static_cast<const uint4 *>(g_bins_p);
         f.chunk_cap = static_cast<uint32_t>(chunk_cap); f.rec_limit = rec_limit;
         f.entry_in = nullptr; f.exit_out = d_ex[0]; f.off_wave = 0;
-        if (leftmost) HIP_TRY(launch_left3_select(t->find3, f, t->emit3_has_len1, false, sblocks, stream));   // pass A: every tile as if nothing reached into it
+        if (leftmost) HIP_TRY(launch_left3_tail(f, t->emit3_has_len1, tblocks, stream));
         else HIP_TRY(launch_find3_tail(f, t->emit3_has_len1, tblocks, stream));
         f.off_wave = lds_tables;
         f.entry_in = d_ex[0]; f.exit_out = d_ex[1];
@@ -1466,7 +1469,8 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
         lap("one more SELECT");
     }
     std::memcpy(r, &ctl[4], 24);
-    *next_begin = ctl[3] != 0 ? f.pos_base + (ctl[3] - 1u) : (len > 64 ? len - 64 : 0);
+    if (leftmost) *next_begin = std::max<uint64_t>(sel_end, ctl[3] != 0 ? f.pos_base - 1u + ctl[3] : 0);
+    else *next_begin = ctl[3] != 0 ? f.pos_base + (ctl[3] - 1u) : (len > 64 ? len - 64 : 0);
     *served = true;
     return DAAC_OK;
 }
@@ -1479,18 +1483,19 @@ daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, 
                         unsigned long long *d_res, bool want_checksum, bool leftmost, unsigned long long acc[3], bool *served) {
     *served = false;
     acc[0] = acc[1] = acc[2] = 0;
-    const uint64_t kWin = leftmost ? (1ull << 30) : static_cast<uint64_t>(g_opt.find3_window.load());
-    if (leftmost && len - begin > kWin) return DAAC_OK;   // (one window: the leftmost iterators' windows are not chained yet)
+    const uint64_t kWin = static_cast<uint64_t>(g_opt.find3_window.load());
     for (uint64_t cur = begin;;) {
-        const uint64_t wend = std::min<uint64_t>(len, cur + kWin);
+        // (leftmost: a window's matches START in it; the detection looks 32 bytes further so that the last ones are whole)
+        const uint64_t wend = len - cur <= kWin ? len : cur + kWin - (leftmost ? 64 : 0);
+        const uint64_t dend = leftmost ? std::min<uint64_t>(len, wend + 32) : wend;
         unsigned long long r[3] = {0, 0, 0};
         uint64_t next = wend;
         bool ok = false;
-        const daac_status st = find_count3_window(pma, t, dev_hay, cur, wend, stream, want_checksum, leftmost, r, &next, &ok);
+        const daac_status st = find_count3_window(pma, t, dev_hay, cur, dend, wend, stream, want_checksum, leftmost, r, &next, &ok);
         if (st != DAAC_OK || !ok) return st;
         for (int k = 0; k < 3; ++k) acc[k] += r[k];
-        if (wend >= len) break;
-        if (next <= cur || next > wend) return DAAC_OK;   // (cannot happen; the walkers then)
+        if (wend >= len || next >= len) break;
+        if (next <= cur || next > dend) return DAAC_OK;   // (cannot happen; the walkers then)
         cur = next;
     }
     hipLaunchKernelGGL(set_result_kernel, dim3(1), dim3(1), 0, stream, d_res, acc[0], acc[1], acc[2]);

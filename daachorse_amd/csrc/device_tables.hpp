@@ -285,6 +285,7 @@ struct Find3Args {
     uint32_t count_only;                 // `.count()`: the selections are counted, their h not looked up
     unsigned long long *result;          // {count, S1, S2} (tallying passes; zeroed by the caller)
     uint32_t first_start;                // left3: virtual position of the first START that counts (the restart point)
+    uint32_t last_start;                 // left3: virtual position of the first start that no longer counts (the next window's)
     uint32_t *last_sel;                  // max over the last two tiles of (virtual position of a selection, the restart point included) + 1
     unsigned int *flag;                  // bit 0: some tile's last word differs from the pass before (one more pass); bit 1: a match this engine
                                          // cannot place (longer than 19 bytes, a duplicate's copy); bit 2: a tile that would not settle
@@ -302,6 +303,7 @@ hipError_t launch_find3_select(const Find3Dev &dev, const Find3Args &a, bool has
 hipError_t launch_find3_tail(const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream);
 // leftmost_find_iter likewise (left3_kernels.hip): exit_out / entry_in hold, per tile, how many positions of the NEXT tile lie under its last match
 uint32_t left3_lds_bytes(const Find3Dev &dev, bool tally);
+hipError_t launch_left3_tail(const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream);
 hipError_t launch_left3_select(const Find3Dev &dev, const Find3Args &a, bool has_len1, bool tally, uint32_t blocks, hipStream_t stream);
 
 struct PfxDev {

@@ -172,6 +172,8 @@ __global__ __launch_bounds__(1024) void left3_select_kernel(const Find3Dev g, co
             const uint32_t base = v0 + lane * 32u;
             if (a.first_start >= base + 32u) C0 = 0xffffffffu;
             else if (a.first_start > base) C0 = (1u << (a.first_start - base)) - 1u;
+            if (a.last_start <= base) C0 = 0xffffffffu;                                          // starts from here on belong to the window behind this one
+            else if (a.last_start < base + 32u) C0 |= ~((1u << (a.last_start - base)) - 1u);
             const uint32_t c_in = t == 0 ? 0u : (a.entry_in ? a.entry_in[t - 1u] : 0u);
             if (lane == 0) C0 |= (1u << (c_in < 31u ? c_in : 31u)) - 1u;
         }
@@ -228,6 +230,9 @@ __global__ __launch_bounds__(1024) void left3_select_kernel(const Find3Dev g, co
             }
             const uint32_t top = l_wave_max(endrel);
             const uint32_t c_out = top > kFind3Tile ? top - kFind3Tile : 0u;
+            // the window's last match ends here (virtual position behind its last byte): one of the last two tiles' business, or nobody's —
+            // then the next window restarts at its own first start (one atomic per TILE on one address made this kernel twice as slow)
+            if (TALLY && lane == 0 && top != 0 && t + 2u >= a.ntiles) atomicMax(a.last_sel, v0 + top);
             if (lane == 0) {
                 if (a.entry_in && a.entry_in[t] != c_out) atomicOr(a.flag, 1u);
                 a.exit_out[t] = c_out;
@@ -332,6 +337,132 @@ __global__ __launch_bounds__(1024) void left3_select_kernel(const Find3Dev g, co
             atomicAdd(a.result + 2, x2);
         }
     }
+}
+
+// Pass A: the last 128 starts of every tile (four lanes a tile, sixteen tiles a wave), solved as if nothing reached into them; leaves how far
+// the tile's last match reaches into the next tile — right whenever the tile's chain of matches falls in step within its last 128 positions
+// (pass B checks).  Same masks, same relaxation as above, within groups of four lanes.
+template <bool HAS1>
+__global__ __launch_bounds__(256) void left3_tail_kernel(const Find3Args a) {
+    __shared__ __attribute__((aligned(16))) uint32_t dm_all[4][16 * 64];   // per wave, per group of four lanes: 128 x u16 length bits by start
+    __shared__ uint32_t cov_all[4][16 * 8];                                // per group: cover words of its four lanes (+ 1)
+    if (!find3_detect_usable(a)) return;
+    const uint32_t lane = threadIdx.x & 63, li = lane & 3u, grp = lane >> 2;
+    const uint32_t wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t wave_global = blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    uint32_t *dm32 = &dm_all[wave_in_wg][grp * 64u];
+    const uint16_t *dm16 = reinterpret_cast<const uint16_t *>(dm32);
+    uint32_t *covm = &cov_all[wave_in_wg][grp * 8u];
+    for (uint32_t t0 = wave_global * 16u; t0 < a.ntiles; t0 += nwaves * 16u) {
+        const uint32_t t = t0 + grp;
+        const bool live = t < a.ntiles;
+        const uint32_t tt = live ? t : a.ntiles - 1u;
+        const uint32_t tail0 = tt * kFind3Tile + (kFind3Tile - 128u);   // first start of the tile's tail
+        const uint32_t p0 = tail0 + li * 32u;
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(a.ann + p0), q1 = *reinterpret_cast<const uint4 *>(a.ann + p0 + 16u);
+        const uint32_t qn = tt + 1u < a.ntiles ? *reinterpret_cast<const uint32_t *>(a.ann + tail0 + 128u) : 0u;
+        const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        uint32_t P1 = 0, P2 = 0, P3 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (HAS1) P1 |= l_nib(w[k] >> 5) << (4 * k);
+            P2 |= l_nib(w[k] >> 6) << (4 * k);
+            P3 |= l_nib(w[k] >> 7) << (4 * k);
+        }
+        uint32_t P2n = l_wave_shl1(P2, 0u), P3n = l_wave_shl1(P3, 0u);
+        if (li == 3u) { P2n = l_nib(qn >> 6); P3n = l_nib(qn >> 7); }
+        const uint32_t H1 = P1, H2 = (P2 >> 1) | (P2n << 31), H3 = (P3 >> 2) | (P3n << 30);
+        // the deep matches that start in the tail end in the tile's second half or just behind it
+        const uint32_t i1k = 2u * tt + 1u;
+        const unsigned long long b0 = a.bin_off[i1k < a.n1k ? i1k : a.n1k], b1 = a.bin_off[i1k + 2u < a.n1k ? i1k + 2u : a.n1k];
+        const uint32_t n = live ? static_cast<uint32_t>(b1 - b0) : 0u;
+        *reinterpret_cast<uint4 *>(dm32 + li * 16u) = uint4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<uint4 *>(dm32 + li * 16u + 4u) = uint4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<uint4 *>(dm32 + li * 16u + 8u) = uint4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<uint4 *>(dm32 + li * 16u + 12u) = uint4{0u, 0u, 0u, 0u};
+        for (uint32_t i = li; __any(i < n); i += 4u) {
+            if (i < n) {
+                const uint4 r = a.binned[b0 + i];
+                const uint32_t len = r.y & 0xffffffu, p = r.x + 1u - len - tail0, lb = len - 4u;
+                if (p < 128u && (r.y >> 24) == 0u) {
+                    if (lb < 16u) atomicOr(&dm32[p >> 1], 1u << (lb + 16u * (p & 1u)));
+                    else atomicOr(a.flag, 2u);
+                }
+            }
+        }
+        uint32_t D = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 d = *reinterpret_cast<const uint4 *>(dm32 + li * 16u + 4u * q);
+            const uint32_t dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) D |= (((dw[k] & 0xffffu) != 0u ? 1u : 0u) | ((dw[k] >> 16) != 0u ? 2u : 0u)) << (8 * q + 2 * k);
+        }
+        const uint32_t NZ = H1 | H2 | H3 | D, G2 = H2 | H3 | D, G3 = H3 | D;
+        uint32_t C0 = 0;
+        if (a.first_start >= p0 + 32u) C0 = 0xffffffffu;
+        else if (a.first_start > p0) C0 = (1u << (a.first_start - p0)) - 1u;
+        if (a.last_start <= p0) C0 = 0xffffffffu;
+        else if (a.last_start < p0 + 32u) C0 |= ~((1u << (a.last_start - p0)) - 1u);
+        const bool wave_deep = __any(D != 0);
+        auto deep_cover = [&](uint32_t S) -> uint32_t {
+            covm[li + 1u] = 0u;
+            if (li == 0) covm[0] = 0u;
+            uint32_t own = 0, m = S & D;
+            while (m != 0) {
+                const uint32_t i = static_cast<uint32_t>(__builtin_ctz(m));
+                m &= m - 1u;
+                const uint32_t L = 4u + 31u - static_cast<uint32_t>(__builtin_clz(static_cast<uint32_t>(dm16[li * 32u + i])));
+                const unsigned long long m64 = ((1ull << (L - 1u)) - 1ull) << (i + 1u);
+                own |= static_cast<uint32_t>(m64);
+                const uint32_t hi = static_cast<uint32_t>(m64 >> 32);
+                if (hi != 0) atomicOr(&covm[li + 1u], hi);
+            }
+            return own | covm[li];
+        };
+        uint32_t S = NZ & ~C0, Cd = 0;
+        bool settled = false;
+        for (uint32_t outer = 0; outer < 40u && !settled; ++outer) {
+            bool inner_ok = false;
+            for (uint32_t it = 0; it < 128u; ++it) {
+                const uint32_t SG2 = S & G2, SG3 = S & G3;
+                uint32_t p2 = l_wave_shr1(SG2, 0u), p3 = l_wave_shr1(SG3, 0u);
+                if (li == 0) { p2 = 0u; p3 = 0u; }
+                const uint32_t C1 = __builtin_amdgcn_alignbit(SG2, p2, 31), C2 = __builtin_amdgcn_alignbit(SG3, p3, 30);
+                const uint32_t Sn = NZ & ~(C0 | C1 | C2 | Cd);
+                const bool moved = __any(Sn != S);
+                S = Sn;
+                if (!moved) { inner_ok = true; break; }
+            }
+            if (!inner_ok) break;
+            if (!wave_deep) { settled = true; break; }
+            const uint32_t Cd2 = deep_cover(S);
+            if (!__any(Cd2 != Cd)) settled = true;
+            Cd = Cd2;
+        }
+        if (!settled) {
+            if (lane == 0) atomicOr(a.flag, 4u);
+            continue;
+        }
+        uint32_t endrel = 0;
+        if (S != 0) {
+            const uint32_t i = 31u - static_cast<uint32_t>(__builtin_clz(S));
+            const uint32_t bit = 1u << i;
+            uint32_t L = (H3 & bit) ? 3u : (H2 & bit) ? 2u : 1u;
+            if (D & bit) L = 4u + 31u - static_cast<uint32_t>(__builtin_clz(static_cast<uint32_t>(dm16[li * 32u + i])));
+            endrel = li * 32u + i + L;
+        }
+        { const uint32_t o = __shfl_xor(endrel, 1, 64); endrel = o > endrel ? o : endrel; }
+        { const uint32_t o = __shfl_xor(endrel, 2, 64); endrel = o > endrel ? o : endrel; }
+        if (live && li == 3u) a.exit_out[t] = endrel > 128u ? endrel - 128u : 0u;
+    }
+}
+
+hipError_t launch_left3_tail(const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream) {
+    if (has_len1) hipLaunchKernelGGL(left3_tail_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(left3_tail_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 uint32_t left3_lds_bytes(const Find3Dev &dev, bool tally) { return (tally ? dev.h1_bytes + dev.h2_bytes + dev.h3c_bytes : 0u) + 16u * kLeft3Wave; }

@@ -99,3 +99,45 @@ def test_left3_one_gib_of_cfg3():
         assert got == ref, kind
         pre = dev[:64 << 20]
         assert p.scan_count(ScanMode.LeftmostFind, pre) == _want(o, pre.cpu().numpy()), kind
+
+
+def test_left3_windows_restart_where_the_last_match_ended():
+    """A haystack beyond one window: a window's matches START in it (the detection looks 32 bytes further), the next one restarts at the end of
+    its last match.  Windows of 8 KiB .. 1 MiB against the oracle, both kinds; then 2.5 GiB of cfg3 in the real windows against the walkers."""
+    import torch
+    pats3 = synth.patterns_cfg3(30000)
+    with1 = synth.patterns_cfg3(5000) + [b"a", b"e", b"q"]
+    deepish = [b"abcd", b"bcdefg", b"cdefghijklmnopqrs", b"defg", b"ghij", b"xy", b"yz", b"zab", b"nopqrstuvwxyzabcdef", b"ab", b"abc"]
+    cases = [(pats3, synth.uniform_haystack((3 << 20) + 7, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)),
+             (pats3, synth.wordsoup_haystack(2 << 20, synth.SEEDS["cfg3_dense"], pats3, 20)),
+             (with1, synth.wordsoup_haystack(1 << 20, 6, with1, 20)),
+             (deepish, np.frombuffer((b"abcdefghijklmnopqrstuvwxyz" * 40000)[:1000003], dtype=np.uint8)),
+             (deepish, np.frombuffer((b"abcdefghijklmnopqrstuvwxyz" + b"-" * 4000) * 200, dtype=np.uint8)),
+             (deepish, synth.uniform_haystack(1 << 20, 9, b"abcdefghijklmnopqrstuvwxyz"))]
+    try:
+        da.set_option("left3", 2)
+        for kind_o in (orc.LEFTMOST_LONGEST, orc.LEFTMOST_FIRST):
+            for pats, hay in cases:
+                o, p = _pma(pats, kind_o)
+                want = _want(o, hay)
+                dev = torch.from_numpy(hay.copy()).cuda()
+                for win in (8192, 8192 + 4096 + 17, 65536, 1 << 20):
+                    da.set_option("find3_window", win)
+                    assert p.scan_count(ScanMode.LeftmostFind, dev) == want, (kind_o, len(pats), len(hay), win)
+                    # (the alphabet repeated: more than 255 deep matches selected in a tile — given up, the walkers answer)
+                    assert da.last_engine() == int(Engine.Gram) or (pats is deepish and hay[0] == ord("a") and hay[26] == ord("a"))
+                    assert p.count(ScanMode.LeftmostFind, dev) == want[0]
+    finally:
+        da.set_option("left3", 1)
+        da.set_option("find3_window", 1 << 30)
+    pats = synth.patterns_cfg3()
+    p = da.DoubleArrayAhoCorasickBuilder().match_kind(da.MatchKind.LeftmostLongest).build(pats)
+    dev = torch.empty((5 << 29) + 4321, dtype=torch.uint8, device="cuda")
+    synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+    got = p.scan_count(ScanMode.LeftmostFind, dev)
+    assert da.last_engine() == int(Engine.Gram)
+    da.set_option("left3", 0)
+    try:
+        assert p.scan_count(ScanMode.LeftmostFind, dev) == got
+    finally:
+        da.set_option("left3", 1)

@@ -49,7 +49,7 @@ profile emit                 "emit3_detect_kernel,emit3_bin_kernel,emit3_expand_
 profile emit_dense           "emit3_detect_kernel,emit3_bin_kernel,emit3_expand_kernel" 2 python $R/tools/time_emit.py 512 dense 3
 profile find_sparse          "find3_,emit3_detect,emit3_bin,chain,restart" 0 python $R/tools/time_find.py 1024 sparse find
 profile find_dense           "chain,restart" 0 python $R/tools/time_find.py 1024 dense find
-profile leftmost_sparse      "chain,restart" 0 python $R/tools/time_find.py 1024 sparse leftmost
+profile leftmost_sparse      "left3_,emit3_detect,emit3_bin,chain,restart" 0 python $R/tools/time_find.py 1024 sparse leftmost
 profile leftmost_dense       "chain,restart" 0 python $R/tools/time_find.py 1024 dense leftmost
 profile cfg5_leftmost        "char" 0 python $R/tools/bench_cfg5.py --mode leftmost --cpu-mib 0
 profile cfg5_find            "char" 0 python $R/tools/bench_cfg5.py --mode find --cpu-mib 0
