@@ -1767,8 +1767,12 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
         return;
     }
     const HostPma &h = pma->host;
+    // find3 / left3 serve the restart iterators' count while the handle's last such request did not meet text made of dictionary words
+    const bool select_text_ok = t->find3_gave_up.load() < 2 && t->find3_rec_per_kib.load() <= 27;
     if (!h.is_standard()) {
-        set(DAAC_REQ_LEFTMOST_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);
+        if (t->left3_ok && g_opt.left3.load() != 0 && !pma->root_has_output() && (select_text_ok || g_opt.left3.load() >= 2))
+            set(DAAC_REQ_LEFTMOST_FIND, DAAC_ENGINE_GRAM, DAAC_KERNEL_SELECT, DAAC_WHY_FASTEST);
+        else set(DAAC_REQ_LEFTMOST_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);
         return;
     }
     // why the byte-class tables were declined, as far as it is known
@@ -1795,7 +1799,9 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
         set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, why_no_gram);
     else set(DAAC_REQ_OVERLAPPING_TUPLES, seg_engine, DAAC_KERNEL_SEGMENT, t->gram2_ok ? DAAC_WHY_DUPLICATES : why_no_gram);
     set(DAAC_REQ_NO_SUFFIX, seg_engine, DAAC_KERNEL_SEGMENT, DAAC_WHY_FASTEST);
-    set(DAAC_REQ_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);  // (the restart iterators run on the double array)
+    if (t->find3_ok && g_opt.find3.load() != 0 && !pma->root_has_output() && (select_text_ok || g_opt.find3.load() >= 2))
+        set(DAAC_REQ_FIND, DAAC_ENGINE_GRAM, DAAC_KERNEL_SELECT, DAAC_WHY_FASTEST);
+    else set(DAAC_REQ_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);  // (the restart iterators run on the double array)
 }
 
 daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
@@ -1873,7 +1879,8 @@ size_t daac_pma_explain(const daac_pma *pma, char *buf, size_t cap) {
     static const char *eng[] = {"auto", "tiered", "darray", "gram", "pfx"};
     static const char *ker[] = {"- (the crate panics: wrong MatchKind)", "gram3 count kernel (one LDS lookup per byte)", "gram count + checksum kernel",
                                 "gram wide-alphabet kernel (31-62 byte classes)", "gram tuple emitter", "pfx (hashed prefix filter + start-anchored walks, any alphabet)",
-                                "segment scanners (one lane per segment)", "micro-step walker over the double array", "chain walkers (speculate / reconcile / emit)"};
+                                "segment scanners (one lane per segment)", "micro-step walker over the double array", "chain walkers (speculate / reconcile / emit)",
+                                "selection over the tuple emitter's detection (find3 / left3: no state chain)"};
     static const char *why[] = {"", "not uploaded yet", "more distinct pattern bytes than the byte-class tables take", "tables do not fit the LDS",
                                 "\"\" is a pattern", "duplicate patterns the tables cannot encode", "the iterator is a chain through its own matches",
                                 "charwise automaton", "trie shape / table limits"};

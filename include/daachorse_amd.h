@@ -109,7 +109,10 @@ typedef enum {
                                   * wide look-alikes; tuples through pfx_emit_kernel + EXPAND: 0.02 - 0.36 TB/s of haystack */
     DAAC_KERNEL_SEGMENT = 6,     /* scan_kernels.hip: one lane per segment, TIERED or DARRAY tables             (0.03 - 0.4 TB/s) */
     DAAC_KERNEL_MICRO = 7,       /* chain_scan.hpp overlap_count_body: micro-step walker over the double array  (0.08 - 0.4 TB/s) */
-    DAAC_KERNEL_CHAIN = 8        /* chain_scan.hpp: speculate / reconcile / emit for the restart iterators      (0.1 - 0.3 TB/s) */
+    DAAC_KERNEL_CHAIN = 8,       /* chain_scan.hpp: speculate / reconcile / emit for the restart iterators      (0.1 - 0.3 TB/s) */
+    DAAC_KERNEL_SELECT = 9       /* find3_kernels.hip / left3_kernels.hip: the restart iterators' count (+ checksum) as a selection over the tuple
+                                    emitter's detection, no state chain (cfg3, random text: 0.36 / 0.31 TB/s); text made of dictionary words goes
+                                    back to DAAC_KERNEL_CHAIN and the plan then says so */
 } daac_kernel_family;
 typedef enum {
     DAAC_WHY_FASTEST = 0,        /* nothing faster exists for this request */
@@ -332,6 +335,10 @@ void daac_stream_close(daac_stream *s);
  *                               Standard bytewise dictionaries with K = 3 tables and no pattern beyond 19 bytes) instead of the chain walkers,
  *                               in windows of find3_window (2^30) end positions, each restarting at the last match of the one before; a handle
  *                               whose last such request met text made of dictionary words goes back to the walkers (2: never), 0: off
+ *   left3 (1)                   leftmost_find_iter's count (+ checksum) likewise (left3_kernels.hip): at upload a leftmost handle's patterns are
+ *                               read back from its trie and built into a Standard automaton whose detection tables the selection — by match
+ *                               STARTS — runs on; same conditions, same windows, same fallback as find3 (2: whatever the text, 0: off — set
+ *                               before the upload to save the second build)
  *   workspace_keep (8 GiB)      bytes of scratch (annotated stream, record list: ~2 per haystack byte) a handle keeps between its tuple-emitter
  *                               and find3 calls instead of asking the pool every time (tools/micro/pool_ops.hip); 0: none
  *   pfx_probe (16384)           AUTO, count (+ checksum) of a dictionary PFX serves: a synchronous scan of a device haystack >= 32 MiB samples

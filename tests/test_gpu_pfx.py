@@ -157,7 +157,7 @@ def test_engine_plan_says_what_will_run():
     da.set_option("pfx", 1)
     REQ = {"count": 0, "checksum": 1, "tuples": 2, "find": 3, "leftmost": 4, "nosuffix": 5}
     hay = torch.from_numpy(synth.uniform_haystack(1 << 20, 3, synth.ALPHA_LOWER_SPACE)).cuda()
-    for pats, kind, expect in ((synth.patterns_cfg3(5000), 0, {"count": (Engine.Gram, 1), "checksum": (Engine.Gram, 2), "tuples": (Engine.Gram, 4)}),
+    for pats, kind, expect in ((synth.patterns_cfg3(5000), 0, {"count": (Engine.Gram, 1), "checksum": (Engine.Gram, 2), "tuples": (Engine.Gram, 4), "find": (Engine.Gram, 9)}),
                                (synth.patterns_binary256(5000), 0, {"count": (Engine.Pfx, 5), "checksum": (Engine.Pfx, 5)}),
                                (synth.patterns_cfg3(2000) + [b""], 0, {})):
         o = orc.OraclePma.build(pats)
@@ -181,7 +181,18 @@ def test_engine_plan_says_what_will_run():
     o = orc.OraclePma.build(synth.patterns_cfg3(2000), kind="LeftmostLongest")
     p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
     info = p.upload().info()
-    assert info.plan_kernel[4] == 8 and info.plan_kernel[0] == 0  # chain walkers; find_overlapping does not apply to the kind
+    assert info.plan_kernel[4] == 9 and info.plan_kernel[0] == 0  # left3's selection (the handle's patterns as a Standard automaton); find_overlapping does not apply to the kind
+    p.scan_count(ScanMode.LeftmostFind, hay[:1 << 16])
+    assert da.last_engine() == info.plan_engine[4] == int(Engine.Gram)
+    da.set_option("left3", 0)
+    try:
+        q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+        info = q.upload().info()
+        assert info.plan_kernel[4] == 8   # chain walkers
+        q.scan_count(ScanMode.LeftmostFind, hay[:1 << 16])
+        assert da.last_engine() == info.plan_engine[4]
+    finally:
+        da.set_option("left3", 1)
 
 
 def test_round3_engines_take_host_haystacks_and_streams():
