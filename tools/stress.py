@@ -266,6 +266,71 @@ def engines_soak(seconds, seed, max_cases=None):
     print(f"engines soak ok: {n_auto} automata ({n_g3} with GRAM tables, {n_pfx} with PFX tables, {n_emit} tuple lists from the GRAM emitter, {n_pfx_emit} from PFX's) in {time.time() - t0:.0f} s (seed {seed})")
 
 
+def select_soak(seconds, seed, max_cases=None):
+    """find3 / left3 (the restart iterators' count + checksum as a selection over the emitter's detection) against the oracle's iterators on
+    random dictionaries over small alphabets: patterns of 1 .. 19 bytes (sometimes longer: the engine declines), with and without one-byte
+    patterns, texts of random symbols / of the patterns themselves / mixed, haystacks at odd addresses, windows of 8 KiB .. 1 GiB, restarts
+    inside the haystack; Standard, LeftmostLongest and LeftmostFirst.  The engines are told to try whatever the text (option = 2): what
+    they cannot settle they hand to the chain walkers, and the answer is the oracle's either way."""
+    import torch
+    from daachorse_amd import Engine
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    n_auto = n_find = n_left = n_decl = 0
+    da.set_option("find3", 2); da.set_option("left3", 2)
+    while (n_auto < max_cases) if max_cases is not None else (time.time() - t0 < seconds):
+        nsym = int(rng.choice([2, 3, 5, 12, 26, 29]))
+        syms = rng.choice(np.arange(256), size=nsym, replace=False).astype(np.uint8)
+        npat = int(rng.choice([3, 40, 600, 6000, 30000]))
+        lo = int(rng.integers(1, 5))
+        hi = int(rng.choice([lo + 1, 4, 8, 14, 19, 19, 24]))
+        hi = max(hi, lo)
+        pats = list({bytes(syms[rng.integers(0, nsym, size=int(rng.integers(lo, hi + 1)))]) for _ in range(npat)})
+        order = rng.permutation(len(pats))
+        pats = [pats[int(i)] for i in order]
+        n = int(rng.integers(1000, 1_500_000))
+        kind_text = rng.random()
+        if kind_text < 0.4:
+            hay = syms[rng.integers(0, nsym, size=n)]
+        elif kind_text < 0.7:
+            hay = np.frombuffer(b"".join(pats[int(i)] for i in rng.integers(0, len(pats), size=n // max(1, (lo + hi) // 2) + 1))[:n], dtype=np.uint8).copy()
+        else:   # words between stretches of noise (some of it no pattern byte at all)
+            parts = []
+            while sum(len(x) for x in parts) < n:
+                parts.append(pats[int(rng.integers(0, len(pats)))])
+                parts.append(bytes(syms[rng.integers(0, nsym, size=int(rng.integers(0, 40)))]) if rng.random() < 0.7 else b"\x00" * int(rng.integers(0, 3000)))
+            hay = np.frombuffer(b"".join(parts)[:n], dtype=np.uint8).copy()
+        win = int(rng.choice([8192, 50000, 1 << 20, 1 << 30]))
+        da.set_option("find3_window", win)
+        dev = torch.from_numpy(hay).cuda()[int(rng.integers(0, 16)):]
+        host = dev.cpu().numpy()
+        n_auto += 1
+        for kind in (orc.STANDARD, orc.LEFTMOST_LONGEST, orc.LEFTMOST_FIRST):
+            o = orc.OraclePma.build(pats, kind=kind)
+            p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+            p.upload()
+            mode = ScanMode.Find if kind == orc.STANDARD else ScanMode.LeftmostFind
+            ms = o.find_iter(host) if kind == orc.STANDARD else o.leftmost_find_iter(host)
+            want = (len(ms), orc.matches_checksum(ms))
+            ctx = (kind, nsym, len(pats), lo, hi, len(host), win, round(kind_text, 2))
+            got = p.scan_count(mode, dev)
+            served = da.last_engine() == int(Engine.Gram)
+            assert got == want, ("count + checksum", ctx, served)
+            assert p.count(mode, dev) == want[0], ("count", ctx)
+            if kind == orc.STANDARD:
+                n_find += served
+            else:
+                n_left += served
+            n_decl += not served
+            if len(ms) > 2:   # a restart inside the haystack: at the end of a match the iterator returned
+                b = int(ms[int(rng.integers(0, len(ms) - 1))]["end"])
+                rest = ms[ms["end"] > b] if kind == orc.STANDARD else ms[ms["start"] >= b]
+                assert p.scan_count(mode, dev, begin=b) == (len(rest), orc.matches_checksum(rest)), ("restart", b, ctx)
+    da.set_option("find3", 1); da.set_option("left3", 1); da.set_option("find3_window", 1 << 30)
+    print(f"select soak ok: {n_auto} dictionaries x 3 kinds ({n_find} find_iter scans served by find3, {n_left} leftmost scans by left3, {n_decl} handed to the chain walkers) "
+          f"in {time.time() - t0:.0f} s (seed {seed})")
+
+
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -273,5 +338,7 @@ if __name__ == "__main__":
         gram_soak(budget, seed + 1000)
     elif len(sys.argv) > 3 and sys.argv[3] == "engines":
         engines_soak(budget, seed + 2000)
+    elif len(sys.argv) > 3 and sys.argv[3] == "select":
+        select_soak(budget, seed + 3000)
     else:
         iter_soak(budget, seed)
