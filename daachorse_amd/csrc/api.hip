@@ -66,6 +66,7 @@ struct Options {
     std::atomic<int64_t> pool{1};               // scratch / result buffers from the stream-ordered pool
     std::atomic<int64_t> pool_keep{0};          // bytes the pool keeps between calls (0 = auto)
     std::atomic<int64_t> left3{1};                    // leftmost_find_iter's count (+ checksum) through left3_kernels.hip (as find3: 2 = whatever the text, 0 = off)
+    std::atomic<int64_t> select_emit{1};              // the restart iterators' tuple list from find3 / left3 (0: the chain walkers')
     std::atomic<int64_t> find3_window{1ll << 30};     // find3: end positions per window (tests: small windows = many restarts)
     std::atomic<int64_t> workspace_keep{8ll << 30};   // bytes of scratch a handle may keep for its emitter / find3 calls (0: none)
     std::atomic<int64_t> char_map_lds{1};
@@ -218,6 +219,7 @@ struct DeviceTables {
     std::atomic<int> pfx_dense{-1};  // the last probe's verdict on the text (scan_count_impl): 1 = most positions survive the filter
     bool find3_ok = false;         // find_iter's count / checksum without a state chain (find3_kernels.hip): K = 3, no pattern beyond 19 bytes
     Find3Dev find3{};
+    Find3Dev find3v{};             // the same tables with the patterns' VALUES (the emitter's V1 / V2 / V3 rank structure): the selection's tuple list
     bool left3_ok = false;         // a leftmost handle whose patterns, as a Standard automaton, got the emitter's and find3's tables: left3_kernels.hip serves leftmost_find_iter
     std::atomic<uint32_t> find3_gave_up{0};
     std::atomic<uint32_t> find3_skips{0};
@@ -727,6 +729,8 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                             if ((st = t->put(h2, f.h2)) != DAAC_OK) return st;
                             if ((st = t->put(hb, f.h3c)) != DAAC_OK) return st;
                             f.h1_bytes = e.v1_bytes; f.h2_bytes = e.v2_bytes; f.h3c_bytes = e.v3c_bytes; f.h3c_dir = e.v3c_dir; f.h3c_val = e.v3c_val; f.C = g2.C;
+                            t->find3v = f;
+                            t->find3v.h1 = e.v1; t->find3v.h2 = e.v2; t->find3v.h3c = e.v3c;
                             t->find3_ok = true;   // (&& emit3_ok, decided below)
                         }
                     }
@@ -1312,6 +1316,15 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
 // BIN of the tuple emitter, then SELECT passes over tiles of 2 048 positions until no tile's last word moves.  The result is left in
 // d_res {count, S1, S2}.  *served = false: the dictionary / request does not qualify, or the text is of the kind the relaxation gives up
 // on (then d_res holds nothing of value and the chain walkers take the request).
+// What a window is asked for beside its sums: the tuples themselves
+struct SelectEmit {
+    bool f16 = false;
+    void *dest = nullptr;      // in: write here (room for dest_cap tuples); null: a buffer of the call's own, handed back in p
+    uint64_t dest_cap = 0;
+    void *p = nullptr;         // out (dest == null): the list (dev_malloc on the call's stream)
+    uint64_t n = 0;            // out: tuples written
+};
+
 // One window: matches with end in (begin, len], len - begin <= 1 GiB; begin is a restart point (0, or the end of a match the iterator
 // returned).  r = {count, S1, S2} of the window; *next_begin = where a window behind this one restarts: the end of the last match
 // selected here, or — none within the last two tiles — 64 bytes before the end (no match ends in between, and the longest pattern is
@@ -1320,7 +1333,8 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
 // There the window's matches START in [begin, sel_end) and the detection runs on to `len` (a match may end behind sel_end); *next_begin = the
 // end of the window's last match, at least sel_end.
 static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t len, uint64_t sel_end, hipStream_t stream,
-                                      bool want_checksum, bool leftmost, unsigned long long r[3], uint64_t *next_begin, bool *served) {
+                                      bool want_checksum, bool leftmost, unsigned long long r[3], uint64_t *next_begin, bool *served,
+                                      SelectEmit *em = nullptr) {
     *served = false;
     const int64_t optv = leftmost ? g_opt.left3.load() : g_opt.find3.load();
     // (DAAC_DEBUG_TIMING=1: the stream is waited for at every lap — kernel times; =2: host time between the laps as the call really runs)
@@ -1356,7 +1370,9 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
     const size_t off_short = 0, off_deep = off_short + ((static_cast<size_t>(n1k) * 4 + 255) & ~size_t(255));
     const size_t off_a = off_deep + ((static_cast<size_t>(n1k) * 4 + 255) & ~size_t(255)), off_b = off_a + ((scan_words * 8 + 255) & ~size_t(255));
     const size_t off_ctl = off_b + ((scan_words * 8 + 255) & ~size_t(255));
-    const size_t off_ex = off_ctl + 256, off_wq = off_ex + 2 * ((static_cast<size_t>(nsteps) * 4 + 255) & ~size_t(255));
+    const size_t tcnt_words = em ? nsteps + 2 + exclusive_scan_scratch(nsteps) : 0;
+    const size_t off_ex = off_ctl + 256, off_tcnt = off_ex + 2 * ((static_cast<size_t>(nsteps) * 4 + 255) & ~size_t(255));
+    const size_t off_wq = off_tcnt + ((tcnt_words * 8 + 255) & ~size_t(255));
     const size_t off_ann = off_wq + ((nwaves * wq_slab * sizeof(uint2) + 255) & ~size_t(255));
     uint32_t per_kib = t->emit3_rec_per_kib.load();
     if (per_kib == 0) per_kib = static_cast<uint32_t>(std::max<int64_t>(1, g_opt.emit_rec_per_kib.load()));
@@ -1387,6 +1403,8 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
     f.result = reinterpret_cast<unsigned long long *>(d_ctl + 4);   // d_ctl: {chunks, DETECT's failure, flag, last selection + 1, - count, S1, S2 -}
     f.flag = d_ctl + 2;
     f.last_sel = d_ctl + 3;
+    unsigned long long *d_tcnt = em ? reinterpret_cast<unsigned long long *>(base + off_tcnt) : nullptr;
+    f.tile_cnt = d_tcnt;
     f.first_start = emit_from;
     f.last_start = (leftmost && sel_end < len) ? static_cast<uint32_t>(emit_from + (sel_end - begin)) : 0xffffffffu;
     f.ctl = d_ctl;
@@ -1453,6 +1471,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
         if (gate && rk > kDenseRecPerKib) return DAAC_OK;
     }
     if (deep_total > std::min<unsigned long long>(rec_gate, chunk_cap * kEmit3Chunk)) return DAAC_OK;   // (the kernels behind DETECT did nothing)
+    const uint32_t *verified = d_ex[1];   // the exits of the last pass (= the entries it was given, once no tile's exit moved)
     for (int pass = 0;; ++pass) {
         const unsigned int flag = ctl[2];
         if (flag & 6u) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }
@@ -1460,6 +1479,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
         if (pass == 5) { t->find3_gave_up.fetch_add(1); return DAAC_OK; }   // (chains that will not fall in step: the walkers' business)
         HIP_TRY(hipMemsetAsync(d_ctl + 2, 0, 32, stream));   // flag, last selection, the three sums
         f.entry_in = d_ex[(pass & 1) ^ 1]; f.exit_out = d_ex[pass & 1];
+        verified = f.exit_out;
         if (leftmost) HIP_TRY(launch_left3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
         else HIP_TRY(launch_find3_select(t->find3, f, t->emit3_has_len1, true, sblocks, stream));
         unsigned int *pin = pinned_words();
@@ -1469,6 +1489,43 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
         lap("one more SELECT");
     }
     std::memcpy(r, &ctl[4], 24);
+    if (em) {   // ---- the list: offsets = a scan over the tiles' counts, then the selection once more, writing ----
+        const uint64_t n = r[0];
+        const size_t tb = em->f16 ? 16 : sizeof(daac_match);
+        em->n = 0; em->p = nullptr;
+        void *dst = em->dest;
+        if (dst) {
+            if (n > em->dest_cap) { set_error("selection emitter: more tuples than the count pass announced"); return DAAC_ERR_DEVICE; }
+        } else {
+            if (n * tb > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+                set_error("match list of " + std::to_string(n) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
+                return DAAC_ERR_AUTOMATON_SCALE;
+            }
+            if (n != 0) { HIP_TRY(dev_malloc(&em->p, n * tb, stream)); dst = em->p; }
+        }
+        if (n != 0) {
+            HIP_TRY(launch_exclusive_scan(d_tcnt, nsteps, d_tcnt + nsteps, d_tcnt + nsteps + 2, stream));
+            HIP_TRY(hipMemsetAsync(d_ctl + 2, 0, 4, stream));
+            f.tile_cnt = nullptr; f.tile_off = d_tcnt; f.out = dst; f.f16 = em->f16 ? 1u : 0u;
+            f.entry_in = verified; f.exit_out = const_cast<uint32_t *>(verified == d_ex[0] ? d_ex[1] : d_ex[0]);
+            if (leftmost) HIP_TRY(launch_left3_emit(t->find3v, f, t->emit3_has_len1, sblocks, stream));
+            else HIP_TRY(launch_find3_emit(t->find3v, f, t->emit3_has_len1, sblocks, stream));
+            unsigned int flag = 0;
+            unsigned int *pin = pinned_words();
+            unsigned long long tot = 0;
+            HIP_TRY(hipMemcpyAsync(pin ? pin : &flag, d_ctl + 2, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(pin ? reinterpret_cast<unsigned long long *>(pin + 2) : &tot, d_tcnt + nsteps, 8, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (pin) { flag = *pin; tot = *reinterpret_cast<unsigned long long *>(pin + 2); }
+            lap("list");
+            if (flag != 0 || tot != n) {   // (cannot happen after a verified tally; the walkers then)
+                if (em->p) { dev_free(em->p, stream); em->p = nullptr; }
+                t->find3_gave_up.fetch_add(1);
+                return DAAC_OK;
+            }
+        }
+        em->n = n;
+    }
     if (leftmost) *next_begin = std::max<uint64_t>(sel_end, ctl[3] != 0 ? f.pos_base - 1u + ctl[3] : 0);
     else *next_begin = ctl[3] != 0 ? f.pos_base + (ctl[3] - 1u) : (len > 64 ? len - 64 : 0);
     *served = true;
@@ -1506,6 +1563,74 @@ daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, 
     return DAAC_OK;
 }
 
+// The restart iterators' tuple LIST from the selection kernels: scan_range_device's contract (begin = a restart point; the list holds the
+// matches up to *next_begin, where the next window restarts).  One window of at most 1 GiB as it comes; a longer range only as a whole
+// haystack (end == total_len): counted first, allocated once, then window by window straight into its place.
+daac_status select_emit(daac_pma *pma, DeviceTables *t, int mode, const uint8_t *dev_hay, uint64_t begin, uint64_t end, uint64_t total_len,
+                        hipStream_t stream, DevMatches &out, uint64_t *next_begin, bool *served) {
+    *served = false;
+    const bool leftmost = mode == DAAC_LEFTMOST_FIND;
+    if (pma->charwise || pma->root_has_output() || end <= begin || pma->host.is_standard() == leftmost) return DAAC_OK;
+    if (!(leftmost ? t->left3_ok : t->find3_ok) || g_opt.select_emit.load() == 0) return DAAC_OK;
+    const uint64_t kWin = static_cast<uint64_t>(g_opt.find3_window.load());
+    daac_status st;
+    if (end - begin <= kWin) {
+        SelectEmit em;
+        em.f16 = out.f16;
+        unsigned long long r[3];
+        uint64_t next = end;
+        bool ok = false;
+        const uint64_t dend = leftmost ? std::min<uint64_t>(total_len, end + 32) : end;
+        if ((st = find_count3_window(pma, t, dev_hay, begin, dend, end, stream, false, leftmost, r, &next, &ok, &em)) != DAAC_OK) return st;
+        if (!ok) return DAAC_OK;
+        if (end < total_len && next <= begin) { if (em.p) dev_free(em.p, stream); return DAAC_OK; }   // (a window without progress: the walkers')
+        out.p = static_cast<daac_match *>(em.p); out.n = em.n; out.s = stream; out.f16_done = out.f16;
+        if (next_begin) *next_begin = end >= total_len ? end : next;
+        t->find3_gave_up.store(0);
+        g_last_engine = DAAC_ENGINE_GRAM;
+        *served = true;
+        return DAAC_OK;
+    }
+    if (end != total_len) return DAAC_OK;
+    unsigned long long acc[3];
+    bool counted = false;
+    DevBuf tmp;
+    HIP_TRY(tmp.alloc(3 * sizeof(unsigned long long), stream));
+    if ((st = find_count3(pma, t, dev_hay, begin, end, stream, static_cast<unsigned long long *>(tmp.p), false, leftmost, acc, &counted)) != DAAC_OK) return st;
+    if (!counted) return DAAC_OK;
+    const uint64_t total = acc[0];
+    const size_t tb = out.f16 ? 16 : sizeof(daac_match);
+    if (total * tb > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+        set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
+        return DAAC_ERR_AUTOMATON_SCALE;
+    }
+    void *d_out = nullptr;
+    HIP_TRY(dev_malloc(&d_out, std::max<size_t>(16, total * tb), stream));
+    uint64_t at = 0;
+    for (uint64_t cur = begin;;) {
+        const uint64_t wend = end - cur <= kWin ? end : cur + kWin - (leftmost ? 64 : 0);
+        const uint64_t dend = leftmost ? std::min<uint64_t>(end, wend + 32) : wend;
+        SelectEmit em;
+        em.f16 = out.f16; em.dest = static_cast<char *>(d_out) + at * tb; em.dest_cap = total - at;
+        unsigned long long r[3];
+        uint64_t next = wend;
+        bool ok = false;
+        st = find_count3_window(pma, t, dev_hay, cur, dend, wend, stream, false, leftmost, r, &next, &ok, &em);
+        if (st != DAAC_OK || !ok) { dev_free(d_out, stream); return st; }
+        at += em.n;
+        if (wend >= end || next >= end) break;
+        if (next <= cur || next > dend) { dev_free(d_out, stream); return DAAC_OK; }
+        cur = next;
+    }
+    if (at != total) { dev_free(d_out, stream); return DAAC_OK; }
+    out.p = static_cast<daac_match *>(d_out); out.n = total; out.s = stream; out.f16_done = out.f16;
+    if (next_begin) *next_begin = end;
+    t->find3_gave_up.store(0);
+    g_last_engine = DAAC_ENGINE_GRAM;
+    *served = true;
+    return DAAC_OK;
+}
+
 // Scans [begin, end) of a haystack whose byte 0 is at `dev_hay` (device pointer; only bytes
 // >= begin - halo are dereferenced) and leaves the matches with end in (begin, end] — plus
 // ROOT's list at end = 0 when begin == 0 — in device memory, in reference order.
@@ -1525,6 +1650,12 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
         bool served = false;
         if ((st = emit_overlapping3(pma, t, dev_hay, begin, end, stream, out, &served)) != DAAC_OK) return st;
         if (served) return DAAC_OK;
+    }
+    if (engine == DAAC_ENGINE_AUTO && (mode == DAAC_FIND || mode == DAAC_LEFTMOST_FIND)) {   // the restart iterators' list from the selection kernels
+        bool served = false;
+        if ((st = select_emit(pma, t, mode, dev_hay, begin, end, total_len, stream, out, next_begin, &served)) != DAAC_OK) return st;
+        if (served) return DAAC_OK;
+        if (next_begin) *next_begin = end;
     }
     if (want_gram) {
         set_error(std::string("the GRAM engine cannot emit tuples for this automaton / request [") + last_error_cstr() + "]");
@@ -2801,6 +2932,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "pfx_probe") g_opt.pfx_probe = value;
     else if (n == "find3") g_opt.find3 = value;
     else if (n == "left3") g_opt.left3 = value;
+    else if (n == "select_emit") g_opt.select_emit = value;
     else if (n == "restart_tier") g_opt.restart_tier = value;
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles" || n == "emit_rec_cap" || n == "emit_version") {}   // (options of the round-3 COUNT + WRITE emitter: accepted, nothing left to steer)

@@ -284,6 +284,10 @@ struct Find3Args {
     uint32_t off_wave;                   // LDS: the h tables at 0 (tallying passes), the per-wave areas from here
     uint32_t count_only;                 // `.count()`: the selections are counted, their h not looked up
     unsigned long long *result;          // {count, S1, S2} (tallying passes; zeroed by the caller)
+    unsigned long long *tile_cnt;        // tallying passes, optional: per tile the number of selected matches
+    const unsigned long long *tile_off;  // emitting pass: per tile the index of its first tuple (exclusive scan of tile_cnt)
+    void *out;                           // emitting pass: the list
+    uint32_t f16;                        // emitting pass: daac_match16 (else daac_match)
     uint32_t first_start;                // left3: virtual position of the first START that counts (the restart point)
     uint32_t last_start;                 // left3: virtual position of the first start that no longer counts (the next window's)
     uint32_t *last_sel;                  // max over the last two tiles of (virtual position of a selection, the restart point included) + 1
@@ -300,6 +304,8 @@ __device__ __forceinline__ bool find3_detect_usable(const Find3Args &a) {
 }
 uint32_t find3_lds_bytes(const Find3Dev &dev, bool tally);
 hipError_t launch_find3_select(const Find3Dev &dev, const Find3Args &a, bool has_len1, bool tally, uint32_t blocks, hipStream_t stream);
+hipError_t launch_find3_emit(const Find3Dev &dev, const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream);
+hipError_t launch_left3_emit(const Find3Dev &dev, const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream);
 hipError_t launch_find3_tail(const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream);
 // leftmost_find_iter likewise (left3_kernels.hip): exit_out / entry_in hold, per tile, how many positions of the NEXT tile lie under its last match
 uint32_t left3_lds_bytes(const Find3Dev &dev, bool tally);

@@ -86,8 +86,24 @@ __device__ __forceinline__ uint32_t q_nib(uint32_t x) { return ((x & 0x01010101u
 
 }  // namespace
 
-// HAS1: the dictionary has one-byte patterns; TALLY: count / checksum the selected matches (passes B ...), else leave the exit words only
-template <bool HAS1, bool TALLY>
+// One tuple of the list: daac_match16 {end, length, value} (one 16-byte store) or daac_match {start, end, value, pad}
+__device__ __forceinline__ void q_put_tuple(void *out, bool f16, unsigned long long slot, unsigned long long end, uint32_t len, uint32_t value) {
+    typedef uint32_t q_u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t q_u32x2 __attribute__((ext_vector_type(2)));
+    if (f16) {
+        *reinterpret_cast<q_u32x4 *>(static_cast<char *>(out) + slot * 16ull) = q_u32x4{static_cast<uint32_t>(end), static_cast<uint32_t>(end >> 32), len, value};
+    } else {
+        char *dst = static_cast<char *>(out) + slot * 24ull;
+        const unsigned long long start = end - len;
+        *reinterpret_cast<q_u32x4 *>(dst) = q_u32x4{static_cast<uint32_t>(start), static_cast<uint32_t>(start >> 32), static_cast<uint32_t>(end), static_cast<uint32_t>(end >> 32)};
+        *reinterpret_cast<q_u32x2 *>(dst + 16) = q_u32x2{value, 0u};
+    }
+}
+
+// HAS1: the dictionary has one-byte patterns; TALLY: count / checksum the selected matches (passes B ...), else leave the exit words only;
+// EMIT: instead of the sums, the tuples themselves — in the iterator's order, tile t's at a.tile_off[t] — with g's tables holding the
+// patterns' VALUES (the emitter's V1 / V2 / V3 rank structure) in place of their h
+template <bool HAS1, bool TALLY, bool EMIT>
 __global__ __launch_bounds__(1024) void find3_select_kernel(const Find3Dev g, const Find3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (!find3_detect_usable(a)) return;
@@ -123,7 +139,7 @@ __global__ __launch_bounds__(1024) void find3_select_kernel(const Find3Dev g, co
         const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
         const unsigned long long b0 = a.bin_off[2u * t], b1 = a.bin_off[(2u * t + 2u) < a.n1k ? 2u * t + 2u : a.n1k];
         const uint32_t n = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b1 - b0));
-        if (TALLY) {
+        if (TALLY) {   // (the stream bytes in LDS: the classes of a selected match's bytes)
             *reinterpret_cast<uint4 *>(annb + 16u + lane * 32u) = q0;
             *reinterpret_cast<uint4 *>(annb + 32u + lane * 32u) = q1;
             if (lane == 0) *reinterpret_cast<uint4 *>(annb) = t != 0 ? *reinterpret_cast<const uint4 *>(a.ann + v0 - 16u) : uint4{0u, 0u, 0u, 0u};
@@ -268,6 +284,62 @@ __global__ __launch_bounds__(1024) void find3_select_kernel(const Find3Dev g, co
         }
         const uint32_t T = S & ~F & ~DS;                       // the short ones
         const uint32_t L3 = T & P3 & ~(A1 | A2), L2 = T & ~L3 & P2 & ~A1;
+        if (!EMIT && a.tile_cnt) {   // how many tuples this tile will hold (the list's offsets are a scan over these)
+            const unsigned long long tot = q_wave_sum(static_cast<unsigned long long>(__popc(T) + __popc(DS)));
+            if (lane == 0) a.tile_cnt[t] = tot;
+        }
+        if (EMIT) {
+            // ---- the tile's tuples in position order: entries {position | length << 11} (0: a deep match — its record's lane writes it) ----
+            const uint32_t nsel = any_deep_sel ? __builtin_amdgcn_readfirstlane(dlist[0]) : 0u;
+            if (nsel >= kFind3Deep) { if (lane == 0) atomicOr(a.flag, 4u); continue; }
+            const uint32_t mine = __popc(T) + __popc(DS);
+            const uint32_t incl = q_wave_incl_scan(mine);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            {
+                uint32_t at = incl - mine, m = T | DS;
+                while (m != 0) {
+                    const uint32_t i = static_cast<uint32_t>(__builtin_ctz(m)), bit = 1u << i;
+                    m &= m - 1u;
+                    const uint32_t pos = lane * 32u + i;
+                    const uint32_t len = (DS & bit) ? 0u : (L3 & bit) ? 3u : (L2 & bit) ? 2u : 1u;
+                    stage[at] = static_cast<uint16_t>(pos | (len << 11));
+                    if (DS & bit)
+                        for (uint32_t k = 1; k <= nsel; ++k)
+                            if ((dlist[k] & 2047u) == pos) dlist[k] |= at << 16;
+                    ++at;
+                }
+            }
+            const unsigned long long tile_base = a.tile_off[t];
+            const unsigned long long end0 = a.pos_base + v0;   // end of a match whose last byte is the tile's position 0
+            auto cls_at = [&](uint32_t byte_addr) -> uint32_t { return *reinterpret_cast<ldsq_cu8 *>(static_cast<uintptr_t>(byte_addr)) & 31u; };
+            for (uint32_t s0 = 0; s0 < total; s0 += 64u) {
+                const bool ok = s0 + lane < total;
+                const uint32_t ent = stage[ok ? s0 + lane : 0u];
+                const uint32_t pos = ent & 2047u, len = ent >> 11;
+                const uint32_t c0 = cls_at(ann_at + 16u + pos), c1 = cls_at(ann_at + 15u + pos), c2 = cls_at(ann_at + 14u + pos);
+                const uint32_t i2 = __umul24(c1, C) + c0, i3 = __umul24(c2, CC) + i2;
+                const uint32_t v1 = *reinterpret_cast<ldsq_cu32 *>(static_cast<uintptr_t>(c0 * 4u));
+                const uint32_t v2 = *reinterpret_cast<ldsq_cu32 *>(static_cast<uintptr_t>(g.h1_bytes + i2 * 4u));
+                const uint32_t wd = *reinterpret_cast<ldsq_cu32 *>(static_cast<uintptr_t>(h3_at + (i3 >> 5) * 4u));
+                const uint32_t dr = *reinterpret_cast<ldsq_cu16 *>(static_cast<uintptr_t>(h3_at + g.h3c_dir + (i3 >> 5) * 2u));
+                const uint32_t v3 = *reinterpret_cast<ldsq_cu32 *>(static_cast<uintptr_t>(h3_at + g.h3c_val + (dr + __popc(wd & ((1u << (i3 & 31u)) - 1u))) * 4u));
+                const uint32_t val = len == 3u ? v3 : len == 2u ? v2 : v1;
+                if (ok && len != 0u) q_put_tuple(a.out, a.f16 != 0, tile_base + s0 + lane, end0 + pos, len, val);
+            }
+            if (nsel != 0) {
+                for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+                    const uint32_t i = i0 + lane;
+                    uint4 r = uint4{0u, 0u, 0u, 0u};
+                    if (i < n) r = a.binned[b0 + i];
+                    const uint32_t key = ((r.x - v0) & (kFind3Tile - 1u)) | ((r.y & 0xffffffu) << 11);
+                    uint32_t slot = 0xffffffffu;
+                    for (uint32_t k = 1; k <= nsel; ++k) { const uint32_t d = dlist[k]; slot = (d & 0xffffu) == key ? d >> 16 : slot; }
+                    if (i < n && (r.y >> 24) == 0u && (r.y & 0xffffffu) < 32u && slot != 0xffffffffu)
+                        q_put_tuple(a.out, a.f16 != 0, tile_base + slot, a.pos_base + r.x, r.y & 0xffffffu, r.z);
+                }
+            }
+            continue;
+        }
         if (a.count_only) {
             cnt += __popc(T) + __popc(DS);
             continue;
@@ -343,7 +415,7 @@ __global__ __launch_bounds__(1024) void find3_select_kernel(const Find3Dev g, co
             }
         }
     }
-    if (TALLY) {
+    if (TALLY && !EMIT) {
         const unsigned long long c = q_wave_sum(cnt), x1 = q_wave_sum(s1), x2 = q_wave_sum(s2);
         if (lane == 0 && c != 0) {
             atomicAdd(a.result, c);
@@ -460,18 +532,23 @@ hipError_t launch_find3_tail(const Find3Args &a, bool has_len1, uint32_t blocks,
     return hipGetLastError();
 }
 
-template <bool HAS1, bool TALLY>
+template <bool HAS1, bool TALLY, bool EMIT>
 static hipError_t launch_find3_inst(const Find3Dev &dev, const Find3Args &a, uint32_t blocks, hipStream_t stream) {
     const uint32_t lds = find3_lds_bytes(dev, TALLY);
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(find3_select_kernel<HAS1, TALLY>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(find3_select_kernel<HAS1, TALLY, EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((find3_select_kernel<HAS1, TALLY>), dim3(blocks), dim3(1024), lds, stream, dev, a);
+    hipLaunchKernelGGL((find3_select_kernel<HAS1, TALLY, EMIT>), dim3(blocks), dim3(1024), lds, stream, dev, a);
     return hipGetLastError();
 }
+// (the kernel's TALLY = false form — exits only — was pass A before the tails had their own kernel; it is not instantiated any more)
 hipError_t launch_find3_select(const Find3Dev &dev, const Find3Args &a, bool has_len1, bool tally, uint32_t blocks, hipStream_t stream) {
-    if (has_len1) return tally ? launch_find3_inst<true, true>(dev, a, blocks, stream) : launch_find3_inst<true, false>(dev, a, blocks, stream);
-    return tally ? launch_find3_inst<false, true>(dev, a, blocks, stream) : launch_find3_inst<false, false>(dev, a, blocks, stream);
+    if (!tally) return hipErrorInvalidValue;
+    return has_len1 ? launch_find3_inst<true, true, false>(dev, a, blocks, stream) : launch_find3_inst<false, true, false>(dev, a, blocks, stream);
+}
+// the tuples of the selected matches (dev: the VALUE tables; a.tile_off / a.out / a.f16 set; a.entry_in = the verified exit words)
+hipError_t launch_find3_emit(const Find3Dev &dev, const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream) {
+    return has_len1 ? launch_find3_inst<true, true, true>(dev, a, blocks, stream) : launch_find3_inst<false, true, true>(dev, a, blocks, stream);
 }
 
 }  // namespace daac

@@ -84,8 +84,23 @@ __device__ __forceinline__ uint32_t l_nib(uint32_t x) { return ((x & 0x01010101u
 
 }  // namespace
 
-// HAS1: the dictionary has one-byte patterns; TALLY: count / checksum the selected matches, else leave the tiles' numbers only (pass A)
-template <bool HAS1, bool TALLY>
+// One tuple of the list: daac_match16 {end, length, value} (one 16-byte store) or daac_match {start, end, value, pad}
+__device__ __forceinline__ void l_put_tuple(void *out, bool f16, unsigned long long slot, unsigned long long end, uint32_t len, uint32_t value) {
+    typedef uint32_t l_u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t l_u32x2 __attribute__((ext_vector_type(2)));
+    if (f16) {
+        *reinterpret_cast<l_u32x4 *>(static_cast<char *>(out) + slot * 16ull) = l_u32x4{static_cast<uint32_t>(end), static_cast<uint32_t>(end >> 32), len, value};
+    } else {
+        char *dst = static_cast<char *>(out) + slot * 24ull;
+        const unsigned long long start = end - len;
+        *reinterpret_cast<l_u32x4 *>(dst) = l_u32x4{static_cast<uint32_t>(start), static_cast<uint32_t>(start >> 32), static_cast<uint32_t>(end), static_cast<uint32_t>(end >> 32)};
+        *reinterpret_cast<l_u32x2 *>(dst + 16) = l_u32x2{value, 0u};
+    }
+}
+
+// HAS1: the dictionary has one-byte patterns; TALLY: count / checksum the selected matches, else leave the tiles' numbers only;
+// EMIT: instead of the sums, the tuples themselves in the iterator's order (tile t's at a.tile_off[t]), g's tables holding VALUES
+template <bool HAS1, bool TALLY, bool EMIT>
 __global__ __launch_bounds__(1024) void left3_select_kernel(const Find3Dev g, const Find3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (!find3_detect_usable(a)) return;
@@ -254,6 +269,63 @@ __global__ __launch_bounds__(1024) void left3_select_kernel(const Find3Dev g, co
             }
         }
         const uint32_t T = S & ~D;
+        if (!EMIT && a.tile_cnt) {
+            const unsigned long long tot = l_wave_sum(static_cast<unsigned long long>(__popc(S)));
+            if (lane == 0) a.tile_cnt[t] = tot;
+        }
+        if (EMIT) {
+            // ---- the tile's tuples in position order: entries {start | length << 11} (0: a deep match — its record's lane writes it) ----
+            const uint32_t nsel = any_deep_sel ? __builtin_amdgcn_readfirstlane(dlist[0]) : 0u;
+            if (nsel >= kFind3Deep) { if (lane == 0) atomicOr(a.flag, 4u); continue; }
+            const uint32_t mine = __popc(S);
+            const uint32_t incl = l_wave_incl_scan(mine);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+            {
+                uint32_t at = incl - mine, m = S;
+                while (m != 0) {
+                    const uint32_t i = static_cast<uint32_t>(__builtin_ctz(m)), bit = 1u << i;
+                    m &= m - 1u;
+                    const uint32_t pos = lane * 32u + i;
+                    const uint32_t len = (D & bit) ? 0u : (H3 & bit) ? 3u : (H2 & bit) ? 2u : 1u;
+                    stage[at] = static_cast<uint16_t>(pos | (len << 11));
+                    if (D & bit)
+                        for (uint32_t k = 1; k <= nsel; ++k)
+                            if ((dlist[k] & 2047u) == pos) dlist[k] |= at << 16;
+                    ++at;
+                }
+            }
+            const unsigned long long tile_base = a.tile_off[t];
+            const unsigned long long end0 = a.pos_base + v0;   // end of a match whose LAST byte is the tile's position 0
+            auto cls_at = [&](uint32_t byte_addr) -> uint32_t { return *reinterpret_cast<ldsl_cu8 *>(static_cast<uintptr_t>(byte_addr)) & 31u; };
+            for (uint32_t s0 = 0; s0 < total; s0 += 64u) {
+                const bool ok = s0 + lane < total;
+                const uint32_t ent = stage[ok ? s0 + lane : 0u];
+                const uint32_t pos = ent & 2047u, len = ent >> 11;
+                const uint32_t c0 = cls_at(ann_at + 16u + pos), c1 = cls_at(ann_at + 17u + pos), c2 = cls_at(ann_at + 18u + pos);
+                const uint32_t i2 = __umul24(c0, C) + c1, i3 = __umul24(c0, CC) + __umul24(c1, C) + c2;
+                const uint32_t v1 = *reinterpret_cast<ldsl_cu32 *>(static_cast<uintptr_t>(c0 * 4u));
+                const uint32_t v2 = *reinterpret_cast<ldsl_cu32 *>(static_cast<uintptr_t>(g.h1_bytes + i2 * 4u));
+                const uint32_t wd = *reinterpret_cast<ldsl_cu32 *>(static_cast<uintptr_t>(h3_at + (i3 >> 5) * 4u));
+                const uint32_t dr = *reinterpret_cast<ldsl_cu16 *>(static_cast<uintptr_t>(h3_at + g.h3c_dir + (i3 >> 5) * 2u));
+                const uint32_t v3 = *reinterpret_cast<ldsl_cu32 *>(static_cast<uintptr_t>(h3_at + g.h3c_val + (dr + __popc(wd & ((1u << (i3 & 31u)) - 1u))) * 4u));
+                const uint32_t val = len == 3u ? v3 : len == 2u ? v2 : v1;
+                if (ok && len != 0u) l_put_tuple(a.out, a.f16 != 0, tile_base + s0 + lane, end0 + pos + len - 1u, len, val);
+            }
+            if (nsel != 0) {
+                for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+                    const uint32_t i = i0 + lane;
+                    uint4 r = uint4{0u, 0u, 0u, 0u};
+                    if (i < n) r = a.binned[b0 + i];
+                    const uint32_t len = r.y & 0xffffffu, p = r.x + 1u - len - v0;
+                    const uint32_t key = p | (len << 11);
+                    uint32_t slot = 0xffffffffu;
+                    for (uint32_t k = 1; k <= nsel; ++k) { const uint32_t d = dlist[k]; slot = (d & 0xffffu) == key ? d >> 16 : slot; }
+                    if (i < n && p < kFind3Tile && len < 32u && (r.y >> 24) == 0u && slot != 0xffffffffu)
+                        l_put_tuple(a.out, a.f16 != 0, tile_base + slot, a.pos_base + r.x, len, r.z);
+                }
+            }
+            continue;
+        }
         if (a.count_only) {
             cnt += __popc(S);
             continue;
@@ -329,7 +401,7 @@ __global__ __launch_bounds__(1024) void left3_select_kernel(const Find3Dev g, co
             }
         }
     }
-    if (TALLY) {
+    if (TALLY && !EMIT) {
         const unsigned long long c = l_wave_sum(cnt), x1 = l_wave_sum(s1), x2 = l_wave_sum(s2);
         if (lane == 0 && c != 0) {
             atomicAdd(a.result, c);
@@ -467,18 +539,22 @@ hipError_t launch_left3_tail(const Find3Args &a, bool has_len1, uint32_t blocks,
 
 uint32_t left3_lds_bytes(const Find3Dev &dev, bool tally) { return (tally ? dev.h1_bytes + dev.h2_bytes + dev.h3c_bytes : 0u) + 16u * kLeft3Wave; }
 
-template <bool HAS1, bool TALLY>
+template <bool HAS1, bool TALLY, bool EMIT>
 static hipError_t launch_left3_inst(const Find3Dev &dev, const Find3Args &a, uint32_t blocks, hipStream_t stream) {
     const uint32_t lds = left3_lds_bytes(dev, TALLY);
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(left3_select_kernel<HAS1, TALLY>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(left3_select_kernel<HAS1, TALLY, EMIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((left3_select_kernel<HAS1, TALLY>), dim3(blocks), dim3(1024), lds, stream, dev, a);
+    hipLaunchKernelGGL((left3_select_kernel<HAS1, TALLY, EMIT>), dim3(blocks), dim3(1024), lds, stream, dev, a);
     return hipGetLastError();
 }
+// (the kernel's TALLY = false form — exits only — was pass A before the tails had their own kernel; it is not instantiated any more)
 hipError_t launch_left3_select(const Find3Dev &dev, const Find3Args &a, bool has_len1, bool tally, uint32_t blocks, hipStream_t stream) {
-    if (has_len1) return tally ? launch_left3_inst<true, true>(dev, a, blocks, stream) : launch_left3_inst<true, false>(dev, a, blocks, stream);
-    return tally ? launch_left3_inst<false, true>(dev, a, blocks, stream) : launch_left3_inst<false, false>(dev, a, blocks, stream);
+    if (!tally) return hipErrorInvalidValue;
+    return has_len1 ? launch_left3_inst<true, true, false>(dev, a, blocks, stream) : launch_left3_inst<false, true, false>(dev, a, blocks, stream);
+}
+hipError_t launch_left3_emit(const Find3Dev &dev, const Find3Args &a, bool has_len1, uint32_t blocks, hipStream_t stream) {
+    return has_len1 ? launch_left3_inst<true, true, true>(dev, a, blocks, stream) : launch_left3_inst<false, true, true>(dev, a, blocks, stream);
 }
 
 }  // namespace daac
