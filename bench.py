@@ -195,6 +195,7 @@ def _event_ms(torch, fn, reps):
 
 
 def restart_legs(da, synth, torch, patterns, local_rank, stream, result, no_cpu, seed_sparse, seed_dense, alpha):
+    import numpy as np
     """find_iter / leftmost_find_iter (bytewise/iter.rs:58-113, 272-340) of the cfg3 dictionary: count + checksum over 1 GiB of the
     sparse and of the dense haystack, under the same clock as the headline number; prefix parity against the oracle."""
     from daachorse_amd import ScanMode
@@ -231,6 +232,30 @@ def restart_legs(da, synth, torch, patterns, local_rank, stream, result, no_cpu,
             out[f"{kind_name}_{hk}"] = {"value": round(n / ms / 1e6, 2), "unit": "GB/s", "frac": round(n / ms / 1e6 / HBM_PEAK_GBS, 4), "kernel_ms": round(ms, 3),
                                         "engine_used": eng, "match_count": int(r[0]),
                                         "matches_per_byte": round(int(r[0]) / n, 4), "traffic": tr[0], "parity_16mib_prefix_vs_oracle": ok}
+            if hk == "sparse":   # the iterator's tuple LIST left in HBM (daac_scan_device16 in this mode), wall time of the call, best of 3
+                da.set_option("max_result_bytes", 64 << 30)
+                best, cnt_list = None, None
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    dm = pma.scan_device(mode, hay, fmt16=True)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    cnt_list = dm.count
+                    dm.free()
+                    best = dt if best is None else min(best, dt)
+                da.set_option("max_result_bytes", 8 << 30)
+                okl = None
+                if oo is not None:
+                    dm = pma.scan_device(mode, hay[:pn], fmt16=True)
+                    got = dm.to_numpy()
+                    dm.free()
+                    okl = bool(len(got) == len(want) and np.array_equal(got["end"], want["end"]) and np.array_equal(got["value"], want["value"]) and
+                               np.array_equal(got["length"].astype(np.uint64), want["end"] - want["start"]))
+                out[f"{kind_name}_{hk}"]["tuples_device"] = {"GB/s": round(n / best / 1e9, 2), "seconds": round(best, 5), "tuples": int(cnt_list),
+                                                             "count_agrees": bool(cnt_list == int(r[0])), "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"),
+                                                             "list_of_16mib_prefix_equals_oracle": okl,
+                                                             "note": "daac_scan_device16 in this mode: the iterator's matches as {end, length, value} in its order, left in HBM"}
             if eng == "gram":
                 out[f"{kind_name}_{hk}"]["method"] = ("find3" if kind_name == "find_iter" else "left3") + ": selection over the emitter's per-position flags, no state chain (the chain walkers serve text made of dictionary words)"
         del pma
@@ -324,6 +349,25 @@ def iterator_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha
             it.close()
             dt = time.perf_counter() - t0
             best16 = dt if best16 is None else min(best16, dt)
+        if name == "cfg3":   # find_iter() of the same automaton over the same host haystack (its windows' lists come from the selection kernels)
+            bestf, cntf = None, 0
+            for rep in range(2):
+                t0 = time.perf_counter()
+                it = pma.find_iter(h, compact=True)
+                cntf = 0
+                while True:
+                    got = it.next_batch8()
+                    if got is None:
+                        break
+                    cntf += len(got[0])
+                it.close()
+                dt = time.perf_counter() - t0
+                bestf = dt if bestf is None else min(bestf, dt)
+            wantf = pma.count(ScanMode.Find, dev)
+            out["cfg3_find_iter"] = {"GB/s": round(n / bestf / 1e9, 2), "seconds": round(bestf, 4), "matches": cntf, "matches_per_byte": round(cntf / n, 4),
+                                     "tuple_GB/s_over_pcie": round(cntf * 8 / bestf / 1e9, 2), "count_agrees_with_count_kernel": bool(cntf == wantf),
+                                     "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"),
+                                     "op": "pma.find_iter(host haystack) to exhaustion, 8-byte tuples (daac_iter_open_compact in DAAC_FIND mode)"}
         want = pma.count(ScanMode.FindOverlapping, dev)
         out[name] = {"GB/s": round(n / best / 1e9, 2), "seconds": round(best, 4), "matches": cnt, "matches_per_byte": round(cnt / n, 4),
                      "wire": "8-byte tuples (daac_iter_open_compact / daac_iter_next_batch8: {value, end relative to the window | length << end_bits})",

@@ -339,6 +339,8 @@ void daac_stream_close(daac_stream *s);
  *                               read back from its trie and built into a Standard automaton whose detection tables the selection — by match
  *                               STARTS — runs on; same conditions, same windows, same fallback as find3 (2: whatever the text, 0: off — set
  *                               before the upload to save the second build)
+ *   select_emit (1)             the tuple LIST of find_iter / leftmost_find_iter (daac_scan, daac_scan_device[16], the lazy iterator's windows) from
+ *                               those selection kernels' emitting form, where find3 / left3 apply; 0: the chain walkers' speculate / reconcile / emit
  *   workspace_keep (8 GiB)      bytes of scratch (annotated stream, record list: ~2 per haystack byte) a handle keeps between its tuple-emitter
  *                               and find3 calls instead of asking the pool every time (tools/micro/pool_ops.hip); 0: none
  *   pfx_probe (16384)           AUTO, count (+ checksum) of a dictionary PFX serves: a synchronous scan of a device haystack >= 32 MiB samples
