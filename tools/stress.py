@@ -276,7 +276,7 @@ def select_soak(seconds, seed, max_cases=None):
     from daachorse_amd import Engine
     rng = np.random.default_rng(seed)
     t0 = time.time()
-    n_auto = n_find = n_left = n_decl = 0
+    n_auto = n_find = n_left = n_decl = n_list = 0
     da.set_option("find3", 2); da.set_option("left3", 2)
     while (n_auto < max_cases) if max_cases is not None else (time.time() - t0 < seconds):
         nsym = int(rng.choice([2, 3, 5, 12, 26, 29]))
@@ -322,12 +322,39 @@ def select_soak(seconds, seed, max_cases=None):
             else:
                 n_left += served
             n_decl += not served
+            # the list itself (the selection kernels' emitting form where they serve; the walkers' otherwise): device formats, then the lazy
+            # iterator over small windows
+            fmt16 = bool(rng.random() < 0.7)
+            dm = p.scan_device(mode, dev, fmt16=fmt16)
+            got = dm.to_numpy()
+            dm.free()
+            if fmt16:
+                assert len(got) == len(ms) and np.array_equal(got["end"], ms["end"]) and np.array_equal(got["length"], ms["end"] - ms["start"]) and \
+                    np.array_equal(got["value"], ms["value"]), ("list16", ctx)
+            else:
+                assert len(got) == len(ms) and np.array_equal(got["start"], ms["start"]) and np.array_equal(got["end"], ms["end"]) and \
+                    np.array_equal(got["value"], ms["value"]), ("list24", ctx)
+            n_list += da.last_engine() == int(Engine.Gram)
+            if rng.random() < 0.5:
+                da.set_option("iter_window", int(rng.choice([4096, 20000, 65536])))
+                it = (p.find_iter if kind == orc.STANDARD else p.leftmost_find_iter)(host)
+                runs = [np.zeros(0, dtype=da.bytewise.MATCH16_DTYPE)]
+                while True:
+                    run = it.next_batch()
+                    if run is None:
+                        break
+                    runs.append(run.copy())
+                it.close()
+                da.set_option("iter_window", 64 << 20)
+                g2 = np.concatenate(runs)
+                assert len(g2) == len(ms) and np.array_equal(g2["end"], ms["end"]) and np.array_equal(g2["length"], ms["end"] - ms["start"]) and \
+                    np.array_equal(g2["value"], ms["value"]), ("iterator", ctx)
             if len(ms) > 2:   # a restart inside the haystack: at the end of a match the iterator returned
                 b = int(ms[int(rng.integers(0, len(ms) - 1))]["end"])
                 rest = ms[ms["end"] > b] if kind == orc.STANDARD else ms[ms["start"] >= b]
                 assert p.scan_count(mode, dev, begin=b) == (len(rest), orc.matches_checksum(rest)), ("restart", b, ctx)
     da.set_option("find3", 1); da.set_option("left3", 1); da.set_option("find3_window", 1 << 30)
-    print(f"select soak ok: {n_auto} dictionaries x 3 kinds ({n_find} find_iter scans served by find3, {n_left} leftmost scans by left3, {n_decl} handed to the chain walkers) "
+    print(f"select soak ok: {n_auto} dictionaries x 3 kinds ({n_find} find_iter scans served by find3, {n_left} leftmost scans by left3, {n_decl} handed to the chain walkers; {n_list} tuple lists from the selection kernels) "
           f"in {time.time() - t0:.0f} s (seed {seed})")
 
 
