@@ -78,6 +78,17 @@ for pass in "$PASS1" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT
   DAAC_PMC_FILTER=emit3_detect,emit3_bin,emit3_expand python $R/tools/pmc_summary.py $d | grep -v duration_us >> $OUT/${TAG}_pmc_sq.txt 2>&1
 done
 
+# the selection kernels of the restart iterators (find3 / left3) with the emitter's front half they run behind
+for what in find leftmost; do
+  for pass in "$PASS1" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+    d=$P/sq_${what}_$(echo $pass | cut -c4-12)
+    rm -rf $d
+    rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $d -o p -- python $R/tools/time_find.py 1024 sparse $what > $d.log 2>&1
+    echo "== ${what}_iter by selection, cfg3 sparse, 1 GiB (count + checksum)" >> $OUT/${TAG}_pmc_sq.txt
+    DAAC_PMC_FILTER=find3_,left3_,emit3_detect,emit3_bin python $R/tools/pmc_summary.py $d | grep -v duration_us >> $OUT/${TAG}_pmc_sq.txt 2>&1
+  done
+done
+
 # the bench lines themselves (they read the traffic file given here; in the repository: profiles/hbm_traffic.json)
 export DAAC_HBM_TRAFFIC_JSON=$OUT/${TAG}_hbm_traffic.json
 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
@@ -86,6 +97,15 @@ python $R/bench.py --haystack dense --no-cpu --no-dense --materialize-mib 0 --no
 python $R/bench.py --workload cfg2 --bytes 1073741824 --no-cpu --materialize-mib 0 --no-extra > $OUT/${TAG}_bench_cfg2.json 2>> $OUT/${TAG}_bench.err
 python $R/tools/time_find.py 1024 sparse > $OUT/${TAG}_find_sparse.txt 2>&1
 python $R/tools/time_find.py 1024 dense > $OUT/${TAG}_find_dense.txt 2>&1
+python $R/tools/time_find_tuples.py 1024 sparse > $OUT/${TAG}_find_tuples.txt 2>&1
+DAAC_OPT_UNUSED=1 python - > $OUT/${TAG}_find_tuples_walkers.txt 2>&1 <<PY
+import sys, runpy
+sys.path.insert(0, "$R")
+import daachorse_amd as da
+da.set_option("select_emit", 0)
+sys.argv = ["time_find_tuples.py", "1024", "sparse"]
+runpy.run_path("$R/tools/time_find_tuples.py", run_name="__main__")
+PY
 python $R/tools/time_emit.py 1024 sparse 3 > $OUT/${TAG}_emit.txt 2>&1
 python $R/tools/time_emit.py 512 dense 3 >> $OUT/${TAG}_emit.txt 2>&1
 python $R/tools/time_iter.py 1024 > $OUT/${TAG}_iterator.txt 2>&1
