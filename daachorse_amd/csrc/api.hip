@@ -1352,7 +1352,9 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
     const Gram3Lds &L = t->emit3_lds;
     const uint64_t halo = pma->halo();
     constexpr uint32_t kStep = 2048;
-    const uint64_t from = begin > halo ? begin - halo : 0;
+    // (a restart point: nothing that begins before it is ever reported, so the detection begins THERE — the chunk-fed steppers hand over a buffer
+    // whose first byte is the restart point, and reading a halo in front of it read in front of the allocation)
+    const uint64_t from = begin;
     const uint8_t *first = dev_hay + from;
     const uint32_t lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(first) & 15u);
     const uint8_t *hay_al = first - lead;
