@@ -62,6 +62,18 @@ def test_invalid_option(pins):
     assert ei.value.code == 2
 
 
+def test_tuning_options_are_known_without_a_gpu():
+    """daac_set_option: the options the documentation names (include/daachorse_amd.h) are accepted, an unknown one is refused with
+    DAAC_ERR_INVALID_ARGUMENT — host logic, no device call."""
+    for name, value, back in (("find3", 2, 1), ("left3", 0, 1), ("select_emit", 0, 1), ("find3_window", 1 << 20, 1 << 30), ("workspace_keep", 0, 8 << 30),
+                              ("pfx_probe", 1, 16384), ("emit", 0, 1), ("iter_window", 1 << 20, 64 << 20)):
+        da.set_option(name, value)
+        da.set_option(name, back)
+    with pytest.raises(da.DaachorseError) as ei:
+        da.set_option("no_such_option", 1)
+    assert ei.value.code == 1
+
+
 @pytest.mark.parametrize("nfb", [1, 2, 16])
 def test_random_sets_build_identically(nfb):
     rng = np.random.default_rng(100 + nfb)
