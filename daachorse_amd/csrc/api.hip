@@ -19,6 +19,7 @@
 #include "device_tables.hpp"
 #include "gram.hpp"
 #include "gram2.hpp"
+#include "gram4.hpp"
 #include "gram2w.hpp"
 #include "pfx.hpp"
 #include "pma.hpp"
@@ -44,7 +45,9 @@ struct Options {
     std::atomic<int64_t> gram_dense{-1};        // -1 = decide per automaton
     std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
     std::atomic<int64_t> gram_version{0};       // 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram3 on the v2 tables), 1 = v1 only,
-                                                // 2 = v2 tables with gram2_kernels.hip, 3 = v2 tables with gram3_kernels.hip for `.count()`
+                                                // 2 = v2 tables with gram2_kernels.hip, 3 = v2 tables with gram3_kernels.hip for `.count()`,
+                                                // 4 = gram4_kernels.hip for `.count()` (what 0 takes where its tables are there)
+    std::atomic<int64_t> gram4_arith{1};        // gram4: byte classes by arithmetic where the dictionary's bytes are one range (0: the class table in LDS)
     std::atomic<int64_t> gram2_dpp{1};
     std::atomic<int64_t> find3{1};              // find_iter's count (+ checksum) of a whole haystack of at most 1 GiB through find3_kernels.hip (selection over the
                                                 // emitter's per-position flags, no state chain) where the dictionary allows; 0: the chain walkers always
@@ -206,6 +209,8 @@ struct DeviceTables {
     GramDev gram{};
     bool gram2_ok = false;     // second table set (gram2.hpp)
     Gram2Dev gram2{};
+    bool gram4_ok = false;     // `.count()` tables of round 5 (gram4.hpp), derived from the second table set
+    Gram4Dev gram4{};
     bool gramw_ok = false;     // wide alphabets (gram2w.hpp)
     bool pfx_ok = false;       // any byte alphabet, `.count()` (pfx.hpp)
     uint32_t n_distinct_bytes = 0;  // distinct pattern bytes (known when the PFX builder ran)
@@ -663,6 +668,36 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             d.exact_ok = exact_ok;
             d.xlane_dpp = g_opt.gram2_dpp.load() != 0;
             t->gram2_ok = d.off_m_count + d.m_bytes <= (1u << 17) && d.lds_count <= 160u * 1024u;
+            if (t->gram2_ok) {   // the same tables in the numbering of gram4_kernels.hip ("no pattern" last: arithmetic byte classes)
+                Gram4Tables g4;
+                build_gram4_tables(g2, g4);
+                Gram4Dev &q = t->gram4;
+                q = Gram4Dev{};
+                if ((st = t->put(g4.cls, q.cls)) != DAAC_OK) return st;
+                if ((st = t->put(g4.m, q.m)) != DAAC_OK) return st;
+                q.m_bytes = p16(g4.m.size() * 4);
+                if (g4.s16) {
+                    std::vector<uint16_t> s16(g4.sdir.begin(), g4.sdir.end());
+                    const uint16_t *ps;
+                    if ((st = t->put(s16, ps)) != DAAC_OK) return st;
+                    q.sdir = ps;
+                    q.s_bytes = p16(s16.size() * 2);
+                    if ((st = t->put(g4.rfull, q.rfull)) != DAAC_OK) return st;
+                    q.rfull_bytes = p16(g4.rfull.size() * 2);
+                } else {
+                    const uint32_t *ps;
+                    if ((st = t->put(g4.sdir, ps)) != DAAC_OK) return st;
+                    q.sdir = ps;
+                    q.s_bytes = p16(g4.sdir.size() * 4);
+                }
+                { const U32x2 *x; if ((st = t->put(g4.dhit_c, x)) != DAAC_OK) return st; q.dhit_c = reinterpret_cast<const uint2 *>(x); }
+                { const U32x4 *x; if ((st = t->put(g4.dhit_t, x)) != DAAC_OK) return st; q.dhit_t = reinterpret_cast<const uint4 *>(x); }
+                { const U32x4 *x; if ((st = t->put(g4.drec_c, x)) != DAAC_OK) return st; q.drec_c = reinterpret_cast<const uint4 *>(x); }
+                { const U32x4 *x; if ((st = t->put(g4.drec_t, x)) != DAAC_OK) return st; q.drec_t = reinterpret_cast<const uint4 *>(x); }
+                q.K = g4.K; q.C = g4.C; q.s16 = g4.s16 ? 1u : 0u; q.arith = g4.arith ? 1u : 0u; q.lo = g4.lo; q.unused_byte = g4.unused_byte;
+                q.n_deep = static_cast<uint32_t>(g4.dhit_c.size());
+                t->gram4_ok = g4.available;
+            }
             if (t->gram2_ok && g2.emit_available) {
                 Gram2EmitDev &e = t->emit;
                 const U32x4 *erec; const U32x2 *ehit;
@@ -2100,7 +2135,35 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     // `.count()` alone on the second table set: the lane-local-mask kernel (gram3_kernels.hip) when asked for (gram_version = 3)
     Gram3Lds g3l{};
     uint32_t g3_ppl = g_opt.gram_ppl.load() == 16 ? 16u : 32u;   // (32 positions per lane measured 3-10 % ahead of 16: profiles/r03_gram3_ab.txt)
-    bool use_g3 = use_g2 && !want_checksum && (gv == 3 || gv == 0);
+    // `.count()` alone: gram4_kernels.hip on the renumbered tables (round 5) wherever they are there; gram_version = 3 keeps gram3
+    Gram4Lds g4l{};
+    uint32_t g4_ppl = 16;
+    bool use_g4 = use_g2 && !want_checksum && t->gram4_ok && (gv == 4 || gv == 0);
+    if (use_g4) {
+        const bool want_rfull = g_opt.gram2_rfull.load() != 0, want_arith = g_opt.gram4_arith.load() != 0;
+        const uint32_t waves = static_cast<uint32_t>(g_opt.threads.load()) > 512 ? 16u : 8u;
+        const int64_t ppl_opt = g_opt.gram_ppl.load();
+        // preference: the per-word directory first (two LDS reads per hit instead of five), then 32 positions per lane
+        struct Shape { uint32_t ppl; bool rfull; } shapes[4] = {{32u, true}, {16u, true}, {32u, false}, {16u, false}};
+        bool planned = false;
+        for (const Shape &sh : shapes) {
+            if ((ppl_opt == 16 || ppl_opt == 32) && sh.ppl != static_cast<uint32_t>(ppl_opt)) continue;
+            if (sh.rfull && !want_rfull) continue;
+            if (gram4_plan(t->gram4, sh.ppl, waves, sh.rfull, want_arith, 160u * 1024u, g4l)) { g4_ppl = sh.ppl; planned = true; break; }
+        }
+        if (!planned && waves == 16) {   // eight waves leave the tables more room
+            for (const Shape &sh : shapes) {
+                if (sh.rfull && !want_rfull) continue;
+                if (gram4_plan(t->gram4, sh.ppl, 8, sh.rfull, want_arith, 160u * 1024u, g4l)) { g4_ppl = sh.ppl; planned = true; break; }
+            }
+        }
+        use_g4 = planned;
+    }
+    if (gv == 4 && use_g2 && !want_checksum && !use_g4) {
+        set_error("gram_version = 4: the gram4 tables are not there for this automaton (or do not fit the LDS with the launch shape asked for)");
+        return DAAC_ERR_UNSUPPORTED;
+    }
+    bool use_g3 = use_g2 && !want_checksum && !use_g4 && (gv == 3 || gv == 0 || gv == 4);
     if (use_g3) {
         // 32 positions per lane: 16 waves per workgroup when the LDS takes their text slots (with the coarser directory), else 8
         const bool want_rfull = g_opt.gram2_rfull.load() != 0;
@@ -2112,7 +2175,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
             use_g3 = gram3_plan(t->gram2, 16, 16, want_rfull, 160u * 1024u, g3l);
         }
     }
-    if (use_g2 && !use_g3 && !t->gram2.exact_ok) {   // (`.count()` alone lives on gram3_kernels.hip; what is left of gram2_kernels.hip computes the checksum too)
+    if (use_g2 && !use_g3 && !use_g4 && !t->gram2.exact_ok) {   // (`.count()` alone lives on gram3_kernels.hip; what is left of gram2_kernels.hip computes the checksum too)
         set_error("GRAM second table set: `.count()` runs on the gram3 kernel (gram_version 0 or 3); the count + checksum kernel needs tables this dictionary has no room for");
         return DAAC_ERR_UNSUPPORTED;
     }
@@ -2170,7 +2233,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         const int64_t region_opt = g_opt.gram_region.load() > 0 ? g_opt.gram_region.load()
                                    : (use_g2 || use_pfx) ? ((len - begin) >= (1ull << 31) ? 262144 : 65536) : 16384;
         while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, region_opt)) && region < (1ull << 30)) region *= 2;
-        ga.ppl = use_pfx ? 16 : use_g3 ? g3_ppl : (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
+        ga.ppl = use_pfx ? 16 : use_g4 ? g4_ppl : use_g3 ? g3_ppl : (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;
         ga.result = d_res;
@@ -2178,10 +2241,11 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         threads = std::min(1024u, std::max(64u, threads & ~63u));
         if (use_gw) threads = 1024;  // the wide kernel has one launch shape
         if (use_g3) threads = g3l.threads;
+        if (use_g4) threads = g4l.threads;
         if (use_pfx) threads = t->pfx.threads;
         const uint32_t wpb = threads / 64;
         uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
-        const uint32_t gram_lds = use_pfx ? t->pfx.lds_bytes : use_g3 ? g3l.lds_bytes : use_gw ? (want_checksum ? t->gramw.lds_exact : t->gramw.lds_count)
+        const uint32_t gram_lds = use_pfx ? t->pfx.lds_bytes : use_g4 ? g4l.lds_bytes : use_g3 ? g3l.lds_bytes : use_gw ? (want_checksum ? t->gramw.lds_exact : t->gramw.lds_count)
                                          : use_g2 ? gram2_lds_bytes(t->gram2, want_checksum) : t->gram.lds_bytes;
         if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / gram_lds));
         const uint32_t blocks = static_cast<uint32_t>(
@@ -2198,10 +2262,11 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         // the option decides, every workgroup samples the haystack at its start and runs the variant the text calls for
         const int64_t tail_opt = g_opt.gram3_tail.load();
         void *wq = nullptr;
-        HIP_TRY(dev_malloc(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * ((use_g3 || use_pfx) ? sizeof(uint4) : sizeof(uint2)), stream));
+        HIP_TRY(dev_malloc(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * ((use_g3 || use_g4 || use_pfx) ? sizeof(uint4) : sizeof(uint2)), stream));
         ga.wq = static_cast<uint2 *>(wq);
         ga.sel_want = tail_opt < 0 ? ((len - begin) >= (1ull << 20) ? 2u : 0u) : tail_opt > 0 ? 1u : 0u;
         const hipError_t le = use_pfx ? launch_pfx_scan(t->pfx, ga, want_checksum, blocks, stream)
+                              : use_g4 ? launch_gram4_scan(t->gram4, ga, g4l, blocks, stream)
                               : use_g3 ? launch_gram3_scan(t->gram2, ga, g3l, blocks, stream)
                               : use_gw ? launch_gram2w_scan(t->gramw, ga, want_checksum, blocks, stream)
                               : use_g2 ? launch_gram2_scan(t->gram2, ga, want_checksum, blocks, threads, stream)
@@ -2929,6 +2994,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram_version") g_opt.gram_version = value;
     else if (n == "gram2_dpp") g_opt.gram2_dpp = value;
     else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
+    else if (n == "gram4_arith") g_opt.gram4_arith = value;
     else if (n == "gram3_tail") g_opt.gram3_tail = value;
     else if (n == "pfx") g_opt.pfx = value;
     else if (n == "pfx_probe") g_opt.pfx_probe = value;

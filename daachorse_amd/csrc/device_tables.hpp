@@ -204,6 +204,35 @@ struct Gram3Lds {
 bool gram3_plan(const Gram2Dev &dev, uint32_t ppl, uint32_t waves, bool want_rfull, uint32_t lds_limit, Gram3Lds &L);
 hipError_t launch_gram3_scan(const Gram2Dev &dev, const GramArgs &a, const Gram3Lds &L, uint32_t blocks, hipStream_t stream);
 
+// `.count()` of round 5 (gram4_kernels.hip); tables of gram4.hpp ("no pattern" is the LAST class, so that byte classes of a
+// dictionary over one byte range are min(byte - lo, C - 1): no class table in LDS).
+constexpr uint32_t kGram4EndsBitDev = 30;  // hit records: the depth-(K+1) state ends a pattern (= kGram4EndsBit of gram4.hpp)
+struct Gram4Dev {
+    const uint8_t *cls;       // 256 byte classes (staged only when the classes are not arithmetic)
+    const uint32_t *m;        // C^K words: continuation bits 0 .. C-2, short-pattern count in bits 30-31
+    const uint16_t *rfull;    // per word of m: set continuation bits before it (null with 65536 depth-(K+1) states or more)
+    const void *sdir;         // per 4 words of m (u16 or u32 entries)
+    const uint2 *dhit_c;      // depth-(K+1) states by rank: {cmap | ends-a-pattern << 30, first_child}
+    const uint4 *dhit_t;      // the same as 16-byte records, single paths below a hit folded into a tail record (bit 31)
+    const uint4 *drec_c;      // walk records {cmap, first_child, own_cnt, 0}, tail records from depth K + 3 on
+    const uint4 *drec_t;      // ... from depth K + 2 on
+    uint32_t m_bytes, rfull_bytes, s_bytes;  // multiples of 16
+    uint32_t K, C, s16, arith, lo, unused_byte, n_deep;
+};
+struct Gram4Lds {
+    uint32_t off_wave;     // first wave's area (0): two text slots, then the hit queue
+    uint32_t wave_stride;
+    uint32_t off_cls;      // 256-byte class table (not staged when `arith`)
+    uint32_t off_s;        // rank directory
+    uint32_t off_m;        // M
+    uint32_t s_bytes;      // bytes of the directory staged
+    uint32_t lds_bytes, threads;
+    uint32_t arith;        // classes by min(byte - lo, C - 1)
+    uint32_t dir;          // 0: u16 per word, 1: u16 per four words, 2: u32 per four words
+};
+bool gram4_plan(const Gram4Dev &dev, uint32_t ppl, uint32_t waves, bool want_rfull, bool want_arith, uint32_t lds_limit, Gram4Lds &L);
+hipError_t launch_gram4_scan(const Gram4Dev &dev, const GramArgs &a, const Gram4Lds &L, uint32_t blocks, hipStream_t stream);
+
 // GRAM tuple emission with detection done ONCE (emit3_kernels.hip): DETECT leaves, per haystack byte, one "annotated class"
 // byte (class | which short patterns end here << 5), per tile of 1024 positions the number of short tuples, and every deep match
 // (longer than K bytes) as a record in a chunked list; the records are binned by tile, the tile counts scanned, and EXPAND turns

@@ -1,0 +1,73 @@
+// GRAM engine, `.count()` tables renumbered for gram4_kernels.hip — see gram4.hpp.
+#include "gram4.hpp"
+
+namespace daac {
+
+void build_gram4_tables(const Gram2Tables &g2, Gram4Tables &out) {
+    out = Gram4Tables{};
+    if (!g2.available) return;
+    const uint32_t K = g2.K, C = g2.C, OTH = C - 1;
+    auto perm = [&](uint32_t c) -> uint32_t { return c == 0 ? OTH : c - 1; };
+    out.K = K;
+    out.C = C;
+    out.unused_byte = g2.unused_byte;
+    out.cls.resize(256);
+    for (uint32_t b = 0; b < 256; ++b) out.cls[b] = static_cast<uint8_t>(perm(g2.cls[b]));
+    // one contiguous range of pattern bytes?  (classes are handed out in byte order, so class(lo) = 0 settles the rest)
+    {
+        uint32_t lo = 256;
+        for (uint32_t b = 0; b < 256; ++b) if (out.cls[b] == 0) lo = b;
+        bool ok = lo < 256;
+        for (uint32_t b = 0; b < 256 && ok; ++b) {
+            const uint32_t u = b - lo;  // wraps for b < lo
+            ok = out.cls[b] == (u < OTH ? u : OTH);
+        }
+        out.arith = ok;
+        out.lo = ok ? lo : 0;
+    }
+    // M in the new index order
+    uint64_t ngram = 1;
+    for (uint32_t i = 0; i < K; ++i) ngram *= C;
+    const uint32_t nm = static_cast<uint32_t>((ngram + 3) & ~3ull);
+    out.m.assign(nm, 0);
+    for (uint32_t g = 0; g < ngram; ++g) {
+        uint32_t rest = g, gn = 0, mul = 1;
+        for (uint32_t i = 0; i < K; ++i) {  // least significant class first
+            gn += perm(rest % C) * mul;
+            mul *= C;
+            rest /= C;
+        }
+        const uint32_t w = g2.m[g];
+        out.m[gn] = (w & 0xc0000000u) | ((w & kGram2MaskBits) >> 1);
+    }
+    out.s16 = g2.s16;
+    out.sdir.assign(nm / 4, 0);
+    if (out.s16) out.rfull.assign(nm, 0);
+    uint32_t run = 0;
+    for (uint32_t g = 0; g < nm; ++g) {
+        if ((g & 3) == 0) out.sdir[g >> 2] = run;
+        if (out.s16) out.rfull[g] = static_cast<uint16_t>(run);
+        run += static_cast<uint32_t>(__builtin_popcount(out.m[g] & kGram4ChildBits));
+    }
+    auto hit_x = [&](uint32_t x) -> uint32_t { return ((x & kGram2MaskBits) >> 1) | ((x & 1u) << kGram4EndsBit); };
+    auto tail_x = [&](uint32_t x) -> uint32_t { return (x & ~(0x1fu << 13)) | (perm((x >> 13) & 0x1fu) << 13); };
+    out.dhit_c.resize(g2.dhit_c.size());
+    for (size_t i = 0; i < g2.dhit_c.size(); ++i) out.dhit_c[i] = U32x2{hit_x(g2.dhit_c[i].x), g2.dhit_c[i].y};
+    out.dhit_t.resize(g2.dhit_t.size());
+    for (size_t i = 0; i < g2.dhit_t.size(); ++i) {
+        const U32x4 r = g2.dhit_t[i];
+        out.dhit_t[i] = (r.x >> 31) ? U32x4{tail_x(r.x), r.y, r.z, r.w} : U32x4{hit_x(r.x), r.y, 0u, 0u};
+    }
+    auto walk = [&](const std::vector<U32x4> &src, std::vector<U32x4> &dst) {
+        dst.resize(src.size());
+        for (size_t i = 0; i < src.size(); ++i) {
+            const U32x4 r = src[i];
+            dst[i] = (r.x >> 31) ? U32x4{tail_x(r.x), r.y, r.z, r.w} : U32x4{(r.x & kGram2MaskBits) >> 1, r.y, r.z, 0u};
+        }
+    };
+    walk(g2.drec_c, out.drec_c);
+    walk(g2.drec_t, out.drec_t);
+    out.available = true;
+}
+
+}  // namespace daac

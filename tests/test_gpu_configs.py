@@ -168,30 +168,37 @@ def test_cfg2_full_256_mib():
 
 
 def test_cfg3_full_4_gib_count_and_checksum():
-    """SURVEY 8d, whole-haystack equality: (count, checksum) of ALL 4 GiB of the cfg3 haystack (BASELINE configs[2]) from the
-    count + checksum kernel and the count from the `.count()` kernel against the oracle (positions beyond 2^32 included)"""
+    """SURVEY 8d, whole-haystack equality: (count, checksum) of ALL 4 GiB of BOTH cfg3 haystacks (BASELINE configs[2]: uniform a-z + space;
+    word soup of the patterns — the text on which the `.count()` kernel runs its tail-record body) from the count + checksum kernel and
+    the count from every `.count()` kernel against the oracle (positions beyond 2^32 included)"""
     import torch
     pats = synth.patterns_cfg3()
     o = orc.OraclePma.build(pats)
     p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
     n = 4 << 30
     dev = torch.empty(n, dtype=torch.uint8, device="cuda")
-    synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
-    host = dev.cpu().numpy()
-    want = o.overlapping_count(host, threads=16)
-    del host
-    assert want[0] > 2_000_000_000
-    assert p.scan_count(ScanMode.FindOverlapping, dev) == want
-    assert da.last_engine() == int(Engine.Gram)
-    assert p.count(ScanMode.FindOverlapping, dev) == want[0]
-    for version, ppl in ((2, 0), (3, 16), (3, 32)):
-        da.set_option("gram_version", version)
-        da.set_option("gram_ppl", ppl)
-        try:
-            assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want[0], (version, ppl)
-        finally:
-            da.set_option("gram_version", 0)
-            da.set_option("gram_ppl", 0)
+    for kind in ("sparse", "dense"):
+        if kind == "sparse":
+            synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+        else:
+            synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20, noise_256=77)
+        host = dev.cpu().numpy()
+        want = o.overlapping_count(host, threads=16)
+        del host
+        assert want[0] > 2_000_000_000
+        assert p.scan_count(ScanMode.FindOverlapping, dev) == want, kind
+        assert da.last_engine() == int(Engine.Gram)
+        assert p.count(ScanMode.FindOverlapping, dev) == want[0], kind
+        for version, ppl, tail in ((2, 0, -1), (3, 16, -1), (3, 32, -1), (4, 16, -1), (4, 32, -1), (4, 16, 0), (4, 16, 1)):
+            da.set_option("gram_version", version)
+            da.set_option("gram_ppl", ppl)
+            da.set_option("gram3_tail", tail)
+            try:
+                assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want[0], (kind, version, ppl, tail)
+            finally:
+                da.set_option("gram_version", 0)
+                da.set_option("gram_ppl", 0)
+                da.set_option("gram3_tail", -1)
 
 
 def test_cfg3_count_kernel_on_a_vector_of_window_counts():
@@ -215,7 +222,7 @@ def test_cfg3_count_kernel_on_a_vector_of_window_counts():
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (bad[:8], got[bad[:8]], want[bad[:8]], los[bad[:8]], his[bad[:8]])
     assert da.last_engine() == int(Engine.Gram)
-    # the lane-local-mask kernel on every eighth window
+    # the round-3 kernel (gram_version = 3; AUTO above ran gram4_kernels.hip) on every eighth window
     da.set_option("gram_version", 3)
     try:
         got3 = np.array([p.count(ScanMode.FindOverlapping, dev[:int(h)], begin=int(l), engine=Engine.Gram) for l, h in zip(los[::8], his[::8])])
@@ -252,11 +259,21 @@ def _checksum_of_device_tuples16(dm):
     return n, ((s1 & 0xFFFFFFFF) << 32) | (s2 & 0xFFFFFFFF)
 
 
+_ORACLE_CFG3 = []
+
+
+def _oracle_cfg3(pats):
+    if not _ORACLE_CFG3:
+        _ORACLE_CFG3.append(orc.OraclePma.build(pats))
+    return _ORACLE_CFG3[0]
+
+
 def test_cfg3_tuples_at_size_checksum_of_the_list():
     """Full-size property of the tuple emitter: the (count, checksum) of the LIST daac_scan_device16 leaves in HBM — computed from the
     tuples themselves on the device — equals what the count + checksum kernel says of the same haystack (which the 4 GiB test pins to the
     oracle).  3.5 GiB of cfg3 = four emitter windows, 2.24 G tuples (tuple indices beyond 2^31 — a sign-extended tile offset faulted there
-    until round 4 — and 34 GB of list), ends beyond 2^32; ends ascend; and the same for 1 GiB of word soup."""
+    until round 4 — and 34 GB of list), ends beyond 2^32; ends ascend; 64 random 1 MiB slices of the haystack compared tuple for tuple
+    (order within an end included) with the oracle; and the same for 1 GiB of word soup."""
     import torch
     pats = synth.patterns_cfg3()
     p = da.DoubleArrayAhoCorasick.new(pats)
@@ -276,8 +293,24 @@ def test_cfg3_tuples_at_size_checksum_of_the_list():
             ends = torch.as_tensor(_DeviceWords(dm.ptr, 2 * dm.count), device="cuda").view(dm.count, 2)[:, 0]
             assert bool((ends[1:] >= ends[:-1]).all()), kind      # by end (as unsigned they are below 2^63: the comparison holds)
             assert int(ends[-1].item()) <= n and int(ends[0].item()) >= 1
+            # ... and 64 random 1 MiB slices of the haystack, tuple for tuple against the oracle (order within an end included):
+            # the list's tuples with lo < end <= hi are those the oracle reports on [lo - 64, hi) with an end beyond the 64 bytes of halo
+            o = _oracle_cfg3(pats)
+            rng = np.random.default_rng(20250 + len(kind))
+            words = torch.as_tensor(_DeviceWords(dm.ptr, 2 * dm.count), device="cuda").view(dm.count, 2)
+            for lo in [0, n - (1 << 20)] + [int(x) for x in rng.integers(64, n - (1 << 20), size=62)]:
+                hi = lo + (1 << 20)
+                i0, i1 = (int(x) for x in torch.searchsorted(ends, torch.tensor([lo, hi], device="cuda", dtype=ends.dtype), right=True))
+                got = words[i0:i1].cpu().numpy()
+                from_ = max(0, lo - 64)
+                ref = o.find_overlapping_iter(dev[from_:hi].cpu().numpy())
+                ref = ref[ref["end"].astype(np.int64) + from_ > lo]
+                assert len(ref) == i1 - i0, (kind, lo, len(ref), i1 - i0)
+                assert np.array_equal(got[:, 0], ref["end"].astype(np.int64) + from_), (kind, lo)
+                assert np.array_equal(got[:, 1] & 0xFFFFFFFF, (ref["end"] - ref["start"]).astype(np.int64)), (kind, lo)      # length
+                assert np.array_equal((got[:, 1] >> 32) & 0xFFFFFFFF, ref["value"].astype(np.int64)), (kind, lo)            # value
             dm.free()
-            del dev, ends
+            del dev, ends, words
             torch.cuda.empty_cache()
         # the PFX engine's list likewise (utf8jp scanned bytewise, 1 GiB: counted first, emitted piece by piece)
         q = da.DoubleArrayAhoCorasick.new(synth.patterns_cfg5())

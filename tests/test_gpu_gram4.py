@@ -1,0 +1,138 @@
+"""`.count()` kernel of round 5 (gram4_kernels.hip, option gram_version = 4; what AUTO takes) against the oracle: every launch
+shape (16 / 32 positions per lane, 1024- and 512-thread workgroups), plain records and tail records from the hit record on,
+both rank directories, arithmetic byte classes and the class table, K = 3 and K = 2, dictionaries whose bytes are not one
+range, unaligned haystacks, shards, haystacks shorter than one step, text in which every position hits and continues."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+import daachorse_amd as da
+from daachorse_amd import Engine, ScanMode, synth
+
+# (positions per lane, tail records, per-word directory, threads per workgroup, arithmetic classes)
+VARIANTS = [(16, 0, 1, 1024, 1), (16, 1, 1, 1024, 1), (32, 0, 1, 1024, 1), (32, 1, 0, 512, 1), (16, 0, 0, 1024, 0), (32, 0, 1, 512, 0), (16, 1, 1, 512, 0), (32, 1, 0, 1024, 1)]
+
+
+def _pma(patterns):
+    o = orc.OraclePma.build(patterns)
+    p, rest = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    assert rest == b""
+    return o, p
+
+
+@pytest.fixture(autouse=True)
+def _reset():
+    yield
+    for k, v in (("gram_version", 0), ("gram4_arith", 1), ("gram_ppl", 0), ("gram3_tail", -1), ("threads", 1024), ("gram2_rfull", 1), ("gram_lds_budget", 158 * 1024), ("gram_slab", 4096),
+                 ("gram_region", 0)):
+        da.set_option(k, v)
+
+
+def _count3(p, hay, ppl, wtext, rfull, threads=1024, arith=1, **kw):
+    da.set_option("gram_version", 4)
+    da.set_option("gram4_arith", arith)
+    da.set_option("gram_ppl", ppl)
+    da.set_option("gram3_tail", wtext)
+    da.set_option("gram2_rfull", rfull)
+    da.set_option("threads", threads)
+    try:
+        got = p.count(ScanMode.FindOverlapping, hay, engine=Engine.Gram, **kw)
+        assert da.last_engine() == int(Engine.Gram)
+        return got
+    finally:
+        da.set_option("gram_version", 0)
+        da.set_option("gram_ppl", 0)
+
+
+def test_gram4_against_the_oracle():
+    import torch
+    rng = np.random.default_rng(303)
+    pats3 = synth.patterns_cfg3(30000)
+    cases = [(synth.patterns_cfg1(), synth.uniform_haystack(70001, 5, synth.ALPHA_ABCD)),
+             (synth.patterns_cfg2(500), synth.uniform_haystack(1 << 20, 6, synth.ALPHA_LOWER)),
+             (pats3, synth.uniform_haystack(3 << 20, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)),
+             (pats3, synth.wordsoup_haystack(3 << 20, synth.SEEDS["cfg3_dense"], pats3, 20)),
+             (["ab", "ab", "b", "abab", "bababab"], np.frombuffer(b"abababbab" * 3000, dtype=np.uint8)),
+             (sorted(set(bytes(rng.choice(np.frombuffer(b"acegikmoqsuwy", dtype=np.uint8), size=int(rng.integers(2, 9)))) for _ in range(3000))),
+              rng.choice(np.frombuffer(b"abcdefghijklmnopqrstuvwxyz{ ", dtype=np.uint8), size=1 << 20)),
+             (sorted(set(bytes(rng.choice(np.arange(0xf0, 0x100, dtype=np.uint8), size=int(rng.integers(2, 7)))) for _ in range(2000))),
+              rng.choice(np.arange(0xe8, 0x100, dtype=np.uint8), size=1 << 20))]
+    for pats, hay in cases:
+        o, _ = _pma(pats)
+        want = o.overlapping_count(hay, threads=8)[0]
+        dev = torch.from_numpy(np.concatenate([np.zeros(5, dtype=np.uint8), hay])).cuda()[5:]  # not 16-byte aligned
+        for budget in (158 * 1024, 24 * 1024):
+            da.set_option("gram_lds_budget", budget)
+            q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+            assert q.upload().info().gram2_available
+            for ppl, wtext, rfull, nb, ar in VARIANTS:
+                assert _count3(q, dev, ppl, wtext, rfull, nb, ar) == want, (len(pats), budget, ppl, wtext, rfull, nb, ar)
+            cut = int(rng.integers(1, len(hay)))
+            assert _count3(q, dev[:cut], 16, 0, 1) + _count3(q, dev, 16, 0, 1, begin=cut) == want, cut
+            assert _count3(q, dev[:cut], 32, 1, 1) + _count3(q, dev, 32, 1, 1, begin=cut) == want, cut
+        da.set_option("gram_lds_budget", 158 * 1024)
+
+
+def test_gram4_short_and_ragged_haystacks():
+    """lengths around the step (1 KiB / 2 KiB) and region sizes, every alignment of the first byte"""
+    import torch
+    rng = np.random.default_rng(404)
+    pats = synth.patterns_cfg3(5000)
+    o, p = _pma(pats)
+    p.upload()
+    base = synth.wordsoup_haystack(1 << 18, 11, pats, 20)
+    buf = torch.from_numpy(base).cuda()
+    da.set_option("gram_region", 2048)
+    lengths = [0, 1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4100, 6143, 6144, 65535, 65536, 65537]
+    lengths += [int(x) for x in rng.integers(1, 1 << 17, size=12)]
+    for n in lengths:
+        off = int(rng.integers(0, 32))
+        h = base[off:off + n]
+        want = o.overlapping_count(h, threads=1)[0] if n else 0
+        for ppl, wtext, rfull, nb, ar in VARIANTS[:5]:
+            assert _count3(p, buf[off:off + n], ppl, wtext, rfull, nb, ar) == want, (n, off, ppl, wtext, ar)
+
+
+def test_gram4_every_position_hits_and_continues():
+    import torch
+    rng = np.random.default_rng(1051)
+    syms = np.frombuffer(b"acinrs", dtype=np.uint8)
+    pats = [bytes(syms[rng.integers(0, 6, size=int(rng.integers(4, 9)))]) for _ in range(5000)]
+    hay = np.frombuffer(b"".join(pats[i] for i in rng.integers(0, 5000, size=60_000).tolist())[:300_000], dtype=np.uint8).copy()
+    for budget in (158 * 1024, 9216):
+        da.set_option("gram_lds_budget", budget)
+        da.set_option("gram_slab", 0)
+        o, p = _pma(pats)
+        p.upload()
+        dev = torch.from_numpy(hay).cuda()[13:]
+        want = o.overlapping_count(dev.cpu().numpy(), threads=8)[0]
+        for ppl, wtext, rfull, nb, ar in VARIANTS:
+            assert _count3(p, dev, ppl, wtext, rfull, nb, ar) == want, (budget, ppl, wtext, rfull, nb, ar)
+    # "aaaa...": every prefix a pattern, every position a hit with a long walk behind it
+    o, p = _pma([b"a" * k for k in range(1, 40)])
+    hay = np.frombuffer(b"a" * 100_000 + b"b" + b"a" * 5000, dtype=np.uint8)
+    want = o.overlapping_count(hay, threads=4)[0]
+    for ppl, wtext, rfull, nb, ar in VARIANTS:
+        assert _count3(p, torch.from_numpy(hay.copy()).cuda(), ppl, wtext, rfull, nb, ar) == want
+
+
+def test_gram4_cfg3_agrees_with_gram2_and_oracle():
+    import torch
+    pats = synth.patterns_cfg3()
+    o, p = _pma(pats)
+    p.upload()
+    n = 64 << 20
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for fill in ("sparse", "dense"):
+        if fill == "sparse":
+            synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+        else:
+            synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20, noise_256=77)
+        want = o.overlapping_count(dev.cpu().numpy(), threads=8)[0]
+        da.set_option("gram_version", 2)
+        assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want
+        for ppl, wtext, rfull, nb, ar in VARIANTS:
+            assert _count3(p, dev, ppl, wtext, rfull, nb, ar) == want, (fill, ppl, wtext, rfull, nb, ar)

@@ -216,6 +216,42 @@ def test_gram2_tables_reproduce_the_match_stream(gram2_check, tmp_path):
     assert subprocess.check_output([gram2_check, str(blob), "160000", str(h)]).decode().startswith("OK")
 
 
+def test_gram4_tables_reproduce_the_count(tmp_path_factory, tmp_path):
+    """the `.count()` tables of round 5 (gram4.hpp: "no pattern" as the last class, arithmetic class map where the dictionary's
+    bytes are one range, per-word rank directory, "ends a pattern" in bit 30) walked with the rules of gram4_kernels.hip — plain
+    records and tail records from the hit record on — == literal automaton walk"""
+    exe = str(tmp_path_factory.mktemp("native") / "gram4_check")
+    csrc = os.path.join(ROOT, "daachorse_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "gram4_check.cpp"),
+                           os.path.join(csrc, "pma.cpp"), os.path.join(csrc, "repack.cpp"), os.path.join(csrc, "gram2.cpp"), os.path.join(csrc, "gram4.cpp")])
+    rng = np.random.default_rng(5)
+    gapped = [bytes(rng.choice(np.frombuffer(b"acegikmoqsuwy", dtype=np.uint8), size=int(rng.integers(1, 9)))) for _ in range(400)]  # not one byte range
+    gapped = sorted(set(gapped))
+    cases = [(["a", "ab", "bab", "bc", "bca", "c", "caa", "abcabcab", "bb"], b"abc ", 1),
+             (["abcabcabd", "bcabd", "cab", "ab", "dddddddd"], b"abcd`e", 1),
+             (synth.patterns_cfg1(), synth.ALPHA_ABCD, 1),
+             (synth.patterns_cfg2(300), synth.ALPHA_LOWER, 1),
+             (synth.patterns_cfg3(20000), synth.ALPHA_LOWER_SPACE, 1),
+             (gapped, b"abcdefghijklmnopqrstuvwxyz{ ", 0),
+             ([b"\x00\x01\x01", b"\x01", b"\x02\x00\x01\x02\x02"], b"\x00\x01\x02\x03\xff", 1),
+             ([b"\xff\xfe", b"\xfe\xfe\xfd\xff", b"\xfd"], b"\xfc\xfd\xfe\xff\x00", 1)]
+    blob, h = tmp_path / "a.blob", tmp_path / "h.bin"
+    for pats, alpha, arith in cases:
+        blob.write_bytes(orc.OraclePma.build(pats).serialize())
+        rng.choice(np.frombuffer(alpha, dtype=np.uint8), size=60000).tofile(h)
+        for budget in (160000, 9000):
+            out = subprocess.check_output([exe, str(blob), str(budget), str(h)]).decode()
+            assert out.startswith("OK") and f"arith={arith}" in out, (out, pats[:3])
+    pats = synth.patterns_cfg3(20000)
+    blob.write_bytes(orc.OraclePma.build(pats).serialize())
+    synth.wordsoup_haystack(100000, synth.SEEDS["cfg3_dense"], pats, 20).tofile(h)
+    out = subprocess.check_output([exe, str(blob), "160000", str(h)]).decode()
+    assert out.startswith("OK") and "K=3" in out and "arith=1 lo=97" in out, out
+    blob.write_bytes(orc.OraclePma.build(["ab", "ab", "b", "abab"]).serialize())
+    np.frombuffer(b"abababbab" * 50, dtype=np.uint8).tofile(h)
+    assert subprocess.check_output([exe, str(blob), "160000", str(h)]).decode().startswith("OK")
+
+
 def test_gram2w_tables_reproduce_the_match_stream(tmp_path):
     """the wide-alphabet GRAM tables (31 .. 62 byte classes, 64-bit words, K = 2) walked with the kernel's rules == literal
     automaton walk; at most 61 pattern bytes"""
