@@ -585,7 +585,7 @@ def main():
                    "matches_per_byte": round(total_count / job_bytes, 4), "host_build_seconds": round(build_s, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
-                     "kernel": ("daac::gram3_kernel" if v2 else "daac::gram_count_kernel") if gram else "daac::scan_kernel",
+                     "kernel": ("daac::gram4_kernel" if v2 else "daac::gram_count_kernel") if gram else "daac::scan_kernel",
                      "kernel_ms": round(avg_kernel_s * 1e3, 4),
                      "algorithmic_bytes_per_launch": nbytes},
         "match_count": total_count, "match_checksum": f"{checksum:016x}" if checksum is not None else None,
@@ -717,7 +717,7 @@ def main():
             "kernel_ms": round(k_s * 1e3, 4), "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"),
             "match_count": oc, "match_checksum": f"{ocs:016x}" if other == "checksum" else None,
             "count_agrees_with_primary": bool(oc == total_count),
-            "traffic": hbm_traffic(f"cfg3_{args.haystack}_{other}", "gram_count_kernel" if other == "checksum" else "gram3_kernel")[0] if args.workload == "cfg3" else None}
+            "traffic": hbm_traffic(f"cfg3_{args.haystack}_{other}", "gram_count_kernel" if other == "checksum" else "gram4_kernel")[0] if args.workload == "cfg3" else None}
         if other == "checksum":
             out["value_count_checksum"] = out["with_checksum"]["value"]  # the op rounds 1 timed: compare THIS with BENCH_r01's `value`
         op["v"] = args.op
@@ -727,10 +727,18 @@ def main():
         fill("dense")
         _, k_s = timed(max(3, args.steps // 4), 1)
         cnt = int(result[0].item())
+        dense_parity = None
+        if not args.no_cpu:   # the tail-record body of the count kernel runs here: the WHOLE word-soup haystack against the oracle (not timed)
+            from oracle import oracle as orc
+            od = orc.OraclePma.deserialize(pma.serialize())
+            usable, _ = cpu_limits()
+            cW = od.overlapping_count(hay[:int(nbytes)].cpu().numpy(), threads=usable)
+            dense_parity = bool(cnt == cW[0] and pma.scan_count(ScanMode.FindOverlapping, hay[:int(nbytes)], engine=engine) == cW)
         out["dense"] = {"haystack": "dense (word soup)", "value": round(nbytes / k_s / 1e9, 2), "unit": "GB/s",
                         "frac": round(nbytes / k_s / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(k_s * 1e3, 4),
                         "engine_used": ENGINE_NAMES.get(da.last_engine(), "?"), "matches_per_byte": round(cnt / nbytes, 4),
-                        "traffic": hbm_traffic("cfg3_dense_count", "gram3_kernel")[0] if args.workload == "cfg3" and args.op == "count" else None}
+                        "parity_whole_haystack": dense_parity,
+                        "traffic": hbm_traffic("cfg3_dense_count", "gram4_kernel")[0] if args.workload == "cfg3" and args.op == "count" else None}
     # ---- a dictionary beyond 31 byte classes: the cfg3 words in mixed case + digits (60 pattern bytes) -----------------
     if world == 1 and not args.no_dense and args.workload == "cfg3":
         del hay
@@ -856,6 +864,11 @@ def main():
         out["cfg5"] = cfg5_legs(da, synth, torch, local_rank, stream, result, args.no_cpu)
         out["iterator"] = iterator_legs(da, synth, torch, np, pma, local_rank, seed_sparse, alpha)
     print(json.dumps(out))
+    # a multi-GPU line that is not what it says fails loudly: the reason is in the line (`distributed`), the exit code says so
+    if dist_used is not None and (dist_used.get("n_ranks_seen") != args.gpus or dist_used.get("strong_equals_one_rank") is False):
+        sys.stdout.flush()
+        raise SystemExit(f"bench.py: --gpus {args.gpus}: ranks seen {dist_used.get('n_ranks_seen')}, strong_equals_one_rank "
+                         f"{dist_used.get('strong_equals_one_rank')} (see `distributed` in the line above)")
 
 
 if __name__ == "__main__":

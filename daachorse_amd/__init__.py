@@ -8,11 +8,11 @@ raises ImportError if it has not been built: there is no CPU fallback.
 from . import _ffi
 from ._ffi import DaachorseError, last_engine, set_option
 from .bytewise import (DoubleArrayAhoCorasick, DoubleArrayAhoCorasickBuilder, Engine, Match, MatchKind, ScanMode,
-                       MATCH_DTYPE, MATCH16_DTYPE)
+                       MATCH_DTYPE, MATCH16_DTYPE, scan_count_multi)
 from .charwise import CharwiseDoubleArrayAhoCorasick, CharwiseDoubleArrayAhoCorasickBuilder
 
 _ffi.lib()  # fail loudly at import time if the extension is missing
 
 __all__ = ["DoubleArrayAhoCorasick", "DoubleArrayAhoCorasickBuilder", "CharwiseDoubleArrayAhoCorasick",
            "CharwiseDoubleArrayAhoCorasickBuilder", "Match", "MatchKind", "ScanMode", "Engine",
-           "DaachorseError", "set_option", "last_engine", "MATCH_DTYPE", "MATCH16_DTYPE"]
+           "DaachorseError", "set_option", "last_engine", "MATCH_DTYPE", "MATCH16_DTYPE", "scan_count_multi"]

@@ -23,6 +23,11 @@ class Match(C.Structure):
     _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("value", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+class Shard(C.Structure):
+    """daac_shard: one device's part of a haystack for daac_scan_count_multi"""
+    _fields_ = [("device", C.c_int), ("hay", C.c_void_p), ("halo", C.c_size_t), ("len", C.c_size_t), ("base", C.c_uint64)]
+
+
 class Info(C.Structure):
     _fields_ = [("struct_size", C.c_uint32),
                 ("match_kind", C.c_uint8), ("num_states", C.c_uint32), ("states_len", C.c_uint64),
@@ -37,7 +42,7 @@ class Info(C.Structure):
                 ("plan_engine", C.c_uint8 * 8), ("plan_kernel", C.c_uint8 * 8), ("plan_reason", C.c_uint8 * 8)]
 
 
-ABI_VERSION = 4  # DAAC_ABI_VERSION of include/daachorse_amd.h this mirror was written against
+ABI_VERSION = 5  # DAAC_ABI_VERSION of include/daachorse_amd.h this mirror was written against
 
 
 def lib():
@@ -95,6 +100,8 @@ def lib():
     L.daac_stream_close.argtypes = [vp]
     L.daac_scan_count_only_range.argtypes = [vp, C.c_int, C.c_int, u8p, sz, sz, C.c_int, vp, P(C.c_uint64), vp]
     L.daac_scan_count_only_range.restype = C.c_int
+    L.daac_scan_count_multi.argtypes = [vp, C.c_int, C.c_int, P(Shard), sz, C.c_int, P(C.c_uint64), P(C.c_uint64)]
+    L.daac_scan_count_multi.restype = C.c_int
     L.daac_scan_device.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp), P(C.c_uint64)]
     L.daac_scan_device.restype = C.c_int
     L.daac_scan_device16.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp), P(C.c_uint64)]

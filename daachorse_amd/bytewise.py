@@ -394,6 +394,25 @@ class DoubleArrayAhoCorasick:
         return cnt.value, cs.value
 
 
+def scan_count_multi(pma, mode, shards, engine=Engine.Auto, checksum=True):
+    """daac_scan_count_multi: one haystack sharded across the GPUs of a node.  `shards` = [(device, buffer, halo, base)]: `buffer` holds
+    `halo` bytes of the haystack in front of the shard and then the shard (a CUDA uint8 tensor on that device, or host bytes for all
+    shards), `base` = haystack position of the shard's first byte.  -> (count, checksum) or count; equal to scan_count / count of the
+    whole haystack."""
+    hs = [_Haystack(b) for _, b, _, _ in shards]
+    if len({h.is_device for h in hs}) > 1:
+        raise DaachorseError(1, "shards must all be device tensors or all host buffers")
+    arr = (_ffi.Shard * len(shards))()
+    for i, ((dev, _, halo, base), h) in enumerate(zip(shards, hs)):
+        if halo > h.len:
+            raise DaachorseError(1, "halo longer than the shard's buffer")
+        arr[i] = _ffi.Shard(int(dev), h.ptr, int(halo), h.len - int(halo), int(base))
+    cnt, cs = C.c_uint64(), C.c_uint64()
+    _ffi.check(_ffi.lib().daac_scan_count_multi(pma._h, int(mode), int(engine), arr, len(shards), hs[0].is_device if hs else 0,
+                                                C.byref(cnt), C.byref(cs) if checksum else None))
+    return (cnt.value, cs.value) if checksum else cnt.value
+
+
 class DoubleArrayAhoCorasickBuilder:
     """reference src/bytewise/builder.rs:21-244"""
 

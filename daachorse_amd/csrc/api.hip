@@ -44,9 +44,8 @@ struct Options {
     std::atomic<int64_t> gram_ppl{0};           // 0 = auto (32 positions per lane for automata without short patterns), 16, 32
     std::atomic<int64_t> gram_dense{-1};        // -1 = decide per automaton
     std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
-    std::atomic<int64_t> gram_version{0};       // 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram3 on the v2 tables), 1 = v1 only,
-                                                // 2 = v2 tables with gram2_kernels.hip, 3 = v2 tables with gram3_kernels.hip for `.count()`,
-                                                // 4 = gram4_kernels.hip for `.count()` (what 0 takes where its tables are there)
+    std::atomic<int64_t> gram_version{0};       // 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram4_kernels.hip), 1 = v1 only,
+                                                // 2 = v2 tables with gram2_kernels.hip, 4 = gram4_kernels.hip for `.count()` or an error
     std::atomic<int64_t> gram4_arith{1};        // gram4: byte classes by arithmetic where the dictionary's bytes are one range (0: the class table in LDS)
     std::atomic<int64_t> gram2_dpp{1};
     std::atomic<int64_t> find3{1};              // find_iter's count (+ checksum) of a whole haystack of at most 1 GiB through find3_kernels.hip (selection over the
@@ -54,7 +53,7 @@ struct Options {
     std::atomic<int64_t> pfx_probe{16384};      // AUTO, `.count()` / count + checksum of a dictionary PFX serves: the micro-step walker takes over where more than
                                                 // this many of 65 536 sampled positions survive PFX's filter (0 = never ask, always PFX)
     std::atomic<int64_t> pfx{1};                // PFX engine: 1 = built for automata the GRAM tables do not serve, 2 = always, 0 = never (read at upload)
-    std::atomic<int64_t> gram3_tail{-1};        // gram3: tail records from the hit record on (-1 = decide per launch)
+    std::atomic<int64_t> gram3_tail{-1};        // gram4 (option names gram_tail / gram3_tail): tail records from the hit record on (-1 = decide per launch)
     std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
     std::atomic<int64_t> emit{1};               // materialising overlapping scans: GRAM tuple emission where it applies (0: segment scanners)
     std::atomic<int64_t> emit_v3_lds{1};        // emit3 EXPAND: values of the 3-byte patterns from a rank structure in LDS when it fits (0: from L2)
@@ -628,13 +627,9 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             if ((st = t->put(cid, d.cid4)) != DAAC_OK) return st;
             if ((st = t->put(g2.hsum, d.hsum)) != DAAC_OK) return st;
             if ((st = t->put(g2.drec, drec)) != DAAC_OK) return st;
-            { const U32x4 *dc; if ((st = t->put(g2.drec_c, dc)) != DAAC_OK) return st; d.drec_c = reinterpret_cast<const uint4 *>(dc); }
             if ((st = t->put(g2.dhit, dhit)) != DAAC_OK) return st;
-            { const U32x2 *hc; if ((st = t->put(g2.dhit_c, hc)) != DAAC_OK) return st; d.dhit_c = reinterpret_cast<const uint2 *>(hc); }
             { const U32x4 *h4; if ((st = t->put(zip_first_child(g2.dhit, g2.cfirst), h4)) != DAAC_OK) return st; d.dhit4 = reinterpret_cast<const uint4 *>(h4); }
             if ((st = t->put(g2.cfirst, d.cfirst)) != DAAC_OK) return st;
-            { const U32x4 *x; if ((st = t->put(g2.dhit_t, x)) != DAAC_OK) return st; d.dhit_t = reinterpret_cast<const uint4 *>(x); }
-            { const U32x4 *x; if ((st = t->put(g2.drec_t, x)) != DAAC_OK) return st; d.drec_t = reinterpret_cast<const uint4 *>(x); }
             d.drec = reinterpret_cast<const uint4 *>(drec);
             d.dhit = reinterpret_cast<const uint2 *>(dhit);
             d.m_bytes = p16(g2.m.size() * 4);
@@ -2045,7 +2040,7 @@ size_t daac_pma_explain(const daac_pma *pma, char *buf, size_t cap) {
     static const char *req[] = {"find_overlapping_iter(h).count()", "find_overlapping count + checksum", "find_overlapping tuples", "find_iter",
                                 "leftmost_find_iter", "find_overlapping_no_suffix_iter"};
     static const char *eng[] = {"auto", "tiered", "darray", "gram", "pfx"};
-    static const char *ker[] = {"- (the crate panics: wrong MatchKind)", "gram3 count kernel (one LDS lookup per byte)", "gram count + checksum kernel",
+    static const char *ker[] = {"- (the crate panics: wrong MatchKind)", "gram4 count kernel (one LDS lookup per byte)", "gram count + checksum kernel",
                                 "gram wide-alphabet kernel (31-62 byte classes)", "gram tuple emitter", "pfx (hashed prefix filter + start-anchored walks, any alphabet)",
                                 "segment scanners (one lane per segment)", "micro-step walker over the double array", "chain walkers (speculate / reconcile / emit)",
                                 "selection over the tuple emitter's detection (find3 / left3: no state chain)"};
@@ -2132,10 +2127,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         return DAAC_ERR_UNSUPPORTED;
     }
     const bool use_g2 = use_gram && g2_can;
-    // `.count()` alone on the second table set: the lane-local-mask kernel (gram3_kernels.hip) when asked for (gram_version = 3)
-    Gram3Lds g3l{};
-    uint32_t g3_ppl = g_opt.gram_ppl.load() == 16 ? 16u : 32u;   // (32 positions per lane measured 3-10 % ahead of 16: profiles/r03_gram3_ab.txt)
-    // `.count()` alone: gram4_kernels.hip on the renumbered tables (round 5) wherever they are there; gram_version = 3 keeps gram3
+    // `.count()` alone: gram4_kernels.hip on the renumbered tables (gram4.hpp), derived from the second table set
     Gram4Lds g4l{};
     uint32_t g4_ppl = 16;
     bool use_g4 = use_g2 && !want_checksum && t->gram4_ok && (gv == 4 || gv == 0);
@@ -2163,20 +2155,8 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         set_error("gram_version = 4: the gram4 tables are not there for this automaton (or do not fit the LDS with the launch shape asked for)");
         return DAAC_ERR_UNSUPPORTED;
     }
-    bool use_g3 = use_g2 && !want_checksum && !use_g4 && (gv == 3 || gv == 0 || gv == 4);
-    if (use_g3) {
-        // 32 positions per lane: 16 waves per workgroup when the LDS takes their text slots (with the coarser directory), else 8
-        const bool want_rfull = g_opt.gram2_rfull.load() != 0;
-        const uint32_t want_threads = static_cast<uint32_t>(g_opt.threads.load());
-        if (g3_ppl == 32 && want_threads > 512 && gram3_plan(t->gram2, 32, 16, want_rfull, 160u * 1024u, g3l)) {
-        } else if (g3_ppl == 32 && want_threads <= 512 && gram3_plan(t->gram2, 32, 8, want_rfull, 160u * 1024u, g3l)) {
-        } else {
-            g3_ppl = 16;
-            use_g3 = gram3_plan(t->gram2, 16, 16, want_rfull, 160u * 1024u, g3l);
-        }
-    }
-    if (use_g2 && !use_g3 && !use_g4 && !t->gram2.exact_ok) {   // (`.count()` alone lives on gram3_kernels.hip; what is left of gram2_kernels.hip computes the checksum too)
-        set_error("GRAM second table set: `.count()` runs on the gram3 kernel (gram_version 0 or 3); the count + checksum kernel needs tables this dictionary has no room for");
+    if (use_g2 && !use_g4 && !t->gram2.exact_ok) {   // (`.count()` alone lives on gram4_kernels.hip; what is left of gram2_kernels.hip computes the checksum too)
+        set_error("GRAM second table set: `.count()` runs on the gram4 kernel (gram_version 0 or 4); the count + checksum kernel needs tables this dictionary has no room for");
         return DAAC_ERR_UNSUPPORTED;
     }
     const bool use_gw = use_gram && !g2_can && !g1_can && gw_can;
@@ -2233,19 +2213,18 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         const int64_t region_opt = g_opt.gram_region.load() > 0 ? g_opt.gram_region.load()
                                    : (use_g2 || use_pfx) ? ((len - begin) >= (1ull << 31) ? 262144 : 65536) : 16384;
         while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, region_opt)) && region < (1ull << 30)) region *= 2;
-        ga.ppl = use_pfx ? 16 : use_g4 ? g4_ppl : use_g3 ? g3_ppl : (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
+        ga.ppl = use_pfx ? 16 : use_g4 ? g4_ppl : (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;
         ga.result = d_res;
         uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
         threads = std::min(1024u, std::max(64u, threads & ~63u));
         if (use_gw) threads = 1024;  // the wide kernel has one launch shape
-        if (use_g3) threads = g3l.threads;
         if (use_g4) threads = g4l.threads;
         if (use_pfx) threads = t->pfx.threads;
         const uint32_t wpb = threads / 64;
         uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
-        const uint32_t gram_lds = use_pfx ? t->pfx.lds_bytes : use_g4 ? g4l.lds_bytes : use_g3 ? g3l.lds_bytes : use_gw ? (want_checksum ? t->gramw.lds_exact : t->gramw.lds_count)
+        const uint32_t gram_lds = use_pfx ? t->pfx.lds_bytes : use_g4 ? g4l.lds_bytes : use_gw ? (want_checksum ? t->gramw.lds_exact : t->gramw.lds_count)
                                          : use_g2 ? gram2_lds_bytes(t->gram2, want_checksum) : t->gram.lds_bytes;
         if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / gram_lds));
         const uint32_t blocks = static_cast<uint32_t>(
@@ -2258,16 +2237,15 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
                            K = use_gw ? 2 : use_g2 ? t->gram2.K : t->gram.K;
             ga.dense = g_opt.gram_dense.load() >= 0 ? g_opt.gram_dense.load() != 0 : n_deep * 100 > C * C * C * (K == 3 ? C : 1);
         }
-        // gram3: tail records from the hit record on pay on text made of dictionary words (+20 %) and cost 3-4 % elsewhere; unless
+        // gram4: tail records from the hit record on pay on text made of dictionary words (+20 %) and cost 3-4 % elsewhere; unless
         // the option decides, every workgroup samples the haystack at its start and runs the variant the text calls for
         const int64_t tail_opt = g_opt.gram3_tail.load();
         void *wq = nullptr;
-        HIP_TRY(dev_malloc(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * ((use_g3 || use_g4 || use_pfx) ? sizeof(uint4) : sizeof(uint2)), stream));
+        HIP_TRY(dev_malloc(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * ((use_g4 || use_pfx) ? sizeof(uint4) : sizeof(uint2)), stream));
         ga.wq = static_cast<uint2 *>(wq);
         ga.sel_want = tail_opt < 0 ? ((len - begin) >= (1ull << 20) ? 2u : 0u) : tail_opt > 0 ? 1u : 0u;
         const hipError_t le = use_pfx ? launch_pfx_scan(t->pfx, ga, want_checksum, blocks, stream)
                               : use_g4 ? launch_gram4_scan(t->gram4, ga, g4l, blocks, stream)
-                              : use_g3 ? launch_gram3_scan(t->gram2, ga, g3l, blocks, stream)
                               : use_gw ? launch_gram2w_scan(t->gramw, ga, want_checksum, blocks, stream)
                               : use_g2 ? launch_gram2_scan(t->gram2, ga, want_checksum, blocks, threads, stream)
                                        : launch_gram_scan(t->gram, ga, blocks, threads, stream);
@@ -2330,6 +2308,67 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
 daac_status daac_scan_count_only_range(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin, int hay_is_device,
                                        void *stream, uint64_t *count, uint64_t *result_dev) {
     return scan_count_impl(pma, mode, engine, hay, len, begin, hay_is_device, stream, count, nullptr, result_dev, false);
+}
+
+// One haystack sharded across the devices of a node (BASELINE configs[3]): the product's own form of what bench.py does with
+// one process per GPU.  One host thread per shard: makes the shard's device current, uploads the tables there if they are not yet, runs
+// daac_scan_count[_only]_range over [halo | shard] with begin = halo (matches with their end inside the shard, wherever they start), and
+// the host adds the counts and the two checksum sums — `base` re-bases a shard's ends (S2 += low32(base) * S1).  No collective: RCCL is
+// for callers that run one process per GPU (daachorse_amd/dist.py) and reduce {count, S1, S2} themselves.
+daac_status daac_scan_count_multi(daac_pma *pma, int mode, int engine, const daac_shard *shards, size_t n, int hay_is_device, uint64_t *count,
+                                  uint64_t *checksum) {
+    if (!pma || !count || (n && !shards)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    daac_status st = check_mode_kind(pma, mode);
+    if (st != DAAC_OK) return st;
+    if (mode != DAAC_FIND_OVERLAPPING && mode != DAAC_FIND_OVERLAPPING_NO_SUFFIX) {
+        set_error("daac_scan_count_multi: find_iter / leftmost_find_iter are chains through their own matches; a shard does not know where the chain enters it");
+        return DAAC_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    const size_t halo_need = pma->halo();
+    for (size_t k = 0; k < n; ++k) {
+        if (shards[k].device < 0 || shards[k].device >= ndev || ((shards[k].len + shards[k].halo) && !shards[k].hay)) {
+            set_error("daac_scan_count_multi: bad shard (device ordinal / null haystack)");
+            return DAAC_ERR_INVALID_ARGUMENT;
+        }
+        if (shards[k].halo < halo_need && shards[k].halo < shards[k].base) {   // fewer bytes in front than a match may reach back, and not the haystack's start
+            set_error("daac_scan_count_multi: a shard needs max_pattern_len - 1 bytes of the haystack in front of it (charwise: max_pattern_len, at least 3)");
+            return DAAC_ERR_INVALID_ARGUMENT;
+        }
+    }
+    int dev0 = 0;
+    HIP_TRY(hipGetDevice(&dev0));
+    struct Out { daac_status st = DAAC_OK; uint64_t count = 0, checksum = 0; int engine = DAAC_ENGINE_AUTO; std::string err; };
+    std::vector<Out> outs(n);
+    auto work = [&](size_t k) {
+        Out &o = outs[k];
+        const daac_shard &sh = shards[k];
+        if (hipSetDevice(sh.device) != hipSuccess) { o.st = DAAC_ERR_DEVICE; o.err = "hipSetDevice failed"; (void)hipGetLastError(); return; }
+        o.st = checksum ? scan_count_impl(pma, mode, engine, sh.hay, sh.halo + sh.len, sh.halo, hay_is_device, nullptr, &o.count, &o.checksum, nullptr, true)
+                        : scan_count_impl(pma, mode, engine, sh.hay, sh.halo + sh.len, sh.halo, hay_is_device, nullptr, &o.count, nullptr, nullptr, false);
+        o.engine = g_last_engine;
+        if (o.st != DAAC_OK) o.err = daac_last_error();
+    };
+    std::vector<std::thread> threads;
+    for (size_t k = 1; k < n; ++k) threads.emplace_back(work, k);
+    if (n) work(0);
+    for (std::thread &t : threads) t.join();
+    (void)hipSetDevice(dev0);
+    uint64_t total = 0;
+    uint32_t s1 = 0, s2 = 0;
+    for (size_t k = 0; k < n; ++k) {
+        if (outs[k].st != DAAC_OK) { set_error("shard " + std::to_string(k) + " (device " + std::to_string(shards[k].device) + "): " + outs[k].err); return outs[k].st; }
+        total += outs[k].count;
+        const uint32_t k1 = static_cast<uint32_t>(outs[k].checksum >> 32), k2 = static_cast<uint32_t>(outs[k].checksum);
+        const uint32_t shift = static_cast<uint32_t>(shards[k].base - shards[k].halo);   // ends were counted from the shard's first resident byte
+        s1 += k1;
+        s2 += k2 + shift * k1;
+    }
+    if (n) g_last_engine = outs[0].engine;
+    *count = total;
+    if (checksum) *checksum = (static_cast<uint64_t>(s1) << 32) | s2;
+    return DAAC_OK;
 }
 
 daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
@@ -2995,7 +3034,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "gram2_dpp") g_opt.gram2_dpp = value;
     else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
     else if (n == "gram4_arith") g_opt.gram4_arith = value;
-    else if (n == "gram3_tail") g_opt.gram3_tail = value;
+    else if (n == "gram3_tail" || n == "gram_tail") g_opt.gram3_tail = value;
     else if (n == "pfx") g_opt.pfx = value;
     else if (n == "pfx_probe") g_opt.pfx_probe = value;
     else if (n == "find3") g_opt.find3 = value;

@@ -137,11 +137,7 @@ struct Gram2Dev {
     const uint16_t *cid4;     // C^K: LDS address of the context's H entry (kGram2OffH + 4 * id)
     const uint32_t *hsum;     // per id: sum of h32
     const uint4 *drec;        // N x {cmap, first_child, own_cnt, own_hsum}  (HBM / L2)
-    const uint4 *drec_c;      // the same for `.count()`, single paths folded into tail records (gram2.hpp)
     const uint2 *dhit;        // depth-(K+1) states by rank: {cmap, own_hsum}
-    const uint2 *dhit_c;      // the same for `.count()`: {cmap | ends-a-pattern, first_child}
-    const uint4 *dhit_t;      // gram3 TAIL: the same as 16-byte records, single paths below a hit folded into a tail record
-    const uint4 *drec_t;      // gram3 TAIL: drec_c with tail records from depth K + 2 on
     const uint4 *dhit4;       // for count + checksum: {cmap, own_hsum, first_child, 0}
     const uint32_t *cfirst;   // depth-(K+1) states by rank: id of the first child
     uint32_t m_bytes, s_bytes, cid_bytes, h_bytes;  // multiples of 16
@@ -194,15 +190,13 @@ struct Gram2EmitDev {
 };
 hipError_t launch_gram2_scan(const Gram2Dev &dev, const GramArgs &a, bool exact, uint32_t blocks, uint32_t threads, hipStream_t stream);
 
-// `.count()` with lane-local hit masks and the step's text staged in LDS (gram3_kernels.hip); tables of Gram2Dev.
+// LDS plan of the tuple emitter's DETECT kernel (emit3_kernels.hip): per-wave text slots and hit queue behind the tables.
 struct Gram3Lds {
     uint32_t off_s;        // rank directory (M sits at 256)
     uint32_t off_wave;     // first wave's area: two text slots, then the hit queue
     uint32_t wave_stride;
     uint32_t lds_bytes, threads, rfull;
 };
-bool gram3_plan(const Gram2Dev &dev, uint32_t ppl, uint32_t waves, bool want_rfull, uint32_t lds_limit, Gram3Lds &L);
-hipError_t launch_gram3_scan(const Gram2Dev &dev, const GramArgs &a, const Gram3Lds &L, uint32_t blocks, hipStream_t stream);
 
 // `.count()` of round 5 (gram4_kernels.hip); tables of gram4.hpp ("no pattern" is the LAST class, so that byte classes of a
 // dictionary over one byte range are min(byte - lo, C - 1): no class table in LDS).

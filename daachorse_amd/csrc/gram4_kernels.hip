@@ -40,6 +40,12 @@ __device__ __forceinline__ uint32_t pin4(uint32_t x) {
     asm("" : "+v"(x));
     return x;
 }
+// a * b + c on the 24-bit multiplier (left to itself the compiler takes v_mad_u64_u32 here: a register pair, a move and an s_nop each)
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
 // lane i <- lane i - 1 of `v`; lane 0 keeps `lane0`
 __device__ __forceinline__ uint32_t wave_shr1_4(uint32_t v, uint32_t lane0) {
     uint32_t d = lane0;
@@ -77,6 +83,11 @@ __device__ __forceinline__ void g4_reduce(unsigned long long cnt, unsigned long 
 template <int K, int Q, bool ARITH, int DIR, bool TAIL>
 __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a, const Gram4Lds &L, char *smem) {
     constexpr int P = 16 * Q;
+#ifdef G4_GS
+    constexpr int GS = G4_GS;                 // M lookups asked for before the first is used
+#else
+    constexpr int GS = 8;
+#endif
     constexpr uint32_t SB = 64u * P;          // bytes a wave takes per step
     constexpr uint32_t SLOT = SB + 32u;       // [12,16) the four bytes before the step | [16, 16 + SB) the step | 16 bytes of the next
     // ONE text slot per wave: what is left in the hit queue at the end of a step (fewer than 64 entries) has its text taken out of the
@@ -455,28 +466,28 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
             // ---- M words of the K-grams ending at j = 0 .. P-1 (the one ending at -1 comes from the lane to the left) ----
             uint32_t H = 0, ccnt = 0, roll = 0, mprev = 0;
 #pragma unroll
-            for (int grp = 0; grp < P / 8; ++grp) {
-                uint32_t mw[8];
+            for (int grp = 0; grp < P / GS; ++grp) {
+                uint32_t mw[GS];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int j = grp * 8 + jj;
+                for (int jj = 0; jj < GS; ++jj) {
+                    const int j = grp * GS + jj;
                     uint32_t x = pin4((kx[K + j] << 2) + offM);                       // 4 c_j + offM              (v_lshl_add_u32)
-                    x = __umul24(kx[K + j - 1], C4) + x;                              // + 4 C c_(j-1)             (v_mad_u32_u24)
-                    if (K == 3) x = __umul24(kx[K + j - 2], CC4) + pin4(x);           // + 4 C^2 c_(j-2)           (v_mad_u32_u24)
+                    x = mad24(kx[K + j - 1], C4, x);                                  // + 4 C c_(j-1)             (v_mad_u32_u24)
+                    if (K == 3) x = mad24(kx[K + j - 2], CC4, x);                     // + 4 C^2 c_(j-2)           (v_mad_u32_u24)
                     mw[jj] = lds_u32(x);
                 }
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int j = grp * 8 + jj;
+                for (int jj = 0; jj < GS; ++jj) {
+                    const int j = grp * GS + jj;
                     roll = __builtin_amdgcn_alignbit(roll, mw[jj], 30);               // two count bits per position
                     // the hit bit of position j enters at the top: after the step's P - 1 shifts it sits at bit 32 - P + j
                     if (j > 0) H = __builtin_amdgcn_alignbit((jj == 0 ? mprev : mw[jj - 1]) >> kx[K + j], H, 1);   // (v_lshrrev_b32, v_alignbit_b32)
+                    if ((j & 15) == 15) {  // 16 positions rolled in: sum the two-bit fields
+                        ccnt += __popc(roll & 0x55555555u) + 2u * __popc(roll & 0xaaaaaaaau);
+                        roll = 0;
+                    }
                 }
-                mprev = mw[7];
-                if ((grp & 1) == 1 || grp == P / 8 - 1) {  // 16 positions rolled in: sum the two-bit fields
-                    ccnt += __popc(roll & 0x55555555u) + 2u * __popc(roll & 0xaaaaaaaau);
-                    roll = 0;
-                }
+                mprev = mw[GS - 1];
             }
             {   // position 0 against the M word of the K-gram ending just before this lane's share
                 const uint32_t mleft = wave_shr1_4(mprev, mcarry);

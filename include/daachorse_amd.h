@@ -32,8 +32,9 @@ extern "C" {
  *   3 (round 3): daac_info starts with struct_size and carries the per-request engine plan; DAAC_ENGINE_PFX; daac_match16 /
  *                daac_scan_device16.
  *   4 (round 4): daac_iter_next_batch; the lazy iterator runs its windows ahead of the consumer on a worker thread; DAAC_ENGINE_JUMP /
- *                DAAC_KERNEL_JUMP are gone (the experiment lives under tools/experiments/jump). */
-#define DAAC_ABI_VERSION 4
+ *                DAAC_KERNEL_JUMP are gone (the experiment lives under tools/experiments/jump).
+ *   5 (round 5): daac_scan_count_multi (one haystack sharded across the devices of a node); options gram4_arith, gram_tail. */
+#define DAAC_ABI_VERSION 5
 uint32_t daac_abi_version(void);
 
 /* src/errors.rs:10-22 (first four), plus the panics / extras of this boundary */
@@ -101,7 +102,7 @@ typedef enum {
 } daac_request;
 typedef enum {
     DAAC_KERNEL_NONE = 0,        /* the request does not apply to this automaton's MatchKind (the crate panics) */
-    DAAC_KERNEL_GRAM_COUNT = 1,  /* gram3_kernels.hip: one LDS lookup per byte, lane-local hit masks           (cfg3: 1.3 TB/s) */
+    DAAC_KERNEL_GRAM_COUNT = 1,  /* gram4_kernels.hip: one LDS lookup per byte, lane-local hit masks           (cfg3: 1.4 TB/s) */
     DAAC_KERNEL_GRAM_EXACT = 2,  /* gram_kernels.hip / gram2_kernels.hip with the checksum                      (cfg3: 1.0 TB/s) */
     DAAC_KERNEL_GRAM_WIDE = 3,   /* gram2w_kernels.hip: 31 .. 62 byte classes                                   (1.0 / 0.9 TB/s) */
     DAAC_KERNEL_GRAM_EMIT = 4,   /* emit3_kernels.hip (gram2_emit_kernels.hip behind it): tuples in reference order (cfg3: 0.22 TB/s of haystack) */
@@ -214,7 +215,7 @@ daac_status daac_charwise_build(const uint8_t *blob, const uint64_t *offsets, co
 daac_status daac_pma_serialize(const daac_pma *pma, uint8_t **buf, size_t *len);
 /* `info->struct_size` must be set by the caller (see daac_info). */
 daac_status daac_pma_info(const daac_pma *pma, daac_info *info);
-/* One line of text per request of the plan ("find_overlapping_iter().count(): engine gram, kernel gram3 ..."); returns the
+/* One line of text per request of the plan ("find_overlapping_iter().count(): engine gram, kernel gram4 ..."); returns the
  * number of bytes the full text needs (incl. the terminating 0); writes at most `cap`. */
 size_t daac_pma_explain(const daac_pma *pma, char *buf, size_t cap);
 void daac_pma_free(daac_pma *pma);
@@ -265,6 +266,24 @@ daac_status daac_scan_count(daac_pma *pma, int mode, int engine, const uint8_t *
  * this with one LDS lookup per haystack byte; every other engine runs its count + checksum scan and drops the checksum. */
 daac_status daac_scan_count_only_range(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin,
                                        int hay_is_device, void *stream, uint64_t *count, uint64_t *result_dev);
+
+/* One haystack sharded across the GPUs of a node (BASELINE configs[3]: 8 shards, one per MI355X).  Shard k is `len` bytes that begin at
+ * haystack position `base`; `hay` points at the `halo` bytes in front of it followed by the shard itself, in the memory of `device`
+ * (or in host memory when hay_is_device = 0).  Every shard but the one at position 0 needs halo >= max_pattern_len - 1 (charwise:
+ * max_pattern_len, at least 3): a match is counted by the shard its END falls in, wherever it starts.  One host thread per shard
+ * runs daac_scan_count[_only]_range on that device (tables are uploaded there on first use); the host adds the counts and — when
+ * `checksum` is not NULL — the checksum sums with every shard's ends re-based to haystack positions, so the result equals
+ * daac_scan_count of the whole haystack.  The find_overlapping modes only (status 6 otherwise: the other two iterators are chains).
+ * Several shards may name the same device.  daac_last_engine() reports shard 0's engine. */
+typedef struct {
+    int device;           /* HIP device ordinal */
+    const uint8_t *hay;   /* `halo` bytes of the haystack in front of the shard, then the shard */
+    size_t halo;          /* bytes in front that are there (the shard at position 0: 0) */
+    size_t len;           /* bytes of the shard */
+    uint64_t base;        /* haystack position of the shard's first byte */
+} daac_shard;
+daac_status daac_scan_count_multi(daac_pma *pma, int mode, int engine, const daac_shard *shards, size_t n, int hay_is_device,
+                                  uint64_t *count, uint64_t *checksum);
 
 /* The same over the tail of a haystack: counts the matches with end in (begin, len] — what one
  * shard of a haystack split across devices contributes.  Bytes before begin - Lmax are never read (they need
@@ -327,10 +346,11 @@ void daac_stream_close(daac_stream *s);
  *   lds_budget (98304), dense_depth (-1 = auto), rows_share_pct (45)   TIERED re-pack
  *   gram_lds_budget (161792), gram_region (0 = auto: 16384 for the first table set, 65536 for the second and PFX, 262144 from 2 GiB on; rounded down to a power of two >= 2048), gram_slab (4096), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto),
  *   gram_ppl (0 = auto: 32 positions per lane and step for automata without short patterns, else 16)
- *   gram_version (0 = auto: `.count()` on the gram3 kernel over the second table set, count + checksum on the first where it applies;
- *                 1 = first table set only, 2 = gram2 kernels only, 3 = gram3 for `.count()`), gram2_dpp (1: DPP wave shifts),
+ *   gram_version (0 = auto: `.count()` on the gram4 kernel over the renumbered second table set, count + checksum on the first where it applies;
+ *                 1 = first table set only, 2 = gram2 kernels only, 4 = gram4 for `.count()` or an error), gram2_dpp (1: DPP wave shifts),
  *   gram2_rfull (1)             rank directory with one entry per M word when LDS allows (0: one per four words)
- *   gram3_tail (-1 = every workgroup samples its text and picks; 0 / 1: the plain / the tail-record body of the gram3 kernel)
+ *   gram_tail (alias gram3_tail; -1 = every workgroup samples its text and picks; 0 / 1: the plain / the tail-record body of the gram4 kernel),
+ *   gram4_arith (1: byte classes by arithmetic where the dictionary's bytes are one range; 0: the class table in LDS)
  *   find3 (1)                   find_iter's count (+ checksum) by selection over the tuple emitter's per-position flags (find3_kernels.hip;
  *                               Standard bytewise dictionaries with K = 3 tables and no pattern beyond 19 bytes) instead of the chain walkers,
  *                               in windows of find3_window (2^30) end positions, each restarting at the last match of the one before; a handle

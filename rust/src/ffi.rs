@@ -2,7 +2,7 @@
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_void};
 
-pub const DAAC_ABI_VERSION: u32 = 4;
+pub const DAAC_ABI_VERSION: u32 = 5;
 
 /// daac_status
 pub const DAAC_OK: i32 = 0;
@@ -40,6 +40,15 @@ pub struct daac_match8 {
     pub value: u32,
     pub end_len: u32,
 }
+/// one device's part of a haystack for daac_scan_count_multi (include/daachorse_amd.h: daac_shard)
+#[repr(C)]
+pub struct daac_shard {
+    pub device: i32,
+    pub hay: *const u8,
+    pub halo: usize,
+    pub len: usize,
+    pub base: u64,
+}
 #[repr(C)]
 pub struct daac_pma {
     _p: [u8; 0],
@@ -72,6 +81,9 @@ extern "C" {
     pub fn daac_iter_close(it: *mut daac_iter);
     pub fn daac_scan_count_only_range(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, begin: usize,
                                       hay_is_device: i32, stream: *mut c_void, count: *mut u64, result_dev: *mut u64) -> i32;
+    /// one haystack sharded across the devices of a node: counts (and checksum sums) of the shards added on the host
+    pub fn daac_scan_count_multi(pma: *mut daac_pma, mode: i32, engine: i32, shards: *const daac_shard, n: usize, hay_is_device: i32,
+                                 count: *mut u64, checksum: *mut u64) -> i32;
     pub fn daac_scan_count(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,
                            stream: *mut c_void, count: *mut u64, checksum: *mut u64, result_dev: *mut u64) -> i32;
     pub fn daac_scan_device(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,

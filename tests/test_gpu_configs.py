@@ -189,7 +189,7 @@ def test_cfg3_full_4_gib_count_and_checksum():
         assert p.scan_count(ScanMode.FindOverlapping, dev) == want, kind
         assert da.last_engine() == int(Engine.Gram)
         assert p.count(ScanMode.FindOverlapping, dev) == want[0], kind
-        for version, ppl, tail in ((2, 0, -1), (3, 16, -1), (3, 32, -1), (4, 16, -1), (4, 32, -1), (4, 16, 0), (4, 16, 1)):
+        for version, ppl, tail in ((2, 0, -1), (4, 16, -1), (4, 32, -1), (4, 16, 0), (4, 16, 1), (4, 32, 0), (4, 32, 1)):
             da.set_option("gram_version", version)
             da.set_option("gram_ppl", ppl)
             da.set_option("gram3_tail", tail)
@@ -222,13 +222,16 @@ def test_cfg3_count_kernel_on_a_vector_of_window_counts():
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (bad[:8], got[bad[:8]], want[bad[:8]], los[bad[:8]], his[bad[:8]])
     assert da.last_engine() == int(Engine.Gram)
-    # the round-3 kernel (gram_version = 3; AUTO above ran gram4_kernels.hip) on every eighth window
-    da.set_option("gram_version", 3)
-    try:
-        got3 = np.array([p.count(ScanMode.FindOverlapping, dev[:int(h)], begin=int(l), engine=Engine.Gram) for l, h in zip(los[::8], his[::8])])
-    finally:
-        da.set_option("gram_version", 0)
-    assert np.array_equal(got3, want[::8])
+    # the other launch shape (16 positions per lane) and the tail-record body on every eighth window
+    for ppl, tail in ((16, 0), (32, 1)):
+        da.set_option("gram_ppl", ppl)
+        da.set_option("gram3_tail", tail)
+        try:
+            got3 = np.array([p.count(ScanMode.FindOverlapping, dev[:int(h)], begin=int(l), engine=Engine.Gram) for l, h in zip(los[::8], his[::8])])
+        finally:
+            da.set_option("gram_ppl", 0)
+            da.set_option("gram3_tail", -1)
+        assert np.array_equal(got3, want[::8]), (ppl, tail)
 
 
 class _DeviceWords:

@@ -852,3 +852,50 @@ def test_compact_lazy_iterator():
         assert [(m.start(), m.end(), m.value()) for m in q.find_overlapping_iter(b"zabab" + b"x" * 5001)] == orc.triples_sev(o.find_overlapping_iter(b"zabab" + b"x" * 5001))
     finally:
         da.set_option("iter_window", 64 << 20)
+
+
+def test_scan_count_multi_shards_on_one_device():
+    """daac_scan_count_multi (SURVEY 8e in the product: one haystack sharded across the devices of a node, host-side sum): shards that all
+    name device 0 — random cuts, halos of exactly max_pattern_len - 1 bytes and longer, device and host buffers, bytewise (GRAM, PFX,
+    DARRAY dictionaries) and charwise — equal the whole haystack's count + checksum from the oracle; a halo that is too short and the
+    chain iterators are refused."""
+    import torch
+    rng = np.random.default_rng(808)
+    pats3 = synth.patterns_cfg3(20000)
+    cases = [(pats3, synth.wordsoup_haystack(3 << 20, synth.SEEDS["cfg3_dense"], pats3, 20), False),
+             (synth.patterns_cfg2(500), synth.uniform_haystack(2 << 20, 6, synth.ALPHA_LOWER), False),
+             (synth.patterns_binary256(3000), rng.integers(0, 256, size=1 << 20).astype(np.uint8), False),
+             (["全世界", "世界", "に", "世", "界に"], np.frombuffer(("全世界に世界に" * 40000).encode(), dtype=np.uint8).copy(), True)]
+    for pats, hay, charwise in cases:
+        if charwise:
+            o = orc.OracleCharwisePma.build(pats)
+            p, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(o.serialize())
+            want = o.find_overlapping_iter(hay)
+        else:
+            o = orc.OraclePma.build(pats)
+            p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+            want = o.find_overlapping_iter(hay)
+        expect = (len(want), orc.matches_checksum(want))
+        lmax = p.info().max_pattern_len
+        need = max(lmax, 3) if charwise else lmax - 1
+        n = len(hay)
+        dev = torch.from_numpy(hay).cuda()
+        for nshards in (1, 2, 8):
+            cuts = [0] + sorted(int(x) for x in rng.integers(1, n, size=nshards - 1)) + [n]
+            for extra in (0, 37):
+                shards_dev, shards_host = [], []
+                for k in range(nshards):
+                    b, e = cuts[k], cuts[k + 1]
+                    halo = min(b, need + extra)
+                    shards_dev.append((0, dev[b - halo:e], halo, b))
+                    shards_host.append((0, hay[b - halo:e], halo, b))
+                assert da.scan_count_multi(p, ScanMode.FindOverlapping, shards_dev) == expect, (len(pats), nshards, extra)
+                assert da.scan_count_multi(p, ScanMode.FindOverlapping, shards_dev, checksum=False) == expect[0]
+            assert da.scan_count_multi(p, ScanMode.FindOverlapping, shards_host) == expect, (len(pats), nshards, "host")
+        if need > 1:
+            with pytest.raises(da.DaachorseError) as ei:
+                da.scan_count_multi(p, ScanMode.FindOverlapping, [(0, dev[:100], 0, 0), (0, dev[100 - (need - 1):], need - 1, 100)])
+            assert ei.value.code == 1
+        with pytest.raises(da.DaachorseError) as ei:
+            da.scan_count_multi(p, ScanMode.Find, [(0, dev, 0, 0)])
+        assert ei.value.code == 6

@@ -15,14 +15,13 @@ from daachorse_amd import Engine, ScanMode, synth
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 DEFAULTS = {"gram3_tail": -1, "gram4_arith": 1, "gram_version": 0, "gram_ppl": 0, "gram2_rfull": 1, "gram_region": 0, "threads": 1024, "blocks_per_cu": 0, "gram_slab": 4096}
 VARIANTS = [
-    ("gram2 (r02 default)", {"gram_version": 2}),
-    ("gram3 p16", {"gram_version": 3, "gram_ppl": 16}),
-    ("gram3 p16 wtext", {"gram_version": 3, "gram_ppl": 16, "gram3_tail": 1}),
-    ("gram3 p32", {"gram_version": 3, "gram_ppl": 32}),
-    ("gram3 p32 wtext", {"gram_version": 3, "gram_ppl": 32, "gram3_tail": 1}),
-    ("gram3 p16 region 16k", {"gram_version": 3, "gram_ppl": 16, "gram_region": 16384}),
-    ("gram3 p16 region 256k", {"gram_version": 3, "gram_ppl": 16, "gram_region": 262144}),
-    ("gram3 p16 sdir", {"gram_version": 3, "gram_ppl": 16, "gram2_rfull": 0}),
+    ("gram4 auto", {"gram_version": 4}),
+    ("gram4 p16", {"gram_version": 4, "gram_ppl": 16}),
+    ("gram4 p32", {"gram_version": 4, "gram_ppl": 32}),
+    ("gram4 p32 plain", {"gram_version": 4, "gram_ppl": 32, "gram3_tail": 0}),
+    ("gram4 p32 tail", {"gram_version": 4, "gram_ppl": 32, "gram3_tail": 1}),
+    ("gram4 p32 class table", {"gram_version": 4, "gram_ppl": 32, "gram4_arith": 0}),
+    ("gram4 p32 coarse directory", {"gram_version": 4, "gram_ppl": 32, "gram2_rfull": 0}),
 ]
 if len(sys.argv) > 2:
     VARIANTS = [(n, o) for n, o in json.load(open(sys.argv[2]))]

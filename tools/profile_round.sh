@@ -41,10 +41,10 @@ PY
 }
 
 B="python $R/bench.py --steps 8 --warmup 2 --no-cpu --no-dense --materialize-mib 0 --no-extra"
-profile cfg3_sparse_count    "gram3_kernel,gram2_kernel,gram_count_kernel" 2 $B
+profile cfg3_sparse_count    "gram4_kernel,gram2_kernel,gram_count_kernel" 2 $B
 profile cfg3_sparse_checksum "gram_count_kernel,gram2_kernel" 2 $B --op checksum
-profile cfg3_dense_count     "gram3_kernel" 2 $B --haystack dense
-profile cfg2_count           "gram3_kernel" 2 $B --workload cfg2 --bytes 1073741824
+profile cfg3_dense_count     "gram4_kernel" 2 $B --haystack dense
+profile cfg2_count           "gram4_kernel" 2 $B --workload cfg2 --bytes 1073741824
 profile emit                 "emit3_detect_kernel,emit3_bin_kernel,emit3_expand_kernel" 2 python $R/tools/time_emit.py 1024 sparse 3
 profile emit_dense           "emit3_detect_kernel,emit3_bin_kernel,emit3_expand_kernel" 2 python $R/tools/time_emit.py 512 dense 3
 profile find_sparse          "find3_,emit3_detect,emit3_bin,chain,restart" 0 python $R/tools/time_find.py 1024 sparse find
