@@ -300,6 +300,50 @@ def cfg5_legs(da, synth, torch, local_rank, stream, result, no_cpu):
     return out
 
 
+def stream_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha, no_cpu):
+    """The chunk-fed steppers (daac_stream_*: FindOverlappingStepper / FindStepper / find_overlapping_no_suffix fed 64 MiB device chunks, SURVEY
+    8f-2): every feed scans [kept tail | chunk] on the engines the eager scans use and hands the chunk's matches to the host; 512 MiB of the cfg3
+    haystack (bound by the 24-byte tuples' way back over PCIe) and of cfg2's sparse haystack; the first chunks' tuples against the oracle."""
+    from daachorse_amd import ScanMode
+    n, chunk = 512 << 20, 64 << 20
+    out = {"bytes": n, "chunk_bytes": chunk, "op": "daac_stream_open + daac_stream_feed over 64 MiB device chunks, every chunk's tuple list handed to the host"}
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    p2 = da.DoubleArrayAhoCorasick.new(synth.patterns_cfg2())
+    p2.upload(local_rank)
+    for name, pma, fill in (("cfg3", pma_cfg3, lambda: synth.device_uniform(dev, seed_sparse, alpha)),
+                            ("cfg2_sparse", p2, lambda: synth.device_uniform(dev, synth.SEEDS["cfg2_hay"], synth.ALPHA_PRINTABLE))):
+        fill()
+        torch.cuda.synchronize()
+        leg = {}
+        for mode_name, make in (("find_overlapping_stepper", pma.find_overlapping_stepper), ("find_stepper", pma.find_stepper),
+                                ("find_overlapping_no_suffix_stepper", pma.find_overlapping_no_suffix_stepper)):
+            best, cnt, first = None, 0, None
+            for rep in range(2):
+                st = make()
+                cnt = 0
+                t0 = time.perf_counter()
+                for b in range(0, n, chunk):
+                    m = st.feed(dev[b:b + chunk])
+                    cnt += len(m)
+                    if b == 0 and rep == 0:
+                        first = np.array(m[:200000], copy=True)
+                dt = time.perf_counter() - t0
+                del st
+                best = dt if best is None else min(best, dt)
+            leg[mode_name] = {"GB/s": round(n / best / 1e9, 2), "seconds": round(best, 4), "matches": cnt,
+                              "engine_used": ENGINE_NAMES.get(da.last_engine(), "?")}
+            if not no_cpu and mode_name != "find_overlapping_no_suffix_stepper":
+                from oracle import oracle as orc
+                o = orc.OraclePma.deserialize(pma.serialize())
+                pre = dev[:8 << 20].cpu().numpy()
+                want = (o.find_overlapping_iter(pre) if mode_name == "find_overlapping_stepper" else o.find_iter(pre))[:len(first)]
+                k = min(len(want), len(first), 100000)   # (the prefix: what lies well inside the first 8 MiB)
+                leg[mode_name]["parity_first_tuples_vs_oracle"] = bool(k > 0 and np.array_equal(first["start"][:k], want["start"][:k]) and
+                                                                     np.array_equal(first["end"][:k], want["end"][:k]) and np.array_equal(first["value"][:k], want["value"][:k]))
+        out[name] = leg
+    return out
+
+
 def iterator_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha):
     """Iterator::next driven to exhaustion over HOST haystacks (page-locked): daac_iter_next_batch run by run, every tuple looked at
     (runs counted; a third pass also sums the ends on one host thread).  cfg3 (0.6 matches per byte: bound by the tuples' way back over PCIe) and cfg2's sparse haystack
@@ -863,6 +907,7 @@ def main():
         out["restart"] = restart_legs(da, synth, torch, patterns, local_rank, stream, result, args.no_cpu, seed_sparse, seed_dense, alpha)
         out["cfg5"] = cfg5_legs(da, synth, torch, local_rank, stream, result, args.no_cpu)
         out["iterator"] = iterator_legs(da, synth, torch, np, pma, local_rank, seed_sparse, alpha)
+        out["stream"] = stream_legs(da, synth, torch, np, pma, local_rank, seed_sparse, alpha, args.no_cpu)
     print(json.dumps(out))
     # a multi-GPU line that is not what it says fails loudly: the reason is in the line (`distributed`), the exit code says so
     if dist_used is not None and (dist_used.get("n_ranks_seen") != args.gpus or dist_used.get("strong_equals_one_rank") is False):

@@ -78,6 +78,8 @@ def lib():
     L.daac_pma_explain.restype = sz
     L.daac_pma_free.argtypes = [vp]
     L.daac_pma_upload.argtypes = [vp, C.c_int]
+    L.daac_pma_trim.argtypes = [vp]
+    L.daac_pma_trim.restype = C.c_int
     L.daac_scan.argtypes = [vp, C.c_int, C.c_int, u8p, sz, C.c_int, vp, P(vp)]
     L.daac_matches_count.argtypes = [vp]
     L.daac_matches_count.restype = sz

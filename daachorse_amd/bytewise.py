@@ -323,6 +323,11 @@ class DoubleArrayAhoCorasick:
         _ffi.check(_ffi.lib().daac_pma_upload(self._h, device))
         return self
 
+    def trim(self):
+        """daac_pma_trim: gives back the scratch the handle keeps between calls (tables stay)"""
+        _ffi.check(_ffi.lib().daac_pma_trim(self._h))
+        return self
+
     # ---- lazy iterators, crate names (bytewise.rs:190-203, 292-314, 410-428, 547-566) --------------------
     # (compact=True: daac_iter_open_compact — 8-byte tuples over PCIe, read with next_batch8(); iterating match by match works on either)
     def find_iter(self, haystack, engine=Engine.Auto, stream=None, compact=False):

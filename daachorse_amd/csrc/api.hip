@@ -226,6 +226,7 @@ struct DeviceTables {
     Find3Dev find3v{};             // the same tables with the patterns' VALUES (the emitter's V1 / V2 / V3 rank structure): the selection's tuple list
     bool left3_ok = false;         // a leftmost handle whose patterns, as a Standard automaton, got the emitter's and find3's tables: left3_kernels.hip serves leftmost_find_iter
     std::atomic<uint32_t> find3_gave_up{0};
+    std::atomic<uint32_t> find3_retry{0}, emit3_retry{0};   // large requests turned away since the engines gave up (every sixteenth tries again)
     std::atomic<uint32_t> find3_skips{0};
     std::atomic<uint32_t> find3_rec_per_kib{0};   // deep matches per KiB the last find3 request met, + 1 (0: none yet): text made of the dictionary's
                                                    // own words keeps DETECT's walkers busy (3.4 ms per GiB against 1.4) and the chain walkers are faster there
@@ -590,7 +591,16 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     // leftmost_find_iter's matches among the ones the emitter's detection finds.
     HostPma shadow;
     bool have_shadow = false;
-    if (!h.is_standard() && g_opt.left3.load() != 0 && !pma->root_has_output()) {
+    // (the shadow is only ever used by left3, which takes dictionaries of at most 19-byte patterns over at most 29 distinct bytes:
+    // neither a second automaton nor its tables are built for a handle that cannot qualify)
+    bool shadow_can = !h.is_standard() && g_opt.left3.load() != 0 && !pma->root_has_output() && h.max_pattern_len() <= 19;
+    if (shadow_can) {
+        bool seen[256] = {false};
+        uint32_t distinct = 0;
+        for (const LStateRec &r : h.lstates) { const uint32_t c = check_of(r.opos_ch); if (!seen[c]) { seen[c] = true; ++distinct; } }
+        shadow_can = distinct <= 30;   // (CHECK bytes of the slots: every pattern byte labels some edge; an unused slot's adds at most one)
+    }
+    if (shadow_can) {
         std::vector<uint8_t> blob; std::vector<uint64_t> offs; std::vector<uint32_t> vals;
         if (recover_patterns(h, blob, offs, vals) &&
             build_bytewise(blob.data(), offs.data(), vals.data(), vals.size(), DAAC_STANDARD, 16, shadow) == DAAC_OK) {
@@ -1166,7 +1176,9 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
                               DevMatches &out, bool *served, bool raw = false, void *dest = nullptr, uint64_t dest_cap = 0) {
     *served = false;
     if (!(raw ? t->pfx_emit_ok : t->emit3_ok) || g_opt.emit.load() == 0 || end <= begin) return DAAC_OK;
-    if (t->emit3_gave_up.load() >= 2 && end - begin >= (1u << 20)) return DAAC_OK;   // (short scans may still try: they cost little)
+    // (short scans may still try: they cost little; of the large ones every sixteenth looks again — one pair of adversarial haystacks
+    // is not the text of a long-lived handle for ever)
+    if (t->emit3_gave_up.load() >= 2 && end - begin >= (1u << 20) && (t->emit3_retry.fetch_add(1) & 15u) != 15u) return DAAC_OK;
     const Gram2EmitDev &e = raw ? t->pfx_emit : t->emit;
     const Gram3Lds &L = t->emit3_lds;
     const uint64_t halo = pma->halo();
@@ -1372,7 +1384,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
     const bool dbg_sync = dbg_env && dbg_env[0] == '1';
     auto lap = [&](const char *what) { if (dbg_env) { if (dbg_sync) (void)hipStreamSynchronize(stream); dbg_mark(what); } };
     if (!(leftmost ? t->left3_ok : t->find3_ok) || optv == 0 || len <= begin || len - begin > (1ull << 30)) return DAAC_OK;
-    if (t->find3_gave_up.load() >= 2 && len - begin >= (1u << 20)) return DAAC_OK;
+    if (t->find3_gave_up.load() >= 2 && len - begin >= (1u << 20) && (t->find3_retry.fetch_add(1) & 15u) != 15u) return DAAC_OK;
     // (option find3 = 2: whatever the text)
     const uint32_t kDenseRecPerKib = 26;
     if (optv < 2 && t->find3_rec_per_kib.load() > kDenseRecPerKib + 1 && len - begin >= (1u << 20) &&
@@ -2066,6 +2078,24 @@ size_t daac_pma_explain(const daac_pma *pma, char *buf, size_t cap) {
     return s.size() + 1;
 }
 
+// Gives back what the handle keeps between calls beside its tables: the emitter's / selection kernels' workspace on every device it was
+// uploaded to (option workspace_keep bounds it while it is kept).  A workspace a scan is using right now stays.
+daac_status daac_pma_trim(daac_pma *pma) {
+    if (!pma) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    std::lock_guard<std::mutex> g(pma->mu);
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (auto &kv : pma->dev) {
+        DeviceTables *t = kv.second.get();
+        if (!t || t->ws_busy.exchange(true)) continue;
+        if (t->ws_p && hipSetDevice(kv.first) == hipSuccess) { (void)hipFree(t->ws_p); t->ws_p = nullptr; t->ws_bytes = 0; }
+        t->ws_want.store(0);
+        t->ws_busy.store(false);
+    }
+    if (have_prev) (void)hipSetDevice(prev);
+    return DAAC_OK;
+}
+
 void daac_pma_free(daac_pma *pma) { delete pma; }
 
 daac_status daac_pma_upload(daac_pma *pma, int device) {
@@ -2582,6 +2612,8 @@ struct daac_iter {
     uint64_t cur_base = 0;
     size_t cur_n = 0, pos = 0;
     bool holding = false;
+    bool started = false;          // the worker runs from the first next() on: an iterator that is only opened (the Rust cursor's
+                                   // `.count()` fast path opens one and counts beside it) scans and copies nothing
 
     void run();
 };
@@ -2741,6 +2773,7 @@ extern "C" {
 
 static daac_status iter_open_impl(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream,
                                   bool compact, daac_iter **out);
+void daac_iter_close(daac_iter *it);
 daac_status daac_iter_open(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream,
                            daac_iter **out) {
     return iter_open_impl(pma, mode, engine, hay, len, hay_is_device, stream, false, out);
@@ -2782,18 +2815,31 @@ static daac_status iter_open_impl(daac_pma *pma, int mode, int engine, const uin
         it->hay_is_device = true;
     }
     // whatever the caller queued on its stream (a device haystack being written, the staging copy above) comes first
-    HIP_TRY(hipStreamSynchronize(it->user_stream));
+    if (hipStreamSynchronize(it->user_stream) != hipSuccess) {
+        const daac_status e = hip_fail(hipGetLastError(), "iterator: the caller's stream");
+        if (it->owned_dev) (void)hipFree(it->owned_dev);
+        return e;
+    }
     it->kit = iter_kits().take(it->device);
     if (!it->kit) { if (it->owned_dev) (void)hipFree(it->owned_dev); set_error("iterator: no streams / events to be had"); return DAAC_ERR_DEVICE; }
     it->s_scan = it->kit->s_scan; it->s_h2d = it->kit->s_h2d; it->s_d2h = it->kit->s_d2h; it->s_d2h2 = it->kit->s_d2h2;
-    for (IterWindow &w : it->win) HIP_TRY(hipEventCreateWithFlags(&w.copied, hipEventDisableTiming));
-    it->worker = std::thread([p = it.get()] { p->run(); });
+    for (IterWindow &w : it->win) {
+        if (hipEventCreateWithFlags(&w.copied, hipEventDisableTiming) != hipSuccess) {
+            const daac_status e = hip_fail(hipGetLastError(), "iterator: events");
+            daac_iter_close(it.release());   // gives back the kit, the staged haystack and the events made so far
+            return e;
+        }
+    }
     *out = it.release();
     return DAAC_OK;
 }
 
 // The next window's tuples (blocks until the worker has them); 1 = it->cur / cur_n are set, 0 = exhausted, < 0 = -daac_status
 static int iter_advance(daac_iter *it) {
+    if (!it->started) {   // the first next(): the worker starts scanning now
+        it->started = true;
+        it->worker = std::thread([it] { it->run(); });
+    }
     for (;;) {
         if (it->holding) {   // give the slot back
             { std::lock_guard<std::mutex> g(it->mu); ++it->consumed; }
@@ -2875,7 +2921,7 @@ void daac_iter_close(daac_iter *it) {
         if (w.host) { if (w.host_pinned) pinned_pool().give(w.host, w.host_bytes); else std::free(w.host); }
         if (w.copied) (void)hipEventDestroy(w.copied);
     }
-    iter_kits().give(it->kit);   // (the worker has drained its streams)
+    if (it->kit) iter_kits().give(it->kit);   // (the worker, if it ever ran, has drained its streams)
     if (it->owned_dev) (void)hipFree(it->owned_dev);
     if (switched) (void)hipSetDevice(prev);
     delete it;

@@ -223,6 +223,9 @@ void daac_pma_free(daac_pma *pma);
 /* Re-packs the automaton for the GPU and copies it to `device` (idempotent).  Scans upload
  * lazily to the current device if this was not called. */
 daac_status daac_pma_upload(daac_pma *pma, int device);
+/* Releases the scratch a handle keeps between calls beside its tables (the tuple emitter's and the selection kernels' workspace, up to
+ * option workspace_keep bytes per device): for processes that hold many handles.  Tables stay; the next scan allocates again. */
+daac_status daac_pma_trim(daac_pma *pma);
 
 /* ---- scans ----------------------------------------------------------------------------------- */
 

@@ -57,6 +57,14 @@ pub struct daac_pma {
 pub struct daac_iter {
     _p: [u8; 0],
 }
+#[repr(C)]
+pub struct daac_stream {
+    _p: [u8; 0],
+}
+#[repr(C)]
+pub struct daac_matches {
+    _p: [u8; 0],
+}
 
 #[link(name = "daachorse_amd")]
 extern "C" {
@@ -91,6 +99,15 @@ extern "C" {
     pub fn daac_scan_device16(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,
                               stream: *mut c_void, dev_out: *mut *mut daac_match16, count: *mut u64) -> i32;
     pub fn daac_device_free(p: *mut c_void);
+    /// releases the scratch a handle keeps between calls (tables stay)
+    pub fn daac_pma_trim(pma: *mut daac_pma) -> i32;
+    // the chunk-fed steppers (stepper_hip.rs): FindStepper / FindOverlappingStepper / the *_from_iter entry points
+    pub fn daac_stream_open(pma: *mut daac_pma, mode: i32, engine: i32, stream: *mut c_void, out: *mut *mut daac_stream) -> i32;
+    pub fn daac_stream_feed(s: *mut daac_stream, chunk: *const u8, len: usize, chunk_is_device: i32, out: *mut *mut daac_matches) -> i32;
+    pub fn daac_stream_close(s: *mut daac_stream);
+    pub fn daac_matches_count(m: *const daac_matches) -> usize;
+    pub fn daac_matches_data(m: *const daac_matches) -> *const daac_match;
+    pub fn daac_matches_free(m: *mut daac_matches);
 }
 
 /// Owner of a `daac_pma*`: the device twin of one automaton, immutable after upload.

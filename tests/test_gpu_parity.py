@@ -899,3 +899,30 @@ def test_scan_count_multi_shards_on_one_device():
         with pytest.raises(da.DaachorseError) as ei:
             da.scan_count_multi(p, ScanMode.Find, [(0, dev, 0, 0)])
         assert ei.value.code == 6
+
+
+def test_trim_and_iterators_that_are_never_pulled():
+    """daac_pma_trim gives the kept scratch back and the next scans allocate again; a lazy iterator that is opened and closed without a
+    next() never starts its worker (the Rust cursor's `.count()` opens one and counts beside it), one that is pulled after a trim works"""
+    import torch
+    pats = synth.patterns_cfg3(20000)
+    o = orc.OraclePma.build(pats)
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    hay = synth.wordsoup_haystack(4 << 20, synth.SEEDS["cfg3_dense"], pats, 20)
+    dev = torch.from_numpy(hay).cuda()
+    want = o.find_overlapping_iter(hay)
+    for _ in range(2):
+        dm = p.scan_device(ScanMode.FindOverlapping, dev)
+        assert dm.count == len(want)
+        dm.free()
+        free_before = torch.cuda.mem_get_info()[0]
+        p.trim()
+        assert torch.cuda.mem_get_info()[0] >= free_before
+        for _ in range(3):
+            it = p.find_overlapping_iter(hay)
+            it.close()
+        assert p.count(ScanMode.FindOverlapping, dev) == len(want)
+        it = p.find_overlapping_iter(hay)
+        first = next(iter(it))
+        assert (first.start(), first.end(), first.value()) == (int(want["start"][0]), int(want["end"][0]), int(want["value"][0]))
+        it.close()
