@@ -10,7 +10,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdaachorse_amd.so")
 
 SOURCES = ["pma.cpp", "repack.cpp", "gram.cpp", "gram2.cpp", "gram4.cpp", "gram2w.cpp", "pfx.cpp", "builder.cpp", "charwise.cpp", "charwise_builder.cpp", "api.hip", "scan_kernels.hip",
-           "gram_kernels.hip", "gram2_kernels.hip", "gram4_kernels.hip", "pfx_kernels.hip", "emit3_kernels.hip", "find3_kernels.hip", "left3_kernels.hip", "gram2w_kernels.hip", "restart_kernels.hip", "tier_chain_kernels.hip", "charwise_kernels.hip", "synth.hip"]
+           "gram_kernels.hip", "gram2_kernels.hip", "gram4_kernels.hip", "pfx_kernels.hip", "emit3_kernels.hip", "find3_kernels.hip", "left3_kernels.hip", "gram2w_kernels.hip", "restart_kernels.hip", "charwise_kernels.hip", "synth.hip"]
 HEADERS = ["pma.hpp", "repack.hpp", "gram.hpp", "gram2.hpp", "gram4.hpp", "gram2w.hpp", "pfx.hpp", "charwise.hpp", "build_common.hpp", "device_tables.hpp", "chain_scan.hpp", os.path.join("..", "..", "include", "daachorse_amd.h"),
            os.path.join("..", "..", "include", "daac_synth.h")]
 

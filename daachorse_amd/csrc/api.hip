@@ -59,8 +59,6 @@ struct Options {
     std::atomic<int64_t> emit_v3_lds{1};        // emit3 EXPAND: values of the 3-byte patterns from a rank structure in LDS when it fits (0: from L2)
     std::atomic<int64_t> emit_stagger{0};       // emit3 EXPAND: the waves of a CU start this many x 1024 cycles apart (0: together)
     std::atomic<int64_t> emit_rec_per_kib{32};  // emit3: deep-match records the list is first sized for, per KiB of haystack (a rerun sizes it exactly)
-    std::atomic<int64_t> restart_tier{0};       // 1: find_iter of Standard bytewise automata chains over the TIERED tables (measured 7-9 % slower
-                                                // than over the double array on cfg3: half the waves per CU, and a match costs a gather more)
     std::atomic<int64_t> restart_bpc{8};        // 256-thread workgroups per CU of the chain walkers
     std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
     std::atomic<int64_t> chain_rounds{24};
@@ -906,7 +904,6 @@ struct Plan {
     bool tier;
     bool charwise = false;  // the charwise engine (scan_kernel<CharEngine> / char_restart_kernel)
     bool restart = false;   // find_iter / leftmost_find_iter: the restart scanners (DARRAY tables)
-    bool tier_chain = false;  // ... find_iter of a Standard bytewise automaton: the chain passes run over the TIERED tables
     bool leftmost = false;
     uint32_t blocks, threads;
     ScanArgs a;
@@ -977,8 +974,6 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
     if (pl.restart) {
         pl.threads = 256;
         pl.blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * static_cast<uint64_t>(std::max<int64_t>(1, g_opt.restart_bpc.load())), (nseg + 255) / 256)));
-        pl.tier_chain = !pl.charwise && !pl.leftmost && t->tier_ok && t->tier.root_flag == 0 && g_opt.restart_tier.load() != 0 &&
-                        t->tier.lds_bytes + 512u <= 160u * 1024u;
     }
     return DAAC_OK;
 }
@@ -986,9 +981,6 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
 hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, hipStream_t s, unsigned long long *next_begin = nullptr) {
     if (pl.restart && pl.chain.x_prev != nullptr) {  // totals and per-segment counts are sums of tallies; only writing re-scans
         const int pass = kmode == 2 ? 2 : 3;
-        if (pl.tier_chain)
-            return launch_tier_chain(t->tier, pl.a, pl.chain, pass, kmode, next_begin,
-                                     static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(t->num_cu, (pl.a.nseg + 1023) / 1024))), s);
         return pl.charwise ? launch_char_chain(t->chr, pl.a, pl.chain, pass, kmode, pl.leftmost, next_begin, pl.blocks, s)
                            : launch_chain(t->da, pl.a, pl.chain, pass, kmode, pl.leftmost, next_begin, pl.blocks, s);
     }
@@ -1047,9 +1039,6 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
     c.tally_delta = tallies + n;
     c.x_out = x_spec;
     auto run = [&](int pass) {
-        if (pl.tier_chain)
-            return launch_tier_chain(t->tier, pl.a, c, pass, 0, nullptr,
-                                     static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(t->num_cu, (pl.a.nseg + 1023) / 1024))), stream);
         return pl.charwise ? launch_char_chain(t->chr, pl.a, c, pass, 0, pl.leftmost, nullptr, pl.blocks, stream)
                            : launch_chain(t->da, pl.a, c, pass, 0, pl.leftmost, nullptr, pl.blocks, stream);
     };
@@ -3086,7 +3075,7 @@ daac_status daac_set_option(const char *name, int64_t value) {
     else if (n == "find3") g_opt.find3 = value;
     else if (n == "left3") g_opt.left3 = value;
     else if (n == "select_emit") g_opt.select_emit = value;
-    else if (n == "restart_tier") g_opt.restart_tier = value;
+    else if (n == "restart_tier") {}   // (the TIERED chain walkers of round 3 — measured 7-9 % slower than the double array's — left the library: accepted, without effect)
     else if (n == "emit") g_opt.emit = value;
     else if (n == "emit_tiles" || n == "emit_rec_cap" || n == "emit_version") {}   // (options of the round-3 COUNT + WRITE emitter: accepted, nothing left to steer)
     else if (n == "emit_stagger") g_opt.emit_stagger = value;

@@ -375,10 +375,6 @@ hipError_t launch_char_restart_scan(const CharDev &dev, const ScanArgs &a, int k
 // (0 totals, 1 per-segment counts)
 hipError_t launch_chain(const DArrayDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
                         unsigned long long *next_begin, uint32_t blocks, hipStream_t stream);
-// the same passes for FindIterator of a Standard bytewise automaton over the TIERED tables (tier_chain_kernels.hip): 1024-thread
-// workgroups, one per CU, the LDS tiers staged per workgroup
-hipError_t launch_tier_chain(const TierDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, unsigned long long *next_begin,
-                             uint32_t blocks, hipStream_t stream);
 hipError_t launch_char_chain(const CharDev &dev, const ScanArgs &a, const ChainArgs &c, int pass, int kmode, bool leftmost,
                              unsigned long long *next_begin, uint32_t blocks, hipStream_t stream);
 hipError_t launch_exclusive_scan(unsigned long long *v, uint64_t n, unsigned long long *total, unsigned long long *scratch, hipStream_t stream);

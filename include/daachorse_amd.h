@@ -32,7 +32,7 @@ extern "C" {
  *   3 (round 3): daac_info starts with struct_size and carries the per-request engine plan; DAAC_ENGINE_PFX; daac_match16 /
  *                daac_scan_device16.
  *   4 (round 4): daac_iter_next_batch; the lazy iterator runs its windows ahead of the consumer on a worker thread; DAAC_ENGINE_JUMP /
- *                DAAC_KERNEL_JUMP are gone (the experiment lives under tools/experiments/jump).
+ *                DAAC_KERNEL_JUMP are gone (the experiment is in the history: commit c51e1c3 and before, tools/experiments/jump).
  *   5 (round 5): daac_scan_count_multi (one haystack sharded across the devices of a node); options gram4_arith, gram_tail. */
 #define DAAC_ABI_VERSION 5
 uint32_t daac_abi_version(void);
@@ -375,9 +375,9 @@ void daac_stream_close(daac_stream *s);
  *                               GRAM tables, or PFX's for any byte alphabet) where it applies (0: segment scanners);
  *   emit_rec_per_kib (32)       deep-match records per KiB of haystack the record list is first sized for (a handle remembers what its
  *                               last scan met; a list that proves too short is sized exactly and the detection is rerun once)
- *   emit_version, emit_tiles, emit_rec_cap   options of the round-3 COUNT + WRITE emitter (now tools/experiments/emit_v1): accepted, without effect
+ *   emit_version, emit_tiles, emit_rec_cap   options of the round-3 COUNT + WRITE emitter (gone; in the history up to round 4): accepted, without effect
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
- *   restart_tier (0)            1: find_iter of Standard bytewise automata runs its chains over the TIERED tables instead of the double array
+ *   restart_tier                (the TIERED chain walkers left the library in round 5: accepted, without effect)
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners
  *   restart_bpc (8)             256-lane workgroups per CU of the chain walkers (they are bound by VALU issue at full occupancy)
  *   char_map_lds (1)            charwise walkers: ASCII and the populated stretch of the code mapper staged in LDS when they fit 32 KB

@@ -768,7 +768,7 @@ def test_engine_options_do_not_change_answers():
     cwant = {"ov": co.find_overlapping_iter(ctext), "find": co.find_iter(ctext), "lm": col.leftmost_find_iter(ctext)}
     try:
         for opts in ({}, {"pool": 0}, {"overlap_micro": 0}, {"overlap_micro": 2}, {"char_map_lds": 0}, {"char_row_lds": 0}, {"restart_chain": 0},
-                     {"restart_tier": 1}, {"seg_bytes": 4096, "overlap_micro": 2}):
+                     {"seg_bytes": 4096, "overlap_micro": 2}):
             for k, v in opts.items():
                 da.set_option(k, v)
             _, p = _pma(pats)       # (tables are laid out at upload: a fresh handle per setting)
@@ -788,9 +788,9 @@ def test_engine_options_do_not_change_answers():
             assert cpl.scan_count(ScanMode.LeftmostFind, ctext) == (len(cwant["lm"]), orc.matches_checksum(cwant["lm"])), opts
             assert _same(cp.scan(ScanMode.FindOverlapping, ctext), cwant["ov"]), opts
             for k in opts:
-                da.set_option(k, {"pool": 1, "overlap_micro": 1, "char_map_lds": 1, "char_row_lds": 1, "restart_chain": 1, "restart_tier": 0, "seg_bytes": 0}[k])
+                da.set_option(k, {"pool": 1, "overlap_micro": 1, "char_map_lds": 1, "char_row_lds": 1, "restart_chain": 1, "seg_bytes": 0}[k])
     finally:
-        for k, v in {"pool": 1, "overlap_micro": 1, "char_map_lds": 1, "char_row_lds": 1, "restart_chain": 1, "restart_tier": 0, "seg_bytes": 0}.items():
+        for k, v in {"pool": 1, "overlap_micro": 1, "char_map_lds": 1, "char_row_lds": 1, "restart_chain": 1, "seg_bytes": 0}.items():
             da.set_option(k, v)
 
 

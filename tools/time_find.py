@@ -15,8 +15,7 @@ else:
     synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
 res = {}
 only = sys.argv[3] if len(sys.argv) > 3 else ""   # "find" / "leftmost": that iterator alone (one kernel family per profile)
-for name, kind, mode, opts in (("find_iter (tier chains)", da.MatchKind.Standard, ScanMode.Find, {"restart_tier": 1}),
-                               ("find_iter (double array)", da.MatchKind.Standard, ScanMode.Find, {"restart_tier": 0}),
+for name, kind, mode, opts in (("find_iter (double array)", da.MatchKind.Standard, ScanMode.Find, {}),
                                ("leftmost_find_iter LL", da.MatchKind.LeftmostLongest, ScanMode.LeftmostFind, {})):
     if (only == "find" and "double array" not in name) or (only == "leftmost" and "leftmost" not in name):
         continue
@@ -36,4 +35,3 @@ for name, kind, mode, opts in (("find_iter (tier chains)", da.MatchKind.Standard
     name = f"{name} [engine {da.last_engine()}]"
     print(f"{name:40s} {hk} {mib} MiB: {best * 1e3:8.2f} ms  {hay.numel() / best / 1e9:7.1f} GB/s  count={r[0]} checksum={r[1]:016x}", flush=True)
     res[(kind, name.split(' (')[0])] = r
-da.set_option("restart_tier", 0)
