@@ -591,18 +591,14 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     bool have_shadow = false;
     // (the shadow is only ever used by left3, which takes dictionaries of at most 19-byte patterns over at most 29 distinct bytes:
     // neither a second automaton nor its tables are built for a handle that cannot qualify)
-    bool shadow_can = !h.is_standard() && g_opt.left3.load() != 0 && !pma->root_has_output() && h.max_pattern_len() <= 19;
-    if (shadow_can) {
-        bool seen[256] = {false};
-        uint32_t distinct = 0;
-        for (const LStateRec &r : h.lstates) { const uint32_t c = check_of(r.opos_ch); if (!seen[c]) { seen[c] = true; ++distinct; } }
-        shadow_can = distinct <= 30;   // (CHECK bytes of the slots: every pattern byte labels some edge; an unused slot's adds at most one)
-    }
+    const bool shadow_can = !h.is_standard() && g_opt.left3.load() != 0 && !pma->root_has_output() && h.max_pattern_len() <= 19;
     if (shadow_can) {
         std::vector<uint8_t> blob; std::vector<uint64_t> offs; std::vector<uint32_t> vals;
-        if (recover_patterns(h, blob, offs, vals) &&
-            build_bytewise(blob.data(), offs.data(), vals.data(), vals.size(), DAAC_STANDARD, 16, shadow) == DAAC_OK) {
-            have_shadow = true;
+        if (recover_patterns(h, blob, offs, vals)) {
+            bool seen[256] = {false};
+            uint32_t distinct = 0;
+            for (uint8_t c : blob) if (!seen[c]) { seen[c] = true; ++distinct; }
+            if (distinct <= 29 && build_bytewise(blob.data(), offs.data(), vals.data(), vals.size(), DAAC_STANDARD, 16, shadow) == DAAC_OK) have_shadow = true;
         }
     }
     const HostPma &hg2 = have_shadow ? shadow : h;
@@ -1376,9 +1372,27 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
     if (t->find3_gave_up.load() >= 2 && len - begin >= (1u << 20) && (t->find3_retry.fetch_add(1) & 15u) != 15u) return DAAC_OK;
     // (option find3 = 2: whatever the text)
     const uint32_t kDenseRecPerKib = 26;
-    if (optv < 2 && t->find3_rec_per_kib.load() > kDenseRecPerKib + 1 && len - begin >= (1u << 20) &&
-        (t->find3_skips.fetch_add(1) & 15u) != 15u)   // (every sixteenth such request looks again: the text may have changed)
-        return DAAC_OK;
+    if (optv < 2 && t->find3_rec_per_kib.load() > kDenseRecPerKib + 1 && len - begin >= (1u << 20)) {
+        // Text of dictionary words goes to the chain walkers without a detection.  Every sixteenth such request looks again — at a SAMPLE:
+        // the first 4 MiB go through this function (detection, selection, result thrown away: ~20 us), which refreshes the handle's
+        // records-per-KiB; the whole request is only detected when the sample says the text has changed.  (Round 4 ran the full
+        // detection on those requests: 3.5 ms per GiB spent and discarded, profiles/r04_leftmost_dense_kernel_stats.csv.)
+        static thread_local bool probing = false;
+        if (probing || (t->find3_skips.fetch_add(1) & 15u) != 15u) return DAAC_OK;
+        constexpr uint64_t kSample = 4ull << 20;
+        if (len - begin > 2 * kSample) {
+            unsigned long long sr[3];
+            uint64_t snext = 0;
+            bool sserved = false;
+            probing = true;
+            t->find3_rec_per_kib.store(0);   // (the sample itself must not be turned away by the gate)
+            const daac_status sst = find_count3_window(pma, t, dev_hay, begin, begin + kSample, begin + kSample, stream, false, leftmost, sr, &snext, &sserved);
+            probing = false;
+            if (sst != DAAC_OK) return sst;
+            if (t->find3_rec_per_kib.load() == 0) t->find3_rec_per_kib.store(kDenseRecPerKib + 2);   // (the sample gave no verdict: as before)
+            if (t->find3_rec_per_kib.load() > kDenseRecPerKib + 1) return DAAC_OK;
+        }
+    }
     const Gram2EmitDev &e = t->emit;
     const Gram3Lds &L = t->emit3_lds;
     const uint64_t halo = pma->halo();
