@@ -2163,7 +2163,8 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     // `.count()` alone: gram4_kernels.hip on the renumbered tables (gram4.hpp), derived from the second table set
     Gram4Lds g4l{};
     uint32_t g4_ppl = 16;
-    bool use_g4 = use_g2 && !want_checksum && t->gram4_ok && (gv == 4 || gv == 0);
+    // (gram_version = 2 asks for gram2_kernels.hip, which counts with its checksum tables: a dictionary without room for those counts here)
+    bool use_g4 = use_g2 && !want_checksum && t->gram4_ok && (gv == 4 || gv == 0 || (gv == 2 && !t->gram2.exact_ok));
     if (use_g4) {
         const bool want_rfull = g_opt.gram2_rfull.load() != 0, want_arith = g_opt.gram4_arith.load() != 0;
         const uint32_t waves = static_cast<uint32_t>(g_opt.threads.load()) > 512 ? 16u : 8u;

@@ -177,6 +177,9 @@ def engines_soak(seconds, seed, max_cases=None):
     while (n_auto < max_cases) if max_cases is not None else (time.time() - t0 < seconds):
         nsym = int(rng.choice([2, 5, 12, 26, 29, 31, 60, 256]))
         syms = rng.choice(np.arange(256), size=nsym, replace=False).astype(np.uint8)
+        if nsym < 256 and rng.random() < 0.4:   # one contiguous byte range (what gram4's arithmetic class map takes), also at either end of the byte values
+            first = int(rng.choice([0, 256 - nsym, int(rng.integers(0, 257 - nsym))]))
+            syms = np.arange(first, first + nsym).astype(np.uint8)
         npat = int(rng.choice([3, 40, 600, 6000]))
         lo = int(rng.integers(1, 5))
         hi = int(rng.choice([lo + 1, 8, 14, 24, 60]))
@@ -186,6 +189,9 @@ def engines_soak(seconds, seed, max_cases=None):
         n = int(rng.integers(1000, 1_500_000))
         if rng.random() < 0.5:
             hay = syms[rng.integers(0, nsym, size=n)]
+            if rng.random() < 0.5:   # bytes of no pattern in between (just below / above a range, anything)
+                noise = rng.random(n) < 0.1
+                hay = np.where(noise, rng.choice(np.array([int(syms.min()) - 1, int(syms.max()) + 1, 0, 255, int(rng.integers(0, 256))]) % 256, size=n), hay).astype(np.uint8)
         else:  # text made of the patterns themselves
             hay = np.frombuffer(b"".join(pats[int(i)] for i in rng.integers(0, len(pats), size=n // max(1, (lo + hi) // 2) + 1))[:n], dtype=np.uint8).copy()
         o = orc.OraclePma.build(pats)
