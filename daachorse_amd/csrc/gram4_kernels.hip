@@ -83,11 +83,7 @@ __device__ __forceinline__ void g4_reduce(unsigned long long cnt, unsigned long 
 template <int K, int Q, bool ARITH, int DIR, bool TAIL>
 __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a, const Gram4Lds &L, char *smem) {
     constexpr int P = 16 * Q;
-#ifdef G4_GS
-    constexpr int GS = G4_GS;                 // M lookups asked for before the first is used
-#else
     constexpr int GS = 8;
-#endif
     constexpr uint32_t SB = 64u * P;          // bytes a wave takes per step
     constexpr uint32_t SLOT = SB + 32u;       // [12,16) the four bytes before the step | [16, 16 + SB) the step | 16 bytes of the next
     // ONE text slot per wave: what is left in the hit queue at the end of a step (fewer than 64 entries) has its text taken out of the
@@ -165,9 +161,6 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
     // at their first record, and the few that do not kept 64 lanes busy for five or six more rounds: 12 % of the kernel.)
     auto drain = [&]() {
         const uint4 *__restrict__ recs = TAIL ? g.drec_t : g.drec_c;
-#if defined(G4X) && G4X == 5
-        cnt32 += wq_n; wq_n = 0;
-#endif
         uint32_t n_in = wq_n;
         bool raw = !TAIL;   // plain: the first pass reads what the batches left: {position, hit record x, hit record y, four text bytes}
         while (n_in != 0) {
@@ -236,10 +229,6 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
     uint32_t p2_t0 = 0, p2_t1 = 0;       // the seven bytes from position + 2 on
     bool p2_live = false, p2_any = false;        // per lane / wave-uniform
     auto push_walker = [&](bool go, const uint4 &entry) {
-#if defined(G4X) && G4X == 4
-        cnt32 += go ? entry.x : 0u;
-        return;
-#endif
         const unsigned long long m = __ballot(go);
         if (m != 0) {
             if (go) {
@@ -357,25 +346,17 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
                 under += sub > 2 ? __popc(qz & 0x3fffffffu) : 0u;
                 rank = base + under;
             }
-#if defined(G4X) && G4X == 3
-            cnt32 += rank;
-#else
             if (TAIL) {
                 pend = g.dhit_t[rank];
             } else {
                 const uint2 h = g.dhit_c[rank];
                 pend = uint4{h.x, h.y, 0u, 0u};
             }
-#endif
         } else {
             pend_t0 = 0;   // (an idle lane: nothing of it may look like a branch that goes on)
             pend_t1 = 0;
         }
-#if defined(G4X) && G4X == 3
-        pend_valid = false;
-#else
         pend_valid = true;
-#endif
     };
 
     uint64_t region = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg;
@@ -425,13 +406,11 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
             fetch(sb + 2ull * SB, pf1);
 
             // ---- what the last step left in the queue leaves the slot; then this step's text goes in ----
-#if !(defined(G4X) && G4X == 2)
             if (q_tail != q_head) {
                 const uint32_t n_left = q_tail - q_head;
                 derive(st_n, n_left);
                 st_n += n_left;
             }
-#endif
             const uint32_t slot = tb;                             // wave-uniform
             const uint32_t my_text = slot + 16u + lane * P;       // LDS address of this lane's first byte
             posbias = static_cast<uint32_t>(sb) - (slot + 16u);
@@ -496,10 +475,6 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
             }
             cnt32 += ccnt;
 
-#if defined(G4X) && G4X == 1
-            cnt32 += __popc(H);
-            H = 0;
-#endif
             // ---- queue the hits, one per lane and turn ----
             const uint32_t text_adj = my_text - (32u - P);
             for (;;) {
@@ -515,24 +490,13 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
                 const uint32_t slot_addr = ((at << 2) & (kRing4 * 4u - 4u)) | ringb;   // (v_lshlrev_b32, v_and_or_b32)
                 if (has) *reinterpret_cast<lds4_u32 *>(static_cast<uintptr_t>(slot_addr)) = entry;
                 q_tail += static_cast<uint32_t>(__popcll(m));
-#if defined(G4X) && G4X == 2
-                if (q_tail - q_head >= 64u) q_head += 64u;
-#else
                 if (st_n + q_tail - q_head >= 64u) process_batch(64u);
-#endif
             }
-#if defined(G4X) && G4X == 2
-            q_head = q_tail;
-#endif
         }
         tot_cnt += cnt32;  // per region: 32 bits cannot overflow within one
         cnt32 = 0;
       }
-#if defined(G4X) && G4X == 2
-      q_head = q_tail;
-#else
       if (st_n + q_tail - q_head != 0) process_batch(st_n + q_tail - q_head);
-#endif
       consume_pending();
       finish_second();
       drain();
@@ -643,10 +607,6 @@ bool gram4_plan(const Gram4Dev &dev, uint32_t ppl, uint32_t waves, bool want_rfu
 
 // a.sel_want: 0 = plain records, 1 = tail records from the hit record on, 2 = every workgroup decides by its density probe
 hipError_t launch_gram4_scan(const Gram4Dev &dev, const GramArgs &a, const Gram4Lds &L, uint32_t blocks, hipStream_t stream) {
-#if defined(G4X)
-    if (dev.K == 3 && L.threads == 1024) return a.ppl == 32 ? launch4_k<3, 2, 1024>(dev, a, L, blocks, stream) : launch4_k<3, 1, 1024>(dev, a, L, blocks, stream);
-    return hipErrorInvalidValue;
-#endif
     if (a.ppl == 32 && L.threads == 1024)
         return dev.K == 3 ? launch4_k<3, 2, 1024>(dev, a, L, blocks, stream) : launch4_k<2, 2, 1024>(dev, a, L, blocks, stream);
     if (a.ppl == 32)

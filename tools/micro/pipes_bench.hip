@@ -78,6 +78,19 @@ static double g_clk = 2.4e9;
 #define A_BFI(k) "v_bfi_b32 %" #k ", %" #k ", %8, %8\n"
 #define A_READLANE(k) "v_readlane_b32 s20, %" #k ", 5\n"
 #define A_MADU16(k) "v_mad_u16 %" #k ", %" #k ", %8, %8\n"
+// round 5: what a packed-u16 main path of the count kernel would be made of
+#define A_SUB(k) "v_sub_u32 %" #k ", %" #k ", %8\n"
+#define A_OR(k) "v_or_b32 %" #k ", %" #k ", %8\n"
+#define A_XOR(k) "v_xor_b32 %" #k ", %" #k ", %8\n"
+#define A_MINU(k) "v_min_u32 %" #k ", %" #k ", %8\n"
+#define A_PKSUB16(k) "v_pk_sub_u16 %" #k ", %" #k ", %8\n"
+#define A_PKMIN16(k) "v_pk_min_u16 %" #k ", %" #k ", %8\n"
+#define A_MADU32U16(k) "v_mad_u32_u16 %" #k ", %" #k ", %8, %8 op_sel:[1,0,0,0]\n"
+#define A_DOT2U16(k) "v_dot2_u32_u16 %" #k ", %" #k ", %8, %8\n"
+#define A_LSHRSDWA(k) "v_lshrrev_b32_sdwa %" #k ", %8, %" #k " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
+#define A_LSHRV(k) "v_lshrrev_b32 %" #k ", %8, %" #k "\n"
+#define A_SUBSDWA(k) "v_sub_u32_sdwa %" #k ", %" #k ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n"
+#define A_ANDK(k) "v_and_b32 %" #k ", 0xff00ff, %" #k "\n"
 #define NOCLOB
 #define CLOB_VCC : "vcc"
 #define CLOB_S : "s20", "s21"
@@ -130,6 +143,18 @@ VALU_KERNEL(k_or3, A_OR3, NOCLOB)
 VALU_KERNEL(k_bfi, A_BFI, NOCLOB)
 VALU_KERNEL(k_readlane, A_READLANE, CLOB_S)
 VALU_KERNEL(k_madu16, A_MADU16, NOCLOB)
+VALU_KERNEL(k_sub, A_SUB, NOCLOB)
+VALU_KERNEL(k_or, A_OR, NOCLOB)
+VALU_KERNEL(k_xor, A_XOR, NOCLOB)
+VALU_KERNEL(k_minu, A_MINU, NOCLOB)
+VALU_KERNEL(k_pksub16, A_PKSUB16, NOCLOB)
+VALU_KERNEL(k_pkmin16, A_PKMIN16, NOCLOB)
+VALU_KERNEL(k_madu32u16, A_MADU32U16, NOCLOB)
+VALU_KERNEL(k_dot2u16, A_DOT2U16, NOCLOB)
+VALU_KERNEL(k_lshrsdwa, A_LSHRSDWA, NOCLOB)
+VALU_KERNEL(k_lshrv, A_LSHRV, NOCLOB)
+VALU_KERNEL(k_subsdwa, A_SUBSDWA, NOCLOB)
+VALU_KERNEL(k_andk, A_ANDK, NOCLOB)
 
 // packed f32 (register pairs) and 64-bit adds
 __global__ __launch_bounds__(1024) void k_pkfma(uint32_t *out, uint32_t seed, int iters) {
@@ -401,6 +426,7 @@ int main(int argc, char **argv) {
     RV(k_mov) RV(k_movsdwa) RV(k_addsdwa) RV(k_lshlsdwa) RV(k_movdpp) RV(k_movwshr) RV(k_adddpp) RV(k_fma) RV(k_fadd) RV(k_fmul) RV(k_fmac)
     RV(k_cvtub0) RV(k_cvtub2) RV(k_cvtu32) RV(k_cvtf32) RV(k_pkmad16) RV(k_pkadd16) RV(k_pklshl16) RV(k_lshladd) RV(k_cndmask) RV(k_cmp) RV(k_cmps)
     RV(k_mbcnt) RV(k_dot4) RV(k_sad) RV(k_mullo) RV(k_maxu) RV(k_xad) RV(k_andor) RV(k_or3) RV(k_bfi) RV(k_readlane) RV(k_madu16)
+    RV(k_sub) RV(k_or) RV(k_xor) RV(k_minu) RV(k_pksub16) RV(k_pkmin16) RV(k_madu32u16) RV(k_dot2u16) RV(k_lshrsdwa) RV(k_lshrv) RV(k_subsdwa) RV(k_andk)
     RV(k_pkfma) RV(k_lshladd64) RV(k_mad64) RV(k_cndmask_s)
     if (run_valu("k_cmp_cnd (2 instr)", k_cmp_cnd, 16)) return 1;
     if (run_valu("k_cmps_cnd (2 instr)", k_cmps_cnd, 16)) return 1;
