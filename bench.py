@@ -300,6 +300,43 @@ def cfg5_legs(da, synth, torch, local_rank, stream, result, no_cpu):
     return out
 
 
+def multi_legs(da, synth, torch, pma_cfg3, local_rank, alpha):
+    """daac_scan_count_multi (the product's multi-device entry point, SURVEY 8e / BASELINE configs[3]) with every visible device — on a
+    one-GPU box: 8 virtual shards of 512 MiB that all name device 0 (the shard arithmetic, the host threads and the host-side sum are
+    those of the 8-GPU node; the shards then share one device, so the figure is a single device's).  Shard k is seeded cfg4's
+    0xDAAC0014 + k and carries the last max_pattern_len - 1 bytes of shard k - 1 in front; checked against one scan of the shards laid
+    end to end."""
+    from daachorse_amd import ScanMode
+    ndev = torch.cuda.device_count()
+    nsh, shard = 8, 512 << 20
+    halo = pma_cfg3.info().max_pattern_len - 1
+    whole = torch.empty(nsh * shard, dtype=torch.uint8, device="cuda")
+    for k in range(nsh):
+        synth.device_uniform(whole[k * shard:(k + 1) * shard], synth.SEEDS["cfg4_hay"] + k, alpha)
+    shards = []
+    keep = []
+    for k in range(nsh):
+        dev = k % ndev
+        h = halo if k else 0
+        piece = whole[k * shard - h:(k + 1) * shard]
+        if dev != torch.cuda.current_device():
+            piece = piece.to(f"cuda:{dev}")
+            keep.append(piece)
+        shards.append((dev, piece, h, k * shard))
+    torch.cuda.synchronize()
+    out = {"shards": nsh, "shard_bytes": shard, "devices": ndev, "op": "daac_scan_count_multi: one host thread per shard, counts (+ checksum sums) added on the host"}
+    for name, cs in (("count", False), ("count_checksum", True)):
+        best, got = None, None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            got = da.scan_count_multi(pma_cfg3, ScanMode.FindOverlapping, shards, checksum=cs)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        one = pma_cfg3.scan_count(ScanMode.FindOverlapping, whole) if cs else pma_cfg3.count(ScanMode.FindOverlapping, whole)
+        out[name] = {"GB/s": round(nsh * shard / best / 1e9, 2), "seconds": round(best, 5), "equals_one_scan_of_the_whole": bool(got == one)}
+    return out
+
+
 def stream_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha, no_cpu):
     """The chunk-fed steppers (daac_stream_*: FindOverlappingStepper / FindStepper / find_overlapping_no_suffix fed 64 MiB device chunks, SURVEY
     8f-2): every feed scans [kept tail | chunk] on the engines the eager scans use and hands the chunk's matches to the host; 512 MiB of the cfg3
@@ -908,6 +945,7 @@ def main():
         out["cfg5"] = cfg5_legs(da, synth, torch, local_rank, stream, result, args.no_cpu)
         out["iterator"] = iterator_legs(da, synth, torch, np, pma, local_rank, seed_sparse, alpha)
         out["stream"] = stream_legs(da, synth, torch, np, pma, local_rank, seed_sparse, alpha, args.no_cpu)
+        out["multi"] = multi_legs(da, synth, torch, pma, local_rank, alpha)
     print(json.dumps(out))
     # a multi-GPU line that is not what it says fails loudly: the reason is in the line (`distributed`), the exit code says so
     if dist_used is not None and (dist_used.get("n_ranks_seen") != args.gpus or dist_used.get("strong_equals_one_rank") is False):

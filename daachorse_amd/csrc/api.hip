@@ -1080,6 +1080,14 @@ __global__ void repack16_kernel(const daac_match *in, uint4 *out, unsigned long 
     }
 }
 
+// r = {count, S1, S2} of [from, len) scanned as a haystack of its own, h = the same of [from, begin): what ends in (begin, len], ends re-based
+__global__ void shard_subtract_kernel(unsigned long long *r, const unsigned long long *h, unsigned long long from32) {
+    r[0] -= h[0];
+    r[1] -= h[1];
+    r[2] -= h[2];
+    r[2] += (r[1] & 0xffffffffull) * from32;
+}
+
 __global__ void shard_fixup_kernel(unsigned long long *r, unsigned long long begin32, unsigned long long c, unsigned long long s1,
                                    unsigned long long s2) {
     r[2] += (r[1] & 0xffffffffull) * begin32 + s2;
@@ -2232,20 +2240,24 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     if (!find3_served) g_last_engine = use_pfx ? DAAC_ENGINE_PFX : use_gram ? DAAC_ENGINE_GRAM : (pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY);
     if (find3_served) {
     } else if ((use_gram || use_pfx) && len != begin) {
-        // A shard [begin, len) is scanned as a haystack of its own: that counts every occurrence lying inside it,
-        // with ends relative to `begin`.  What is missing are the occurrences that start before `begin` and end
-        // after it (at most Lmax - 1 bytes in); they are added below from a materialising scan of that sliver.
-        const uint8_t *sub = dev_hay + begin;
+        // A shard [begin, len): the occurrences with their end in (begin, len] = those of [from, len) scanned as a haystack of its own,
+        // from = begin - halo, minus those of [from, begin) scanned as a haystack of its own (what lies wholly inside the halo) — two launches
+        // of the same kernel, the second over at most max_pattern_len - 1 bytes into a scratch result, and one fix-up kernel that subtracts
+        // and re-bases the ends (they were counted from `from`).  All on the stream, nothing read back.  (Until round 5 the shard itself was
+        // scanned and the occurrences across `begin` came from a materialising scan of a sliver, synchronised and summed on the host:
+        // ~1 ms per call, a quarter of a 4 GiB shard's scan — what every rank of a multi-GPU scan paid.)
+        const uint64_t from = begin - std::min<uint64_t>(begin, pl.a.halo);
+        const uint8_t *sub = dev_hay + from;
         GramArgs ga{};
         ga.lead = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(sub) & 15u);
         ga.hay_al = sub - ga.lead;
-        ga.vlen = ga.lead + static_cast<uint64_t>(len - begin);
+        ga.vlen = ga.lead + static_cast<uint64_t>(len - from);
         // a power of two >= 2 KiB: regions then never straddle a multiple of 4 GiB (the kernel keeps 32-bit positions per epoch)
         uint64_t region = 2048;
         // (second table set: 256 KiB regions once there are several per wave — a region's start costs a handful of dependent
         // loads and the refill of the prefetch pipeline: 64 KiB regions measured 2-6 % slower on 4 GiB)
         const int64_t region_opt = g_opt.gram_region.load() > 0 ? g_opt.gram_region.load()
-                                   : (use_g2 || use_pfx) ? ((len - begin) >= (1ull << 31) ? 262144 : 65536) : 16384;
+                                   : (use_g2 || use_pfx) ? ((len - from) >= (1ull << 31) ? 262144 : 65536) : 16384;
         while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, region_opt)) && region < (1ull << 30)) region *= 2;
         ga.ppl = use_pfx ? 16 : use_g4 ? g4_ppl : (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
         ga.region_bytes = region;
@@ -2278,34 +2290,35 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         HIP_TRY(dev_malloc(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * ((use_g4 || use_pfx) ? sizeof(uint4) : sizeof(uint2)), stream));
         ga.wq = static_cast<uint2 *>(wq);
         ga.sel_want = tail_opt < 0 ? ((len - begin) >= (1ull << 20) ? 2u : 0u) : tail_opt > 0 ? 1u : 0u;
-        const hipError_t le = use_pfx ? launch_pfx_scan(t->pfx, ga, want_checksum, blocks, stream)
-                              : use_g4 ? launch_gram4_scan(t->gram4, ga, g4l, blocks, stream)
-                              : use_gw ? launch_gram2w_scan(t->gramw, ga, want_checksum, blocks, stream)
-                              : use_g2 ? launch_gram2_scan(t->gram2, ga, want_checksum, blocks, threads, stream)
-                                       : launch_gram_scan(t->gram, ga, blocks, threads, stream);
+        auto launch_count = [&](const GramArgs &g, uint32_t nblocks) -> hipError_t {
+            return use_pfx ? launch_pfx_scan(t->pfx, g, want_checksum, nblocks, stream)
+                   : use_g4 ? launch_gram4_scan(t->gram4, g, g4l, nblocks, stream)
+                   : use_gw ? launch_gram2w_scan(t->gramw, g, want_checksum, nblocks, stream)
+                   : use_g2 ? launch_gram2_scan(t->gram2, g, want_checksum, nblocks, threads, stream)
+                            : launch_gram_scan(t->gram, g, nblocks, threads, stream);
+        };
+        hipError_t le = launch_count(ga, blocks);
+        DevBuf halo_res;
+        if (le == hipSuccess && from != begin) {   // what lies wholly inside the halo, counted the same way (ends from `from` as well)
+            le = halo_res.alloc(3 * sizeof(unsigned long long), stream);
+            if (le == hipSuccess) le = hipMemsetAsync(halo_res.p, 0, 3 * sizeof(unsigned long long), stream);
+            GramArgs gh = ga;
+            gh.vlen = ga.lead + (begin - from);
+            gh.nregions = (gh.vlen + gh.region_bytes - 1) / gh.region_bytes;   // (one: a halo is shorter than any region)
+            gh.result = static_cast<unsigned long long *>(halo_res.p);
+            gh.sel_want = 0;
+            if (le == hipSuccess) le = launch_count(gh, 1);   // (the first workgroup's slab of the walker queue: the scan before has drained it)
+            if (le == hipSuccess) {
+                hipLaunchKernelGGL(shard_subtract_kernel, dim3(1), dim3(1), 0, stream, d_res, static_cast<const unsigned long long *>(halo_res.p),
+                                   static_cast<unsigned long long>(from & 0xffffffffull));
+                le = hipGetLastError();
+            }
+        } else if (le == hipSuccess && from != 0) {
+            hipLaunchKernelGGL(shard_fixup_kernel, dim3(1), dim3(1), 0, stream, d_res, static_cast<unsigned long long>(from & 0xffffffffull), 0ull, 0ull, 0ull);
+            le = hipGetLastError();
+        }
         dev_free(wq, stream);
         HIP_TRY(le);
-        if (begin != 0) {
-            unsigned long long add[3] = {0, 0, 0};
-            const uint64_t sliver_end = std::min<uint64_t>(len, begin + pl.a.halo);
-            if (sliver_end > begin) {
-                MatchBuf edge;
-                if ((st = scan_range_materialize(pma, t, DAAC_FIND_OVERLAPPING, DAAC_ENGINE_AUTO, dev_hay, begin, sliver_end, len, stream, edge,
-                                                 nullptr)) != DAAC_OK)
-                    return st;
-                for (size_t i = 0; i < edge.size(); ++i) {
-                    const daac_match &m = edge.p[i];
-                    if (m.start >= begin) continue;  // lies inside the shard: already counted
-                    const uint32_t h = match_hash32(m.value, static_cast<uint32_t>(m.end - m.start));
-                    add[0] += 1; add[1] += h; add[2] += static_cast<uint32_t>(h * static_cast<uint32_t>(m.end));
-                }
-                g_last_engine = use_pfx ? DAAC_ENGINE_PFX : DAAC_ENGINE_GRAM;  // (the sliver's few bytes went through the segment scanners)
-            }
-            // ends were relative to `begin`: S2 += low32(begin) * S1, then the sliver's tuples
-            hipLaunchKernelGGL(shard_fixup_kernel, dim3(1), dim3(1), 0, stream, d_res, static_cast<unsigned long long>(begin & 0xffffffffull), add[0],
-                               add[1], add[2]);
-            HIP_TRY(hipGetLastError());
-        }
     } else if (pl.a.nseg != 0) {
         HIP_TRY(launch(t, pl, 0, heads, stream));
     }

@@ -201,6 +201,50 @@ def test_cfg3_full_4_gib_count_and_checksum():
                 da.set_option("gram3_tail", -1)
 
 
+def test_cfg4_32_gib_as_eight_shards_on_one_device():
+    """BASELINE configs[3] at its stated size in the form one GPU can run it: the same 100 k automaton, 32 GiB = 8 shards x 4 GiB, shard k
+    seeded 0xDAAC0014 + k, through the product's multi-device entry point daac_scan_count_multi with all eight shards naming
+    device 0 (the 8-GPU node differs in the device ordinals only: one host thread per shard, host-side sum).  The shards are independent
+    haystacks' worth of bytes laid end to end: shard k > 0 carries the last max_pattern_len - 1 bytes of shard k - 1 as its halo, so a
+    match across a seam is counted once, by the shard it ends in.  Against the oracle shard by shard (count + checksum re-based to
+    haystack positions, 16 threads), and `.count()` alone."""
+    import torch
+    pats = synth.patterns_cfg3()
+    o = orc.OraclePma.build(pats)
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    shard = 4 << 30
+    halo = p.info().max_pattern_len - 1
+    bufs, shards = [], []
+    want_n, s1, s2 = 0, 0, 0
+    prev_tail = None
+    for k in range(8):
+        buf = torch.empty(halo + shard, dtype=torch.uint8, device="cuda")
+        synth.device_uniform(buf[halo:], synth.SEEDS["cfg4_hay"] + k, synth.ALPHA_LOWER_SPACE)
+        if prev_tail is not None:
+            buf[:halo] = prev_tail
+        prev_tail = buf[-halo:].clone()
+        view = buf if k else buf[halo:]
+        bufs.append(buf)
+        shards.append((0, view, halo if k else 0, k * shard))
+        # the oracle on this shard alone: matches with their end inside it (the halo in front), ends counted from the haystack's first byte
+        host = view.cpu().numpy()
+        h = halo if k else 0
+        c_all = o.overlapping_count(host, threads=16)
+        c_halo = o.overlapping_count(host[:h], threads=1) if h else (0, 0)
+        n_k = c_all[0] - c_halo[0]
+        a1, a2 = (c_all[1] >> 32) - (c_halo[1] >> 32), (c_all[1] & 0xFFFFFFFF) - (c_halo[1] & 0xFFFFFFFF)
+        base = k * shard - h
+        want_n += n_k
+        s1 = (s1 + a1) & 0xFFFFFFFF
+        s2 = (s2 + a2 + (base & 0xFFFFFFFF) * a1) & 0xFFFFFFFF
+        del host
+    want = (want_n, (s1 << 32) | s2)
+    assert want_n > 16_000_000_000
+    assert da.scan_count_multi(p, ScanMode.FindOverlapping, shards) == want
+    assert da.last_engine() == int(Engine.Gram)
+    assert da.scan_count_multi(p, ScanMode.FindOverlapping, shards, checksum=False) == want[0]
+
+
 def test_cfg3_count_kernel_on_a_vector_of_window_counts():
     """The `.count()` kernel is observed through ONE integer per call; a missed match here and a double count there would cancel.
     4 096 windows (begin, len) of random sizes and alignments over 64 MiB of the cfg3 haystack, each counted on its own

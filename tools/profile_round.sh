@@ -89,6 +89,30 @@ for what in find leftmost; do
   done
 done
 
+# BASELINE configs[4] (charwise leftmost_find_iter) on the chain walkers, and what a position-parallel route over the same text would start
+# from: the PFX count / count + checksum kernels on cfg5's patterns scanned bytewise (utf8jp)
+for pass in "$PASS1" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM"; do
+  d=$P/sq_cfg5_$(echo $pass | cut -c4-12)
+  rm -rf $d
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $d -o p -- python $R/tools/bench_cfg5.py --mode leftmost --cpu-mib 0 > $d.log 2>&1
+  echo "== cfg5: charwise leftmost_find_iter (LeftmostLongest), 1 GiB, chain walkers" >> $OUT/${TAG}_pmc_sq.txt
+  DAAC_PMC_FILTER=char_chain python $R/tools/pmc_summary.py $d | grep -v duration_us >> $OUT/${TAG}_pmc_sq.txt 2>&1
+  d=$P/sq_utf8jp_$(echo $pass | cut -c4-12)
+  rm -rf $d
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $d -o p -- python $R/tools/ab_pfx.py 1024 > $d.log 2>&1
+  echo "== cfg5's patterns scanned bytewise (utf8jp) on PFX: .count() and count + checksum, 1 GiB of the same text" >> $OUT/${TAG}_pmc_sq.txt
+  DAAC_PMC_FILTER="pfx_kernel<6" python $R/tools/pmc_summary.py $d | grep -v duration_us >> $OUT/${TAG}_pmc_sq.txt 2>&1
+done
+
+# the `.count()` kernel stage by stage (needs abtmp/lib_g4x1..5.so: tools/mkvar5.sh g4xN gram4_kernels -DG4X=N) and the main path alone under bench.py
+if ls $R/abtmp/lib_g4x1.so > /dev/null 2>&1; then
+  (cd $R && bash tools/ab_libs3.sh 4096 tools/ab_count_shapes.json 2>&1 | grep "cfg\|==") > $OUT/${TAG}_gram4_decomposition.txt
+  (cd $R && bash tools/pmc_gram4.sh sparse) > $OUT/${TAG}_pmc_decomp_sparse.txt 2>&1
+  (cd $R && bash tools/pmc_gram4.sh dense) > $OUT/${TAG}_pmc_decomp_dense.txt 2>&1
+  (cd $R && bash tools/method_ceiling.sh $TAG) > $P/method_ceiling.log 2>&1
+  cd /tmp
+fi
+
 # the bench lines themselves (they read the traffic file given here; in the repository: profiles/hbm_traffic.json)
 export DAAC_HBM_TRAFFIC_JSON=$OUT/${TAG}_hbm_traffic.json
 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
