@@ -112,6 +112,8 @@ def lib():
     L.daac_device_to_host.argtypes = [vp, vp, sz]
     L.daac_device_to_host.restype = C.c_int
     L.daac_set_option.argtypes = [C.c_char_p, C.c_int64]
+    L.daac_pma_set_option.argtypes = [vp, C.c_char_p, C.c_int64, C.c_int]
+    L.daac_pma_set_option.restype = C.c_int
     L.daac_last_engine.argtypes = []
     L.daac_last_engine.restype = C.c_int
     L.daac_synth_uniform.argtypes = [vp, sz, C.c_uint64, vp, C.c_uint32, C.c_uint64, vp]

@@ -323,6 +323,11 @@ class DoubleArrayAhoCorasick:
         _ffi.check(_ffi.lib().daac_pma_upload(self._h, device))
         return self
 
+    def set_option(self, name, value=None):
+        """daac_pma_set_option: an option for THIS handle (overrides the process-wide daac_set_option value); value=None removes the override"""
+        _ffi.check(_ffi.lib().daac_pma_set_option(self._h, name.encode(), 0 if value is None else int(value), 1 if value is None else 0))
+        return self
+
     def trim(self):
         """daac_pma_trim: gives back the scratch the handle keeps between calls (tables stay)"""
         _ffi.check(_ffi.lib().daac_pma_trim(self._h))

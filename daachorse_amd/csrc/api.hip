@@ -74,6 +74,25 @@ struct Options {
                                                 // (off: measured slower on cfg5, 88 vs 104 GB/s — the stretch is L1-resident anyway)
 };
 static Options g_opt;
+// Options are process-wide defaults (daac_set_option) that a HANDLE may override (daac_pma_set_option): a scan looks an option up through OPT(),
+// which takes the override of the handle the calling thread is working for (PmaScope, set by every entry point that is given a handle, an
+// iterator or a stream — and by the iterator's worker thread) and the process-wide value otherwise.  Two threads that scan two handles with
+// different settings no longer share one set of atomics.
+static thread_local const ::daac_pma *tl_pma = nullptr;
+struct PmaScope {
+    const ::daac_pma *prev;
+    explicit PmaScope(const ::daac_pma *p) : prev(tl_pma) { tl_pma = p; }
+    ~PmaScope() { tl_pma = prev; }
+    PmaScope(const PmaScope &) = delete;
+    PmaScope &operator=(const PmaScope &) = delete;
+};
+bool pma_override(const ::daac_pma *p, const char *field, int64_t *value);   // (defined below daac_pma)
+static inline int64_t opt_get(const char *field, const std::atomic<int64_t> &global) {
+    int64_t v;
+    if (tl_pma && pma_override(tl_pma, field, &v)) return v;
+    return global.load();
+}
+#define OPT(X) opt_get(#X, g_opt.X)
 static thread_local int g_last_engine = DAAC_ENGINE_AUTO;  // engine of this thread's most recent scan (daac_last_engine)
 
 static daac_status hip_fail(hipError_t e, const char *what) {
@@ -268,6 +287,10 @@ struct DeviceTables {
 using namespace daac;
 
 struct daac_pma {
+    // per-handle option overrides (daac_pma_set_option): field name of Options -> value
+    mutable std::mutex opt_mu;
+    std::map<std::string, int64_t> opt_ov;
+    std::atomic<int> opt_n{0};
     bool charwise = false;  // which of the two containers is populated
     HostPma host;           // DoubleArrayAhoCorasick<u32>
     HostCharPma chost;      // CharwiseDoubleArrayAhoCorasick<u32>
@@ -289,6 +312,15 @@ struct daac_pma {
         return lmax > 0 ? lmax - 1 : 0;
     }
 };
+
+bool daac::pma_override(const ::daac_pma *p, const char *field, int64_t *value) {
+    if (p->opt_n.load(std::memory_order_relaxed) == 0) return false;
+    std::lock_guard<std::mutex> g(p->opt_mu);
+    const auto it = p->opt_ov.find(field);
+    if (it == p->opt_ov.end()) return false;
+    *value = it->second;
+    return true;
+}
 
 // Host-side list of match tuples.  Page-locked memory: the device writes tuples at HBM speed and a pageable
 // destination (plus its zero fill) turned the copy back into the slowest part of a materialising scan.
@@ -409,7 +441,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             uint32_t staged = 0;
             for (uint32_t i = lo; i < c.table_len; ++i) staged += ct.table[i] != kInvalidCode;
             // worth it only if most of the alphabet lives in the stretch
-            c.map_in_lds = g_opt.char_map_lds.load() != 0 && lo < c.table_len && pma->chost.alphabet_size < 0xffffu &&
+            c.map_in_lds = OPT(char_map_lds) != 0 && lo < c.table_len && pma->chost.alphabet_size < 0xffffu &&
                            staged * 4u >= pma->chost.alphabet_size * 3u;
         }
         // the walkers' records: the output_pos word also carries the state's child filter (device_tables.hpp, CharDev::wstates)
@@ -440,7 +472,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         {
             const uint32_t A = pma->chost.alphabet_size;
             std::vector<U32x2> row(A, U32x2{2u << 30, 0u});
-            bool ok = c.map_in_lds != 0 && g_opt.char_row_lds.load() != 0 && A != 0;
+            bool ok = c.map_in_lds != 0 && OPT(char_row_lds) != 0 && A != 0;
             const CStateRec &rt = ct.states[0];
             for (uint32_t code = 0; ok && code < A; ++code) {
                 if (rt.base == 0) break;
@@ -501,9 +533,9 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     // TIERED engine
     {
         RepackOptions ro;
-        ro.lds_budget = static_cast<uint32_t>(g_opt.lds_budget.load());
-        ro.dense_depth = static_cast<int>(g_opt.dense_depth.load());
-        ro.rows_share_pct = static_cast<uint32_t>(g_opt.rows_share_pct.load());
+        ro.lds_budget = static_cast<uint32_t>(OPT(lds_budget));
+        ro.dense_depth = static_cast<int>(OPT(dense_depth));
+        ro.rows_share_pct = static_cast<uint32_t>(OPT(rows_share_pct));
         TierTables tt;
         if (build_tier_tables(h, ro, tt)) {
             TierDev &d = t->tier;
@@ -534,7 +566,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             // GRAM count engine, derived from the tier tables
             GramTables gt;
             // (the option bounds the tables; tables AND the hit rings of a 1024-thread workgroup have to fit the 160 KB a workgroup can have)
-            const int64_t g1_budget = std::min<int64_t>(g_opt.gram_lds_budget.load(), 160 * 1024 - 16 * 128 * 8);
+            const int64_t g1_budget = std::min<int64_t>(OPT(gram_lds_budget), 160 * 1024 - 16 * 128 * 8);
             if (tt.N < (1u << 27) && g1_budget > 0 && build_gram_tables(h, tt, static_cast<uint32_t>(g1_budget), gt)) {
                 GramDev &g = t->gram;
                 const U32x2 *combo; const U32x4 *drec; const U32x2 *dhit;
@@ -563,7 +595,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 // Without the rank directory two workgroups may fit one CU (<= 80 KB each); worth it when
                 // the level is small, i.e. B hits are rare whatever the text.
                 g.rank_in_lds = !(g.off_brank + 16u * 1024u <= 80u * 1024u && gt.dhit.size() <= 8192);
-                if (g_opt.gram_rank_in_lds.load() >= 0) g.rank_in_lds = g_opt.gram_rank_in_lds.load() != 0;
+                if (OPT(gram_rank_in_lds) >= 0) g.rank_in_lds = OPT(gram_rank_in_lds) != 0;
                 if (g.rank_in_lds) {
                     g.off_bsuper = g.off_brank + p16(gt.brank.size());
                     g.off_scratch = g.off_bsuper + p16(gt.bsuper.size() * 4);
@@ -591,7 +623,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     bool have_shadow = false;
     // (the shadow is only ever used by left3, which takes dictionaries of at most 19-byte patterns over at most 29 distinct bytes:
     // neither a second automaton nor its tables are built for a handle that cannot qualify)
-    const bool shadow_can = !h.is_standard() && g_opt.left3.load() != 0 && !pma->root_has_output() && h.max_pattern_len() <= 19;
+    const bool shadow_can = !h.is_standard() && OPT(left3) != 0 && !pma->root_has_output() && h.max_pattern_len() <= 19;
     if (shadow_can) {
         std::vector<uint8_t> blob; std::vector<uint64_t> offs; std::vector<uint32_t> vals;
         if (recover_patterns(h, blob, offs, vals)) {
@@ -605,7 +637,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     {
         Gram2Tables g2;
         const uint32_t ring_bytes = 16u * 128u * 8u;  // one 128-entry x 8-byte hit ring per wave of a 1024-thread workgroup
-        const int64_t budget = g_opt.gram_lds_budget.load() - static_cast<int64_t>(ring_bytes);
+        const int64_t budget = OPT(gram_lds_budget) - static_cast<int64_t>(ring_bytes);
         if (budget > 0 && build_gram2_tables(hg2, static_cast<uint32_t>(budget), g2)) {
             Gram2Dev &d = t->gram2;
             auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
@@ -653,7 +685,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
                 d.rfull_bytes = p16(rf.size() * 2);
                 d.off_ring_rfull = d.off_s_count + d.rfull_bytes;
                 d.lds_rfull = d.off_ring_rfull + ring_bytes;
-                d.rfull_ok = d.lds_rfull <= static_cast<uint32_t>(g_opt.gram_lds_budget.load()) && g_opt.gram2_rfull.load() != 0;
+                d.rfull_ok = d.lds_rfull <= static_cast<uint32_t>(OPT(gram_lds_budget)) && OPT(gram2_rfull) != 0;
             }
             d.off_m_exact = kGram2OffH + d.h_bytes;
             d.off_s_exact = d.off_m_exact + d.m_bytes;
@@ -665,7 +697,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
             d.K = g2.K; d.C = g2.C; d.s16 = g2.s16; d.unused_byte = g2.unused_byte;
             d.n_deep = static_cast<uint32_t>(g2.dhit.size());
             d.exact_ok = exact_ok;
-            d.xlane_dpp = g_opt.gram2_dpp.load() != 0;
+            d.xlane_dpp = OPT(gram2_dpp) != 0;
             t->gram2_ok = d.off_m_count + d.m_bytes <= (1u << 17) && d.lds_count <= 160u * 1024u;
             if (t->gram2_ok) {   // the same tables in the numbering of gram4_kernels.hip ("no pattern" last: arithmetic byte classes)
                 Gram4Tables g4;
@@ -784,7 +816,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
     if (!t->gram_ok && !t->gram2_ok) {
         Gram2WTables gw;
         const uint32_t ring_bytes = 16u * 128u * 8u;
-        const int64_t budget = g_opt.gram_lds_budget.load() - static_cast<int64_t>(ring_bytes);
+        const int64_t budget = OPT(gram_lds_budget) - static_cast<int64_t>(ring_bytes);
         if (budget > 0 && build_gram2w_tables(h, static_cast<uint32_t>(budget), gw)) {
             Gram2WDev &d = t->gramw;
             auto p16 = [](size_t x) { return static_cast<uint32_t>((x + 15) & ~size_t(15)); };
@@ -818,7 +850,7 @@ static daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) 
         }
     }
     // PFX engine: `.count()` for every bytewise Standard automaton the GRAM tables do not serve (any alphabet); pfx = 2 builds it always
-    if (g_opt.pfx.load() == 2 || (g_opt.pfx.load() == 1 && !t->gram_ok && !t->gram2_ok && !t->gramw_ok)) {
+    if (OPT(pfx) == 2 || (OPT(pfx) == 1 && !t->gram_ok && !t->gram2_ok && !t->gramw_ok)) {
         PfxTables px;
         const bool px_ok = build_pfx_tables(h, 160u * 1024u - 16u * (2u * 1056u + 512u) - 64u - 1024u, px);
         t->n_distinct_bytes = px.n_distinct_bytes;
@@ -943,14 +975,14 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
     // must reach the same verdict as a lane that has been following the text for longer: Lmax whole bytes, so that a
     // pattern of maximal length ending exactly at the cut is seen too.
     if (pl.restart) halo = std::max(halo, pma->max_pattern_len());
-    uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
+    uint32_t threads = static_cast<uint32_t>(OPT(threads));
     threads = std::min(1024u, std::max(64u, threads & ~63u));
-    uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
+    uint32_t bpc = static_cast<uint32_t>(OPT(blocks_per_cu));
     const uint32_t lds = pl.tier ? t->tier.lds_bytes : 4096u;
     if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / std::max(lds, 1u)));
     const uint64_t lanes = static_cast<uint64_t>(t->num_cu) * bpc * threads;
     const uint64_t len = end - begin;
-    uint64_t S = static_cast<uint64_t>(g_opt.seg_bytes.load());
+    uint64_t S = static_cast<uint64_t>(OPT(seg_bytes));
     if (S == 0) {
         S = (len + lanes - 1) / lanes;
         const uint64_t min_seg = std::max<uint64_t>(pl.restart ? 1024 : 256, 16ull * halo);  // restart scans keep 56 B of chain state per segment
@@ -969,7 +1001,7 @@ daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int 
     pl.a.total_len = end;
     if (pl.restart) {
         pl.threads = 256;
-        pl.blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * static_cast<uint64_t>(std::max<int64_t>(1, g_opt.restart_bpc.load())), (nseg + 255) / 256)));
+        pl.blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * static_cast<uint64_t>(std::max<int64_t>(1, OPT(restart_bpc))), (nseg + 255) / 256)));
     }
     return DAAC_OK;
 }
@@ -982,7 +1014,7 @@ hipError_t launch(const DeviceTables *t, const Plan &pl, int kmode, bool heads, 
     }
     // count (+ checksum) of an overlapping scan the GRAM tables do not serve: the micro-step walker over segments (2048 lanes
     // per CU, a segment each) instead of the byte-at-a-time segment scanners
-    if (kmode == 0 && !pl.restart && g_opt.overlap_micro.load() != 0 && (pl.charwise || !pl.tier || g_opt.overlap_micro.load() == 2) &&
+    if (kmode == 0 && !pl.restart && OPT(overlap_micro) != 0 && (pl.charwise || !pl.tier || OPT(overlap_micro) == 2) &&
         pl.a.seg_bytes + pl.a.halo < (1ull << 30)) {  // (the walker counts in 32-bit offsets from where it enters its segment)
         const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * 8, (pl.a.nseg + 255) / 256)));
         if (pl.charwise && t->chr.root_flag == 0) return launch_char_overlap_count(t->chr, pl.a, heads, blocks, s);
@@ -1020,7 +1052,7 @@ static unsigned int *pinned_words() {
 
 daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, hipStream_t stream, ChainBuffers &cb) {
     pl.chain = ChainArgs{};
-    if (!pl.restart || pma->root_has_output() || g_opt.restart_chain.load() == 0 || pl.a.nseg == 0) return DAAC_OK;
+    if (!pl.restart || pma->root_has_output() || OPT(restart_chain) == 0 || pl.a.nseg == 0) return DAAC_OK;
     const uint64_t n = pl.a.nseg;
     cb.s = stream;
     HIP_TRY(dev_malloc(&cb.buf, (3 * n + 2) * sizeof(unsigned long long) + 2 * n * sizeof(uint4), stream));
@@ -1040,7 +1072,7 @@ daac_status chain_resolve(const daac_pma *pma, const DeviceTables *t, Plan &pl, 
     };
     HIP_TRY(run(0));
     const unsigned long long *prev = x_spec;
-    const int max_rounds = static_cast<int>(std::max<int64_t>(1, g_opt.chain_rounds.load()));
+    const int max_rounds = static_cast<int>(std::max<int64_t>(1, OPT(chain_rounds)));
     for (int round = 0; round < max_rounds; ++round) {
         unsigned long long *out = (round & 1) ? xb : xa;
         c.x_spec = x_spec; c.x_prev = prev; c.x_out = out;
@@ -1125,7 +1157,7 @@ struct Scratch {
     size_t used = 0, pool_bytes = 0;
     std::vector<void *> pool_allocs;
     Scratch(DeviceTables *t_, hipStream_t s_, size_t expect) : t(t_), s(s_) {
-        const uint64_t keep = static_cast<uint64_t>(g_opt.workspace_keep.load());
+        const uint64_t keep = static_cast<uint64_t>(OPT(workspace_keep));
         const uint64_t want = std::max<uint64_t>(expect, t->ws_want.load());
         if (keep == 0 || expect > keep || t->ws_busy.exchange(true)) return;
         borrowed = true;
@@ -1168,7 +1200,7 @@ struct Scratch {
 daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, uint64_t begin, uint64_t end, hipStream_t stream,
                               DevMatches &out, bool *served, bool raw = false, void *dest = nullptr, uint64_t dest_cap = 0) {
     *served = false;
-    if (!(raw ? t->pfx_emit_ok : t->emit3_ok) || g_opt.emit.load() == 0 || end <= begin) return DAAC_OK;
+    if (!(raw ? t->pfx_emit_ok : t->emit3_ok) || OPT(emit) == 0 || end <= begin) return DAAC_OK;
     // (short scans may still try: they cost little; of the large ones every sixteenth looks again — one pair of adversarial haystacks
     // is not the text of a long-lived handle for ever)
     if (t->emit3_gave_up.load() >= 2 && end - begin >= (1u << 20) && (t->emit3_retry.fetch_add(1) & 15u) != 15u) return DAAC_OK;
@@ -1203,13 +1235,13 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
     if (tiles_total >= (1ull << 32)) return DAAC_OK;
     // DETECT geometry (gram3's): regions of 64 KiB (256 KiB for the large windows), one 16- or 8-wave workgroup per CU
     uint32_t region = (end - begin) >= (1ull << 31) ? 262144u : 65536u;
-    if (g_opt.gram_region.load() >= 2048) { region = 2048; while (region * 2 <= static_cast<uint64_t>(g_opt.gram_region.load()) && region < (1u << 20)) region *= 2; }
+    if (OPT(gram_region) >= 2048) { region = 2048; while (region * 2 <= static_cast<uint64_t>(OPT(gram_region)) && region < (1u << 20)) region *= 2; }
     const uint32_t wpb = raw ? t->pfx.threads / 64 : L.threads / 64;
     uint64_t max_regions = 0;
     for (const Win &w : wins) max_regions = std::max<uint64_t>(max_regions, (static_cast<uint64_t>(w.vlen) + region - 1) / region);
     const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (max_regions + wpb - 1) / wpb)));
     const uint64_t nwaves = static_cast<uint64_t>(blocks) * wpb;
-    const uint32_t wq_slab = static_cast<uint32_t>(std::max<int64_t>(64 * 32 + 128 + 64, g_opt.gram_slab.load()));
+    const uint32_t wq_slab = static_cast<uint32_t>(std::max<int64_t>(64 * 32 + 128 + 64, OPT(gram_slab)));
     const size_t wq_entry = raw ? sizeof(uint4) : sizeof(uint2);
 
     const size_t scan_words = tiles_total + 2 + exclusive_scan_scratch(tiles_total);
@@ -1219,7 +1251,7 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
     const size_t off_wq = off_ctl + 256, off_ann = off_wq + ((nwaves * wq_slab * wq_entry + 255) & ~size_t(255));
     // the record list: sized for what the last scans of this automaton met (or the option's guess), rerun once with the exact number
     uint32_t per_kib = t->emit3_rec_per_kib.load();
-    if (per_kib == 0) per_kib = static_cast<uint32_t>(std::max<int64_t>(1, g_opt.emit_rec_per_kib.load()));
+    if (per_kib == 0) per_kib = static_cast<uint32_t>(std::max<int64_t>(1, OPT(emit_rec_per_kib)));
     uint64_t chunk_cap = ((end - begin) / 1024 + 1) * per_kib / kEmit3Chunk * 2 + 2 * nwaves + 16;
     const size_t g1_bytes = off_ann + ann_total + 256;
     Scratch sc(t, stream, g1_bytes + chunk_cap * (static_cast<size_t>(kEmit3Chunk) * sizeof(uint4) * 3 / 2 + 4) + 4096);   // (+ the binned copy: the list is at most half empty)
@@ -1280,7 +1312,7 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
     g_last_engine = raw ? DAAC_ENGINE_PFX : DAAC_ENGINE_GRAM;
     const size_t tuple_bytes = out.f16 ? 16 : sizeof(daac_match);
     if (total == 0) { *served = true; return DAAC_OK; }
-    if (!dest && total * tuple_bytes > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+    if (!dest && total * tuple_bytes > static_cast<unsigned long long>(OPT(max_result_bytes))) {
         set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
         return DAAC_ERR_AUTOMATON_SCALE;
     }
@@ -1317,10 +1349,10 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         if (raw) { a.ann = w.hay_al; a.vlen = w.vlen; a.emit_from = w.emit_from; }
         // the rank structure goes to LDS when the workgroups still fit with it: two of eight waves (16-byte tuples), three of four (24-byte)
         const uint32_t xwaves = (out.f16 && !raw) ? 8u : 4u;
-        a.v3_in_lds = (!raw && e.v3c != nullptr && g_opt.emit_v3_lds.load() != 0 &&
+        a.v3_in_lds = (!raw && e.v3c != nullptr && OPT(emit_v3_lds) != 0 &&
                        emit3_expand_lds_bytes(e, xwaves, out.f16, true) <= (160u * 1024u) / (out.f16 ? 2u : 3u)) ? 1u : 0u;
         a.off_wave = e.v1_bytes + e.v2_bytes + (a.v3_in_lds ? e.v3c_bytes : 0u);
-        a.stagger = a.ntiles >= 65536u ? static_cast<uint32_t>(std::max<int64_t>(0, std::min<int64_t>(64, g_opt.emit_stagger.load()))) : 0u;
+        a.stagger = a.ntiles >= 65536u ? static_cast<uint32_t>(std::max<int64_t>(0, std::min<int64_t>(64, OPT(emit_stagger)))) : 0u;
         a.fail = d_ctl + 1;
         const uint32_t xblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * ((out.f16 && !raw) ? 2u : 4u), (a.ntiles + xwaves - 1) / xwaves)));
         if (raw) HIP_TRY(launch_emit3_expand_raw(e, a, out.f16, xblocks, stream));
@@ -1371,7 +1403,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
                                       bool want_checksum, bool leftmost, unsigned long long r[3], uint64_t *next_begin, bool *served,
                                       SelectEmit *em = nullptr) {
     *served = false;
-    const int64_t optv = leftmost ? g_opt.left3.load() : g_opt.find3.load();
+    const int64_t optv = leftmost ? OPT(left3) : OPT(find3);
     // (DAAC_DEBUG_TIMING=1: the stream is waited for at every lap — kernel times; =2: host time between the laps as the call really runs)
     const char *dbg_env = std::getenv("DAAC_DEBUG_TIMING");
     const bool dbg_sync = dbg_env && dbg_env[0] == '1';
@@ -1420,7 +1452,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
     const uint64_t nregions = (static_cast<uint64_t>(vlen) + region - 1) / region;
     const uint32_t blocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu), (nregions + wpb - 1) / wpb)));
     const uint64_t nwaves = static_cast<uint64_t>(blocks) * wpb;
-    const uint32_t wq_slab = static_cast<uint32_t>(std::max<int64_t>(64 * 32 + 128 + 64, g_opt.gram_slab.load()));
+    const uint32_t wq_slab = static_cast<uint32_t>(std::max<int64_t>(64 * 32 + 128 + 64, OPT(gram_slab)));
     const size_t scan_words = n1k + 2 + exclusive_scan_scratch(n1k);
     const size_t off_short = 0, off_deep = off_short + ((static_cast<size_t>(n1k) * 4 + 255) & ~size_t(255));
     const size_t off_a = off_deep + ((static_cast<size_t>(n1k) * 4 + 255) & ~size_t(255)), off_b = off_a + ((scan_words * 8 + 255) & ~size_t(255));
@@ -1430,7 +1462,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
     const size_t off_wq = off_tcnt + ((tcnt_words * 8 + 255) & ~size_t(255));
     const size_t off_ann = off_wq + ((nwaves * wq_slab * sizeof(uint2) + 255) & ~size_t(255));
     uint32_t per_kib = t->emit3_rec_per_kib.load();
-    if (per_kib == 0) per_kib = static_cast<uint32_t>(std::max<int64_t>(1, g_opt.emit_rec_per_kib.load()));
+    if (per_kib == 0) per_kib = static_cast<uint32_t>(std::max<int64_t>(1, OPT(emit_rec_per_kib)));
     uint64_t chunk_cap = ((len - begin) / 1024 + 1) * per_kib / kEmit3Chunk * 2 + 2 * nwaves + 16;
     const size_t g1_bytes = off_ann + static_cast<size_t>(nsteps) * kStep + 256;
     Scratch sc(t, stream, g1_bytes + chunk_cap * (static_cast<size_t>(kEmit3Chunk) * sizeof(uint4) * 2 + 4) + 4096);
@@ -1552,7 +1584,7 @@ static daac_status find_count3_window(daac_pma *pma, DeviceTables *t, const uint
         if (dst) {
             if (n > em->dest_cap) { set_error("selection emitter: more tuples than the count pass announced"); return DAAC_ERR_DEVICE; }
         } else {
-            if (n * tb > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+            if (n * tb > static_cast<unsigned long long>(OPT(max_result_bytes))) {
                 set_error("match list of " + std::to_string(n) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
                 return DAAC_ERR_AUTOMATON_SCALE;
             }
@@ -1595,7 +1627,7 @@ daac_status find_count3(daac_pma *pma, DeviceTables *t, const uint8_t *dev_hay, 
                         unsigned long long *d_res, bool want_checksum, bool leftmost, unsigned long long acc[3], bool *served) {
     *served = false;
     acc[0] = acc[1] = acc[2] = 0;
-    const uint64_t kWin = static_cast<uint64_t>(g_opt.find3_window.load());
+    const uint64_t kWin = static_cast<uint64_t>(OPT(find3_window));
     for (uint64_t cur = begin;;) {
         // (leftmost: a window's matches START in it; the detection looks 32 bytes further so that the last ones are whole)
         const uint64_t wend = len - cur <= kWin ? len : cur + kWin - (leftmost ? 64 : 0);
@@ -1626,8 +1658,8 @@ daac_status select_emit(daac_pma *pma, DeviceTables *t, int mode, const uint8_t 
     *served = false;
     const bool leftmost = mode == DAAC_LEFTMOST_FIND;
     if (pma->charwise || pma->root_has_output() || end <= begin || pma->host.is_standard() == leftmost) return DAAC_OK;
-    if (!(leftmost ? t->left3_ok : t->find3_ok) || g_opt.select_emit.load() == 0) return DAAC_OK;
-    const uint64_t kWin = static_cast<uint64_t>(g_opt.find3_window.load());
+    if (!(leftmost ? t->left3_ok : t->find3_ok) || OPT(select_emit) == 0) return DAAC_OK;
+    const uint64_t kWin = static_cast<uint64_t>(OPT(find3_window));
     daac_status st;
     if (end - begin <= kWin) {
         SelectEmit em;
@@ -1655,7 +1687,7 @@ daac_status select_emit(daac_pma *pma, DeviceTables *t, int mode, const uint8_t 
     if (!counted) return DAAC_OK;
     const uint64_t total = acc[0];
     const size_t tb = out.f16 ? 16 : sizeof(daac_match);
-    if (total * tb > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+    if (total * tb > static_cast<unsigned long long>(OPT(max_result_bytes))) {
         set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
         return DAAC_ERR_AUTOMATON_SCALE;
     }
@@ -1733,7 +1765,7 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
             uint64_t total = 0;
             if ((st = scan_count_impl(pma, DAAC_FIND_OVERLAPPING, DAAC_ENGINE_AUTO, dev_hay, end, begin, 1, stream, &total, nullptr, nullptr, false)) != DAAC_OK) return st;
             const size_t tb = out.f16 ? 16 : sizeof(daac_match);
-            if (total * tb > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+            if (total * tb > static_cast<unsigned long long>(OPT(max_result_bytes))) {
                 set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
                 return DAAC_ERR_AUTOMATON_SCALE;
             }
@@ -1788,7 +1820,7 @@ daac_status scan_range_device(daac_pma *pma, DeviceTables *t, int mode, int engi
     const bool positional = pl.restart && !pl.leftmost && pma->root_has_output();
     if (pl.restart && !positional && next_begin) *next_begin = std::max<uint64_t>(nb, end);
     if (total == 0) return DAAC_OK;
-    if (total * sizeof(daac_match) > static_cast<unsigned long long>(g_opt.max_result_bytes.load())) {
+    if (total * sizeof(daac_match) > static_cast<unsigned long long>(OPT(max_result_bytes))) {
         set_error("match list of " + std::to_string(total) + " tuples exceeds max_result_bytes; iterate with daac_iter_* instead");
         return DAAC_ERR_AUTOMATON_SCALE;
     }
@@ -1956,7 +1988,7 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
     // find3 / left3 serve the restart iterators' count while the handle's last such request did not meet text made of dictionary words
     const bool select_text_ok = t->find3_gave_up.load() < 2 && t->find3_rec_per_kib.load() <= 27;
     if (!h.is_standard()) {
-        if (t->left3_ok && g_opt.left3.load() != 0 && !pma->root_has_output() && (select_text_ok || g_opt.left3.load() >= 2))
+        if (t->left3_ok && OPT(left3) != 0 && !pma->root_has_output() && (select_text_ok || OPT(left3) >= 2))
             set(DAAC_REQ_LEFTMOST_FIND, DAAC_ENGINE_GRAM, DAAC_KERNEL_SELECT, DAAC_WHY_FASTEST);
         else set(DAAC_REQ_LEFTMOST_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);
         return;
@@ -1967,9 +1999,9 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
     else if (t->n_distinct_bytes > 61) why_no_gram = DAAC_WHY_ALPHABET;
     else if (t->n_distinct_bytes != 0) why_no_gram = DAAC_WHY_LDS;
     const int seg_engine = t->tier_ok ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY;
-    const int micro = g_opt.overlap_micro.load() >= (t->tier_ok ? 2 : 1) ? DAAC_KERNEL_MICRO : DAAC_KERNEL_SEGMENT;
+    const int micro = OPT(overlap_micro) >= (t->tier_ok ? 2 : 1) ? DAAC_KERNEL_MICRO : DAAC_KERNEL_SEGMENT;
     const int micro_engine = micro == DAAC_KERNEL_MICRO ? DAAC_ENGINE_DARRAY : seg_engine;
-    const int64_t gv = g_opt.gram_version.load();
+    const int64_t gv = OPT(gram_version);
     if (t->gram2_ok && gv != 1) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_COUNT, DAAC_WHY_FASTEST);
     else if (t->gram_ok) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EXACT, DAAC_WHY_FASTEST);
     else if (t->gramw_ok) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_WIDE, DAAC_WHY_FASTEST);
@@ -1979,18 +2011,19 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
     else if (t->gramw_ok && t->gramw.exact_ok) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_WIDE, DAAC_WHY_FASTEST);
     else if (t->pfx_ok) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);  // (as scan_count_impl: PFX wherever no GRAM table set serves the request)
     else set(DAAC_REQ_OVERLAPPING_CHECKSUM, micro_engine, micro, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);
-    if (t->emit3_ok && t->emit3_gave_up.load() < 2 && g_opt.emit.load() != 0)
+    if (t->emit3_ok && t->emit3_gave_up.load() < 2 && OPT(emit) != 0)
         set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EMIT, DAAC_WHY_FASTEST);
-    else if (t->pfx_emit_ok && t->emit3_gave_up.load() < 2 && g_opt.emit.load() != 0)
+    else if (t->pfx_emit_ok && t->emit3_gave_up.load() < 2 && OPT(emit) != 0)
         set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, why_no_gram);
     else set(DAAC_REQ_OVERLAPPING_TUPLES, seg_engine, DAAC_KERNEL_SEGMENT, t->gram2_ok ? DAAC_WHY_DUPLICATES : why_no_gram);
     set(DAAC_REQ_NO_SUFFIX, seg_engine, DAAC_KERNEL_SEGMENT, DAAC_WHY_FASTEST);
-    if (t->find3_ok && g_opt.find3.load() != 0 && !pma->root_has_output() && (select_text_ok || g_opt.find3.load() >= 2))
+    if (t->find3_ok && OPT(find3) != 0 && !pma->root_has_output() && (select_text_ok || OPT(find3) >= 2))
         set(DAAC_REQ_FIND, DAAC_ENGINE_GRAM, DAAC_KERNEL_SELECT, DAAC_WHY_FASTEST);
     else set(DAAC_REQ_FIND, DAAC_ENGINE_DARRAY, pma->root_has_output() ? DAAC_KERNEL_SEGMENT : DAAC_KERNEL_CHAIN, DAAC_WHY_CHAIN);  // (the restart iterators run on the double array)
 }
 
 daac_status daac_pma_info(const daac_pma *pma, daac_info *info) {
+    PmaScope scope_(pma);
     if (!pma || !info) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     const uint32_t cap = info->struct_size;
     if (cap < 8 || cap > (1u << 16)) {
@@ -2110,6 +2143,7 @@ daac_status daac_pma_trim(daac_pma *pma) {
 void daac_pma_free(daac_pma *pma) { delete pma; }
 
 daac_status daac_pma_upload(daac_pma *pma, int device) {
+    PmaScope scope_(pma);
     if (!pma) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     std::lock_guard<std::mutex> g(pma->mu);
     DeviceTables *t = nullptr;
@@ -2118,6 +2152,7 @@ daac_status daac_pma_upload(daac_pma *pma, int device) {
 
 static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, size_t begin, int hay_is_device,
                                    void *stream_, uint64_t *count, uint64_t *checksum, uint64_t *result_dev, bool want_checksum) {
+    PmaScope scope_(pma);
     if (!pma || (len && !hay) || (!result_dev && (!count || (want_checksum && !checksum))) || begin > len) {
         set_error("bad argument");
         return DAAC_ERR_INVALID_ARGUMENT;
@@ -2130,7 +2165,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
     // which GRAM table set serves this request: the second one where it applies (count only: always; with checksum: when
     // CID/H fit next to M), else the first
-    const int64_t gv = g_opt.gram_version.load();
+    const int64_t gv = OPT(gram_version);
     // (measured on cfg3: with the checksum both table sets spend three LDS lookups per position and the first is a little
     // faster; `.count()` alone needs one lookup per position on the second and runs 20-25 % faster there)
     const bool g1_can = t->gram_ok && gv != 2;
@@ -2141,7 +2176,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     // PFX: `.count()` for automata over any byte alphabet — what AUTO takes where the GRAM tables do not apply
     bool use_pfx = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && t->pfx_ok &&
                    len - begin < (1ull << 35) && (engine == DAAC_ENGINE_PFX || (engine == DAAC_ENGINE_AUTO && !use_gram));
-    if (use_pfx && engine == DAAC_ENGINE_AUTO && g_opt.pfx_probe.load() != 0) {
+    if (use_pfx && engine == DAAC_ENGINE_AUTO && OPT(pfx_probe) != 0) {
         // PFX is a filter: where the text's G-grams are mostly trie prefixes the micro-step walker over the double array is faster.  A
         // synchronous scan of a device haystack of 32 MiB or more samples the text (one small kernel + a read-back) and leaves its
         // verdict in the handle; every other call goes by the last verdict (none yet: PFX).
@@ -2154,7 +2189,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
             HIP_TRY(hipMemcpyAsync(pin ? pin : &got, tmp, 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             if (pin) got = *pin;
-            dense = got > static_cast<unsigned int>(std::max<int64_t>(0, g_opt.pfx_probe.load())) ? 1 : 0;
+            dense = got > static_cast<unsigned int>(std::max<int64_t>(0, OPT(pfx_probe))) ? 1 : 0;
             t->pfx_dense.store(dense);
         }
         if (dense > 0) use_pfx = false;   // (no verdict yet: PFX, as the handle's plan says)
@@ -2174,9 +2209,9 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     // (gram_version = 2 asks for gram2_kernels.hip, which counts with its checksum tables: a dictionary without room for those counts here)
     bool use_g4 = use_g2 && !want_checksum && t->gram4_ok && (gv == 4 || gv == 0 || (gv == 2 && !t->gram2.exact_ok));
     if (use_g4) {
-        const bool want_rfull = g_opt.gram2_rfull.load() != 0, want_arith = g_opt.gram4_arith.load() != 0;
-        const uint32_t waves = static_cast<uint32_t>(g_opt.threads.load()) > 512 ? 16u : 8u;
-        const int64_t ppl_opt = g_opt.gram_ppl.load();
+        const bool want_rfull = OPT(gram2_rfull) != 0, want_arith = OPT(gram4_arith) != 0;
+        const uint32_t waves = static_cast<uint32_t>(OPT(threads)) > 512 ? 16u : 8u;
+        const int64_t ppl_opt = OPT(gram_ppl);
         // preference: the per-word directory first (two LDS reads per hit instead of five), then 32 positions per lane
         struct Shape { uint32_t ppl; bool rfull; } shapes[4] = {{32u, true}, {16u, true}, {32u, false}, {16u, false}};
         bool planned = false;
@@ -2256,36 +2291,36 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         uint64_t region = 2048;
         // (second table set: 256 KiB regions once there are several per wave — a region's start costs a handful of dependent
         // loads and the refill of the prefetch pipeline: 64 KiB regions measured 2-6 % slower on 4 GiB)
-        const int64_t region_opt = g_opt.gram_region.load() > 0 ? g_opt.gram_region.load()
+        const int64_t region_opt = OPT(gram_region) > 0 ? OPT(gram_region)
                                    : (use_g2 || use_pfx) ? ((len - from) >= (1ull << 31) ? 262144 : 65536) : 16384;
         while (region * 2 <= static_cast<uint64_t>(std::max<int64_t>(2048, region_opt)) && region < (1ull << 30)) region *= 2;
-        ga.ppl = use_pfx ? 16 : use_g4 ? g4_ppl : (!use_g2 && !use_gw && !t->gram.has_short && g_opt.gram_ppl.load() != 16) ? 32 : 16;
+        ga.ppl = use_pfx ? 16 : use_g4 ? g4_ppl : (!use_g2 && !use_gw && !t->gram.has_short && OPT(gram_ppl) != 16) ? 32 : 16;
         ga.region_bytes = region;
         ga.nregions = (ga.vlen + region - 1) / region;
         ga.result = d_res;
-        uint32_t threads = static_cast<uint32_t>(g_opt.threads.load());
+        uint32_t threads = static_cast<uint32_t>(OPT(threads));
         threads = std::min(1024u, std::max(64u, threads & ~63u));
         if (use_gw) threads = 1024;  // the wide kernel has one launch shape
         if (use_g4) threads = g4l.threads;
         if (use_pfx) threads = t->pfx.threads;
         const uint32_t wpb = threads / 64;
-        uint32_t bpc = static_cast<uint32_t>(g_opt.blocks_per_cu.load());
+        uint32_t bpc = static_cast<uint32_t>(OPT(blocks_per_cu));
         const uint32_t gram_lds = use_pfx ? t->pfx.lds_bytes : use_g4 ? g4l.lds_bytes : use_gw ? (want_checksum ? t->gramw.lds_exact : t->gramw.lds_count)
                                          : use_g2 ? gram2_lds_bytes(t->gram2, want_checksum) : t->gram.lds_bytes;
         if (bpc == 0) bpc = std::max(1u, std::min(2048u / threads, (160u * 1024u) / gram_lds));
         const uint32_t blocks = static_cast<uint32_t>(
             std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * bpc, (ga.nregions + wpb - 1) / wpb)));
         // room for what one step can queue at worst (64 * ppl + 128 walkers) on top of a useful fill level
-        ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(64 * ga.ppl + 128 + 64, g_opt.gram_slab.load()));  // (a step can queue 64 * ppl walkers)
+        ga.wq_slab = static_cast<uint32_t>(std::max<int64_t>(64 * ga.ppl + 128 + 64, OPT(gram_slab)));  // (a step can queue 64 * ppl walkers)
         // more than ~1 % of the (K+1)-grams are trie prefixes: some lane of the wave hits on nearly every position
         {
             const uint64_t n_deep = use_gw ? t->gramw.n_deep : use_g2 ? t->gram2.n_deep : t->gram.n_deep, C = use_gw ? t->gramw.C : use_g2 ? t->gram2.C : t->gram.C,
                            K = use_gw ? 2 : use_g2 ? t->gram2.K : t->gram.K;
-            ga.dense = g_opt.gram_dense.load() >= 0 ? g_opt.gram_dense.load() != 0 : n_deep * 100 > C * C * C * (K == 3 ? C : 1);
+            ga.dense = OPT(gram_dense) >= 0 ? OPT(gram_dense) != 0 : n_deep * 100 > C * C * C * (K == 3 ? C : 1);
         }
         // gram4: tail records from the hit record on pay on text made of dictionary words (+20 %) and cost 3-4 % elsewhere; unless
         // the option decides, every workgroup samples the haystack at its start and runs the variant the text calls for
-        const int64_t tail_opt = g_opt.gram3_tail.load();
+        const int64_t tail_opt = OPT(gram3_tail);
         void *wq = nullptr;
         HIP_TRY(dev_malloc(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * ((use_g4 || use_pfx) ? sizeof(uint4) : sizeof(uint2)), stream));
         ga.wq = static_cast<uint2 *>(wq);
@@ -2364,6 +2399,7 @@ daac_status daac_scan_count_only_range(daac_pma *pma, int mode, int engine, cons
 // for callers that run one process per GPU (daachorse_amd/dist.py) and reduce {count, S1, S2} themselves.
 daac_status daac_scan_count_multi(daac_pma *pma, int mode, int engine, const daac_shard *shards, size_t n, int hay_is_device, uint64_t *count,
                                   uint64_t *checksum) {
+    PmaScope scope_(pma);
     if (!pma || !count || (n && !shards)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
@@ -2420,6 +2456,7 @@ daac_status daac_scan_count_multi(daac_pma *pma, int mode, int engine, const daa
 
 daac_status daac_scan(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
                       daac_matches **out) {
+    PmaScope scope_(pma);
     if (!pma || !out || (len && !hay)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     DeviceTables *t = nullptr;
@@ -2443,10 +2480,12 @@ static daac_status scan_device_impl(daac_pma *pma, int mode, int engine, const u
 
 daac_status daac_scan_device(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
                              daac_match **dev_out, uint64_t *count) {
+    PmaScope scope_(pma);
     return scan_device_impl(pma, mode, engine, hay, len, hay_is_device, stream_, reinterpret_cast<void **>(dev_out), count, false);
 }
 daac_status daac_scan_device16(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream_,
                                daac_match16 **dev_out, uint64_t *count) {
+    PmaScope scope_(pma);
     return scan_device_impl(pma, mode, engine, hay, len, hay_is_device, stream_, reinterpret_cast<void **>(dev_out), count, true);
 }
 
@@ -2636,10 +2675,11 @@ struct daac_iter {
 };
 
 void daac_iter::run() {
+    PmaScope scope_(pma);
     (void)hipSetDevice(device);
     auto fail_with = [&](IterWindow &w, daac_status st) { w.st = st; w.err = last_error_cstr(); w.n = 0; };
     DeviceTables *t = nullptr;
-    uint64_t window = std::max<uint64_t>(4096, static_cast<uint64_t>(g_opt.iter_window.load()));
+    uint64_t window = std::max<uint64_t>(4096, static_cast<uint64_t>(OPT(iter_window)));
     if (compact) window = std::min<uint64_t>(window, (1ull << end_bits) - pma->halo() - 4096);   // (a restart window runs on to a sync point: less than a pattern further)
     // windows grow from 16 MiB to the full size: the consumer has its first matches after a small window's scan and copy, not a big one's
     auto window_of = [&](uint64_t k) -> uint64_t { return std::min<uint64_t>(window, (16ull << 20) << std::min<uint64_t>(k, 16)); };
@@ -2801,6 +2841,7 @@ daac_status daac_iter_open_compact(daac_pma *pma, int mode, int engine, const ui
 }
 static daac_status iter_open_impl(daac_pma *pma, int mode, int engine, const uint8_t *hay, size_t len, int hay_is_device, void *stream,
                                   bool compact, daac_iter **out) {
+    PmaScope scope_(pma);
     if (!pma || !out || (len && !hay)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     DeviceTables *t = nullptr;
     daac_status st = check_mode_kind(pma, mode);
@@ -2995,6 +3036,7 @@ static daac_status last_complete_char_end(const uint8_t *dev_virt, uint64_t from
 extern "C" {
 
 daac_status daac_stream_open(daac_pma *pma, int mode, int engine, void *stream, daac_stream **out) {
+    PmaScope scope_(pma);
     if (!pma || !out) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     if (mode == DAAC_LEFTMOST_FIND) {
         set_error("the reference has no stepper for leftmost automata (a leftmost match needs the text after it)");
@@ -3015,6 +3057,7 @@ daac_status daac_stream_open(daac_pma *pma, int mode, int engine, void *stream, 
 }
 
 daac_status daac_stream_feed(daac_stream *s, const uint8_t *chunk, size_t len, int chunk_is_device, daac_matches **out) {
+    PmaScope scope_(s ? s->pma : nullptr);
     if (!s || !out || (len && !chunk)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
     std::unique_ptr<daac_matches> m(new daac_matches);
     if (len == 0 && s->started) { *out = m.release(); return DAAC_OK; }
@@ -3077,50 +3120,45 @@ void daac_stream_close(daac_stream *s) { delete s; }
 
 extern "C" {
 
+// user-facing option name -> {field of Options (the name OPT() looks up), the process-wide atomic}; `value` is clamped where the option has a range
+static bool option_slot(const std::string &n, int64_t &value, const char *&field, std::atomic<int64_t> *&slot) {
+#define SLOT(NAME) if (n == #NAME) { field = #NAME; slot = &g_opt.NAME; return true; }
+    SLOT(seg_bytes) SLOT(lds_budget) SLOT(dense_depth) SLOT(rows_share_pct) SLOT(blocks_per_cu) SLOT(threads) SLOT(iter_window) SLOT(max_result_bytes)
+    SLOT(gram_lds_budget) SLOT(gram_region) SLOT(gram_slab) SLOT(gram_dense) SLOT(gram_ppl) SLOT(gram_version) SLOT(gram2_dpp) SLOT(gram2_rfull)
+    SLOT(gram4_arith) SLOT(gram3_tail) SLOT(pfx) SLOT(pfx_probe) SLOT(find3) SLOT(left3) SLOT(select_emit) SLOT(emit) SLOT(emit_stagger) SLOT(emit_v3_lds)
+    SLOT(emit_rec_per_kib) SLOT(gram_rank_in_lds) SLOT(restart_chain) SLOT(restart_bpc) SLOT(chain_rounds) SLOT(overlap_micro) SLOT(pool) SLOT(pool_keep)
+    SLOT(char_map_lds) SLOT(char_row_lds)
+#undef SLOT
+    if (n == "gram_tail") { field = "gram3_tail"; slot = &g_opt.gram3_tail; return true; }
+    if (n == "find3_window") { value = std::min<int64_t>(1ll << 30, std::max<int64_t>(8192, value)); field = "find3_window"; slot = &g_opt.find3_window; return true; }
+    if (n == "workspace_keep") { value = std::max<int64_t>(0, value); field = "workspace_keep"; slot = &g_opt.workspace_keep; return true; }
+    // options of engines that left the library (the TIERED chain walkers, the round-3 COUNT + WRITE emitter): accepted, nothing left to steer
+    if (n == "restart_tier" || n == "emit_tiles" || n == "emit_rec_cap" || n == "emit_version") { field = nullptr; slot = nullptr; return true; }
+    return false;
+}
+
 daac_status daac_set_option(const char *name, int64_t value) {
     if (!name) { set_error("null option name"); return DAAC_ERR_INVALID_ARGUMENT; }
-    const std::string n(name);
-    if (n == "seg_bytes") g_opt.seg_bytes = value;
-    else if (n == "lds_budget") g_opt.lds_budget = value;
-    else if (n == "dense_depth") g_opt.dense_depth = value;
-    else if (n == "rows_share_pct") g_opt.rows_share_pct = value;
-    else if (n == "blocks_per_cu") g_opt.blocks_per_cu = value;
-    else if (n == "threads") g_opt.threads = value;
-    else if (n == "iter_window") g_opt.iter_window = value;
-    else if (n == "max_result_bytes") g_opt.max_result_bytes = value;
-    else if (n == "gram_lds_budget") g_opt.gram_lds_budget = value;
-    else if (n == "gram_region") g_opt.gram_region = value;
-    else if (n == "gram_slab") g_opt.gram_slab = value;
-    else if (n == "gram_dense") g_opt.gram_dense = value;
-    else if (n == "gram_ppl") g_opt.gram_ppl = value;
-    else if (n == "gram_version") g_opt.gram_version = value;
-    else if (n == "gram2_dpp") g_opt.gram2_dpp = value;
-    else if (n == "gram2_rfull") g_opt.gram2_rfull = value;
-    else if (n == "gram4_arith") g_opt.gram4_arith = value;
-    else if (n == "gram3_tail" || n == "gram_tail") g_opt.gram3_tail = value;
-    else if (n == "pfx") g_opt.pfx = value;
-    else if (n == "pfx_probe") g_opt.pfx_probe = value;
-    else if (n == "find3") g_opt.find3 = value;
-    else if (n == "left3") g_opt.left3 = value;
-    else if (n == "select_emit") g_opt.select_emit = value;
-    else if (n == "restart_tier") {}   // (the TIERED chain walkers of round 3 — measured 7-9 % slower than the double array's — left the library: accepted, without effect)
-    else if (n == "emit") g_opt.emit = value;
-    else if (n == "emit_tiles" || n == "emit_rec_cap" || n == "emit_version") {}   // (options of the round-3 COUNT + WRITE emitter: accepted, nothing left to steer)
-    else if (n == "emit_stagger") g_opt.emit_stagger = value;
-    else if (n == "emit_v3_lds") g_opt.emit_v3_lds = value;
-    else if (n == "emit_rec_per_kib") g_opt.emit_rec_per_kib = value;
-    else if (n == "gram_rank_in_lds") g_opt.gram_rank_in_lds = value;
-    else if (n == "restart_chain") g_opt.restart_chain = value;
-    else if (n == "restart_bpc") g_opt.restart_bpc = value;
-    else if (n == "chain_rounds") g_opt.chain_rounds = value;
-    else if (n == "overlap_micro") g_opt.overlap_micro = value;
-    else if (n == "pool") g_opt.pool = value;
-    else if (n == "pool_keep") g_opt.pool_keep = value;
-    else if (n == "find3_window") g_opt.find3_window = std::min<int64_t>(1ll << 30, std::max<int64_t>(8192, value));
-    else if (n == "workspace_keep") g_opt.workspace_keep = std::max<int64_t>(0, value);
-    else if (n == "char_map_lds") g_opt.char_map_lds = value;
-    else if (n == "char_row_lds") g_opt.char_row_lds = value;
-    else { set_error("unknown option: " + n); return DAAC_ERR_INVALID_ARGUMENT; }
+    const char *field = nullptr;
+    std::atomic<int64_t> *slot = nullptr;
+    if (!option_slot(name, value, field, slot)) { set_error(std::string("unknown option: ") + name); return DAAC_ERR_INVALID_ARGUMENT; }
+    if (slot) slot->store(value);
+    return DAAC_OK;
+}
+
+// The same option for ONE handle: overrides the process-wide value for every scan, iterator and stream of `pma` (and, for the options read
+// when the tables are laid out — gram_lds_budget, pfx, left3, lds_budget, char_map_lds ... — for its next daac_pma_upload).  `unset` != 0 takes
+// the override away.  `pool` / `pool_keep` (the device's allocator) have no per-handle meaning: status 1.
+daac_status daac_pma_set_option(daac_pma *pma, const char *name, int64_t value, int unset) {
+    if (!pma || !name) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    const char *field = nullptr;
+    std::atomic<int64_t> *slot = nullptr;
+    if (!option_slot(name, value, field, slot)) { set_error(std::string("unknown option: ") + name); return DAAC_ERR_INVALID_ARGUMENT; }
+    if (slot == &g_opt.pool || slot == &g_opt.pool_keep) { set_error("pool / pool_keep are properties of the device's allocator, not of a handle"); return DAAC_ERR_INVALID_ARGUMENT; }
+    if (!field) return DAAC_OK;
+    std::lock_guard<std::mutex> g(pma->opt_mu);
+    if (unset) pma->opt_ov.erase(field); else pma->opt_ov[field] = value;
+    pma->opt_n.store(static_cast<int>(pma->opt_ov.size()));
     return DAAC_OK;
 }
 

@@ -33,7 +33,8 @@ extern "C" {
  *                daac_scan_device16.
  *   4 (round 4): daac_iter_next_batch; the lazy iterator runs its windows ahead of the consumer on a worker thread; DAAC_ENGINE_JUMP /
  *                DAAC_KERNEL_JUMP are gone (the experiment is in the history: commit c51e1c3 and before, tools/experiments/jump).
- *   5 (round 5): daac_scan_count_multi (one haystack sharded across the devices of a node); options gram4_arith, gram_tail. */
+ *   5 (round 5): daac_scan_count_multi (one haystack sharded across the devices of a node); daac_pma_set_option (options per handle);
+ *                daac_pma_trim; options gram4_arith, gram_tail. */
 #define DAAC_ABI_VERSION 5
 uint32_t daac_abi_version(void);
 
@@ -389,6 +390,11 @@ void daac_stream_close(daac_stream *s);
  *   iter_window (64 MiB)        haystack bytes per window of the lazy iterator (the first windows are 16 and 32 MiB: matches arrive early)
  *   max_result_bytes (8 GiB)    largest match list daac_scan may materialise */
 daac_status daac_set_option(const char *name, int64_t value);
+/* The same option for ONE handle (ABI 5): overrides the process-wide value for every scan, iterator and stream of `pma` — and, for the
+ * options read when the tables are laid out (gram_lds_budget, lds_budget, pfx, left3, char_map_lds, char_row_lds ...), for its next
+ * daac_pma_upload.  Two threads scanning two handles with different settings do not share state.  unset != 0 removes the override.
+ * `pool` / `pool_keep` belong to the device's allocator, not to a handle (status 1). */
+daac_status daac_pma_set_option(daac_pma *pma, const char *name, int64_t value, int unset);
 
 #ifdef __cplusplus
 }

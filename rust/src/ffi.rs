@@ -99,6 +99,8 @@ extern "C" {
     pub fn daac_scan_device16(pma: *mut daac_pma, mode: i32, engine: i32, hay: *const u8, len: usize, hay_is_device: i32,
                               stream: *mut c_void, dev_out: *mut *mut daac_match16, count: *mut u64) -> i32;
     pub fn daac_device_free(p: *mut c_void);
+    /// an option for one handle (overrides the process-wide daac_set_option value; unset != 0 removes the override)
+    pub fn daac_pma_set_option(pma: *mut daac_pma, name: *const c_char, value: i64, unset: i32) -> i32;
     /// releases the scratch a handle keeps between calls (tables stay)
     pub fn daac_pma_trim(pma: *mut daac_pma) -> i32;
     // the chunk-fed steppers (stepper_hip.rs): FindStepper / FindOverlappingStepper / the *_from_iter entry points

@@ -926,3 +926,52 @@ def test_trim_and_iterators_that_are_never_pulled():
         first = next(iter(it))
         assert (first.start(), first.end(), first.value()) == (int(want["start"][0]), int(want["end"][0]), int(want["value"][0]))
         it.close()
+
+
+def test_options_per_handle():
+    """daac_pma_set_option: two handles of one dictionary with different settings — the engine version, the launch shape, the body of the
+    count kernel, the emitter switched off — scanned from two threads at once give the oracle's answers, the process-wide options untouched
+    (a third handle follows them); an unknown name and the allocator's options are refused."""
+    import threading
+    import torch
+    pats = synth.patterns_cfg3(20000)
+    o = orc.OraclePma.build(pats)
+    hay = synth.wordsoup_haystack(6 << 20, synth.SEEDS["cfg3_dense"], pats, 20)
+    dev = torch.from_numpy(hay).cuda()
+    want = o.overlapping_count(hay, threads=8)
+    a, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    b, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    c, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    a.set_option("gram_ppl", 16).set_option("gram_tail", 0).set_option("gram4_arith", 0).set_option("emit", 0)
+    b.set_option("gram_ppl", 32).set_option("gram_tail", 1).set_option("gram2_rfull", 0).set_option("threads", 512)
+    errs = []
+
+    def work(p, n):
+        try:
+            for _ in range(n):
+                assert p.count(ScanMode.FindOverlapping, dev) == want[0]
+                assert p.scan_count(ScanMode.FindOverlapping, dev) == want
+        except Exception as e:  # noqa
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(p, 6)) for p in (a, b, c)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    m = 200_000
+    ref = o.find_overlapping_iter(hay[:m])
+    for p, by_emitter in ((a, False), (b, True), (c, True)):   # a's emitter is off: the segment scanners write its list
+        dm = p.scan_device(ScanMode.FindOverlapping, dev[:m])
+        got = dm.to_numpy()
+        dm.free()
+        assert (da.last_engine() == int(Engine.Gram)) == by_emitter, (da.last_engine(), by_emitter)
+        assert len(got) == len(ref) and np.array_equal(got["end"], ref["end"]) and np.array_equal(got["value"], ref["value"])
+    a.set_option("emit")   # the override goes: the process-wide value (1) again
+    dm = a.scan_device(ScanMode.FindOverlapping, dev[:m])
+    dm.free()
+    assert da.last_engine() == int(Engine.Gram)
+    for name in ("no_such_option", "pool"):
+        with pytest.raises(da.DaachorseError) as ei:
+            a.set_option(name, 1)
+        assert ei.value.code == 1
