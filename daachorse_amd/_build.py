@@ -9,9 +9,9 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdaachorse_amd.so")
 
-SOURCES = ["pma.cpp", "repack.cpp", "gram.cpp", "gram2.cpp", "gram4.cpp", "gram2w.cpp", "pfx.cpp", "builder.cpp", "charwise.cpp", "charwise_builder.cpp", "api.hip", "scan_kernels.hip",
+SOURCES = ["pma.cpp", "repack.cpp", "gram.cpp", "gram2.cpp", "gram4.cpp", "gram2w.cpp", "pfx.cpp", "builder.cpp", "charwise.cpp", "charwise_builder.cpp", "api_upload.hip", "api_scan.hip", "api_select.hip", "api_iter.hip", "api_options.hip", "scan_kernels.hip",
            "gram_kernels.hip", "gram2_kernels.hip", "gram4_kernels.hip", "pfx_kernels.hip", "emit3_kernels.hip", "find3_kernels.hip", "left3_kernels.hip", "gram2w_kernels.hip", "restart_kernels.hip", "charwise_kernels.hip", "synth.hip"]
-HEADERS = ["pma.hpp", "repack.hpp", "gram.hpp", "gram2.hpp", "gram4.hpp", "gram2w.hpp", "pfx.hpp", "charwise.hpp", "build_common.hpp", "device_tables.hpp", "chain_scan.hpp", os.path.join("..", "..", "include", "daachorse_amd.h"),
+HEADERS = ["api_internal.hpp", "pma.hpp", "repack.hpp", "gram.hpp", "gram2.hpp", "gram4.hpp", "gram2w.hpp", "pfx.hpp", "charwise.hpp", "build_common.hpp", "device_tables.hpp", "chain_scan.hpp", os.path.join("..", "..", "include", "daachorse_amd.h"),
            os.path.join("..", "..", "include", "daac_synth.h")]
 
 

@@ -28,7 +28,7 @@ typedef uint32_t g_u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int kGroup = 4;     // positions whose LDS reads are issued together (lgkmcnt tracks at most 15 reads)
 constexpr uint32_t kRing = 128;  // entries of a wave's hit stack in LDS (at most 63 left over + 64 new)
 constexpr int kPrefetch = 1;  // haystack chunks in flight per lane beyond the current one
-constexpr uint32_t kOffBbits = 1024;  // LDS layout: 256 classes as u32, then the B bitmap (api.hip)
+constexpr uint32_t kOffBbits = 1024;  // LDS layout: 256 classes as u32, then the B bitmap (api_upload.hip)
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 
 // 24-bit multiply-adds, spelled out: left to itself hipcc turns some `__umul24(a, b) + c` of the gram

@@ -1,6 +1,6 @@
 // leftmost_find_iter without a state chain (gfx950): count (+ checksum) of the leftmost iterators' match stream (reference
 // src/bytewise/iter.rs:272-340, LeftmostLongest and LeftmostFirst) from the front half of the tuple emitter, run on a Standard automaton
-// of the same patterns (api.hip builds that shadow at upload from the handle's own trie).
+// of the same patterns (api_upload.hip builds that shadow at upload from the handle's own trie).
 //
 // The leftmost iterator restarted at r reports the match with the smallest START >= r, the longest one among those that start there
 // (LeftmostFirst: the earliest-registered one — the builder drops every pattern below an earlier-registered one, nfa_builder.rs:60-66, so

@@ -21,6 +21,14 @@ for d in sys.argv[1:]:
             for name, v in sorted(c.items()):
                 print(f"   {name:28s} {sum(v) / len(v):.5g}  (n={len(v)})")
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        if os.environ.get("DAAC_PMC_MEAN"):  # one line per kernel instead of one per launch
+            dur = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if any(x in r["Kernel_Name"] for x in KEYS):
+                    dur[r["Kernel_Name"][:70]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            for k, v in dur.items():
+                print(f"   mean_us {sum(v) / len(v):10.1f}  (n={len(v)})  {k}")
+            continue
         for r in csv.DictReader(open(f)):
             if any(x in r["Kernel_Name"] for x in KEYS):
                 print("   duration_us", (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, "vgpr", r.get("VGPR_Count"),
