@@ -418,6 +418,8 @@ struct Scratch {
 daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out);   // pma->mu held
 daac_status get_tables(daac_pma *pma, DeviceTables **out);                  // of the current device, uploading on first use
 // api_scan.hip
+struct CountRoute { bool g1_can, g2_can, gw_can, gram, pfx; };   // the GRAM table sets that can serve; GRAM at all; PFX (before its probe of the text)
+CountRoute count_route(const daac_pma *pma, const DeviceTables *t, int mode, int engine, bool want_checksum, uint64_t span);
 daac_status check_mode_kind(const daac_pma *pma, int mode);
 daac_status diverged();
 daac_status make_plan(const daac_pma *pma, const DeviceTables *t, int mode, int engine, uint64_t begin, uint64_t end, Plan &pl, bool &heads);

@@ -369,6 +369,24 @@ daac_status stage_window(const uint8_t *host_hay, uint64_t copy_from, uint64_t e
     return DAAC_OK;
 }
 
+
+// Which engine counts an overlapping scan of `span` bytes (scan_count_impl runs what this says; fill_plan reports it).  GRAM: the second
+// table set where it applies (count only: always; with the checksum: when CID / H fit next to M), else the first, else the wide one; PFX:
+// what AUTO takes where no GRAM table set applies (before the text has been probed: PFX is a filter, and dense text goes to the walkers).
+// (measured on cfg3: with the checksum both table sets spend three LDS lookups per position and the first is a little faster; `.count()`
+// alone needs one lookup per position on the second and runs 20-25 % faster there)
+CountRoute count_route(const daac_pma *pma, const DeviceTables *t, int mode, int engine, bool want_checksum, uint64_t span) {
+    CountRoute r{};
+    const int64_t gv = OPT(gram_version);
+    r.g1_can = t->gram_ok && gv != 2;
+    r.g2_can = t->gram2_ok && (!want_checksum || t->gram2.exact_ok) && gv != 1 && !(gv == 0 && want_checksum && r.g1_can) && !(gv == 3 && want_checksum && r.g1_can);
+    r.gw_can = t->gramw_ok && (!want_checksum || t->gramw.exact_ok);  // wide alphabets: built only where the others are not
+    const bool applies = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && span < (1ull << 35);
+    r.gram = applies && (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (r.g2_can || r.g1_can || r.gw_can)));
+    r.pfx = applies && t->pfx_ok && (engine == DAAC_ENGINE_PFX || (engine == DAAC_ENGINE_AUTO && !r.gram));
+    return r;
+}
+
 }  // namespace api
 }  // namespace daac
 
@@ -387,19 +405,11 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     daac_status st = check_mode_kind(pma, mode);
     if (st != DAAC_OK) return st;
     if ((st = get_tables(pma, &t)) != DAAC_OK) return st;
-    // which GRAM table set serves this request: the second one where it applies (count only: always; with checksum: when
-    // CID/H fit next to M), else the first
+    // which engine and which GRAM table set serve this request (count_route: the decision daac_pma_info's plan reports as well)
     const int64_t gv = OPT(gram_version);
-    // (measured on cfg3: with the checksum both table sets spend three LDS lookups per position and the first is a little
-    // faster; `.count()` alone needs one lookup per position on the second and runs 20-25 % faster there)
-    const bool g1_can = t->gram_ok && gv != 2;
-    const bool g2_can = t->gram2_ok && (!want_checksum || t->gram2.exact_ok) && gv != 1 && !(gv == 0 && want_checksum && g1_can) && !(gv == 3 && want_checksum && g1_can);
-    const bool gw_can = t->gramw_ok && (!want_checksum || t->gramw.exact_ok);  // wide alphabets: built only where the others are not
-    const bool use_gram = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && len - begin < (1ull << 35) &&
-                          (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (g2_can || g1_can || gw_can)));
-    // PFX: `.count()` for automata over any byte alphabet — what AUTO takes where the GRAM tables do not apply
-    bool use_pfx = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && t->pfx_ok &&
-                   len - begin < (1ull << 35) && (engine == DAAC_ENGINE_PFX || (engine == DAAC_ENGINE_AUTO && !use_gram));
+    const CountRoute route = count_route(pma, t, mode, engine, want_checksum, len - begin);
+    const bool g1_can = route.g1_can, g2_can = route.g2_can, gw_can = route.gw_can, use_gram = route.gram;
+    bool use_pfx = route.pfx;
     if (use_pfx && engine == DAAC_ENGINE_AUTO && OPT(pfx_probe) != 0) {
         // PFX is a filter: where the text's G-grams are mostly trie prefixes the micro-step walker over the double array is faster.  A
         // synchronous scan of a device haystack of 32 MiB or more samples the text (one small kernel + a read-back) and leaves its

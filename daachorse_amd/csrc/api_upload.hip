@@ -719,16 +719,15 @@ static void fill_plan(const daac_pma *pma, const DeviceTables *t, daac_info &f) 
     const int seg_engine = t->tier_ok ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY;
     const int micro = OPT(overlap_micro) >= (t->tier_ok ? 2 : 1) ? DAAC_KERNEL_MICRO : DAAC_KERNEL_SEGMENT;
     const int micro_engine = micro == DAAC_KERNEL_MICRO ? DAAC_ENGINE_DARRAY : seg_engine;
-    const int64_t gv = OPT(gram_version);
-    if (t->gram2_ok && gv != 1) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_COUNT, DAAC_WHY_FASTEST);
-    else if (t->gram_ok) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EXACT, DAAC_WHY_FASTEST);
-    else if (t->gramw_ok) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_WIDE, DAAC_WHY_FASTEST);
-    else if (t->pfx_ok) set(DAAC_REQ_OVERLAPPING_COUNT, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, why_no_gram);
-    else set(DAAC_REQ_OVERLAPPING_COUNT, micro_engine, micro, why_no_gram);
-    if (t->gram_ok || (t->gram2_ok && t->gram2.exact_ok)) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EXACT, DAAC_WHY_FASTEST);
-    else if (t->gramw_ok && t->gramw.exact_ok) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_WIDE, DAAC_WHY_FASTEST);
-    else if (t->pfx_ok) set(DAAC_REQ_OVERLAPPING_CHECKSUM, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);  // (as scan_count_impl: PFX wherever no GRAM table set serves the request)
-    else set(DAAC_REQ_OVERLAPPING_CHECKSUM, micro_engine, micro, (t->gram2_ok || t->gramw_ok) ? DAAC_WHY_LDS : why_no_gram);
+    // count / count + checksum: what scan_count_impl will run (the same decision function)
+    for (const bool cs : {false, true}) {
+        const int req = cs ? DAAC_REQ_OVERLAPPING_CHECKSUM : DAAC_REQ_OVERLAPPING_COUNT;
+        const CountRoute cr = count_route(pma, t, DAAC_FIND_OVERLAPPING, DAAC_ENGINE_AUTO, cs, 0);
+        const int why = (cs && (t->gram2_ok || t->gramw_ok)) ? DAAC_WHY_LDS : why_no_gram;   // (tables there, their checksum half without room)
+        if (cr.gram) set(req, DAAC_ENGINE_GRAM, cr.g2_can ? (cs ? DAAC_KERNEL_GRAM_EXACT : DAAC_KERNEL_GRAM_COUNT) : cr.g1_can ? DAAC_KERNEL_GRAM_EXACT : DAAC_KERNEL_GRAM_WIDE, DAAC_WHY_FASTEST);
+        else if (cr.pfx) set(req, DAAC_ENGINE_PFX, DAAC_KERNEL_PFX, why);
+        else set(req, micro_engine, micro, why);
+    }
     if (t->emit3_ok && t->emit3_gave_up.load() < 2 && OPT(emit) != 0)
         set(DAAC_REQ_OVERLAPPING_TUPLES, DAAC_ENGINE_GRAM, DAAC_KERNEL_GRAM_EMIT, DAAC_WHY_FASTEST);
     else if (t->pfx_emit_ok && t->emit3_gave_up.load() < 2 && OPT(emit) != 0)
