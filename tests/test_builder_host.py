@@ -72,6 +72,14 @@ def test_tuning_options_are_known_without_a_gpu():
     with pytest.raises(da.DaachorseError) as ei:
         da.set_option("no_such_option", 1)
     assert ei.value.code == 1
+    # daac_pma_set_option: the same names per handle (what the -m gpu tests use: nothing process-wide is left behind); the device's
+    # allocator is nobody's handle
+    p = da.DoubleArrayAhoCorasick.new([b"ab", b"bc"])
+    p.set_option("find3", 2).set_option("gram_tail", 1).set_option("find3")
+    for name in ("no_such_option", "pool", "pool_keep"):
+        with pytest.raises(da.DaachorseError) as ei:
+            p.set_option(name, 1)
+        assert ei.value.code == 1, name
 
 
 @pytest.mark.parametrize("nfb", [1, 2, 16])

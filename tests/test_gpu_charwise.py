@@ -37,13 +37,7 @@ def cpins():
         return json.load(f)
 
 
-@pytest.fixture(autouse=True)
-def _reset_options():
-    yield
-    da.set_option("seg_bytes", 0)
-    da.set_option("iter_window", 64 << 20)
-    da.set_option("restart_chain", 1)
-    da.set_option("char_map_lds", 0)
+# (launch shapes and engine switches are set on the HANDLE under test, daac_pma_set_option: nothing process-wide to reset)
 
 
 def _pair(patterns, kind=0, values=None):
@@ -98,9 +92,8 @@ def test_golden_vector_tables_all_four_iterators(vectors):
         got = p.scan(API_MODE[runner["api"]], case["haystack"])
         assert [(int(m["value"]), int(m["start"]), int(m["end"])) for m in got] == want, (runner, case["name"])
         for seg in (0, 16):  # default plan, and one lane per 16 bytes
-            da.set_option("seg_bytes", seg)
+            p.set_option("seg_bytes", seg)
             assert _check_all_forms(o, p, runner["api"], case["haystack"], (runner, case["name"], seg))
-        da.set_option("seg_bytes", 0)
         n += 1
     assert n == 61 + 57 + 93 + 91
 
@@ -112,7 +105,7 @@ def test_multibyte_pins(cpins):
             continue
         _, p = _pair(ka["patterns"], ka["kind"])
         for seg in (0, 16):
-            da.set_option("seg_bytes", seg)
+            p.set_option("seg_bytes", seg)
             assert _sev(p.scan(API_MODE[ka["api"]], ka["haystack"])) == [tuple(t) for t in ka["matches_sev"]], ka["cite"]
 
 
@@ -127,15 +120,15 @@ def test_fuzz_multibyte_all_iterators(alpha, chain):
     the restart iterators both ways (chain = 1: speculate / reconcile / emit, 0: sync-point scanners)"""
     rng = np.random.default_rng(len(alpha) * 7 + 1)
     A = ALPHABETS[alpha]
-    da.set_option("restart_chain", chain)
     for trial in range(10):
         pats = _words(rng, int(rng.integers(1, 60)), A, 5)
         text = "".join(A[i] for i in rng.integers(0, len(A), size=int(rng.integers(0, 3000))))
         for kind in (0, 1, 2):
             o, p = _pair(pats, kind)
+            p.set_option("restart_chain", chain)
             for api in APIS_OF_KIND[kind]:
                 for seg in (0, 16, 48):
-                    da.set_option("seg_bytes", seg)
+                    p.set_option("seg_bytes", seg)
                     assert _check_all_forms(o, p, api, text, (alpha, trial, kind, api, seg))
 
 
@@ -155,7 +148,7 @@ def test_fuzz_empty_pattern_in_the_set():
                 o, p = _pair(pats, kind)
                 for api in APIS_OF_KIND[kind]:
                     for seg in (0, 16):
-                        da.set_option("seg_bytes", seg)
+                        p.set_option("seg_bytes", seg)
                         ok = _check_all_forms(o, p, api, text, (alpha, trial, kind, api, seg))
                         ran += ok
                         unsupported += not ok
@@ -194,7 +187,6 @@ def _dictionary(rng, n):
 def test_dictionary_scale_text(map_lds):
     """config-5-shaped case: a 20 k-word dictionary, 2 MB of text made of dictionary words and noise
     (map_lds = 1: the chain scanners with the code mapper staged in LDS; read when the automaton is uploaded)"""
-    da.set_option("char_map_lds", map_lds)
     rng = np.random.default_rng(5)
     words, base, freq = _dictionary(rng, 20000)
     parts = []
@@ -206,6 +198,7 @@ def test_dictionary_scale_text(map_lds):
     text = "".join(parts)
     for kind, apis in ((0, ["find_overlapping_iter", "find_iter"]), (1, ["leftmost_find_iter"])):
         o, p = _pair(words, kind)
+        p.set_option("char_map_lds", map_lds)   # (read at upload)
         for api in apis:
             want = getattr(o, api)(text)
             assert len(want) > 100000
@@ -221,9 +214,9 @@ def test_lazy_windows_and_shard_tails_cut_characters():
     pats = _words(rng, 80, A, 4)
     text = "".join(A[i] for i in rng.integers(0, len(A), size=40000))
     raw = text.encode()
-    da.set_option("iter_window", 4096)
     for kind in (0, 1):
         o, p = _pair(pats, kind)
+        p.set_option("iter_window", 4096)
         for api in APIS_OF_KIND[kind]:
             want = _sev(getattr(o, api)(text))
             assert [(m.start(), m.end(), m.value()) for m in getattr(p, api)(text)] == want, api

@@ -190,15 +190,10 @@ def test_cfg3_full_4_gib_count_and_checksum():
         assert da.last_engine() == int(Engine.Gram)
         assert p.count(ScanMode.FindOverlapping, dev) == want[0], kind
         for version, ppl, tail in ((2, 0, -1), (4, 16, -1), (4, 32, -1), (4, 16, 0), (4, 16, 1), (4, 32, 0), (4, 32, 1)):
-            da.set_option("gram_version", version)
-            da.set_option("gram_ppl", ppl)
-            da.set_option("gram3_tail", tail)
-            try:
-                assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want[0], (kind, version, ppl, tail)
-            finally:
-                da.set_option("gram_version", 0)
-                da.set_option("gram_ppl", 0)
-                da.set_option("gram3_tail", -1)
+            p.set_option("gram_version", version).set_option("gram_ppl", ppl).set_option("gram3_tail", tail)   # (the handle's own: daac_pma_set_option)
+            assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want[0], (kind, version, ppl, tail)
+        for name in ("gram_version", "gram_ppl", "gram3_tail"):
+            p.set_option(name)
 
 
 def test_cfg4_32_gib_as_eight_shards_on_one_device():
@@ -268,13 +263,8 @@ def test_cfg3_count_kernel_on_a_vector_of_window_counts():
     assert da.last_engine() == int(Engine.Gram)
     # the other launch shape (16 positions per lane) and the tail-record body on every eighth window
     for ppl, tail in ((16, 0), (32, 1)):
-        da.set_option("gram_ppl", ppl)
-        da.set_option("gram3_tail", tail)
-        try:
-            got3 = np.array([p.count(ScanMode.FindOverlapping, dev[:int(h)], begin=int(l), engine=Engine.Gram) for l, h in zip(los[::8], his[::8])])
-        finally:
-            da.set_option("gram_ppl", 0)
-            da.set_option("gram3_tail", -1)
+        p.set_option("gram_ppl", ppl).set_option("gram3_tail", tail)
+        got3 = np.array([p.count(ScanMode.FindOverlapping, dev[:int(h)], begin=int(l), engine=Engine.Gram) for l, h in zip(los[::8], his[::8])])
         assert np.array_equal(got3, want[::8]), (ppl, tail)
 
 
@@ -324,50 +314,49 @@ def test_cfg3_tuples_at_size_checksum_of_the_list():
     import torch
     pats = synth.patterns_cfg3()
     p = da.DoubleArrayAhoCorasick.new(pats)
-    da.set_option("max_result_bytes", 64 << 30)
-    try:
-        for kind, n in (("sparse", (7 << 29) + 12345), ("dense", 1 << 30)):
-            dev = torch.empty(n, dtype=torch.uint8, device="cuda")
-            if kind == "sparse":
-                synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
-            else:
-                synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20)
-            want = p.scan_count(ScanMode.FindOverlapping, dev)
-            dm = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
-            assert da.last_engine() == int(Engine.Gram)
-            assert _checksum_of_device_tuples16(dm) == want, kind
-            assert kind != "sparse" or dm.count > (1 << 31)
-            ends = torch.as_tensor(_DeviceWords(dm.ptr, 2 * dm.count), device="cuda").view(dm.count, 2)[:, 0]
-            assert bool((ends[1:] >= ends[:-1]).all()), kind      # by end (as unsigned they are below 2^63: the comparison holds)
-            assert int(ends[-1].item()) <= n and int(ends[0].item()) >= 1
-            # ... and 64 random 1 MiB slices of the haystack, tuple for tuple against the oracle (order within an end included):
-            # the list's tuples with lo < end <= hi are those the oracle reports on [lo - 64, hi) with an end beyond the 64 bytes of halo
-            o = _oracle_cfg3(pats)
-            rng = np.random.default_rng(20250 + len(kind))
-            words = torch.as_tensor(_DeviceWords(dm.ptr, 2 * dm.count), device="cuda").view(dm.count, 2)
-            for lo in [0, n - (1 << 20)] + [int(x) for x in rng.integers(64, n - (1 << 20), size=62)]:
-                hi = lo + (1 << 20)
-                i0, i1 = (int(x) for x in torch.searchsorted(ends, torch.tensor([lo, hi], device="cuda", dtype=ends.dtype), right=True))
-                got = words[i0:i1].cpu().numpy()
-                from_ = max(0, lo - 64)
-                ref = o.find_overlapping_iter(dev[from_:hi].cpu().numpy())
-                ref = ref[ref["end"].astype(np.int64) + from_ > lo]
-                assert len(ref) == i1 - i0, (kind, lo, len(ref), i1 - i0)
-                assert np.array_equal(got[:, 0], ref["end"].astype(np.int64) + from_), (kind, lo)
-                assert np.array_equal(got[:, 1] & 0xFFFFFFFF, (ref["end"] - ref["start"]).astype(np.int64)), (kind, lo)      # length
-                assert np.array_equal((got[:, 1] >> 32) & 0xFFFFFFFF, ref["value"].astype(np.int64)), (kind, lo)            # value
-            dm.free()
-            del dev, ends, words
-            torch.cuda.empty_cache()
-        # the PFX engine's list likewise (utf8jp scanned bytewise, 1 GiB: counted first, emitted piece by piece)
-        q = da.DoubleArrayAhoCorasick.new(synth.patterns_cfg5())
-        m = (1 << 30) - (1 << 30) % synth.CFG5_SLOT
-        dev = torch.empty(m, dtype=torch.uint8, device="cuda")
-        synth.device_zipf_text(dev)
-        want = q.scan_count(ScanMode.FindOverlapping, dev)
-        dm = q.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
-        assert da.last_engine() == int(Engine.Pfx)
-        assert _checksum_of_device_tuples16(dm) == want
+    p.set_option("max_result_bytes", 64 << 30)   # (this handle may hand out a 34 GB list)
+    for kind, n in (("sparse", (7 << 29) + 12345), ("dense", 1 << 30)):
+        dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+        if kind == "sparse":
+            synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
+        else:
+            synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20)
+        want = p.scan_count(ScanMode.FindOverlapping, dev)
+        dm = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
+        assert da.last_engine() == int(Engine.Gram)
+        assert _checksum_of_device_tuples16(dm) == want, kind
+        assert kind != "sparse" or dm.count > (1 << 31)
+        ends = torch.as_tensor(_DeviceWords(dm.ptr, 2 * dm.count), device="cuda").view(dm.count, 2)[:, 0]
+        assert bool((ends[1:] >= ends[:-1]).all()), kind      # by end (as unsigned they are below 2^63: the comparison holds)
+        assert int(ends[-1].item()) <= n and int(ends[0].item()) >= 1
+        # ... and 64 random 1 MiB slices of the haystack, tuple for tuple against the oracle (order within an end included):
+        # the list's tuples with lo < end <= hi are those the oracle reports on [lo - 64, hi) with an end beyond the 64 bytes of halo
+        o = _oracle_cfg3(pats)
+        rng = np.random.default_rng(20250 + len(kind))
+        words = torch.as_tensor(_DeviceWords(dm.ptr, 2 * dm.count), device="cuda").view(dm.count, 2)
+        for lo in [0, n - (1 << 20)] + [int(x) for x in rng.integers(64, n - (1 << 20), size=62)]:
+            hi = lo + (1 << 20)
+            i0, i1 = (int(x) for x in torch.searchsorted(ends, torch.tensor([lo, hi], device="cuda", dtype=ends.dtype), right=True))
+            got = words[i0:i1].cpu().numpy()
+            from_ = max(0, lo - 64)
+            ref = o.find_overlapping_iter(dev[from_:hi].cpu().numpy())
+            ref = ref[ref["end"].astype(np.int64) + from_ > lo]
+            assert len(ref) == i1 - i0, (kind, lo, len(ref), i1 - i0)
+            assert np.array_equal(got[:, 0], ref["end"].astype(np.int64) + from_), (kind, lo)
+            assert np.array_equal(got[:, 1] & 0xFFFFFFFF, (ref["end"] - ref["start"]).astype(np.int64)), (kind, lo)      # length
+            assert np.array_equal((got[:, 1] >> 32) & 0xFFFFFFFF, ref["value"].astype(np.int64)), (kind, lo)            # value
         dm.free()
-    finally:
-        da.set_option("max_result_bytes", 8 << 30)
+        del dev, ends, words
+        torch.cuda.empty_cache()
+    # the PFX engine's list likewise (utf8jp scanned bytewise, 1 GiB: counted first, emitted piece by piece)
+    q = da.DoubleArrayAhoCorasick.new(synth.patterns_cfg5())
+    q.set_option("max_result_bytes", 64 << 30)
+    m = (1 << 30) - (1 << 30) % synth.CFG5_SLOT
+    dev = torch.empty(m, dtype=torch.uint8, device="cuda")
+    synth.device_zipf_text(dev)
+    want = q.scan_count(ScanMode.FindOverlapping, dev)
+    dm = q.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
+    assert da.last_engine() == int(Engine.Pfx)
+    assert _checksum_of_device_tuples16(dm) == want
+    dm.free()
+

@@ -51,9 +51,9 @@ def test_find3_against_the_oracle():
             assert p.count(ScanMode.Find, dev) == want[0]
         # a restart inside the haystack: the chain begins at `b` (a sync point of the caller's), ends stay absolute
         b = int(rng.integers(1, len(hay) - 1))
-        da.set_option("find3", 0)
+        p.set_option("find3", 0)   # (this handle's: daac_pma_set_option)
         ref = p.scan_count(ScanMode.Find, dev, begin=b)
-        da.set_option("find3", 1)
+        p.set_option("find3")
         assert p.scan_count(ScanMode.Find, dev, begin=b) == ref, (len(pats), b)
         # host haystack
         assert p.scan_count(ScanMode.Find, hay) == want
@@ -90,15 +90,13 @@ def test_find3_one_gib_of_cfg3():
         # chain walkers serve that handle's requests from then on; find3 = 2 insists)
         assert da.last_engine() == (int(Engine.Gram) if kind == "sparse" else int(Engine.DArray)), kind
         if kind == "dense":
-            da.set_option("find3", 2)
+            p.set_option("find3", 2)
             assert p.scan_count(ScanMode.Find, dev) == got and da.last_engine() == int(Engine.Gram)
             assert p.count(ScanMode.Find, dev) == got[0]
-        da.set_option("find3", 0)
-        try:
-            ref = p.scan_count(ScanMode.Find, dev)
-            assert da.last_engine() == int(Engine.DArray)
-        finally:
-            da.set_option("find3", 1)
+        p.set_option("find3", 0)
+        ref = p.scan_count(ScanMode.Find, dev)
+        assert da.last_engine() == int(Engine.DArray)
+        p.set_option("find3")
         assert got == ref, kind
         pre = dev[:64 << 20]
         assert p.scan_count(ScanMode.Find, pre) == _want(o, pre.cpu().numpy()), kind
@@ -118,34 +116,26 @@ def test_find3_windows_restart_where_the_last_match_ended():
              (deepish, np.frombuffer((b"abcdefghijklmnopqrstuvwxyz" * 40000)[:1000003], dtype=np.uint8)),
              (deepish, np.frombuffer((b"abcdefghijklmnopqrstuvwxyz" + b"-" * 4000) * 200, dtype=np.uint8)),   # stretches without any match: the 64-byte rule
              (deepish, synth.uniform_haystack(1 << 20, 9, b"abcdefghijklmnopqrstuvwxyz"))]
-    try:
-        da.set_option("find3", 2)
-        for pats, hay in cases:
-            o, p = _pma(pats)
-            want = _want(o, hay)
-            dev = torch.from_numpy(hay.copy()).cuda()
-            for win in (8192, 8192 + 4096 + 17, 65536, 1 << 20):
-                da.set_option("find3_window", win)
-                assert p.scan_count(ScanMode.Find, dev) == want, (len(pats), len(hay), win)
-                assert da.last_engine() == int(Engine.Gram)
-                assert p.count(ScanMode.Find, dev) == want[0]
-            b = len(hay) // 3
-            da.set_option("find3", 0)
-            ref = p.scan_count(ScanMode.Find, dev, begin=b)
-            da.set_option("find3", 2)
-            da.set_option("find3_window", 100000)
-            assert p.scan_count(ScanMode.Find, dev, begin=b) == ref
-    finally:
-        da.set_option("find3", 1)
-        da.set_option("find3_window", 1 << 30)
+    for pats, hay in cases:
+        o, p = _pma(pats)
+        p.set_option("find3", 2)
+        want = _want(o, hay)
+        dev = torch.from_numpy(hay.copy()).cuda()
+        for win in (8192, 8192 + 4096 + 17, 65536, 1 << 20):
+            p.set_option("find3_window", win)
+            assert p.scan_count(ScanMode.Find, dev) == want, (len(pats), len(hay), win)
+            assert da.last_engine() == int(Engine.Gram)
+            assert p.count(ScanMode.Find, dev) == want[0]
+        b = len(hay) // 3
+        p.set_option("find3", 0)
+        ref = p.scan_count(ScanMode.Find, dev, begin=b)
+        p.set_option("find3", 2).set_option("find3_window", 100000)
+        assert p.scan_count(ScanMode.Find, dev, begin=b) == ref
     pats = synth.patterns_cfg3()
     p = da.DoubleArrayAhoCorasick.new(pats)
     dev = torch.empty((5 << 29) + 4321, dtype=torch.uint8, device="cuda")
     synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
     got = p.scan_count(ScanMode.Find, dev)
     assert da.last_engine() == int(Engine.Gram)
-    da.set_option("find3", 0)
-    try:
-        assert p.scan_count(ScanMode.Find, dev) == got
-    finally:
-        da.set_option("find3", 1)
+    p.set_option("find3", 0)
+    assert p.scan_count(ScanMode.Find, dev) == got

@@ -23,28 +23,13 @@ def _pma(patterns):
     return o, p
 
 
-@pytest.fixture(autouse=True)
-def _reset():
-    yield
-    for k, v in (("gram_version", 0), ("gram4_arith", 1), ("gram_ppl", 0), ("gram3_tail", -1), ("threads", 1024), ("gram2_rfull", 1), ("gram_lds_budget", 158 * 1024), ("gram_slab", 4096),
-                 ("gram_region", 0)):
-        da.set_option(k, v)
-
-
 def _count3(p, hay, ppl, wtext, rfull, threads=1024, arith=1, **kw):
-    da.set_option("gram_version", 4)
-    da.set_option("gram4_arith", arith)
-    da.set_option("gram_ppl", ppl)
-    da.set_option("gram3_tail", wtext)
-    da.set_option("gram2_rfull", rfull)
-    da.set_option("threads", threads)
-    try:
-        got = p.count(ScanMode.FindOverlapping, hay, engine=Engine.Gram, **kw)
-        assert da.last_engine() == int(Engine.Gram)
-        return got
-    finally:
-        da.set_option("gram_version", 0)
-        da.set_option("gram_ppl", 0)
+    """the launch shape is the HANDLE's (daac_pma_set_option): nothing process-wide is touched, nothing to reset"""
+    for k, v in (("gram_version", 4), ("gram4_arith", arith), ("gram_ppl", ppl), ("gram3_tail", wtext), ("gram2_rfull", rfull), ("threads", threads)):
+        p.set_option(k, v)
+    got = p.count(ScanMode.FindOverlapping, hay, engine=Engine.Gram, **kw)
+    assert da.last_engine() == int(Engine.Gram)
+    return got
 
 
 def test_gram4_against_the_oracle():
@@ -65,15 +50,14 @@ def test_gram4_against_the_oracle():
         want = o.overlapping_count(hay, threads=8)[0]
         dev = torch.from_numpy(np.concatenate([np.zeros(5, dtype=np.uint8), hay])).cuda()[5:]  # not 16-byte aligned
         for budget in (158 * 1024, 24 * 1024):
-            da.set_option("gram_lds_budget", budget)
             q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+            q.set_option("gram_lds_budget", budget)   # (read at upload)
             assert q.upload().info().gram2_available
             for ppl, wtext, rfull, nb, ar in VARIANTS:
                 assert _count3(q, dev, ppl, wtext, rfull, nb, ar) == want, (len(pats), budget, ppl, wtext, rfull, nb, ar)
             cut = int(rng.integers(1, len(hay)))
             assert _count3(q, dev[:cut], 16, 0, 1) + _count3(q, dev, 16, 0, 1, begin=cut) == want, cut
             assert _count3(q, dev[:cut], 32, 1, 1) + _count3(q, dev, 32, 1, 1, begin=cut) == want, cut
-        da.set_option("gram_lds_budget", 158 * 1024)
 
 
 def test_gram4_short_and_ragged_haystacks():
@@ -85,7 +69,7 @@ def test_gram4_short_and_ragged_haystacks():
     p.upload()
     base = synth.wordsoup_haystack(1 << 18, 11, pats, 20)
     buf = torch.from_numpy(base).cuda()
-    da.set_option("gram_region", 2048)
+    p.set_option("gram_region", 2048)
     lengths = [0, 1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4100, 6143, 6144, 65535, 65536, 65537]
     lengths += [int(x) for x in rng.integers(1, 1 << 17, size=12)]
     for n in lengths:
@@ -103,9 +87,8 @@ def test_gram4_every_position_hits_and_continues():
     pats = [bytes(syms[rng.integers(0, 6, size=int(rng.integers(4, 9)))]) for _ in range(5000)]
     hay = np.frombuffer(b"".join(pats[i] for i in rng.integers(0, 5000, size=60_000).tolist())[:300_000], dtype=np.uint8).copy()
     for budget in (158 * 1024, 9216):
-        da.set_option("gram_lds_budget", budget)
-        da.set_option("gram_slab", 0)
         o, p = _pma(pats)
+        p.set_option("gram_lds_budget", budget).set_option("gram_slab", 0)
         p.upload()
         dev = torch.from_numpy(hay).cuda()[13:]
         want = o.overlapping_count(dev.cpu().numpy(), threads=8)[0]
@@ -132,7 +115,7 @@ def test_gram4_cfg3_agrees_with_gram2_and_oracle():
         else:
             synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20, noise_256=77)
         want = o.overlapping_count(dev.cpu().numpy(), threads=8)[0]
-        da.set_option("gram_version", 2)
+        p.set_option("gram_version", 2)
         assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want
         for ppl, wtext, rfull, nb, ar in VARIANTS:
             assert _count3(p, dev, ppl, wtext, rfull, nb, ar) == want, (fill, ppl, wtext, rfull, nb, ar)

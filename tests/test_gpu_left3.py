@@ -55,10 +55,10 @@ def test_left3_against_the_oracle():
                 assert got == want, (kind_name, len(pats), len(hay), shift, da.last_engine())
                 assert p.count(ScanMode.LeftmostFind, dev) == want[0]
             b = int(rng.integers(1, len(hay) - 1))
-            da.set_option("left3", 0)
+            p.set_option("left3", 0)   # (this handle's: daac_pma_set_option)
             ref = p.scan_count(ScanMode.LeftmostFind, dev, begin=b)
             assert da.last_engine() != int(Engine.Gram)
-            da.set_option("left3", 1)
+            p.set_option("left3")
             assert p.scan_count(ScanMode.LeftmostFind, dev, begin=b) == ref, (kind_name, len(pats), b)
             assert p.scan_count(ScanMode.LeftmostFind, hay) == want
     assert served >= 24, served   # (the small dictionaries may have no K = 3 tables: the walkers answer, equally)
@@ -88,14 +88,12 @@ def test_left3_one_gib_of_cfg3():
         got = p.scan_count(ScanMode.LeftmostFind, dev)
         assert da.last_engine() == (int(Engine.Gram) if kind == "sparse" else int(Engine.DArray)), kind
         if kind == "dense":
-            da.set_option("left3", 2)
+            p.set_option("left3", 2)
             assert p.scan_count(ScanMode.LeftmostFind, dev) == got and da.last_engine() == int(Engine.Gram)
-        da.set_option("left3", 0)
-        try:
-            ref = p.scan_count(ScanMode.LeftmostFind, dev)
-            assert da.last_engine() == int(Engine.DArray)
-        finally:
-            da.set_option("left3", 1)
+        p.set_option("left3", 0)
+        ref = p.scan_count(ScanMode.LeftmostFind, dev)
+        assert da.last_engine() == int(Engine.DArray)
+        p.set_option("left3")
         assert got == ref, kind
         pre = dev[:64 << 20]
         assert p.scan_count(ScanMode.LeftmostFind, pre) == _want(o, pre.cpu().numpy()), kind
@@ -114,30 +112,23 @@ def test_left3_windows_restart_where_the_last_match_ended():
              (deepish, np.frombuffer((b"abcdefghijklmnopqrstuvwxyz" * 40000)[:1000003], dtype=np.uint8)),
              (deepish, np.frombuffer((b"abcdefghijklmnopqrstuvwxyz" + b"-" * 4000) * 200, dtype=np.uint8)),
              (deepish, synth.uniform_haystack(1 << 20, 9, b"abcdefghijklmnopqrstuvwxyz"))]
-    try:
-        da.set_option("left3", 2)
-        for kind_o in (orc.LEFTMOST_LONGEST, orc.LEFTMOST_FIRST):
-            for pats, hay in cases:
-                o, p = _pma(pats, kind_o)
-                want = _want(o, hay)
-                dev = torch.from_numpy(hay.copy()).cuda()
-                for win in (8192, 8192 + 4096 + 17, 65536, 1 << 20):
-                    da.set_option("find3_window", win)
-                    assert p.scan_count(ScanMode.LeftmostFind, dev) == want, (kind_o, len(pats), len(hay), win)
-                    # (the alphabet repeated: more than 255 deep matches selected in a tile — given up, the walkers answer)
-                    assert da.last_engine() == int(Engine.Gram) or (pats is deepish and hay[0] == ord("a") and hay[26] == ord("a"))
-                    assert p.count(ScanMode.LeftmostFind, dev) == want[0]
-    finally:
-        da.set_option("left3", 1)
-        da.set_option("find3_window", 1 << 30)
+    for kind_o in (orc.LEFTMOST_LONGEST, orc.LEFTMOST_FIRST):
+        for pats, hay in cases:
+            o, p = _pma(pats, kind_o)
+            p.set_option("left3", 2)
+            want = _want(o, hay)
+            dev = torch.from_numpy(hay.copy()).cuda()
+            for win in (8192, 8192 + 4096 + 17, 65536, 1 << 20):
+                p.set_option("find3_window", win)
+                assert p.scan_count(ScanMode.LeftmostFind, dev) == want, (kind_o, len(pats), len(hay), win)
+                # (the alphabet repeated: more than 255 deep matches selected in a tile — given up, the walkers answer)
+                assert da.last_engine() == int(Engine.Gram) or (pats is deepish and hay[0] == ord("a") and hay[26] == ord("a"))
+                assert p.count(ScanMode.LeftmostFind, dev) == want[0]
     pats = synth.patterns_cfg3()
     p = da.DoubleArrayAhoCorasickBuilder().match_kind(da.MatchKind.LeftmostLongest).build(pats)
     dev = torch.empty((5 << 29) + 4321, dtype=torch.uint8, device="cuda")
     synth.device_uniform(dev, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
     got = p.scan_count(ScanMode.LeftmostFind, dev)
     assert da.last_engine() == int(Engine.Gram)
-    da.set_option("left3", 0)
-    try:
-        assert p.scan_count(ScanMode.LeftmostFind, dev) == got
-    finally:
-        da.set_option("left3", 1)
+    p.set_option("left3", 0)
+    assert p.scan_count(ScanMode.LeftmostFind, dev) == got

@@ -43,7 +43,7 @@ def _check_counts(p, mode, hay, want):
     if mode == ScanMode.FindOverlapping:
         served = False
         for version in (1, 2, 0):  # first table set, second, the default choice
-            da.set_option("gram_version", version)
+            p.set_option("gram_version", version)   # (the handle's own setting: daac_pma_set_option)
             try:
                 got = p.scan_count(mode, hay, engine=Engine.Gram)
                 assert got == expect, ("gram", version)
@@ -54,7 +54,7 @@ def _check_counts(p, mode, hay, want):
                 assert p.count(mode, hay, engine=Engine.Gram) == expect[0], ("gram count", version)
             except da.DaachorseError as e:
                 assert e.code == 6
-        da.set_option("gram_version", 0)
+        p.set_option("gram_version")
         return served
     return False
 
@@ -64,15 +64,8 @@ def _same(a, b):
         np.array_equal(a["value"], b["value"])
 
 
-@pytest.fixture(autouse=True)
-def _reset_options():
-    yield
-    da.set_option("seg_bytes", 0)
-    da.set_option("iter_window", 64 << 20)
-    da.set_option("restart_chain", 1)
-    da.set_option("chain_rounds", 24)
-    da.set_option("gram_version", 0)
-    da.set_option("gram2_dpp", 1)
+# (launch shapes, table budgets and engine switches are set on the HANDLE under test — daac_pma_set_option, `p.set_option(...)` — so no test
+# leaves anything process-wide behind and there is no reset fixture; the process-wide form has test_options below)
 
 
 def test_golden_vectors_overlapping(vectors):
@@ -156,13 +149,13 @@ def test_fuzz_small_alphabets(seg_bytes):
     """Random tiny pattern sets (incl. "", duplicates) over {a,b,c}; 16-byte segments make nearly
     every match straddle a segment boundary, which is what the halo has to get right."""
     rng = np.random.default_rng(1234 + seg_bytes)
-    da.set_option("seg_bytes", seg_bytes)
     gram_runs = 0
     for it in range(60):
         npat = int(rng.integers(1, 7))
         pats = [bytes(rng.integers(97, 100, size=int(rng.integers(0, 6))).astype(np.uint8)) for _ in range(npat)]
         hay = rng.integers(97, 100 + (it % 2), size=int(rng.integers(0, 400)), dtype=np.uint8)
         o, p = _pma(pats)
+        p.set_option("seg_bytes", seg_bytes)
         want = o.find_overlapping_iter(hay)
         want_ns = o.find_overlapping_no_suffix_iter(hay)
         for eng in ENGINES:
@@ -200,7 +193,7 @@ def test_lazy_iterator_windows():
     o, p = _pma(pats)
     hay = rng.choice(np.frombuffer(b"abrcd", dtype=np.uint8), size=50_000)
     want = _sev(o.find_overlapping_iter(hay))
-    da.set_option("iter_window", 4096)
+    p.set_option("iter_window", 4096)
     got = [(m.start(), m.end(), m.value()) for m in p.find_overlapping_iter(hay)]
     assert got == want
 
@@ -270,11 +263,10 @@ def test_cfg3_100k_patterns():
     for eng in ENGINES + [Engine.Gram, Engine.Auto]:
         assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want_cc, eng
     # a small K (tables squeezed into a few KB of LDS) must give the same answer
-    da.set_option("gram_lds_budget", 9216)
     p2, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    p2.set_option("gram_lds_budget", 9216)   # (read at upload)
     assert p2.upload().info().gram_k == 2
     assert p2.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want_cc
-    da.set_option("gram_lds_budget", 158 * 1024)
 
 
 def test_gram2_tables_on_the_device():
@@ -295,21 +287,14 @@ def test_gram2_tables_on_the_device():
         dev = torch.from_numpy(np.concatenate([np.zeros(5, dtype=np.uint8), hay])).cuda()[5:]  # not 16-byte aligned
         want = o.overlapping_count(hay, threads=8)
         for dpp, budget in ((1, 158 * 1024), (0, 158 * 1024), (1, 24 * 1024)):
-            da.set_option("gram2_dpp", dpp)
-            da.set_option("gram_lds_budget", budget)
             q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
-            da.set_option("gram_version", 2)
-            try:
-                assert q.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want, (len(pats), dpp, budget)
-                assert q.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want[0], (len(pats), dpp, budget)
-                assert da.last_engine() == int(Engine.Gram)
-                cut = int(rng.integers(1, len(hay)))
-                head, tail = q.count(ScanMode.FindOverlapping, dev[:cut]), q.count(ScanMode.FindOverlapping, dev, begin=cut)
-                assert head + tail == want[0], cut
-            finally:
-                da.set_option("gram_version", 0)
-                da.set_option("gram2_dpp", 1)
-                da.set_option("gram_lds_budget", 158 * 1024)
+            q.set_option("gram2_dpp", dpp).set_option("gram_lds_budget", budget).set_option("gram_version", 2)
+            assert q.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want, (len(pats), dpp, budget)
+            assert q.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want[0], (len(pats), dpp, budget)
+            assert da.last_engine() == int(Engine.Gram)
+            cut = int(rng.integers(1, len(hay)))
+            head, tail = q.count(ScanMode.FindOverlapping, dev[:cut]), q.count(ScanMode.FindOverlapping, dev, begin=cut)
+            assert head + tail == want[0], cut
         if budget == 24 * 1024 and len(pats) > 1000:
             assert q.info().gram2_k == 2
     # declined automata: the request falls through to the other engines / an error for engine = GRAM with version 2
@@ -375,75 +360,67 @@ def test_gram_tuple_emitter():
              (pats3, synth.uniform_haystack((1 << 20) + 777, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)),
              (pats3, synth.wordsoup_haystack(1 << 20, synth.SEEDS["cfg3_dense"], pats3, 20)),
              (extra_pats, np.frombuffer(extra_text, dtype=np.uint8))]
-    try:
-        for pats, hay in cases:
-            o, _ = _pma(pats)
-            want = o.find_overlapping_iter(hay)
-            for tiles, budget, shift in ((64, 158 * 1024, 0), (1, 158 * 1024, 3), (2, 24 * 1024, 9), (3, 158 * 1024, 5)):
-                da.set_option("gram_region", 2048 * tiles if tiles < 64 else 0)   # regions of one to three DETECT steps: every seam between waves
-                da.set_option("gram_lds_budget", budget)
-                p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
-                dev = torch.from_numpy(np.concatenate([np.zeros(shift, dtype=np.uint8), hay])).cuda()[shift:]
-                got = p.scan(ScanMode.FindOverlapping, dev, engine=Engine.Gram)  # Engine.Gram: no silent fallback
-                assert _same(got, want), (len(pats), len(hay), tiles, budget)
-                dm = p.scan_device(ScanMode.FindOverlapping, dev)
-                assert da.last_engine() == int(Engine.Gram) and dm.count == len(want)
-                assert _same(dm.to_numpy(), want)
-                if len(want) > 100:
-                    mid = dm.to_numpy(first=len(want) // 2, n=50)
-                    assert _same(mid, want[len(want) // 2:len(want) // 2 + 50])
-                with pytest.raises(da.DaachorseError):
-                    dm.to_numpy(first=len(want), n=1)
-                dm.free()
-                d16 = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
-                assert da.last_engine() == int(Engine.Gram) and d16.count == len(want) and _same16(d16.to_numpy(), want)
-                d16.free()
-            da.set_option("gram_region", 0)
-            da.set_option("gram_lds_budget", 158 * 1024)
-            # lazy windows begin wherever the previous one ended: inside matches, off the tile grid
-            p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
-            da.set_option("iter_window", 4096 + 37)
-            sub = hay[:60000]
-            wsub = o.find_overlapping_iter(sub)
-            lazy = [(m.start(), m.end(), m.value()) for m in p.find_overlapping_iter(sub)]
-            assert lazy == [(int(x["start"]), int(x["end"]), int(x["value"])) for x in wsub]
-            da.set_option("iter_window", 64 << 20)
-        # more deep matches between two checkpoints than a chunk holds: the scan falls back and stays exact
-        pats = [b"a" * k for k in range(1, 17)]
-        hay = np.frombuffer(b"a" * 5000 + b"b" + b"a" * 3000, dtype=np.uint8)
-        o, p = _pma(pats)
+    for pats, hay in cases:
+        o, _ = _pma(pats)
         want = o.find_overlapping_iter(hay)
-        got = p.scan(ScanMode.FindOverlapping, hay)
-        # (thirteen deep matches per position: the emitter gives this text up and the segment scanners serve it)
-        assert _same(got, want) and da.last_engine() != int(Engine.Gram)
-        d16 = p.scan_device(ScanMode.FindOverlapping, hay, fmt16=True)  # another engine's list, repacked on the device
-        assert da.last_engine() != int(Engine.Gram) and _same16(d16.to_numpy(), want)
-        d16.free()
-        # more extras in one tile than the expansion places (every prefix of a long run a pattern): falls back too
-        o, p = _pma([b"z" * k for k in range(1, 60)])
-        hay = np.frombuffer(b"z" * 4000, dtype=np.uint8)
-        assert _same(p.scan(ScanMode.FindOverlapping, hay), o.find_overlapping_iter(hay)) and da.last_engine() != int(Engine.Gram)
-        # a record list sized too small: DETECT counts what it cannot store and the scan is rerun with the exact size
-        da.set_option("emit_rec_per_kib", 1)
-        o, p = _pma(pats3)
-        hay = synth.wordsoup_haystack(3 << 20, 5, pats3, 20)
-        got = p.scan(ScanMode.FindOverlapping, hay, engine=Engine.Gram)
-        assert _same(got, o.find_overlapping_iter(hay))
-        da.set_option("emit_rec_per_kib", 32)
-        # the other iterators in the 16-byte format (repacked)
-        o, p = _pma(pats3[:2000])
-        hay = synth.wordsoup_haystack(50000, 3, pats3[:2000], 20)
-        d16 = p.scan_device(ScanMode.Find, hay, fmt16=True)
-        assert _same16(d16.to_numpy(), o.find_iter(hay))
-        # automata the emitter declines (duplicates among the short patterns): still served, by the segment scanners
-        o, p = _pma(["ab", "ab", "abc"])
-        assert _same(p.scan(ScanMode.FindOverlapping, b"xabcabab"), o.find_overlapping_iter(b"xabcabab"))
-        with pytest.raises(da.DaachorseError) as ei:
-            p.scan(ScanMode.FindOverlapping, b"xabcabab", engine=Engine.Gram)
-        assert ei.value.code == 6
-    finally:
-        for k, v in (("gram_region", 0), ("gram_lds_budget", 158 * 1024), ("iter_window", 64 << 20), ("emit_rec_per_kib", 32)):
-            da.set_option(k, v)
+        for tiles, budget, shift in ((64, 158 * 1024, 0), (1, 158 * 1024, 3), (2, 24 * 1024, 9), (3, 158 * 1024, 5)):
+            p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+            p.set_option("gram_region", 2048 * tiles if tiles < 64 else 0)   # regions of one to three DETECT steps: every seam between waves
+            p.set_option("gram_lds_budget", budget)   # (read at upload)
+            dev = torch.from_numpy(np.concatenate([np.zeros(shift, dtype=np.uint8), hay])).cuda()[shift:]
+            got = p.scan(ScanMode.FindOverlapping, dev, engine=Engine.Gram)  # Engine.Gram: no silent fallback
+            assert _same(got, want), (len(pats), len(hay), tiles, budget)
+            dm = p.scan_device(ScanMode.FindOverlapping, dev)
+            assert da.last_engine() == int(Engine.Gram) and dm.count == len(want)
+            assert _same(dm.to_numpy(), want)
+            if len(want) > 100:
+                mid = dm.to_numpy(first=len(want) // 2, n=50)
+                assert _same(mid, want[len(want) // 2:len(want) // 2 + 50])
+            with pytest.raises(da.DaachorseError):
+                dm.to_numpy(first=len(want), n=1)
+            dm.free()
+            d16 = p.scan_device(ScanMode.FindOverlapping, dev, fmt16=True)
+            assert da.last_engine() == int(Engine.Gram) and d16.count == len(want) and _same16(d16.to_numpy(), want)
+            d16.free()
+        # lazy windows begin wherever the previous one ended: inside matches, off the tile grid
+        p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+        p.set_option("iter_window", 4096 + 37)
+        sub = hay[:60000]
+        wsub = o.find_overlapping_iter(sub)
+        lazy = [(m.start(), m.end(), m.value()) for m in p.find_overlapping_iter(sub)]
+        assert lazy == [(int(x["start"]), int(x["end"]), int(x["value"])) for x in wsub]
+    # more deep matches between two checkpoints than a chunk holds: the scan falls back and stays exact
+    pats = [b"a" * k for k in range(1, 17)]
+    hay = np.frombuffer(b"a" * 5000 + b"b" + b"a" * 3000, dtype=np.uint8)
+    o, p = _pma(pats)
+    want = o.find_overlapping_iter(hay)
+    got = p.scan(ScanMode.FindOverlapping, hay)
+    # (thirteen deep matches per position: the emitter gives this text up and the segment scanners serve it)
+    assert _same(got, want) and da.last_engine() != int(Engine.Gram)
+    d16 = p.scan_device(ScanMode.FindOverlapping, hay, fmt16=True)  # another engine's list, repacked on the device
+    assert da.last_engine() != int(Engine.Gram) and _same16(d16.to_numpy(), want)
+    d16.free()
+    # more extras in one tile than the expansion places (every prefix of a long run a pattern): falls back too
+    o, p = _pma([b"z" * k for k in range(1, 60)])
+    hay = np.frombuffer(b"z" * 4000, dtype=np.uint8)
+    assert _same(p.scan(ScanMode.FindOverlapping, hay), o.find_overlapping_iter(hay)) and da.last_engine() != int(Engine.Gram)
+    # a record list sized too small: DETECT counts what it cannot store and the scan is rerun with the exact size
+    o, p = _pma(pats3)
+    p.set_option("emit_rec_per_kib", 1)
+    hay = synth.wordsoup_haystack(3 << 20, 5, pats3, 20)
+    got = p.scan(ScanMode.FindOverlapping, hay, engine=Engine.Gram)
+    assert _same(got, o.find_overlapping_iter(hay))
+    # the other iterators in the 16-byte format (repacked)
+    o, p = _pma(pats3[:2000])
+    hay = synth.wordsoup_haystack(50000, 3, pats3[:2000], 20)
+    d16 = p.scan_device(ScanMode.Find, hay, fmt16=True)
+    assert _same16(d16.to_numpy(), o.find_iter(hay))
+    # automata the emitter declines (duplicates among the short patterns): still served, by the segment scanners
+    o, p = _pma(["ab", "ab", "abc"])
+    assert _same(p.scan(ScanMode.FindOverlapping, b"xabcabab"), o.find_overlapping_iter(b"xabcabab"))
+    with pytest.raises(da.DaachorseError) as ei:
+        p.scan(ScanMode.FindOverlapping, b"xabcabab", engine=Engine.Gram)
+    assert ei.value.code == 6
 
 
 def test_shard_tail_counts_add_up():
@@ -478,9 +455,6 @@ def test_fuzz_find_and_leftmost(seg_bytes, chain):
     chain = 1: speculate / reconcile / emit; 0: the sync-point scanners; 2: one reconciliation round only,
     so that texts whose chains do not fall in step at once exercise the fallback."""
     rng = np.random.default_rng(4321 + seg_bytes)
-    da.set_option("seg_bytes", seg_bytes)
-    da.set_option("restart_chain", 1 if chain else 0)
-    da.set_option("chain_rounds", 1 if chain == 2 else 24)
     for it in range(50):
         npat = int(rng.integers(1, 7))
         pats = [bytes(rng.integers(97, 100, size=int(rng.integers(1, 6))).astype(np.uint8)) for _ in range(npat)]
@@ -492,6 +466,7 @@ def test_fuzz_find_and_leftmost(seg_bytes, chain):
             hay = rng.integers(97, 100 + (it % 3), size=int(rng.integers(0, 500)), dtype=np.uint8)
         for kind in ("Standard", "LeftmostLongest", "LeftmostFirst"):
             o, p = _pma(pats, kind=kind)
+            p.set_option("seg_bytes", seg_bytes).set_option("restart_chain", 1 if chain else 0).set_option("chain_rounds", 1 if chain == 2 else 24)
             if kind == "Standard":
                 want, mode = o.find_iter(hay), ScanMode.Find
             else:
@@ -518,15 +493,15 @@ def test_sync_point_verdicts_do_not_depend_on_the_warm_up():
     """Regression (found by tools/stress.py): text that never returns to ROOT, a pattern of maximal length ending
     exactly at a segment cut.  A lane warming up over Lmax - 1 bytes saw ROOT there, a lane that had followed the
     text did not, and their regions overlapped."""
-    da.set_option("restart_chain", 0)
     for pats, unit in ((["cab", "cbabab"], "cabcbabab"), (["ab", "abcabc", "cabca"], "abcabc"), (["aaaa", "a"], "aaaa")):
         text = (unit * 400).encode()
         for kind, api, mode in (("LeftmostLongest", "leftmost_find_iter", ScanMode.LeftmostFind), ("LeftmostFirst", "leftmost_find_iter", ScanMode.LeftmostFind),
                                 ("Standard", "find_iter", ScanMode.Find)):
             o, p = _pma(pats, kind=kind)
+            p.set_option("restart_chain", 0)
             want = getattr(o, api)(text)
             for seg in (16, 32, 48, 64, 0):
-                da.set_option("seg_bytes", seg)
+                p.set_option("seg_bytes", seg)
                 assert _same(p.scan(mode, text), want), (pats, kind, seg)
                 assert p.scan_count(mode, text) == (len(want), orc.matches_checksum(want)), (pats, kind, seg)
 
@@ -547,8 +522,8 @@ def test_find_and_leftmost_dictionaries():
                 assert _same(p.scan(mode, dev), want), kind
                 assert p.scan_count(mode, dev) == (len(want), orc.matches_checksum(want)), kind
     # lazy iterator across windows that end at sync points
-    da.set_option("iter_window", 8192)
     o, p = _pma(pats, kind="LeftmostLongest")
+    p.set_option("iter_window", 8192)
     small = dense[:200_000]
     want = _sev(o.leftmost_find_iter(small))
     assert [(m.start(), m.end(), m.value()) for m in p.leftmost_find_iter(small)] == want
@@ -581,9 +556,8 @@ def test_concurrent_scans_share_one_handle():
     hay = synth.wordsoup_haystack(400_000, synth.SEEDS["cfg3_dense"], pats, 20)
     dev = torch.from_numpy(hay).cuda()
     want = {"ov": o.find_overlapping_iter(hay), "find": o.find_iter(hay), "lm": ol.leftmost_find_iter(hay)}
-    da.set_option("pfx", 2)
+    p.set_option("pfx", 2)   # (read at upload: PFX tables as well)
     p.upload(0)
-    da.set_option("pfx", 1)
     pl.upload(0)
     errors = []
 
@@ -622,9 +596,8 @@ def test_gram_haystack_beyond_4_gib():
     buf = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
     dev = buf[3:3 + n]
     synth.device_wordsoup(dev, synth.SEEDS["cfg3_dense"], pats, 20)
-    da.set_option("pfx", 2)
+    p.set_option("pfx", 2)
     p.upload()
-    da.set_option("pfx", 1)
     got = p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram)
     host = dev.cpu().numpy()
     want = o.overlapping_count(host, threads=min(128, os.cpu_count() or 1))
@@ -662,21 +635,14 @@ def test_gram_text_made_of_patterns_overflows_nothing():
     syms = np.frombuffer(b"acinrs", dtype=np.uint8)
     pats = [bytes(syms[rng.integers(0, 6, size=int(rng.integers(4, 9)))]) for _ in range(5000)]
     hay = np.frombuffer(b"".join(pats[i] for i in rng.integers(0, 5000, size=60_000).tolist())[:300_000], dtype=np.uint8).copy()
-    da.set_option("gram_lds_budget", 9216)
-    da.set_option("gram_ppl", 16)
-    da.set_option("gram_slab", 0)
-    try:
-        o, p = _pma(pats)
-        dev = torch.from_numpy(hay).cuda()[13:]
-        want = o.overlapping_count(dev.cpu().numpy(), threads=8)
-        assert p.upload().info().gram_k == 2
-        assert p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want
-        da.set_option("gram_ppl", 0)
-        assert p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want
-    finally:
-        da.set_option("gram_lds_budget", 158 * 1024)
-        da.set_option("gram_ppl", 0)
-        da.set_option("gram_slab", 4096)
+    o, p = _pma(pats)
+    p.set_option("gram_lds_budget", 9216).set_option("gram_ppl", 16).set_option("gram_slab", 0)
+    dev = torch.from_numpy(hay).cuda()[13:]
+    want = o.overlapping_count(dev.cpu().numpy(), threads=8)
+    assert p.upload().info().gram_k == 2
+    assert p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want
+    p.set_option("gram_ppl")
+    assert p.scan_count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want
 
 
 def test_chain_walkers_step_back_and_window_edges():
@@ -697,7 +663,7 @@ def test_chain_walkers_step_back_and_window_edges():
             o, p = _pma(pats, kind=kind)
             want = getattr(o, api)(hay)
             for seg in (0, 16, 48, 256):
-                da.set_option("seg_bytes", seg)
+                p.set_option("seg_bytes", seg)
                 assert _same(p.scan(mode, hay), want), (pats, kind, seg)
                 assert p.scan_count(mode, hay) == (len(want), orc.matches_checksum(want)), (pats, kind, seg)
                 assert p.count(mode, hay) == len(want), (pats, kind, seg)
@@ -709,13 +675,11 @@ def test_chain_walkers_step_back_and_window_edges():
         cp, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(co.serialize())
         want = getattr(co, api)(text)
         for seg in (0, 16, 64, 1024):
-            da.set_option("seg_bytes", seg)
             for rows in (1, 0):
-                da.set_option("char_row_lds", rows)
                 cp2, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(co.serialize())
+                cp2.set_option("seg_bytes", seg).set_option("char_row_lds", rows)   # (the second one read at upload)
                 assert _same(cp2.scan(mode, text), want), (kind, seg, rows)
                 assert cp2.scan_count(mode, text) == (len(want), orc.matches_checksum(want)), (kind, seg, rows)
-    da.set_option("char_row_lds", 1)
 
 
 def test_gram_tail_records():
@@ -752,7 +716,7 @@ def test_gram_tail_records():
 
 
 def test_engine_options_do_not_change_answers():
-    """The knobs that pick between implementations of the same scan (stream-ordered pool or hipMalloc, the micro-step walker
+    """The knobs that pick between implementations of the same scan (the micro-step walker
     or the byte-at-a-time segment scanners for counts, mapper / ROOT's row in LDS or in L2, sync-point scanners or chains)
     must not change a single number."""
     rng = np.random.default_rng(5)
@@ -766,32 +730,27 @@ def test_engine_options_do_not_change_answers():
     co = orc.OracleCharwisePma.build(cpats)
     col = orc.OracleCharwisePma.build(cpats, kind=1)
     cwant = {"ov": co.find_overlapping_iter(ctext), "find": co.find_iter(ctext), "lm": col.leftmost_find_iter(ctext)}
-    try:
-        for opts in ({}, {"pool": 0}, {"overlap_micro": 0}, {"overlap_micro": 2}, {"char_map_lds": 0}, {"char_row_lds": 0}, {"restart_chain": 0},
-                     {"seg_bytes": 4096, "overlap_micro": 2}):
+    for opts in ({}, {"overlap_micro": 0}, {"overlap_micro": 2}, {"char_map_lds": 0}, {"char_row_lds": 0}, {"restart_chain": 0},
+                 {"seg_bytes": 4096, "overlap_micro": 2}):
+        _, p = _pma(pats)       # (tables are laid out at upload: a fresh handle per setting, the setting the handle's own)
+        _, pl = _pma(pats, kind="LeftmostLongest")
+        cp, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(co.serialize())
+        cpl, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(col.serialize())
+        for handle in (p, pl, cp, cpl):
             for k, v in opts.items():
-                da.set_option(k, v)
-            _, p = _pma(pats)       # (tables are laid out at upload: a fresh handle per setting)
-            _, pl = _pma(pats, kind="LeftmostLongest")
-            cp, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(co.serialize())
-            cpl, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(col.serialize())
-            for eng in (Engine.Auto, Engine.DArray, Engine.Tiered):
-                assert p.scan_count(ScanMode.FindOverlapping, hay, engine=eng) == (len(want["ov"]), orc.matches_checksum(want["ov"])), (opts, eng)
-            assert p.scan_count(ScanMode.Find, hay) == (len(want["find"]), orc.matches_checksum(want["find"])), opts
-            assert pl.scan_count(ScanMode.LeftmostFind, hay) == (len(want["lm"]), orc.matches_checksum(want["lm"])), opts
-            assert _same(pl.scan(ScanMode.LeftmostFind, hay), want["lm"]), opts
-            dm = p.scan_device(ScanMode.FindOverlapping, hay)
-            assert _same(dm.to_numpy(), want["ov"]), opts
-            dm.free()
-            assert cp.scan_count(ScanMode.FindOverlapping, ctext) == (len(cwant["ov"]), orc.matches_checksum(cwant["ov"])), opts
-            assert cp.scan_count(ScanMode.Find, ctext) == (len(cwant["find"]), orc.matches_checksum(cwant["find"])), opts
-            assert cpl.scan_count(ScanMode.LeftmostFind, ctext) == (len(cwant["lm"]), orc.matches_checksum(cwant["lm"])), opts
-            assert _same(cp.scan(ScanMode.FindOverlapping, ctext), cwant["ov"]), opts
-            for k in opts:
-                da.set_option(k, {"pool": 1, "overlap_micro": 1, "char_map_lds": 1, "char_row_lds": 1, "restart_chain": 1, "seg_bytes": 0}[k])
-    finally:
-        for k, v in {"pool": 1, "overlap_micro": 1, "char_map_lds": 1, "char_row_lds": 1, "restart_chain": 1, "seg_bytes": 0}.items():
-            da.set_option(k, v)
+                handle.set_option(k, v)
+        for eng in (Engine.Auto, Engine.DArray, Engine.Tiered):
+            assert p.scan_count(ScanMode.FindOverlapping, hay, engine=eng) == (len(want["ov"]), orc.matches_checksum(want["ov"])), (opts, eng)
+        assert p.scan_count(ScanMode.Find, hay) == (len(want["find"]), orc.matches_checksum(want["find"])), opts
+        assert pl.scan_count(ScanMode.LeftmostFind, hay) == (len(want["lm"]), orc.matches_checksum(want["lm"])), opts
+        assert _same(pl.scan(ScanMode.LeftmostFind, hay), want["lm"]), opts
+        dm = p.scan_device(ScanMode.FindOverlapping, hay)
+        assert _same(dm.to_numpy(), want["ov"]), opts
+        dm.free()
+        assert cp.scan_count(ScanMode.FindOverlapping, ctext) == (len(cwant["ov"]), orc.matches_checksum(cwant["ov"])), opts
+        assert cp.scan_count(ScanMode.Find, ctext) == (len(cwant["find"]), orc.matches_checksum(cwant["find"])), opts
+        assert cpl.scan_count(ScanMode.LeftmostFind, ctext) == (len(cwant["lm"]), orc.matches_checksum(cwant["lm"])), opts
+        assert _same(cp.scan(ScanMode.FindOverlapping, ctext), cwant["ov"]), opts
 
 
 def test_compact_lazy_iterator():
@@ -803,55 +762,54 @@ def test_compact_lazy_iterator():
     hay = synth.wordsoup_haystack(400_000, 9, pats, 20)
     cpats = synth.patterns_cfg5(3000)
     chay = synth.zipf_text(48 * 6000)
-    da.set_option("iter_window", 50_000)
-    try:
-        for kind, mode, api in ((0, ScanMode.FindOverlapping, "find_overlapping_iter"), (0, ScanMode.Find, "find_iter"),
-                                (0, ScanMode.FindOverlappingNoSuffix, "find_overlapping_no_suffix_iter"), (1, ScanMode.LeftmostFind, "leftmost_find_iter")):
-            for charwise in (False, True):
-                if charwise:
-                    o = orc.OracleCharwisePma.build(cpats, kind=kind)
-                    p, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(o.serialize())
-                    h = chay
-                else:
-                    o = orc.OraclePma.build(pats, kind=kind)
-                    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
-                    h = hay
-                want = getattr(o, api)(h)
-                it = getattr(p, api)(h, compact=True)
-                ends, lens, vals, nruns = [], [], [], 0
-                while True:
-                    got = it.next_batch8()
-                    if got is None:
-                        break
-                    run, base, eb = got
-                    nruns += 1
-                    ends.append((run["end_len"] & np.uint32((1 << eb) - 1)).astype(np.uint64) + np.uint64(base))
-                    lens.append(run["end_len"] >> np.uint32(eb)); vals.append(run["value"].copy())
-                it.close()
-                assert nruns > 3, (api, charwise)
-                e, l, v = np.concatenate(ends), np.concatenate(lens), np.concatenate(vals)
-                assert len(e) == len(want) and np.array_equal(e, want["end"]) and np.array_equal(l, (want["end"] - want["start"]).astype(np.uint32)) and \
-                    np.array_equal(v, want["value"]), (api, charwise)
-                # match by match on a compact iterator, and the 16-byte runs on an ordinary one
-                k = int(rng.integers(1000, 3000))
-                got = [(m.start(), m.end(), m.value()) for _, m in zip(range(k), getattr(p, api)(h, compact=True))]
-                assert got == orc.triples_sev(want[:k]), (api, charwise)
-        p, _ = da.DoubleArrayAhoCorasick.deserialize(orc.OraclePma.build(pats).serialize())
-        with pytest.raises(da.DaachorseError) as ei:
-            p.find_overlapping_iter(hay, compact=True).next_batch()
-        assert ei.value.code == 6
-        with pytest.raises(da.DaachorseError) as ei:
-            p.find_overlapping_iter(hay).next_batch8()
-        assert ei.value.code == 6
-        # a dictionary with a pattern of several KB has no compact form (the 16-byte iterator serves it)
-        o = orc.OraclePma.build([b"ab", b"x" * 5000])
-        q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
-        with pytest.raises(da.DaachorseError) as ei:
-            q.find_overlapping_iter(hay, compact=True)
-        assert ei.value.code == 6
-        assert [(m.start(), m.end(), m.value()) for m in q.find_overlapping_iter(b"zabab" + b"x" * 5001)] == orc.triples_sev(o.find_overlapping_iter(b"zabab" + b"x" * 5001))
-    finally:
-        da.set_option("iter_window", 64 << 20)
+    for kind, mode, api in ((0, ScanMode.FindOverlapping, "find_overlapping_iter"), (0, ScanMode.Find, "find_iter"),
+                            (0, ScanMode.FindOverlappingNoSuffix, "find_overlapping_no_suffix_iter"), (1, ScanMode.LeftmostFind, "leftmost_find_iter")):
+        for charwise in (False, True):
+            if charwise:
+                o = orc.OracleCharwisePma.build(cpats, kind=kind)
+                p, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(o.serialize())
+                h = chay
+            else:
+                o = orc.OraclePma.build(pats, kind=kind)
+                p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+                h = hay
+            p.set_option("iter_window", 50_000)   # (the handle's own: daac_pma_set_option)
+            want = getattr(o, api)(h)
+            it = getattr(p, api)(h, compact=True)
+            ends, lens, vals, nruns = [], [], [], 0
+            while True:
+                got = it.next_batch8()
+                if got is None:
+                    break
+                run, base, eb = got
+                nruns += 1
+                ends.append((run["end_len"] & np.uint32((1 << eb) - 1)).astype(np.uint64) + np.uint64(base))
+                lens.append(run["end_len"] >> np.uint32(eb)); vals.append(run["value"].copy())
+            it.close()
+            assert nruns > 3, (api, charwise)
+            e, l, v = np.concatenate(ends), np.concatenate(lens), np.concatenate(vals)
+            assert len(e) == len(want) and np.array_equal(e, want["end"]) and np.array_equal(l, (want["end"] - want["start"]).astype(np.uint32)) and \
+                np.array_equal(v, want["value"]), (api, charwise)
+            # match by match on a compact iterator, and the 16-byte runs on an ordinary one
+            k = int(rng.integers(1000, 3000))
+            got = [(m.start(), m.end(), m.value()) for _, m in zip(range(k), getattr(p, api)(h, compact=True))]
+            assert got == orc.triples_sev(want[:k]), (api, charwise)
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(orc.OraclePma.build(pats).serialize())
+    p.set_option("iter_window", 50_000)
+    with pytest.raises(da.DaachorseError) as ei:
+        p.find_overlapping_iter(hay, compact=True).next_batch()
+    assert ei.value.code == 6
+    with pytest.raises(da.DaachorseError) as ei:
+        p.find_overlapping_iter(hay).next_batch8()
+    assert ei.value.code == 6
+    # a dictionary with a pattern of several KB has no compact form (the 16-byte iterator serves it)
+    o = orc.OraclePma.build([b"ab", b"x" * 5000])
+    q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    q.set_option("iter_window", 50_000)
+    with pytest.raises(da.DaachorseError) as ei:
+        q.find_overlapping_iter(hay, compact=True)
+    assert ei.value.code == 6
+    assert [(m.start(), m.end(), m.value()) for m in q.find_overlapping_iter(b"zabab" + b"x" * 5001)] == orc.triples_sev(o.find_overlapping_iter(b"zabab" + b"x" * 5001))
 
 
 def test_scan_count_multi_shards_on_one_device():

@@ -12,18 +12,14 @@ import daachorse_amd as da
 from daachorse_amd import Engine, ScanMode, synth
 
 
-@pytest.fixture(autouse=True)
-def _opts():
-    da.set_option("pfx", 2)  # build the PFX tables for every automaton they can serve (default: only where GRAM does not apply)
-    yield
-    da.set_option("pfx", 1)
-    da.set_option("gram_region", 0)
-
-
-def _pma(patterns):
+def _pma(patterns, pfx=2):
+    """pfx = 2 (this handle's own setting, daac_pma_set_option; read at upload): the PFX tables are built whatever else serves the automaton
+    (default: only where GRAM does not apply)"""
     o = orc.OraclePma.build(patterns)
     p, rest = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
     assert rest == b""
+    if pfx is not None:
+        p.set_option("pfx", pfx)
     return o, p
 
 
@@ -73,10 +69,9 @@ def test_pfx_against_the_oracle():
         cut = int(rng.integers(1, len(hay)))
         assert _count(p, dev[:cut]) + _count(p, dev, begin=cut) == want, cut
         assert _add(_count_checksum(p, dev[:cut]), _count_checksum(p, dev, begin=cut)) == both, cut
-        da.set_option("gram_region", 2048)
+        p.set_option("gram_region", 2048)
         assert _count(p, dev) == want
         assert _count_checksum(p, dev) == both
-        da.set_option("gram_region", 0)
 
 
 def test_pfx_short_and_ragged_haystacks():
@@ -87,7 +82,7 @@ def test_pfx_short_and_ragged_haystacks():
     p.upload()
     base = rng.integers(0, 8, size=1 << 18).astype(np.uint8)
     buf = torch.from_numpy(base).cuda()
-    da.set_option("gram_region", 2048)
+    p.set_option("gram_region", 2048)
     lengths = [0, 1, 2, 3, 4, 5, 6, 7, 15, 16, 17, 63, 64, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4100, 65535, 65536, 65537]
     lengths += [int(x) for x in rng.integers(1, 1 << 17, size=12)]
     for n in lengths:
@@ -100,9 +95,8 @@ def test_pfx_short_and_ragged_haystacks():
 def test_pfx_is_what_auto_takes_for_wide_alphabets():
     """256 pattern bytes: no GRAM table set applies; `.count()` and count + checksum run on PFX"""
     import torch
-    da.set_option("pfx", 1)
     pats = synth.patterns_binary256(30000)
-    o, p = _pma(pats)
+    o, p = _pma(pats, pfx=None)
     info = p.upload().info()
     assert not info.gram_available and not info.gram2_available
     dev = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
@@ -154,7 +148,6 @@ def test_pfx_on_a_vector_of_window_counts():
 def test_engine_plan_says_what_will_run():
     """daac_info.plan_* / daac_pma_explain: the engine a request gets is known before the scan, and it is the engine that then serves it"""
     import torch
-    da.set_option("pfx", 1)
     REQ = {"count": 0, "checksum": 1, "tuples": 2, "find": 3, "leftmost": 4, "nosuffix": 5}
     hay = torch.from_numpy(synth.uniform_haystack(1 << 20, 3, synth.ALPHA_LOWER_SPACE)).cuda()
     for pats, kind, expect in ((synth.patterns_cfg3(5000), 0, {"count": (Engine.Gram, 1), "checksum": (Engine.Gram, 2), "tuples": (Engine.Gram, 4), "find": (Engine.Gram, 9)}),
@@ -184,15 +177,12 @@ def test_engine_plan_says_what_will_run():
     assert info.plan_kernel[4] == 9 and info.plan_kernel[0] == 0  # left3's selection (the handle's patterns as a Standard automaton); find_overlapping does not apply to the kind
     p.scan_count(ScanMode.LeftmostFind, hay[:1 << 16])
     assert da.last_engine() == info.plan_engine[4] == int(Engine.Gram)
-    da.set_option("left3", 0)
-    try:
-        q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
-        info = q.upload().info()
-        assert info.plan_kernel[4] == 8   # chain walkers
-        q.scan_count(ScanMode.LeftmostFind, hay[:1 << 16])
-        assert da.last_engine() == info.plan_engine[4]
-    finally:
-        da.set_option("left3", 1)
+    q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    q.set_option("left3", 0)
+    info = q.upload().info()
+    assert info.plan_kernel[4] == 8   # chain walkers
+    q.scan_count(ScanMode.LeftmostFind, hay[:1 << 16])
+    assert da.last_engine() == info.plan_engine[4]
 
 
 def test_round3_engines_take_host_haystacks_and_streams():
@@ -227,15 +217,15 @@ def test_engines_that_cannot_serve_a_request_say_so():
     o = orc.OraclePma.build([b"ab", b"bc", b"abc"])
     hay = np.frombuffer(b"xxabcabyy" * 50, dtype=np.uint8)
     want = o.find_overlapping_iter(hay)
-    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())   # (the fixture's pfx = 2: PFX tables built)
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    p.set_option("pfx", 2)   # PFX tables built (read at upload)
     assert _same(p.scan(ScanMode.FindOverlapping, hay, engine=Engine.Pfx), want)
     assert da.last_engine() == int(Engine.Pfx)
     assert [(m.start(), m.end(), m.value()) for m in p.find_overlapping_iter(hay, engine=Engine.Pfx)] == orc.triples_sev(want)
     with pytest.raises(da.DaachorseError) as ei:
         p.find_overlapping_stepper(engine=Engine.Pfx)
     assert ei.value.code == 6
-    da.set_option("pfx", 1)
-    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())   # (default: no PFX tables where GRAM serves)
     got = p.scan(ScanMode.FindOverlapping, hay)
     assert len(got) == len(want)
     for eng in (int(Engine.Pfx), 77):
@@ -301,24 +291,21 @@ def test_pfx_tuples_against_the_oracle():
         # a prefix, and the automatic engine choice on a dictionary no GRAM table serves
         cut = int(rng.integers(1, min(len(hay), 5000)))
         assert _same(p.scan(ScanMode.FindOverlapping, dev[:cut], engine=Engine.Pfx), o.find_overlapping_iter(hay[:cut])), cut
-        da.set_option("gram_region", 2048)
+        p.set_option("gram_region", 2048)
         assert _same(p.scan(ScanMode.FindOverlapping, dev, engine=Engine.Pfx), want)
-        da.set_option("gram_region", 0)
+        p.set_option("gram_region")
         # the lazy iterator over the same bytes (windows with begin > 0)
-        da.set_option("iter_window", 1 << 16)
-        try:
-            it = p.find_overlapping_iter(hay[:200000], engine=Engine.Pfx)
-            runs = []
-            while True:
-                r = it.next_batch()
-                if r is None:
-                    break
-                runs.append(r.copy())
-            it.close()
-            got16 = np.concatenate(runs) if runs else np.zeros(0, dtype=bytewise_match16())
-            assert _same16(got16, o.find_overlapping_iter(hay[:200000])), len(pats)
-        finally:
-            da.set_option("iter_window", 64 << 20)
+        p.set_option("iter_window", 1 << 16)
+        it = p.find_overlapping_iter(hay[:200000], engine=Engine.Pfx)
+        runs = []
+        while True:
+            r = it.next_batch()
+            if r is None:
+                break
+            runs.append(r.copy())
+        it.close()
+        got16 = np.concatenate(runs) if runs else np.zeros(0, dtype=bytewise_match16())
+        assert _same16(got16, o.find_overlapping_iter(hay[:200000])), len(pats)
     # text shorter than a key, an empty text
     o, p = _pma([b"abcd", b"abcde", b"x"])
     for text in (b"", b"ab", b"x", b"abc", b"abcd", b"xabcdex"):
@@ -348,7 +335,6 @@ def test_wide_dictionary_look_alikes():
     patterns) and o200k-like (200 000 byte-level tokens, all 256 one-byte patterns among them), built by the PRODUCT's builder: count,
     count + checksum and tuples against the oracle on 8 MiB of their text."""
     import torch
-    da.set_option("pfx", 1)
     for name in ("unidic_like", "o200k_like"):
         if name == "unidic_like":
             pats = synth.patterns_unidic_like()
@@ -382,7 +368,6 @@ def test_the_probe_sends_dense_text_to_the_walker():
     positions survive the filter (every character of the text is a pattern) the micro-step walker over the double array takes the scan, on
     text the filter thins out PFX does — the counts agree with each other and with a shard sum either way."""
     import torch
-    da.set_option("pfx", 1)
     pats = synth.patterns_unidic_like(60_000)
     p = da.DoubleArrayAhoCorasick.new(pats)
     n = (48 << 20) - (48 << 20) % synth.CFG5_SLOT
@@ -398,13 +383,10 @@ def test_the_probe_sends_dense_text_to_the_walker():
     want = p.count(ScanMode.FindOverlapping, dev, engine=Engine.DArray)
     assert p.count(ScanMode.FindOverlapping, dev) == want
     assert da.last_engine() == int(Engine.Pfx)
-    da.set_option("pfx_probe", 0)
-    try:
-        synth.device_zipf_text(dev)
-        p.count(ScanMode.FindOverlapping, dev)
-        assert da.last_engine() == int(Engine.Pfx)
-    finally:
-        da.set_option("pfx_probe", 16384)
+    p.set_option("pfx_probe", 0)
+    synth.device_zipf_text(dev)
+    p.count(ScanMode.FindOverlapping, dev)
+    assert da.last_engine() == int(Engine.Pfx)
 
 
 def test_pfx_tuples_piece_by_piece():
@@ -412,7 +394,6 @@ def test_pfx_tuples_piece_by_piece():
     whole GiB of match-dense text would be tens of GB per call); the pieces' lists, put together, are the oracle's list — matches that
     straddle a piece boundary included."""
     import torch
-    da.set_option("pfx", 1)
     pats = synth.patterns_cfg5(20_000)
     p = da.DoubleArrayAhoCorasick.new(pats)
     o = orc.OraclePma.deserialize(p.serialize())

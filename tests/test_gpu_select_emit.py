@@ -37,47 +37,41 @@ def _cases():
 def test_select_tuple_lists_against_the_oracle():
     import torch
     served = 0
-    try:
-        da.set_option("find3", 2); da.set_option("left3", 2)
-        for kind, mode, api in ((orc.STANDARD, ScanMode.Find, "find_iter"), (orc.LEFTMOST_LONGEST, ScanMode.LeftmostFind, "leftmost_find_iter"),
-                                (orc.LEFTMOST_FIRST, ScanMode.LeftmostFind, "leftmost_find_iter")):
-            for pats, hay in _cases():
-                o = orc.OraclePma.build(pats, kind=kind)
-                p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
-                want = getattr(o, api)(hay)
-                dev = torch.from_numpy(np.concatenate([np.zeros(3, dtype=np.uint8), hay])).cuda()[3:]
-                for win in (1 << 30, 70000):   # one window / windows inside the call (a haystack "beyond one window")
-                    da.set_option("find3_window", win)
-                    dm = p.scan_device(mode, dev, fmt16=True)
-                    served += da.last_engine() == int(Engine.Gram)
-                    assert _same16(dm.to_numpy(), want), (api, kind, len(pats), len(hay), win)
-                    dm.free()
-                    dm = p.scan_device(mode, dev)
-                    assert _same(dm.to_numpy(), want), (api, kind, len(pats), len(hay), win)
-                    dm.free()
-                da.set_option("find3_window", 1 << 30)
-                # the eager host list and the lazy iterator over small windows
-                assert _same(p.scan(mode, hay), want), (api, kind, "daac_scan")
-                da.set_option("iter_window", 40000)
-                it = getattr(p, api)(hay)
-                runs = []
-                while True:
-                    run = it.next_batch()
-                    if run is None:
-                        break
-                    runs.append(run.copy())
-                it.close()
-                da.set_option("iter_window", 64 << 20)
-                assert len(runs) > 3 and _same16(np.concatenate(runs), want), (api, kind, "iterator")
-                # the walkers' list is the same list
-                da.set_option("select_emit", 0)
+    for kind, mode, api in ((orc.STANDARD, ScanMode.Find, "find_iter"), (orc.LEFTMOST_LONGEST, ScanMode.LeftmostFind, "leftmost_find_iter"),
+                            (orc.LEFTMOST_FIRST, ScanMode.LeftmostFind, "leftmost_find_iter")):
+        for pats, hay in _cases():
+            o = orc.OraclePma.build(pats, kind=kind)
+            p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+            p.set_option("find3", 2).set_option("left3", 2)   # (the handle's own settings: daac_pma_set_option)
+            want = getattr(o, api)(hay)
+            dev = torch.from_numpy(np.concatenate([np.zeros(3, dtype=np.uint8), hay])).cuda()[3:]
+            for win in (1 << 30, 70000):   # one window / windows inside the call (a haystack "beyond one window")
+                p.set_option("find3_window", win)
                 dm = p.scan_device(mode, dev, fmt16=True)
-                assert da.last_engine() != int(Engine.Gram) and _same16(dm.to_numpy(), want)
+                served += da.last_engine() == int(Engine.Gram)
+                assert _same16(dm.to_numpy(), want), (api, kind, len(pats), len(hay), win)
                 dm.free()
-                da.set_option("select_emit", 1)
-    finally:
-        for k, v in (("find3", 1), ("left3", 1), ("find3_window", 1 << 30), ("iter_window", 64 << 20), ("select_emit", 1)):
-            da.set_option(k, v)
+                dm = p.scan_device(mode, dev)
+                assert _same(dm.to_numpy(), want), (api, kind, len(pats), len(hay), win)
+                dm.free()
+            p.set_option("find3_window")
+            # the eager host list and the lazy iterator over small windows
+            assert _same(p.scan(mode, hay), want), (api, kind, "daac_scan")
+            p.set_option("iter_window", 40000)
+            it = getattr(p, api)(hay)
+            runs = []
+            while True:
+                run = it.next_batch()
+                if run is None:
+                    break
+                runs.append(run.copy())
+            it.close()
+            assert len(runs) > 3 and _same16(np.concatenate(runs), want), (api, kind, "iterator")
+            # the walkers' list is the same list
+            p.set_option("select_emit", 0)
+            dm = p.scan_device(mode, dev, fmt16=True)
+            assert da.last_engine() != int(Engine.Gram) and _same16(dm.to_numpy(), want)
+            dm.free()
     assert served >= 30, served
 
 

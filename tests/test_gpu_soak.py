@@ -50,20 +50,15 @@ def test_table_sets_never_exceed_the_lds_of_a_workgroup():
     o = orc.OraclePma.build(pats)
     want = o.overlapping_count(hay, threads=4)
     dev = torch.from_numpy(hay).cuda()
-    da.set_option("pfx", 2)
-    try:
-        for budget in (158 * 1024, 200 * 1024, 40 * 1024):
-            da.set_option("gram_lds_budget", budget)
-            p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
-            info = p.upload().info()
-            assert info.num_classes == 29
-            assert not info.gram_available or info.gram_lds_bytes <= 160 * 1024, (budget, info.gram_lds_bytes)
-            for eng in (Engine.Auto, Engine.Gram, Engine.Pfx, Engine.DArray):
-                try:
-                    assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want, (budget, eng)
-                    assert p.count(ScanMode.FindOverlapping, dev, engine=eng) == want[0], (budget, eng)
-                except da.DaachorseError as e:
-                    assert e.code == 6, (budget, eng, str(e))  # "this engine does not serve the request" is the only refusal allowed
-    finally:
-        da.set_option("gram_lds_budget", 158 * 1024)
-        da.set_option("pfx", 1)
+    for budget in (158 * 1024, 200 * 1024, 40 * 1024):
+        p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+        p.set_option("pfx", 2).set_option("gram_lds_budget", budget)   # (this handle's own settings, read at upload)
+        info = p.upload().info()
+        assert info.num_classes == 29
+        assert not info.gram_available or info.gram_lds_bytes <= 160 * 1024, (budget, info.gram_lds_bytes)
+        for eng in (Engine.Auto, Engine.Gram, Engine.Pfx, Engine.DArray):
+            try:
+                assert p.scan_count(ScanMode.FindOverlapping, dev, engine=eng) == want, (budget, eng)
+                assert p.count(ScanMode.FindOverlapping, dev, engine=eng) == want[0], (budget, eng)
+            except da.DaachorseError as e:
+                assert e.code == 6, (budget, eng, str(e))  # "this engine does not serve the request" is the only refusal allowed

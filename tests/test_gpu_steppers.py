@@ -71,7 +71,7 @@ def test_fuzz_chunkings(flavour):
         else:
             o = orc.OracleCharwisePma.build(pats)
             p, _ = da.CharwiseDoubleArrayAhoCorasick.deserialize(o.serialize())
-        da.set_option("seg_bytes", int(rng.choice([0, 16, 64])))
+        p.set_option("seg_bytes", int(rng.choice([0, 16, 64])))
         for api, oapi in STEPPERS:
             want = _sev(getattr(o, oapi)(text))
             cuts = _cuts(rng, len(raw))
@@ -79,7 +79,6 @@ def test_fuzz_chunkings(flavour):
                 cuts = sorted(cuts + cuts[:2])  # repeated cut positions = empty chunks
             got = _feed_all(getattr(p, api)(), raw, cuts)
             assert got == want, (flavour, api, pats, cuts, text[:100])
-    da.set_option("seg_bytes", 0)
 
 
 def test_long_stream_device_chunks_and_bounded_carry():
