@@ -113,6 +113,11 @@ if ls $R/abtmp/lib_g4x1.so > /dev/null 2>&1; then
   cd /tmp
 fi
 
+# the wide look-alike dictionaries' kernels (SQ + L2 counters) and what a turn of the charwise walkers does on cfg5 (needs abtmp/cwprof: tools/cw_taxonomy.sh build)
+(cd $R && bash tools/pmc_wide.sh 256) > $OUT/${TAG}_pmc_wide.txt 2>&1
+if [ -f $R/abtmp/cwprof/libdaachorse_amd.so ]; then (cd $R && bash tools/cw_taxonomy.sh run 1024) > $OUT/${TAG}_cfg5_turn_taxonomy.txt 2>&1; fi
+cd /tmp
+
 # the bench lines themselves (they read the traffic file given here; in the repository: profiles/hbm_traffic.json)
 export DAAC_HBM_TRAFFIC_JSON=$OUT/${TAG}_hbm_traffic.json
 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
