@@ -343,7 +343,7 @@ def stream_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha, 
     haystack (bound by the 24-byte tuples' way back over PCIe) and of cfg2's sparse haystack; the first chunks' tuples against the oracle."""
     from daachorse_amd import ScanMode
     n, chunk = 512 << 20, 64 << 20
-    out = {"bytes": n, "chunk_bytes": chunk, "op": "daac_stream_open + daac_stream_feed over 64 MiB device chunks, every chunk's tuple list handed to the host"}
+    out = {"bytes": n, "chunk_bytes": chunk, "op": "daac_stream_open + daac_stream_feed over 64 MiB device chunks, every chunk's tuple list handed to the host (24-byte tuples; `compact`: daac_stream_feed_compact, 8-byte tuples)"}
     dev = torch.empty(n, dtype=torch.uint8, device="cuda")
     p2 = da.DoubleArrayAhoCorasick.new(synth.patterns_cfg2())
     p2.upload(local_rank)
@@ -369,6 +369,24 @@ def stream_legs(da, synth, torch, np, pma_cfg3, local_rank, seed_sparse, alpha, 
                 best = dt if best is None else min(best, dt)
             leg[mode_name] = {"GB/s": round(n / best / 1e9, 2), "seconds": round(best, 4), "matches": cnt,
                               "engine_used": ENGINE_NAMES.get(da.last_engine(), "?")}
+            # the same stream through daac_stream_feed_compact: 8-byte tuples in the stream object's page-locked block (round 6)
+            best8, cnt8, first8 = None, 0, None
+            for rep in range(2):
+                st = make()
+                cnt8 = 0
+                t0 = time.perf_counter()
+                for b in range(0, n, chunk):
+                    run, base, bits = st.feed_compact(dev[b:b + chunk])
+                    cnt8 += len(run)
+                    if b == 0 and rep == 0:
+                        first8 = st.decode8(run[:200000], base, bits)
+                dt = time.perf_counter() - t0
+                del st
+                best8 = dt if best8 is None else min(best8, dt)
+            leg[mode_name]["compact"] = {"GB/s": round(n / best8 / 1e9, 2), "seconds": round(best8, 4), "matches": cnt8,
+                                         "same_first_tuples_as_feed": bool(cnt8 == cnt and first8 is not None and len(first8) == len(first) and
+                                                                           np.array_equal(first8["start"], first["start"]) and np.array_equal(first8["end"], first["end"]) and
+                                                                           np.array_equal(first8["value"], first["value"]))}
             if not no_cpu and mode_name != "find_overlapping_no_suffix_stepper":
                 from oracle import oracle as orc
                 o = orc.OraclePma.deserialize(pma.serialize())

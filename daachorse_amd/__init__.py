@@ -6,7 +6,7 @@ with hand-written HIP kernels for gfx950.  Importing the package loads the HIP l
 raises ImportError if it has not been built: there is no CPU fallback.
 """
 from . import _ffi
-from ._ffi import DaachorseError, last_engine, set_option
+from ._ffi import DaachorseError, last_engine, last_kernel, set_option
 from .bytewise import (DoubleArrayAhoCorasick, DoubleArrayAhoCorasickBuilder, Engine, Match, MatchKind, ScanMode,
                        MATCH_DTYPE, MATCH16_DTYPE, scan_count_multi)
 from .charwise import CharwiseDoubleArrayAhoCorasick, CharwiseDoubleArrayAhoCorasickBuilder
@@ -15,4 +15,4 @@ _ffi.lib()  # fail loudly at import time if the extension is missing
 
 __all__ = ["DoubleArrayAhoCorasick", "DoubleArrayAhoCorasickBuilder", "CharwiseDoubleArrayAhoCorasick",
            "CharwiseDoubleArrayAhoCorasickBuilder", "Match", "MatchKind", "ScanMode", "Engine",
-           "DaachorseError", "set_option", "last_engine", "MATCH_DTYPE", "MATCH16_DTYPE", "scan_count_multi"]
+           "DaachorseError", "set_option", "last_engine", "last_kernel", "MATCH_DTYPE", "MATCH16_DTYPE", "scan_count_multi"]

@@ -42,7 +42,7 @@ class Info(C.Structure):
                 ("plan_engine", C.c_uint8 * 8), ("plan_kernel", C.c_uint8 * 8), ("plan_reason", C.c_uint8 * 8)]
 
 
-ABI_VERSION = 5  # DAAC_ABI_VERSION of include/daachorse_amd.h this mirror was written against
+ABI_VERSION = 6  # DAAC_ABI_VERSION of include/daachorse_amd.h this mirror was written against
 
 
 def lib():
@@ -99,6 +99,8 @@ def lib():
     L.daac_iter_close.argtypes = [vp]
     L.daac_stream_open.argtypes = [vp, C.c_int, C.c_int, vp, P(vp)]
     L.daac_stream_feed.argtypes = [vp, u8p, sz, C.c_int, P(vp)]
+    L.daac_stream_feed_compact.argtypes = [vp, u8p, sz, C.c_int, P(vp), P(sz), P(C.c_uint64), P(C.c_uint32)]
+    L.daac_stream_feed_compact.restype = C.c_int
     L.daac_stream_close.argtypes = [vp]
     L.daac_scan_count_only_range.argtypes = [vp, C.c_int, C.c_int, u8p, sz, sz, C.c_int, vp, P(C.c_uint64), vp]
     L.daac_scan_count_only_range.restype = C.c_int
@@ -116,6 +118,8 @@ def lib():
     L.daac_pma_set_option.restype = C.c_int
     L.daac_last_engine.argtypes = []
     L.daac_last_engine.restype = C.c_int
+    L.daac_last_kernel.argtypes = []
+    L.daac_last_kernel.restype = C.c_char_p
     L.daac_synth_uniform.argtypes = [vp, sz, C.c_uint64, vp, C.c_uint32, C.c_uint64, vp]
     L.daac_synth_wordsoup.argtypes = [vp, sz, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint32,
                                       vp, C.c_uint32, C.c_uint64, vp]
@@ -139,6 +143,11 @@ def check(status):
 def last_engine():
     """daac_engine that served this thread's most recent scan"""
     return lib().daac_last_engine()
+
+
+def last_kernel():
+    """daac_last_kernel: kernel family + launch shape of this thread's most recent count (a diagnostic string)"""
+    return lib().daac_last_kernel().decode()
 
 
 def set_option(name, value):

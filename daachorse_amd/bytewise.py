@@ -229,6 +229,27 @@ class _Stepper:
             return np.zeros(0, dtype=MATCH_DTYPE)
         return np.asarray(_MatchList(out, n))
 
+    def feed_compact(self, chunk):
+        """daac_stream_feed_compact: the same feed with the chunk's matches as 8-byte tuples -> (view {value u32, end_len u32}, end_base, end_bits),
+        end = end_base + (end_len & ((1 << end_bits) - 1)), length = end_len >> end_bits; the view is valid until the next feed"""
+        h = _Haystack(chunk)
+        p, n, base, eb = C.c_void_p(), C.c_size_t(), C.c_uint64(), C.c_uint32()
+        _ffi.check(_ffi.lib().daac_stream_feed_compact(self._s, h.ptr, h.len, h.is_device, C.byref(p), C.byref(n), C.byref(base), C.byref(eb)))
+        if n.value == 0:
+            return np.zeros(0, dtype=MATCH8_DTYPE), base.value, eb.value
+        buf = (C.c_char * (n.value * 8)).from_address(p.value)
+        return np.frombuffer(buf, dtype=MATCH8_DTYPE), base.value, eb.value
+
+    @staticmethod
+    def decode8(run, end_base, end_bits):
+        """8-byte tuples -> MATCH_DTYPE {start, end, value}"""
+        out = np.zeros(len(run), dtype=MATCH_DTYPE)
+        el = run["end_len"].astype(np.uint64)
+        out["end"] = np.uint64(end_base) + (el & np.uint64((1 << end_bits) - 1))
+        out["start"] = out["end"] - (el >> np.uint64(end_bits))
+        out["value"] = run["value"]
+        return out
+
     def __del__(self):
         try:
             if self._s:

@@ -12,6 +12,8 @@
 #include <map>
 #include <memory>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -31,71 +33,97 @@ namespace daac {
 const char *last_error_cstr();
 
 // ------------------------------------------------------------------------------------ options
+// One list (X-macro): field name = user-facing option name, default.  `upload` marks the options that are read when a handle's tables
+// are laid out (daac_pma_set_option tells a caller who sets one on a handle that already has tables on a device).
+//      X(name, default, read at upload)
+#define DAAC_OPTIONS(X)                                                                                                                      \
+    X(seg_bytes, 0, 0)                   /* 0 = auto */                                                                                      \
+    X(lds_budget, 96 * 1024, 1)                                                                                                              \
+    X(dense_depth, -1, 1)                                                                                                                    \
+    X(rows_share_pct, 45, 1)                                                                                                                 \
+    X(blocks_per_cu, 0, 0)               /* 0 = auto */                                                                                      \
+    X(threads, 1024, 0)                                                                                                                      \
+    X(iter_window, 64ll << 20, 0)        /* lazy iterator: haystack bytes per window (the first windows are smaller: 16, 32 MiB) */          \
+    X(max_result_bytes, 8ll << 30, 0)                                                                                                        \
+    X(gram_lds_budget, 158 * 1024, 1)                                                                                                        \
+    X(gram_region, 0, 0)                 /* 0 = auto: 16 KiB for the first table set, 64 / 256 KiB for the second */                         \
+    X(gram_slab, 4096, 0)                                                                                                                    \
+    X(gram_ppl, 0, 0)                    /* 0 = auto, 16, 32 positions per lane and step */                                                  \
+    X(gram_dense, -1, 0)                 /* -1 = decide per automaton */                                                                     \
+    X(gram_rank_in_lds, -1, 1)           /* -1 = decide per automaton */                                                                     \
+    X(gram_version, 0, 0)                /* 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram4_kernels.hip), 1 = v1 \
+                                            only, 2 = v2 tables with gram2_kernels.hip, 4 (3: its name until ABI 5) = gram4 or an error */   \
+    X(gram4_arith, 1, 0)                 /* gram4: byte classes by arithmetic where the dictionary's bytes are one range (0: class table) */ \
+    X(gram4_filter, 1, 0)                /* gram4: the LDS filter in front of rank + gather where it fits (0: per-word rank directory) */      \
+    X(gram2_dpp, 1, 0)                   /* v2: neighbour exchange through DPP wave shifts (0: ds_bpermute) */                               \
+    X(find3, 1, 0)                       /* find_iter's count through find3_kernels.hip where the dictionary allows (2: whatever the text,   \
+                                            0: the chain walkers always) */                                                                  \
+    X(pfx_probe, 16384, 0)               /* AUTO: the micro-step walker takes over where more than this many of 65 536 sampled positions     \
+                                            survive PFX's filter (0 = never ask, always PFX) */                                              \
+    X(pfx, 1, 1)                         /* PFX engine: 1 = built for automata the GRAM tables do not serve, 2 = always, 0 = never */        \
+    X(gram_tail, -1, 0)                  /* gram4: tail records from the hit record on (-1 = decide per launch); also as gram3_tail */       \
+    X(gram2_rfull, 1, 0)                 /* one rank-directory entry per M word when LDS allows */                                           \
+    X(emit, 1, 0)                        /* materialising overlapping scans: GRAM tuple emission where it applies (0: segment scanners) */    \
+    X(emit_rec_per_kib, 32, 0)           /* emit3: deep-match records the list is first sized for, per KiB of haystack */                    \
+    X(restart_bpc, 8, 0)                 /* 256-thread workgroups per CU of the chain walkers */                                             \
+    X(restart_chain, 1, 0)               /* find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only) */       \
+    X(chain_rounds, 24, 0)                                                                                                                   \
+    X(overlap_micro, 1, 0)               /* counts of overlapping scans outside GRAM: 1 micro-step walker, 2 also instead of TIERED, 0 off */ \
+    X(pool, 1, 0)                        /* scratch / result buffers from the stream-ordered pool */                                         \
+    X(pool_keep, 0, 0)                   /* bytes the pool keeps between calls (0 = auto) */                                                 \
+    X(left3, 1, 0)                       /* leftmost_find_iter's count through left3_kernels.hip (as find3: 2 = whatever the text, 0 = off) */ \
+    X(select_emit, 1, 0)                 /* the restart iterators' tuple list from find3 / left3 (0: the chain walkers') */                  \
+    X(find3_window, 1ll << 30, 0)        /* find3: end positions per window (tests: small windows = many restarts) */                        \
+    X(workspace_keep, 8ll << 30, 0)      /* bytes of scratch a handle may keep for its emitter / find3 calls (0: none) */                    \
+    X(char_map_lds, 1, 1)                /* charwise chain scans: the populated stretch of the code mapper in LDS */                         \
+    X(char_row_lds, 1, 1)                /* ... and ROOT's row of children beside it */                                                      \
+    X(char_multi, 1, 0)                  /* charwise chain walkers: symbols settled by ROOT's row are taken without a memory round (0: one symbol per turn) */ \
+    X(stream_compact, 1, 0)
+
+enum OptionId : int {
+#define X(NAME, DEF, UP) OPT_##NAME,
+    DAAC_OPTIONS(X)
+#undef X
+    OPT_COUNT
+};
+static_assert(OPT_COUNT <= 64, "per-handle override mask is one 64-bit word");
 struct Options {
-    std::atomic<int64_t> seg_bytes{0};       // 0 = auto
-    std::atomic<int64_t> lds_budget{96 * 1024};
-    std::atomic<int64_t> dense_depth{-1};
-    std::atomic<int64_t> rows_share_pct{45};
-    std::atomic<int64_t> blocks_per_cu{0};   // 0 = auto
-    std::atomic<int64_t> threads{1024};
-    std::atomic<int64_t> iter_window{64ll << 20};   // lazy iterator: haystack bytes per window (the first windows are smaller: 16, 32 MiB)
-    std::atomic<int64_t> max_result_bytes{8ll << 30};
-    std::atomic<int64_t> gram_lds_budget{158 * 1024};
-    std::atomic<int64_t> gram_region{0};           // 0 = auto: 16 KiB for the first table set, 64 KiB for the second
-    std::atomic<int64_t> gram_slab{4096};
-    std::atomic<int64_t> gram_ppl{0};           // 0 = auto (32 positions per lane for automata without short patterns), 16, 32
-    std::atomic<int64_t> gram_dense{-1};        // -1 = decide per automaton
-    std::atomic<int64_t> gram_rank_in_lds{-1};  // -1 = decide per automaton
-    std::atomic<int64_t> gram_version{0};       // 0 = auto (count + checksum: v1 where it applies, else v2; `.count()`: gram4_kernels.hip), 1 = v1 only,
-                                                // 2 = v2 tables with gram2_kernels.hip, 4 = gram4_kernels.hip for `.count()` or an error
-    std::atomic<int64_t> gram4_arith{1};        // gram4: byte classes by arithmetic where the dictionary's bytes are one range (0: the class table in LDS)
-    std::atomic<int64_t> gram2_dpp{1};
-    std::atomic<int64_t> find3{1};              // find_iter's count (+ checksum) of a whole haystack of at most 1 GiB through find3_kernels.hip (selection over the
-                                                // emitter's per-position flags, no state chain) where the dictionary allows; 0: the chain walkers always
-    std::atomic<int64_t> pfx_probe{16384};      // AUTO, `.count()` / count + checksum of a dictionary PFX serves: the micro-step walker takes over where more than
-                                                // this many of 65 536 sampled positions survive PFX's filter (0 = never ask, always PFX)
-    std::atomic<int64_t> pfx{1};                // PFX engine: 1 = built for automata the GRAM tables do not serve, 2 = always, 0 = never (read at upload)
-    std::atomic<int64_t> gram3_tail{-1};        // gram4 (option names gram_tail / gram3_tail): tail records from the hit record on (-1 = decide per launch)
-    std::atomic<int64_t> gram2_rfull{1};        // v2 count-only: one directory entry per M word when LDS allows          // v2: neighbour exchange through DPP wave shifts (0: ds_bpermute)
-    std::atomic<int64_t> emit{1};               // materialising overlapping scans: GRAM tuple emission where it applies (0: segment scanners)
-    std::atomic<int64_t> emit_v3_lds{1};        // emit3 EXPAND: values of the 3-byte patterns from a rank structure in LDS when it fits (0: from L2)
-    std::atomic<int64_t> emit_stagger{0};       // emit3 EXPAND: the waves of a CU start this many x 1024 cycles apart (0: together)
-    std::atomic<int64_t> emit_rec_per_kib{32};  // emit3: deep-match records the list is first sized for, per KiB of haystack (a rerun sizes it exactly)
-    std::atomic<int64_t> restart_bpc{8};        // 256-thread workgroups per CU of the chain walkers
-    std::atomic<int64_t> restart_chain{1};      // find_iter / leftmost_find_iter: speculate-reconcile-emit (0 = sync-point scanners only)
-    std::atomic<int64_t> chain_rounds{24};
-    std::atomic<int64_t> overlap_micro{1};      // counts of overlapping scans outside GRAM: 1 micro-step walker (charwise, DARRAY), 2 also instead of TIERED, 0 off
-    std::atomic<int64_t> pool{1};               // scratch / result buffers from the stream-ordered pool
-    std::atomic<int64_t> pool_keep{0};          // bytes the pool keeps between calls (0 = auto)
-    std::atomic<int64_t> left3{1};                    // leftmost_find_iter's count (+ checksum) through left3_kernels.hip (as find3: 2 = whatever the text, 0 = off)
-    std::atomic<int64_t> select_emit{1};              // the restart iterators' tuple list from find3 / left3 (0: the chain walkers')
-    std::atomic<int64_t> find3_window{1ll << 30};     // find3: end positions per window (tests: small windows = many restarts)
-    std::atomic<int64_t> workspace_keep{8ll << 30};   // bytes of scratch a handle may keep for its emitter / find3 calls (0: none)
-    std::atomic<int64_t> char_map_lds{1};
-    std::atomic<int64_t> char_row_lds{1};       // ... and ROOT's row of children beside it       // charwise chain scans: stage the populated stretch of the code mapper in LDS
-                                                // (off: measured slower on cfg5, 88 vs 104 GB/s — the stretch is L1-resident anyway)
+    std::atomic<int64_t> v[OPT_COUNT];
+    Options() {
+#define X(NAME, DEF, UP) v[OPT_##NAME].store(static_cast<int64_t>(DEF));
+        DAAC_OPTIONS(X)
+#undef X
+    }
 };
 inline Options g_opt;
 // Options are process-wide defaults (daac_set_option) that a HANDLE may override (daac_pma_set_option): a scan looks an option up through OPT(),
 // which takes the override of the handle the calling thread is working for (PmaScope, set by every entry point that is given a handle, an
-// iterator or a stream — and by the iterator's worker thread) and the process-wide value otherwise.  Two threads that scan two handles with
-// different settings no longer share one set of atomics.
+// iterator or a stream — and by the worker threads of the iterator and of daac_scan_count_multi) and the process-wide value otherwise.  An
+// override is a slot of an array in the handle + a bit of a mask: a lookup takes no lock and builds no string (round-5 advisor).
+struct OptionOverrides {
+    std::atomic<uint64_t> mask{0};
+    std::atomic<int64_t> v[OPT_COUNT];
+    OptionOverrides() { for (auto &x : v) x.store(0); }
+};
+inline thread_local const OptionOverrides *tl_ov = nullptr;
 inline thread_local const ::daac_pma *tl_pma = nullptr;
+const OptionOverrides *overrides_of(const ::daac_pma *p);   // (defined below daac_pma)
 struct PmaScope {
     const ::daac_pma *prev;
-    explicit PmaScope(const ::daac_pma *p) : prev(tl_pma) { tl_pma = p; }
-    ~PmaScope() { tl_pma = prev; }
+    const OptionOverrides *prev_ov;
+    explicit PmaScope(const ::daac_pma *p) : prev(tl_pma), prev_ov(tl_ov) { tl_pma = p; tl_ov = p ? overrides_of(p) : nullptr; }
+    ~PmaScope() { tl_pma = prev; tl_ov = prev_ov; }
     PmaScope(const PmaScope &) = delete;
     PmaScope &operator=(const PmaScope &) = delete;
 };
-bool pma_override(const ::daac_pma *p, const char *field, int64_t *value);   // (defined below daac_pma)
-static inline int64_t opt_get(const char *field, const std::atomic<int64_t> &global) {
-    int64_t v;
-    if (tl_pma && pma_override(tl_pma, field, &v)) return v;
-    return global.load();
+static inline int64_t opt_get(int id) {
+    const OptionOverrides *o = tl_ov;
+    if (o && ((o->mask.load(std::memory_order_acquire) >> id) & 1ull)) return o->v[id].load(std::memory_order_relaxed);
+    return g_opt.v[id].load(std::memory_order_relaxed);
 }
-#define OPT(X) opt_get(#X, g_opt.X)
+#define OPT(X) opt_get(OPT_##X)
 inline thread_local int g_last_engine = DAAC_ENGINE_AUTO;  // engine of this thread's most recent scan (daac_last_engine)
+inline thread_local std::string g_last_kernel;               // ... and the kernel + launch shape of its most recent count (daac_last_kernel)
 
 inline daac_status hip_fail(hipError_t e, const char *what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));
@@ -121,14 +149,14 @@ inline int pool_mode_of_current_device() {
     int mode = g_pool_mode[dev].load();
     if (mode >= 0) return mode;
     mode = 0;
-    if (g_opt.pool.load() != 0) {
+    if (g_opt.v[OPT_pool].load() != 0) {
         int supported = 0;
         hipMemPool_t pool;
         if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, dev) == hipSuccess && supported &&
             hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
             size_t fr = 0, tot = 0;
             (void)hipMemGetInfo(&fr, &tot);
-            uint64_t keep = static_cast<uint64_t>(g_opt.pool_keep.load());
+            uint64_t keep = static_cast<uint64_t>(g_opt.v[OPT_pool_keep].load());
             if (keep == 0) keep = std::min<uint64_t>(32ull << 30, tot / 8);
             if (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) mode = 1;
         }
@@ -238,16 +266,39 @@ struct DeviceTables {
 
 using namespace daac;
 
+// daac_scan_count_multi: one persistent host thread per (handle, device), with a stream of its own — created the first time a shard names
+// the device, joined when the handle is freed.  A job makes no assumption about the calling thread: the worker has made its device current
+// and put the handle's options in scope (PmaScope) once, at its start.  (Round 5 started and joined one std::thread per shard and call,
+// on the device's default stream, without the handle's options in scope on any shard but the first.)
+struct ShardWorker {
+    int device = 0;
+    const ::daac_pma *pma = nullptr;
+    hipStream_t stream = nullptr;
+    unsigned long long *d_res = nullptr;    // 3 u64 per shard of the job in hand, device
+    unsigned long long *h_res = nullptr;    // ... and page-locked host
+    size_t res_cap = 0;                     // shards the two buffers hold
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void(ShardWorker &)>> jobs;
+    bool stop = false, failed = false;      // failed: the device could not be made current / no stream
+    ShardWorker(int dev, const ::daac_pma *p);
+    ~ShardWorker();
+    ShardWorker(const ShardWorker &) = delete;
+    ShardWorker &operator=(const ShardWorker &) = delete;
+    void post(std::function<void(ShardWorker &)> job);
+    bool reserve(size_t shards);            // (worker thread only)
+};
+
 struct daac_pma {
-    // per-handle option overrides (daac_pma_set_option): field name of Options -> value
-    mutable std::mutex opt_mu;
-    std::map<std::string, int64_t> opt_ov;
-    std::atomic<int> opt_n{0};
+    OptionOverrides opt_ov;   // per-handle option overrides (daac_pma_set_option)
     bool charwise = false;  // which of the two containers is populated
     HostPma host;           // DoubleArrayAhoCorasick<u32>
     HostCharPma chost;      // CharwiseDoubleArrayAhoCorasick<u32>
     std::mutex mu;
     std::map<int, std::unique_ptr<DeviceTables>> dev;
+    std::mutex workers_mu;
+    std::map<int, std::unique_ptr<ShardWorker>> workers;   // daac_scan_count_multi's, by device (declared after `dev`: joined before the tables go)
 
     bool is_standard() const { return charwise ? chost.is_standard() : host.is_standard(); }
     bool root_has_output() const { return charwise ? chost.states[kRoot].output_pos != 0 : output_pos_of(host.opos_ch(kRoot)) != 0; }
@@ -265,14 +316,7 @@ struct daac_pma {
     }
 };
 
-inline bool daac::pma_override(const ::daac_pma *p, const char *field, int64_t *value) {
-    if (p->opt_n.load(std::memory_order_relaxed) == 0) return false;
-    std::lock_guard<std::mutex> g(p->opt_mu);
-    const auto it = p->opt_ov.find(field);
-    if (it == p->opt_ov.end()) return false;
-    *value = it->second;
-    return true;
-}
+inline const daac::OptionOverrides *daac::overrides_of(const ::daac_pma *p) { return &p->opt_ov; }
 
 // Host-side list of match tuples.  Page-locked memory: the device writes tuples at HBM speed and a pageable
 // destination (plus its zero fill) turned the copy back into the slowest part of a materialising scan.

@@ -446,16 +446,30 @@ void daac_iter_close(daac_iter *it) {
 }  // extern "C"
 
 // ------------------------------------------------------------------------------ chunk-fed steppers
+// A feed scans [kept bytes | chunk].  The two device buffers that hold it (ping-pong: the kept tail of one is copied to the front of the other)
+// and the page-locked block the compact tuples come back in belong to the stream object and grow geometrically: a feed allocates nothing
+// once they are large enough.  (Until round 6 every feed did a hipMalloc of kept + chunk bytes, a synchronise and a hipFree of the last
+// feed's buffer: 0.65 ms per 64 MiB chunk of sparse text, of which the scan was a quarter.)
 struct daac_stream {
     daac_pma *pma;
     int mode, engine;
     hipStream_t stream;
     uint64_t consumed = 0;   // bytes fed so far
     uint64_t resume = 0;     // FIND: where the chain restarts (>= kept_from)
-    uint64_t kept_from = 0;  // stream offset of byte 0 of `kept`
-    void *kept = nullptr;    // device copy of stream bytes [kept_from, consumed)
+    uint64_t kept_from = 0;  // stream offset of byte 0 of the current buffer's text
+    void *buf[2] = {nullptr, nullptr};   // device: text of stream bytes [kept_from, consumed) starts at buf[cur] + skew
+    size_t cap[2] = {0, 0};
+    int cur = 0;
+    int device = -1;
+    uint32_t end_bits = 0;   // compact tuples: 32 - bits of the longest pattern's length (0: not worked out yet)
+    void *pin8 = nullptr;    // page-locked: the last compact feed's tuples
+    size_t pin8_bytes = 0;
+    bool pin8_pinned = false;
     bool started = false;
-    ~daac_stream() { if (kept) (void)hipFree(kept); }
+    ~daac_stream() {
+        for (void *b : buf) if (b) (void)hipFree(b);
+        if (pin8) { if (pin8_pinned) (void)hipHostFree(pin8); else std::free(pin8); }
+    }
 };
 
 // first character boundary at or after `pos` (charwise streams); the bytes are on the device
@@ -514,39 +528,114 @@ daac_status daac_stream_open(daac_pma *pma, int mode, int engine, void *stream, 
     return DAAC_OK;
 }
 
-daac_status daac_stream_feed(daac_stream *s, const uint8_t *chunk, size_t len, int chunk_is_device, daac_matches **out) {
+// One feed.  Exactly one of `out` (24-byte tuples in a host list of its own) and `batch` (8-byte tuples in the stream's page-locked block)
+// is asked for.
+static daac_status stream_feed_impl(daac_stream *s, const uint8_t *chunk, size_t len, int chunk_is_device, daac_matches **out,
+                                    const daac_match8 **batch, size_t *n_out, uint64_t *end_base, uint32_t *end_bits_out) {
     PmaScope scope_(s ? s->pma : nullptr);
-    if (!s || !out || (len && !chunk)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
-    std::unique_ptr<daac_matches> m(new daac_matches);
-    if (len == 0 && s->started) { *out = m.release(); return DAAC_OK; }
+    const bool compact = batch != nullptr;
+    if (!s || (!out && !compact) || (compact && (!n_out || !end_base || !end_bits_out)) || (len && !chunk)) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    std::unique_ptr<daac_matches> m(compact ? nullptr : new daac_matches);
+    if (compact) {
+        if (s->end_bits == 0) {   // length bits above the end, as daac_iter_open_compact
+            uint32_t lb = 1;
+            while ((1ull << lb) <= s->pma->max_pattern_len()) ++lb;
+            s->end_bits = 32 - lb;
+        }
+        if ((1ull << s->end_bits) < 4ull * s->pma->halo() + (1ull << 20)) {
+            set_error("patterns of " + std::to_string(s->pma->max_pattern_len()) + " bytes leave no room for a chunk in the compact tuple; use daac_stream_feed");
+            return DAAC_ERR_UNSUPPORTED;
+        }
+        *batch = nullptr; *n_out = 0; *end_base = s->consumed; *end_bits_out = s->end_bits;
+    }
+    if (len == 0 && s->started) { if (out) *out = m.release(); return DAAC_OK; }
     DeviceTables *t = nullptr;
     daac_status st = get_tables(s->pma, &t);
     if (st != DAAC_OK) return st;
     const uint64_t halo = s->pma->halo();
     const bool find = s->mode == DAAC_FIND;
     const uint64_t total = s->consumed + len;
-    // what of the old bytes the next scan can still look at: FIND restarts at `resume`, the overlapping scans
-    // warm up over the halo
+    // what of the old bytes the next scan can still look at: FIND restarts at `resume`, the overlapping scans warm up over the halo
     const uint64_t keep = find ? s->resume : (s->consumed > halo ? s->consumed - halo : 0);
-    void *fresh = nullptr;
-    HIP_TRY(hipMalloc(&fresh, total - keep + 32));
-    std::unique_ptr<void, void (*)(void *)> guard(fresh, [](void *p) { (void)hipFree(p); });
-    uint8_t *nb = static_cast<uint8_t *>(fresh);
-    if (s->consumed > keep)
-        HIP_TRY(hipMemcpyAsync(nb, static_cast<const uint8_t *>(s->kept) + (keep - s->kept_from), s->consumed - keep, hipMemcpyDeviceToDevice, s->stream));
+    const uint64_t scan_from = find ? s->resume : s->consumed;
+    if (compact && total - std::min(keep, scan_from) >= (1ull << s->end_bits)) {
+        set_error("daac_stream_feed_compact: a chunk (plus what is kept of the earlier ones) must stay below 2^end_bits bytes — feed smaller chunks, or use daac_stream_feed");
+        return DAAC_ERR_UNSUPPORTED;
+    }
+    // the other buffer takes [kept bytes | chunk], keeping the stream's 16-byte phase (the kernels read whole aligned granules)
+    const int nx = s->cur ^ 1;
+    const uint64_t skew = keep & 15;
+    const size_t need = static_cast<size_t>(total - keep + skew + 64);
+    if (s->cap[nx] < need) {
+        if (s->buf[nx]) (void)hipFree(s->buf[nx]);
+        s->buf[nx] = nullptr; s->cap[nx] = 0;
+        const size_t want = std::max(need + need / 4, s->cap[s->cur]);
+        HIP_TRY(hipMalloc(&s->buf[nx], want));
+        s->cap[nx] = want;
+    }
+    uint8_t *nb = static_cast<uint8_t *>(s->buf[nx]) + skew;
+    if (s->consumed > keep) {
+        const uint8_t *old = static_cast<const uint8_t *>(s->buf[s->cur]) + (s->kept_from & 15) + (keep - s->kept_from);
+        HIP_TRY(hipMemcpyAsync(nb, old, s->consumed - keep, hipMemcpyDeviceToDevice, s->stream));
+    }
     if (len) HIP_TRY(hipMemcpyAsync(nb + (s->consumed - keep), chunk, len, chunk_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->stream));
     const uint8_t *virt = nb - keep;  // address stream byte 0 would have
-    if (!find) {
-        // FindOverlappingStepper / no-suffix: everything that ends inside this chunk (and ROOT's list at 0 on the first)
-        if ((st = scan_range_materialize(s->pma, t, s->mode, s->engine, virt, s->consumed, total, total, s->stream, m->v, nullptr)) != DAAC_OK) return st;
-    } else {
+    uint64_t end = total;
+    if (find) {
         // FindStepper: the chain goes on from `resume` as if the text ended here; what it has not decided yet is
         // re-read with the next chunk (a charwise stream also holds an incomplete last character back)
-        uint64_t end = total;
         if (s->pma->charwise && (st = last_complete_char_end(virt, s->resume, total, s->stream, &end)) != DAAC_OK) return st;
         if (end < s->resume) end = s->resume;
-        if ((st = scan_range_materialize(s->pma, t, s->mode, s->engine, virt, s->resume, end, end, s->stream, m->v, nullptr)) != DAAC_OK) return st;
-        uint64_t r = m->v.size() ? m->v.p[m->v.size() - 1].end : s->resume;
+    }
+    uint64_t last_end = scan_from;   // FIND: end of the last match reported (the chain's position)
+    bool any = false;
+    if (!compact) {
+        // FindOverlappingStepper / no-suffix: everything that ends inside this chunk (and ROOT's list at 0 on the first)
+        if ((st = scan_range_materialize(s->pma, t, s->mode, s->engine, virt, scan_from, end, end, s->stream, m->v, nullptr)) != DAAC_OK) return st;
+        if (m->v.size()) { any = true; last_end = m->v.p[m->v.size() - 1].end; }
+    } else {
+        DevMatches dm;
+        dm.f16 = true;
+        if ((st = scan_range_device(s->pma, t, s->mode, s->engine, virt, scan_from, end, end, s->stream, dm, nullptr)) != DAAC_OK) return st;
+        if (dm.n != 0 && !dm.f16_done) {   // an engine that writes daac_match: repacked on the device
+            void *d16 = nullptr;
+            HIP_TRY(dev_malloc(&d16, dm.n * 16, s->stream));
+            (void)launch_repack16(dm.p, d16, dm.n, s->stream);
+            dev_free(dm.release_keep_n(), s->stream);
+            dm.p = static_cast<daac_match *>(d16);
+        }
+        if (dm.n != 0) {
+            const size_t bytes = dm.n * 8;
+            if (s->pin8_bytes < bytes) {
+                if (s->pin8) { if (s->pin8_pinned) (void)hipHostFree(s->pin8); else std::free(s->pin8); }
+                s->pin8 = nullptr; s->pin8_bytes = 0;
+                const size_t want = bytes + bytes / 2 + 4096;
+                void *q = nullptr;
+                if (hipHostMalloc(&q, want, hipHostMallocDefault) == hipSuccess) s->pin8_pinned = true;
+                else { (void)hipGetLastError(); q = std::malloc(want); s->pin8_pinned = false; }
+                if (!q) { set_error("out of host memory for the match list"); return DAAC_ERR_AUTOMATON_SCALE; }
+                s->pin8 = q; s->pin8_bytes = want;
+            }
+            void *d8 = nullptr;
+            HIP_TRY(dev_malloc(&d8, bytes, s->stream));
+            const hipError_t e1 = launch_repack8(dm.p, d8, dm.n, scan_from, s->end_bits, s->stream);
+            const hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(s->pin8, d8, bytes, hipMemcpyDeviceToHost, s->stream) : e1;
+            dev_free(d8, s->stream);
+            HIP_TRY(e2);
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            const daac_match8 *p8 = static_cast<const daac_match8 *>(s->pin8);
+            any = true;
+            last_end = scan_from + (p8[dm.n - 1].end_len & ((1u << s->end_bits) - 1u));
+            size_t skip = 0;
+            if (s->started)   // what ends at position 0 ("" among the patterns) was reported by the first call, even an empty one
+                while (skip < dm.n && scan_from + (p8[skip].end_len & ((1u << s->end_bits) - 1u)) == 0) ++skip;
+            *batch = p8 + skip;
+            *n_out = static_cast<size_t>(dm.n) - skip;
+            *end_base = scan_from;
+        }
+    }
+    if (find) {
+        uint64_t r = any ? last_end : s->resume;
         if (s->pma->root_has_output()) {
             r = end;  // "" among the patterns: one report per position, nothing is ever pending
         } else if (end > halo && r < end - halo) {
@@ -556,20 +645,32 @@ daac_status daac_stream_feed(daac_stream *s, const uint8_t *chunk, size_t len, i
         }
         s->resume = r;
     }
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    if (s->started) {
+    HIP_TRY(hipStreamSynchronize(s->stream));   // (the chunk has been read: the caller may reuse it)
+    if (!compact && s->started) {
         // what ends at position 0 ("" among the patterns) was reported by the first call, even an empty one
         size_t skip = 0;
         while (skip < m->v.n && m->v.p[skip].end == 0) ++skip;
         if (skip) { std::memmove(m->v.p, m->v.p + skip, (m->v.n - skip) * sizeof(daac_match)); m->v.n -= skip; }
     }
-    if (s->kept) (void)hipFree(s->kept);
-    s->kept = guard.release();
+    s->cur = nx;
     s->kept_from = keep;
     s->consumed = total;
     s->started = true;
-    *out = m.release();
+    if (out) *out = m.release();
     return DAAC_OK;
+}
+
+daac_status daac_stream_feed(daac_stream *s, const uint8_t *chunk, size_t len, int chunk_is_device, daac_matches **out) {
+    if (!out) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    return stream_feed_impl(s, chunk, len, chunk_is_device, out, nullptr, nullptr, nullptr, nullptr);
+}
+
+// The same feed with the chunk's matches as 8-byte tuples (daac_match8, as daac_iter_next_batch8 hands them out) in a page-locked block of
+// the stream object, valid until the next feed or close: a third of the bytes of daac_match over PCIe, and no list to allocate and free.
+daac_status daac_stream_feed_compact(daac_stream *s, const uint8_t *chunk, size_t len, int chunk_is_device, const daac_match8 **batch,
+                                     size_t *n, uint64_t *end_base, uint32_t *end_bits) {
+    if (!batch) { set_error("null argument"); return DAAC_ERR_INVALID_ARGUMENT; }
+    return stream_feed_impl(s, chunk, len, chunk_is_device, nullptr, batch, n, end_base, end_bits);
 }
 
 void daac_stream_close(daac_stream *s) { delete s; }

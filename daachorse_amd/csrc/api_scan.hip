@@ -379,7 +379,7 @@ CountRoute count_route(const daac_pma *pma, const DeviceTables *t, int mode, int
     CountRoute r{};
     const int64_t gv = OPT(gram_version);
     r.g1_can = t->gram_ok && gv != 2;
-    r.g2_can = t->gram2_ok && (!want_checksum || t->gram2.exact_ok) && gv != 1 && !(gv == 0 && want_checksum && r.g1_can) && !(gv == 3 && want_checksum && r.g1_can);
+    r.g2_can = t->gram2_ok && (!want_checksum || t->gram2.exact_ok) && gv != 1 && !(gv == 0 && want_checksum && r.g1_can);
     r.gw_can = t->gramw_ok && (!want_checksum || t->gramw.exact_ok);  // wide alphabets: built only where the others are not
     const bool applies = !pma->charwise && mode == DAAC_FIND_OVERLAPPING && pma->host.is_standard() && span < (1ull << 35);
     r.gram = applies && (engine == DAAC_ENGINE_GRAM || (engine == DAAC_ENGINE_AUTO && (r.g2_can || r.g1_can || r.gw_can)));
@@ -443,21 +443,19 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     // (gram_version = 2 asks for gram2_kernels.hip, which counts with its checksum tables: a dictionary without room for those counts here)
     bool use_g4 = use_g2 && !want_checksum && t->gram4_ok && (gv == 4 || gv == 0 || (gv == 2 && !t->gram2.exact_ok));
     if (use_g4) {
-        const bool want_rfull = OPT(gram2_rfull) != 0, want_arith = OPT(gram4_arith) != 0;
+        const bool want_rfull = OPT(gram2_rfull) != 0, want_arith = OPT(gram4_arith) != 0, want_filter = OPT(gram4_filter) != 0;
         const uint32_t waves = static_cast<uint32_t>(OPT(threads)) > 512 ? 16u : 8u;
         const int64_t ppl_opt = OPT(gram_ppl);
-        // preference: the per-word directory first (two LDS reads per hit instead of five), then 32 positions per lane
-        struct Shape { uint32_t ppl; bool rfull; } shapes[4] = {{32u, true}, {16u, true}, {32u, false}, {16u, false}};
+        // preference (profiles/r05_gram4_decomposition.txt: p32 rfull 1 420, p32 coarse 1 378, p16 rfull 1 326 GB/s): 32 positions per lane
+        // first, then the per-word directory (two LDS reads per hit instead of five); eight waves leave the tables more room where sixteen
+        // do not fit.  gram4_plan hands back exactly the shape asked for or nothing.
+        struct Shape { uint32_t ppl; bool rfull; } shapes[4] = {{32u, true}, {32u, false}, {16u, true}, {16u, false}};
         bool planned = false;
-        for (const Shape &sh : shapes) {
-            if ((ppl_opt == 16 || ppl_opt == 32) && sh.ppl != static_cast<uint32_t>(ppl_opt)) continue;
-            if (sh.rfull && !want_rfull) continue;
-            if (gram4_plan(t->gram4, sh.ppl, waves, sh.rfull, want_arith, 160u * 1024u, g4l)) { g4_ppl = sh.ppl; planned = true; break; }
-        }
-        if (!planned && waves == 16) {   // eight waves leave the tables more room
+        for (uint32_t w = waves; w >= 8u && !planned; w >>= 1) {
             for (const Shape &sh : shapes) {
+                if ((ppl_opt == 16 || ppl_opt == 32) && sh.ppl != static_cast<uint32_t>(ppl_opt)) continue;
                 if (sh.rfull && !want_rfull) continue;
-                if (gram4_plan(t->gram4, sh.ppl, 8, sh.rfull, want_arith, 160u * 1024u, g4l)) { g4_ppl = sh.ppl; planned = true; break; }
+                if (gram4_plan(t->gram4, sh.ppl, w, sh.rfull, want_arith, want_filter, 160u * 1024u, g4l)) { g4_ppl = sh.ppl; planned = true; break; }
             }
         }
         use_g4 = planned;
@@ -507,6 +505,17 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
     }
     std::unique_ptr<void, void (*)(void *)> g3(flagbuf, [](void *p) { if (p) (void)hipFree(p); });
     if (!find3_served) g_last_engine = use_pfx ? DAAC_ENGINE_PFX : use_gram ? DAAC_ENGINE_GRAM : (pl.tier ? DAAC_ENGINE_TIERED : DAAC_ENGINE_DARRAY);
+    if (!find3_served) {   // what daac_last_kernel() says: the kernel family and, for the `.count()` kernel, the launch shape the options gave it
+        if (use_g4) {
+            const int64_t tail_opt = OPT(gram_tail);
+            g_last_kernel = "gram4 ppl=" + std::to_string(g4_ppl) + " dir=" + std::to_string(g4l.dir) + " waves=" + std::to_string(g4l.threads / 64) + " arith=" + std::to_string(g4l.arith) +
+                            " filter=" + std::to_string(g4l.filter) + " tail=" + (tail_opt < 0 ? std::string("auto") : std::to_string(tail_opt > 0 ? 1 : 0));
+        } else {
+            g_last_kernel = use_pfx ? "pfx" : use_gw ? "gram2w" : use_g2 ? "gram2" : use_gram ? "gram" : pl.charwise ? "charwise" : pl.tier ? "tiered" : "darray";
+        }
+    } else {
+        g_last_kernel = "find3";
+    }
     if (find3_served) {
     } else if ((use_gram || use_pfx) && len != begin) {
         // A shard [begin, len): the occurrences with their end in (begin, len] = those of [from, len) scanned as a haystack of its own,
@@ -554,7 +563,7 @@ static daac_status scan_count_impl(daac_pma *pma, int mode, int engine, const ui
         }
         // gram4: tail records from the hit record on pay on text made of dictionary words (+20 %) and cost 3-4 % elsewhere; unless
         // the option decides, every workgroup samples the haystack at its start and runs the variant the text calls for
-        const int64_t tail_opt = OPT(gram3_tail);
+        const int64_t tail_opt = OPT(gram_tail);
         void *wq = nullptr;
         HIP_TRY(dev_malloc(&wq, static_cast<size_t>(blocks) * wpb * ga.wq_slab * ((use_g4 || use_pfx) ? sizeof(uint4) : sizeof(uint2)), stream));
         ga.wq = static_cast<uint2 *>(wq);
@@ -626,11 +635,77 @@ daac_status daac_scan_count_only_range(daac_pma *pma, int mode, int engine, cons
     return scan_count_impl(pma, mode, engine, hay, len, begin, hay_is_device, stream, count, nullptr, result_dev, false);
 }
 
+}  // extern "C"
+
+// ---- the shard workers of daac_scan_count_multi (api_internal.hpp: ShardWorker)
+ShardWorker::ShardWorker(int dev, const ::daac_pma *p) : device(dev), pma(p) {
+    th = std::thread([this]() {
+        PmaScope scope_(pma);
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&stream) != hipSuccess) {
+            (void)hipGetLastError();
+            stream = nullptr;
+            std::lock_guard<std::mutex> g(mu);
+            failed = true;
+        }
+        for (;;) {
+            std::function<void(ShardWorker &)> job;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [this]() { return stop || !jobs.empty(); });
+                if (jobs.empty()) break;   // (stop: what was posted before it is still run)
+                job = std::move(jobs.front());
+                jobs.pop_front();
+            }
+            job(*this);
+        }
+        if (d_res) (void)hipFree(d_res);
+        if (h_res) (void)hipHostFree(h_res);
+        if (stream) (void)hipStreamDestroy(stream);
+    });
+}
+ShardWorker::~ShardWorker() {
+    {
+        std::lock_guard<std::mutex> g(mu);
+        stop = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+}
+void ShardWorker::post(std::function<void(ShardWorker &)> job) {
+    {
+        std::lock_guard<std::mutex> g(mu);
+        jobs.push_back(std::move(job));
+    }
+    cv.notify_one();
+}
+bool ShardWorker::reserve(size_t shards) {
+    if (shards <= res_cap) return true;
+    if (d_res) (void)hipFree(d_res);
+    if (h_res) (void)hipHostFree(h_res);
+    d_res = h_res = nullptr;
+    res_cap = 0;
+    const size_t cap = std::max<size_t>(shards, 16), bytes = cap * 3 * sizeof(unsigned long long);
+    void *d = nullptr, *h = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess || hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (d) (void)hipFree(d);
+        return false;
+    }
+    d_res = static_cast<unsigned long long *>(d);
+    h_res = static_cast<unsigned long long *>(h);
+    res_cap = cap;
+    return true;
+}
+
+extern "C" {
+
 // One haystack sharded across the devices of a node (BASELINE configs[3]): the product's own form of what bench.py does with
-// one process per GPU.  One host thread per shard: makes the shard's device current, uploads the tables there if they are not yet, runs
-// daac_scan_count[_only]_range over [halo | shard] with begin = halo (matches with their end inside the shard, wherever they start), and
-// the host adds the counts and the two checksum sums — `base` re-bases a shard's ends (S2 += low32(base) * S1).  No collective: RCCL is
-// for callers that run one process per GPU (daachorse_amd/dist.py) and reduce {count, S1, S2} themselves.
+// one process per GPU.  One persistent host thread per DEVICE the shards name (ShardWorker: created at the handle's first call that names
+// the device, with a stream of its own and the handle's options in scope): it uploads the tables there if they are not yet, queues
+// daac_scan_count[_only]_range over [halo | shard] with begin = halo for every shard of its device back to back — results stay in device
+// memory, nothing is waited for between shards —, synchronises once and hands {count, S1, S2} per shard back; the caller adds the counts
+// and the two checksum sums — `base` re-bases a shard's ends (S2 += low32(base - halo) * S1).  No collective: RCCL is for callers that
+// run one process per GPU (daachorse_amd/dist.py) and reduce {count, S1, S2} themselves.
 daac_status daac_scan_count_multi(daac_pma *pma, int mode, int engine, const daac_shard *shards, size_t n, int hay_is_device, uint64_t *count,
                                   uint64_t *checksum) {
     PmaScope scope_(pma);
@@ -645,8 +720,12 @@ daac_status daac_scan_count_multi(daac_pma *pma, int mode, int engine, const daa
     HIP_TRY(hipGetDeviceCount(&ndev));
     const size_t halo_need = pma->halo();
     for (size_t k = 0; k < n; ++k) {
-        if (shards[k].device < 0 || shards[k].device >= ndev || ((shards[k].len + shards[k].halo) && !shards[k].hay)) {
+        if (shards[k].device < 0 || shards[k].device >= ndev || shards[k].device >= kMaxDevices || ((shards[k].len + shards[k].halo) && !shards[k].hay)) {
             set_error("daac_scan_count_multi: bad shard (device ordinal / null haystack)");
+            return DAAC_ERR_INVALID_ARGUMENT;
+        }
+        if (shards[k].halo > shards[k].base) {   // (the ends are re-based by base - halo)
+            set_error("daac_scan_count_multi: a shard's halo reaches in front of the haystack (halo > base)");
             return DAAC_ERR_INVALID_ARGUMENT;
         }
         if (shards[k].halo < halo_need && shards[k].halo < shards[k].base) {   // fewer bytes in front than a match may reach back, and not the haystack's start
@@ -654,35 +733,81 @@ daac_status daac_scan_count_multi(daac_pma *pma, int mode, int engine, const daa
             return DAAC_ERR_INVALID_ARGUMENT;
         }
     }
-    int dev0 = 0;
-    HIP_TRY(hipGetDevice(&dev0));
-    struct Out { daac_status st = DAAC_OK; uint64_t count = 0, checksum = 0; int engine = DAAC_ENGINE_AUTO; std::string err; };
+    struct Out { daac_status st = DAAC_OK; uint64_t count = 0; uint32_t s1 = 0, s2 = 0; int engine = DAAC_ENGINE_AUTO; std::string err, kernel; };
     std::vector<Out> outs(n);
-    auto work = [&](size_t k) {
-        Out &o = outs[k];
-        const daac_shard &sh = shards[k];
-        if (hipSetDevice(sh.device) != hipSuccess) { o.st = DAAC_ERR_DEVICE; o.err = "hipSetDevice failed"; (void)hipGetLastError(); return; }
-        o.st = checksum ? scan_count_impl(pma, mode, engine, sh.hay, sh.halo + sh.len, sh.halo, hay_is_device, nullptr, &o.count, &o.checksum, nullptr, true)
-                        : scan_count_impl(pma, mode, engine, sh.hay, sh.halo + sh.len, sh.halo, hay_is_device, nullptr, &o.count, nullptr, nullptr, false);
-        o.engine = g_last_engine;
-        if (o.st != DAAC_OK) o.err = daac_last_error();
-    };
-    std::vector<std::thread> threads;
-    for (size_t k = 1; k < n; ++k) threads.emplace_back(work, k);
-    if (n) work(0);
-    for (std::thread &t : threads) t.join();
-    (void)hipSetDevice(dev0);
+    // the shards of each device, in the caller's order
+    std::map<int, std::vector<size_t>> by_dev;
+    for (size_t k = 0; k < n; ++k) by_dev[shards[k].device].push_back(k);
+    struct Latch { std::mutex mu; std::condition_variable cv; size_t left = 0; } latch;
+    latch.left = by_dev.size();
+    const bool want_checksum = checksum != nullptr;
+    std::vector<ShardWorker *> posted;
+    std::string spawn_err;
+    for (auto &kv : by_dev) {
+        ShardWorker *w = nullptr;
+        try {
+            std::lock_guard<std::mutex> g(pma->workers_mu);
+            std::unique_ptr<ShardWorker> &slot = pma->workers[kv.first];
+            if (!slot) slot.reset(new ShardWorker(kv.first, pma));
+            w = slot.get();
+        } catch (const std::exception &e) {   // (std::system_error from std::thread, bad_alloc: nothing may leave an extern "C" function)
+            spawn_err = e.what();
+        }
+        if (!w) {
+            for (size_t k : kv.second) { outs[k].st = DAAC_ERR_DEVICE; outs[k].err = "no worker thread for the device: " + spawn_err; }
+            std::lock_guard<std::mutex> g(latch.mu);
+            --latch.left;
+            continue;
+        }
+        const std::vector<size_t> *mine = &kv.second;
+        w->post([&, mine](ShardWorker &me) {
+            const size_t m = mine->size();
+            bool ok = !me.failed && me.stream != nullptr && me.reserve(m);
+            if (!ok) {
+                for (size_t k : *mine) { outs[k].st = DAAC_ERR_DEVICE; outs[k].err = "the shard's device could not be made current (hipSetDevice / stream / result buffers)"; }
+            } else {
+                size_t queued = 0;
+                for (size_t i = 0; i < m; ++i) {
+                    const size_t k = (*mine)[i];
+                    const daac_shard &sh = shards[k];
+                    Out &o = outs[k];
+                    uint64_t *rd = reinterpret_cast<uint64_t *>(me.d_res + 3 * i);
+                    o.st = scan_count_impl(pma, mode, engine, sh.hay, sh.halo + sh.len, sh.halo, hay_is_device, me.stream, nullptr, nullptr, rd, want_checksum);
+                    o.engine = g_last_engine;
+                    o.kernel = g_last_kernel;
+                    if (o.st != DAAC_OK) o.err = daac_last_error(); else ++queued;
+                }
+                hipError_t e = hipSuccess;
+                if (queued) e = hipMemcpyAsync(me.h_res, me.d_res, m * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, me.stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(me.stream);
+                for (size_t i = 0; i < m; ++i) {
+                    Out &o = outs[(*mine)[i]];
+                    if (o.st != DAAC_OK) continue;
+                    if (e != hipSuccess) { o.st = DAAC_ERR_DEVICE; o.err = std::string("shard scan: ") + hipGetErrorString(e); continue; }
+                    o.count = me.h_res[3 * i];
+                    o.s1 = static_cast<uint32_t>(me.h_res[3 * i + 1]);
+                    o.s2 = static_cast<uint32_t>(me.h_res[3 * i + 2]);
+                }
+                if (e != hipSuccess) (void)hipGetLastError();
+            }
+            std::lock_guard<std::mutex> g(latch.mu);
+            if (--latch.left == 0) latch.cv.notify_all();
+        });
+    }
+    {
+        std::unique_lock<std::mutex> g(latch.mu);
+        latch.cv.wait(g, [&]() { return latch.left == 0; });
+    }
     uint64_t total = 0;
     uint32_t s1 = 0, s2 = 0;
     for (size_t k = 0; k < n; ++k) {
         if (outs[k].st != DAAC_OK) { set_error("shard " + std::to_string(k) + " (device " + std::to_string(shards[k].device) + "): " + outs[k].err); return outs[k].st; }
         total += outs[k].count;
-        const uint32_t k1 = static_cast<uint32_t>(outs[k].checksum >> 32), k2 = static_cast<uint32_t>(outs[k].checksum);
         const uint32_t shift = static_cast<uint32_t>(shards[k].base - shards[k].halo);   // ends were counted from the shard's first resident byte
-        s1 += k1;
-        s2 += k2 + shift * k1;
+        s1 += outs[k].s1;
+        s2 += outs[k].s2 + shift * outs[k].s1;
     }
-    if (n) g_last_engine = outs[0].engine;
+    if (n) { g_last_engine = outs[0].engine; g_last_kernel = outs[0].kernel; }
     *count = total;
     if (checksum) *checksum = (static_cast<uint64_t>(s1) << 32) | s2;
     return DAAC_OK;

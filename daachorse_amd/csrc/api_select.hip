@@ -164,10 +164,9 @@ daac_status emit_overlapping3(daac_pma *pma, DeviceTables *t, const uint8_t *dev
         if (raw) { a.ann = w.hay_al; a.vlen = w.vlen; a.emit_from = w.emit_from; }
         // the rank structure goes to LDS when the workgroups still fit with it: two of eight waves (16-byte tuples), three of four (24-byte)
         const uint32_t xwaves = (out.f16 && !raw) ? 8u : 4u;
-        a.v3_in_lds = (!raw && e.v3c != nullptr && OPT(emit_v3_lds) != 0 &&
+        a.v3_in_lds = (!raw && e.v3c != nullptr &&
                        emit3_expand_lds_bytes(e, xwaves, out.f16, true) <= (160u * 1024u) / (out.f16 ? 2u : 3u)) ? 1u : 0u;
         a.off_wave = e.v1_bytes + e.v2_bytes + (a.v3_in_lds ? e.v3c_bytes : 0u);
-        a.stagger = a.ntiles >= 65536u ? static_cast<uint32_t>(std::max<int64_t>(0, std::min<int64_t>(64, OPT(emit_stagger)))) : 0u;
         a.fail = d_ctl + 1;
         const uint32_t xblocks = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(t->num_cu) * ((out.f16 && !raw) ? 2u : 4u), (a.ntiles + xwaves - 1) / xwaves)));
         if (raw) HIP_TRY(launch_emit3_expand_raw(e, a, out.f16, xblocks, stream));

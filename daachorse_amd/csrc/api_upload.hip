@@ -404,6 +404,14 @@ daac_status upload_locked(daac_pma *pma, int device, DeviceTables **out) {
                 { const U32x4 *x; if ((st = t->put(g4.dhit_t, x)) != DAAC_OK) return st; q.dhit_t = reinterpret_cast<const uint4 *>(x); }
                 { const U32x4 *x; if ((st = t->put(g4.drec_c, x)) != DAAC_OK) return st; q.drec_c = reinterpret_cast<const uint4 *>(x); }
                 { const U32x4 *x; if ((st = t->put(g4.drec_t, x)) != DAAC_OK) return st; q.drec_t = reinterpret_cast<const uint4 *>(x); }
+                // the filter in front of rank + gather (gram4_filter.hpp): as large as the preferred launch shape leaves room for, less a margin
+                {
+                    const uint32_t room = gram4_filter_room(q.m_bytes, q.s_bytes, g4.arith, 160u * 1024u);
+                    if (room > 1024u && build_gram4_filter(g4, room - 512u)) {
+                        if ((st = t->put(g4.bloom, q.bloom)) != DAAC_OK) return st;
+                        q.bloom_words = static_cast<uint32_t>(g4.bloom.size());
+                    }
+                }
                 q.K = g4.K; q.C = g4.C; q.s16 = g4.s16 ? 1u : 0u; q.arith = g4.arith ? 1u : 0u; q.lo = g4.lo; q.unused_byte = g4.unused_byte;
                 q.n_deep = static_cast<uint32_t>(g4.dhit_c.size());
                 t->gram4_ok = g4.available;
@@ -587,6 +595,7 @@ extern "C" {
 
 const char *daac_last_error(void) { return last_error_cstr(); }
 int daac_last_engine(void) { return g_last_engine; }
+const char *daac_last_kernel(void) { return g_last_kernel.c_str(); }
 void daac_free(void *p) { std::free(p); }
 
 daac_status daac_bytewise_from_serialized(const uint8_t *blob, size_t len, daac_pma **out, size_t *consumed) {

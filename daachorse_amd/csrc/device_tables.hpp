@@ -210,6 +210,8 @@ struct Gram4Dev {
     const uint4 *dhit_t;      // the same as 16-byte records, single paths below a hit folded into a tail record (bit 31)
     const uint4 *drec_c;      // walk records {cmap, first_child, own_cnt, 0}, tail records from depth K + 3 on
     const uint4 *drec_t;      // ... from depth K + 2 on
+    const uint32_t *bloom;    // the filter in front of rank + gather (gram4_filter.hpp), null when it was not built
+    uint32_t bloom_words;     // a multiple of 4
     uint32_t m_bytes, rfull_bytes, s_bytes;  // multiples of 16
     uint32_t K, C, s16, arith, lo, unused_byte, n_deep;
 };
@@ -223,8 +225,14 @@ struct Gram4Lds {
     uint32_t lds_bytes, threads;
     uint32_t arith;        // classes by min(byte - lo, C - 1)
     uint32_t dir;          // 0: u16 per word, 1: u16 per four words, 2: u32 per four words
+    uint32_t filter;       // the workgroups whose text is not made of dictionary words stage [coarse directory | Bloom array] at off_s instead and
+    uint32_t off_b;        // ... run the body with the filter: off_b = where the Bloom array then lies, s_bytes_f = bytes of the coarse directory
+    uint32_t s_bytes_f;
 };
-bool gram4_plan(const Gram4Dev &dev, uint32_t ppl, uint32_t waves, bool want_rfull, bool want_arith, uint32_t lds_limit, Gram4Lds &L);
+// the LDS the filter's Bloom array may take at the preferred launch shape (32 positions per lane, 16 waves, coarse directory): what
+// build_gram4_filter is given at upload
+uint32_t gram4_filter_room(uint32_t m_bytes, uint32_t sdir_bytes, bool arith, uint32_t lds_limit);
+bool gram4_plan(const Gram4Dev &dev, uint32_t ppl, uint32_t waves, bool rfull, bool want_arith, bool want_filter, uint32_t lds_limit, Gram4Lds &L);
 hipError_t launch_gram4_scan(const Gram4Dev &dev, const GramArgs &a, const Gram4Lds &L, uint32_t blocks, hipStream_t stream);
 
 // GRAM tuple emission with detection done ONCE (emit3_kernels.hip): DETECT leaves, per haystack byte, one "annotated class"
@@ -268,7 +276,6 @@ struct Expand3Args {
     unsigned long long pos_base;         // end (haystack coordinates) of a match whose last byte is at virtual position v = pos_base + v
     uint32_t off_wave;                   // LDS: V1 at 0, V2 behind it, the per-wave areas from here
     uint32_t has_len1;                   // the dictionary has one-byte patterns
-    uint32_t stagger;                    // start delay per wave of a CU, in units of 1024 cycles x (wave number mod 16)
     uint32_t v3_in_lds;                  // the rank structure of the 3-byte patterns' values is staged behind V2 (else they are read from L2)
     unsigned int *fail;                  // bit 2: more extras in one tile than EXPAND places; bit 3: a slot outside its tile (a bug)
     uint32_t vlen, emit_from;            // RAW (PFX) only: `ann` is the haystack; positions in [emit_from, vlen) can end a one-byte match

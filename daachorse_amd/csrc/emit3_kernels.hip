@@ -1026,10 +1026,7 @@ __global__ __launch_bounds__((F16 && !RAW) ? 512 : 256, (F16 && !RAW) ? 4 : 3) v
     };
     TileIn in_a = TileIn{}, in_b = TileIn{};
     if (a.ntiles == 0) return;
-    // Waves that start together stay together: every wave of the chip computes a tile, then every wave stores ten kilobytes — 40 MB per
-    // round against 32 MB of L2 — and the store bursts and the compute phases do not overlap (profiles/r04_emit3_experiments.txt).  The
-    // sixteen waves of a CU therefore start a sixteenth of a tile's time apart.
-    for (uint32_t d = (wave_global & 15u) * a.stagger; d != 0; --d) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles each
+    // (staggered wave starts were measured and moved nothing: profiles/r04_emit3_experiments.txt, step 8)
     TileS ts0, ts1;
     {
         const TileOff o0 = ask_off(wave_global), o1 = ask_off(wave_global + nwaves);

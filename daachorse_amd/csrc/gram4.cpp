@@ -1,6 +1,8 @@
 // GRAM engine, `.count()` tables renumbered for gram4_kernels.hip — see gram4.hpp.
 #include "gram4.hpp"
 
+#include <algorithm>
+
 namespace daac {
 
 void build_gram4_tables(const Gram2Tables &g2, Gram4Tables &out) {
@@ -68,6 +70,66 @@ void build_gram4_tables(const Gram2Tables &g2, Gram4Tables &out) {
     walk(g2.drec_c, out.drec_c);
     walk(g2.drec_t, out.drec_t);
     out.available = true;
+}
+
+bool build_gram4_filter(Gram4Tables &t, uint32_t max_bytes) {
+    t.bloom.clear();
+    t.filter_keys = 0;
+    if (!t.available) return false;
+    const uint32_t K = t.K, C = t.C, OTH = C - 1;
+    // class -> its byte (the keys are hashed from text bytes): every pattern class must be exactly one byte value
+    uint32_t byte_of[32];
+    uint32_t seen[32] = {0};
+    for (uint32_t b = 0; b < 256; ++b) {
+        const uint32_t c = t.cls[b];
+        if (c < OTH) { byte_of[c] = b; if (++seen[c] > 1) return false; }
+    }
+    for (uint32_t c = 0; c < OTH; ++c) if (seen[c] != 1) return false;
+    uint64_t ngram = 1;
+    for (uint32_t i = 0; i < K; ++i) ngram *= C;
+    // the keys: one pass to count, one to insert
+    uint64_t keys = 0;
+    {
+        uint32_t rank = 0;
+        for (uint64_t g = 0; g < ngram; ++g)
+            for (uint32_t w = t.m[g] & kGram4ChildBits; w != 0; w &= w - 1, ++rank) {
+                const uint32_t x = t.dhit_c[rank].x;
+                keys += static_cast<uint64_t>(__builtin_popcount(x & kGram4ChildBits)) + ((x >> kGram4EndsBit) & 1u);
+            }
+    }
+    if (keys == 0) return false;
+    uint64_t words = std::min<uint64_t>(max_bytes / 4, (keys * 16 + 31) / 32);
+    words &= ~3ull;   // (staged in 16-byte pieces)
+    if (words < 64 || words * 32 < keys * 2) return false;
+    t.bloom.assign(static_cast<size_t>(words), 0u);
+    const uint32_t W = static_cast<uint32_t>(words);
+    uint32_t rank = 0;
+    for (uint64_t g = 0; g < ngram; ++g) {
+        uint32_t w = t.m[g] & kGram4ChildBits;
+        if (w == 0) continue;
+        // the K context bytes, oldest first = lowest byte of x (the most significant class of the index is the oldest)
+        uint32_t xc = 0;
+        {
+            uint64_t rest = g;
+            for (uint32_t i = 0; i < K; ++i) {   // least significant class = the newest context byte
+                xc |= byte_of[rest % C] << (8 * (K - 1 - i));
+                rest /= C;
+            }
+        }
+        for (; w != 0; w &= w - 1, ++rank) {
+            const uint32_t d = static_cast<uint32_t>(__builtin_ctz(w));
+            const uint32_t x = xc | (byte_of[d] << (8 * K));
+            const uint32_t base = g4f_base(x);
+            const uint32_t rx = t.dhit_c[rank].x;
+            if ((rx >> kGram4EndsBit) & 1u) { const G4Probe p = g4f_ends(base, W); t.bloom[p.word] |= p.mask; }
+            for (uint32_t cm = rx & kGram4ChildBits; cm != 0; cm &= cm - 1) {
+                const G4Probe p = g4f_go(base, byte_of[__builtin_ctz(cm)], W);
+                t.bloom[p.word] |= p.mask;
+            }
+        }
+    }
+    t.filter_keys = static_cast<uint32_t>(std::min<uint64_t>(keys, 0xffffffffull));
+    return true;
 }
 
 }  // namespace daac

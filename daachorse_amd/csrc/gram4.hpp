@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "gram2.hpp"
+#include "gram4_filter.hpp"
 
 namespace daac {
 
@@ -41,6 +42,9 @@ struct Gram4Tables {
     std::vector<uint32_t> sdir;    // per 4 words
     std::vector<U32x2> dhit_c;
     std::vector<U32x4> dhit_t, drec_c, drec_t;
+    // the filter in front of rank + gather (gram4_filter.hpp; build_gram4_filter): empty when it was not built
+    std::vector<uint32_t> bloom;
+    uint32_t filter_keys = 0;      // GO + ENDS keys in it
 };
 
 constexpr uint32_t kGram4EndsBit = 30;   // hit records: the depth-(K+1) state ends a pattern
@@ -48,5 +52,9 @@ constexpr uint32_t kGram4ChildBits = 0x3fffffffu;
 
 // `g2` must be available.  Always succeeds for tables gram2.hpp accepts (<= 30 classes).
 void build_gram4_tables(const Gram2Tables &g2, Gram4Tables &out);
+// The Bloom array of gram4_filter.hpp over the keys the tables themselves name (M's continuation bits x the hit records' child maps and
+// "ends a pattern" bits), in at most `max_bytes` of LDS.  Sized at 16 bits per key when there is room; not built (false) below 2 bits per key
+// — it would pass nearly everything — or when a byte class stands for several bytes.
+bool build_gram4_filter(Gram4Tables &t, uint32_t max_bytes);
 
 }  // namespace daac

@@ -19,9 +19,11 @@
 // Roofline: HBM bytes of haystack (1 B read per byte); integer/bit work only, no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 #include "device_tables.hpp"
+#include "gram4_filter.hpp"
 
 namespace daac {
 
@@ -79,9 +81,13 @@ __device__ __forceinline__ void g4_reduce(unsigned long long cnt, unsigned long 
 
 // K = context length; Q = 16-byte chunks a lane takes per step (P = 16 Q positions); ARITH = classes by min(byte - lo, C - 1) (else the
 // 256-byte table in LDS); DIR = 0: one u16 directory entry per M word, 1 / 2: one u16 / u32 entry per four words; TAIL = tail records
-// from the hit record on and a second pending stage (text made of dictionary words)
-template <int K, int Q, bool ARITH, int DIR, bool TAIL>
+// from the hit record on and a second pending stage (text made of dictionary words); FILT = a batch of hits goes through the LDS
+// filter of gram4_filter.hpp first and only what passes — collected 64 at a time — is ranked and asks the L2 for its record (round 6;
+// coarse directory, plain records: text made of dictionary words passes the filter anyway and keeps the TAIL body)
+template <int K, int Q, bool ARITH, int DIR, bool TAIL, bool FILT>
 __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a, const Gram4Lds &L, char *smem) {
+    static_assert(!(FILT && TAIL), "the filter runs in front of the plain records");
+    static_assert(!(FILT && DIR == 0), "the filter's Bloom array lies where the per-word directory would");
     constexpr int P = 16 * Q;
     constexpr int GS = 8;
     constexpr uint32_t SB = 64u * P;          // bytes a wave takes per step
@@ -114,7 +120,12 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
     // bytes behind the hit}; TAIL: {position, state | class << 27, text bytes from position + 2 on, three more | how many << 24}
     const uint64_t slab_index = (static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg) * a.wq_slab;
     uint4 *__restrict__ slab4 = reinterpret_cast<uint4 *>(a.wq) + slab_index;
-    uint32_t wq_n = 0, slab_hi = 0;  // wave-uniform
+    // Positions in the queues, the pending stages and the slab are 32-bit offsets from `epoch_base`, a multiple of 2 GiB: a region (a power
+    // of two of at most 1 GiB) lies inside one epoch, an offset stays below 2^31 + the longest pattern however far a walker moves on, and
+    // the slab is emptied before the epoch changes.  (Until round 6 the epoch was 4 GiB and the offset the position's low word: a walker
+    // that walked across a multiple of 4 GiB wrapped to 0 and read its text 4 GiB too early.)
+    uint32_t wq_n = 0, slab_hi = 0;  // wave-uniform; slab_hi = epoch_base >> 31
+    uint64_t epoch_base = 0;
     const uint32_t drain_early = wave_in_wg * 64u;   // the waves of a workgroup drain at different fill levels (they fill at the same pace: all
                                                      // sixteen waiting on the same round trips at once left the CU idle)
 
@@ -184,7 +195,7 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
                 }
                 uint4 rr = uint4{0u, 0u, 0u, 0u};
                 if (live) rr = recs[state];  // {cmap, first_child, own_cnt, -} or a tail record
-                const uint64_t vn = ((static_cast<uint64_t>(slab_hi) << 32) | e.x) + 2;  // the state consumed the byte before vn
+                const uint64_t vn = epoch_base + e.x + 2;  // the state consumed the byte before vn
                 bool cont = false;
                 uint32_t next_state = 0;
                 if (rr.x >> 31) {   // the rest is one path (idle lanes: a zero record, nothing happens)
@@ -215,7 +226,7 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
 
     // ---- the hit queue: entry = LDS address of the hit byte in one of the wave's two text slots
     uint32_t q_head = 0, q_tail = 0;   // wave-uniform, free running; entries live at (index & (kRing4 - 1))
-    uint32_t posbias = 0;              // (low 32 bits of the virtual position of a byte) - (its LDS address), of the text in the slot
+    uint32_t posbias = 0;              // (virtual position of a byte - epoch_base) - (its LDS address), of the text in the slot
     uint32_t st_n = 0;                 // wave-uniform: lanes [0, st_n) hold an entry of the NEXT batch already taken out of queue and slot
     uint32_t pend_lo = 0;              // the bytes p-3 .. p of the next batch's entry (p = its hit byte); pend_pos / pend_t0 / pend_t1 go with it
     uint4 pend = uint4{0u, 0u, 0u, 0u};  // record read for the previous batch, not yet consumed; zero for idle lanes
@@ -228,6 +239,13 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
     uint32_t p2_pos = 0, p2_state = 0;   // position of the hit byte; the state asked for | class of the byte at position + 2 << 27
     uint32_t p2_t0 = 0, p2_t1 = 0;       // the seven bytes from position + 2 on
     bool p2_live = false, p2_any = false;        // per lane / wave-uniform
+    // FILT: what has passed the filter waits in lanes [0, sb_n) — position, the four bytes up to the hit byte, the four behind it — until 64
+    // are together; the batch whose records are in flight then has its position and text in fp_pos / fp_t0 (pend_* belong to the batch
+    // that is going through the filter)
+    uint32_t sb_n = 0;                 // wave-uniform
+    uint32_t sb_pos = 0, sb_lo = 0, sb_t0 = 0;
+    uint32_t fp_pos = 0, fp_t0 = 0;
+    const uint32_t offB = L.off_b, bloomW = g.bloom_words;
     auto push_walker = [&](bool go, const uint4 &entry) {
         const unsigned long long m = __ballot(go);
         if (m != 0) {
@@ -269,6 +287,12 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
         if (!pend_valid) return;
         pend_valid = false;
         const uint4 r = pend;
+        if (FILT) {
+            const uint32_t k1 = cls_of(fp_t0 & 0xffu);
+            cnt32 += (r.x >> kGram4EndsBitDev) & 1u;
+            push_walker(__builtin_amdgcn_ubfe(r.x, k1, 1) != 0, uint4{fp_pos, r.x, r.y, fp_t0});
+            return;
+        }
         const uint32_t k1 = cls_of(pend_t0 & 0xffu);
         if (!TAIL) {
             cnt32 += (r.x >> kGram4EndsBitDev) & 1u;
@@ -316,42 +340,85 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
         }
         q_head += cnt;
     };
+    // rank of the hit whose bytes p-3 .. p are x_lo -> its record asked for (into `pend`)
+    auto rank_and_ask = [&](uint32_t x_lo) {
+        const uint32_t c1 = cls_of((x_lo >> 8) & 0xffu), c2 = cls_of((x_lo >> 16) & 0xffu), d = cls_of(x_lo >> 24);
+        uint32_t idx = __umul24(c1, C) + c2;
+        if (K == 3) idx = __umul24(cls_of(x_lo & 0xffu), C * C) + idx;
+        // rank of continuation bit d of that M word among all set bits = offset of the depth-(K+1) state
+        const uint32_t am = (idx << 2) + offM;
+        const uint32_t own = lds_u32(am);
+        uint32_t rank;
+        if (DIR == 0) {
+            const uint32_t base = *reinterpret_cast<lds4_cu16 *>(static_cast<uintptr_t>((idx << 1) + offS));
+            rank = base + __popc(own & below(d));
+        } else {
+            const uint32_t grp = offM + ((idx & ~3u) << 2);
+            const uint32_t qx = lds_u32(grp), qy = lds_u32(grp + 4u), qz = lds_u32(grp + 8u);
+            const uint32_t sub = idx & 3u;
+            const uint32_t base = DIR == 1 ? *reinterpret_cast<lds4_cu16 *>(static_cast<uintptr_t>(offS + ((idx >> 2) << 1)))
+                                           : *reinterpret_cast<lds4_cu32 *>(static_cast<uintptr_t>(offS + ((idx >> 2) << 2)));
+            uint32_t under = __popc(own & below(d));
+            under += sub > 0 ? __popc(qx & 0x3fffffffu) : 0u;
+            under += sub > 1 ? __popc(qy & 0x3fffffffu) : 0u;
+            under += sub > 2 ? __popc(qz & 0x3fffffffu) : 0u;
+            rank = base + under;
+        }
+        if (TAIL) {
+            pend = g.dhit_t[rank];
+        } else {
+            const uint2 h = g.dhit_c[rank];
+            pend = uint4{h.x, h.y, 0u, 0u};
+        }
+    };
+    // FILT, second stage: the n <= 64 survivors in lanes [0, n) of sb_* are ranked and ask for their records
+    auto survivors_ask = [&](uint32_t n) {
+        consume_pending();
+        pend = uint4{0u, 0u, 0u, 0u};
+        if (lane < n) rank_and_ask(sb_lo);
+        fp_pos = sb_pos;
+        fp_t0 = lane < n ? sb_t0 : 0u;   // (an idle lane: nothing of it may look like a branch that goes on)
+        pend_valid = true;
+    };
     auto process_batch = [&](uint32_t n) {  // n <= 64 entries: the st_n already taken out + the head of the queue
         __builtin_amdgcn_s_setprio(2);
+        if (FILT) {
+            derive(st_n, n - st_n);
+            st_n = 0;
+            // first stage: the two probes of gram4_filter.hpp on the raw bytes p-K .. p and p + 1
+            const uint32_t fb = g4f_base(K == 3 ? pend_lo : pend_lo >> 8);
+            const G4Probe pg = g4f_go(fb, pend_t0 & 0xffu, bloomW), pe = g4f_ends(fb, bloomW);
+            const uint32_t wg = lds_u32(offB + (pg.word << 2)), we = lds_u32(offB + (pe.word << 2));
+            const bool pass = lane < n && ((wg & pg.mask) == pg.mask || (we & pe.mask) == pe.mask);
+            const unsigned long long pm = __ballot(pass);
+            if (pm != 0) {
+                // survivors move to lanes sb_n, sb_n + 1, .. (mod 64) — one forward permute per word, the others fill the lanes in between —
+                const uint32_t s = static_cast<uint32_t>(__popcll(pm));
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0));
+                const uint32_t tgt = ((pass ? sb_n + r : sb_n + s + lane - r) & 63u) << 2;
+                const uint32_t r_pos = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>(tgt), static_cast<int>(pend_pos)));
+                const uint32_t r_lo = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>(tgt), static_cast<int>(pend_lo)));
+                const uint32_t r_t0 = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>(tgt), static_cast<int>(pend_t0)));
+                const bool mine = lane - sb_n < s;   // lanes [sb_n, sb_n + s) below 64: they join the waiting ones
+                sb_pos = mine ? r_pos : sb_pos;
+                sb_lo = mine ? r_lo : sb_lo;
+                sb_t0 = mine ? r_t0 : sb_t0;
+                if (sb_n + s >= 64u) {   // 64 together: ranked and asked for; what went beyond lane 63 arrived in lanes 0 .. and waits on
+                    survivors_ask(64u);
+                    sb_pos = r_pos; sb_lo = r_lo; sb_t0 = r_t0;
+                    sb_n = sb_n + s - 64u;
+                } else {
+                    sb_n += s;
+                }
+            }
+            return;
+        }
         consume_pending();
         derive(st_n, n - st_n);
         st_n = 0;
         pend = uint4{0u, 0u, 0u, 0u};
         if (lane < n) {
-            const uint32_t x_lo = pend_lo;
-            const uint32_t c1 = cls_of((x_lo >> 8) & 0xffu), c2 = cls_of((x_lo >> 16) & 0xffu), d = cls_of(x_lo >> 24);
-            uint32_t idx = __umul24(c1, C) + c2;
-            if (K == 3) idx = __umul24(cls_of(x_lo & 0xffu), C * C) + idx;
-            // rank of continuation bit d of that M word among all set bits = offset of the depth-(K+1) state
-            const uint32_t am = (idx << 2) + offM;
-            const uint32_t own = lds_u32(am);
-            uint32_t rank;
-            if (DIR == 0) {
-                const uint32_t base = *reinterpret_cast<lds4_cu16 *>(static_cast<uintptr_t>((idx << 1) + offS));
-                rank = base + __popc(own & below(d));
-            } else {
-                const uint32_t grp = offM + ((idx & ~3u) << 2);
-                const uint32_t qx = lds_u32(grp), qy = lds_u32(grp + 4u), qz = lds_u32(grp + 8u);
-                const uint32_t sub = idx & 3u;
-                const uint32_t base = DIR == 1 ? *reinterpret_cast<lds4_cu16 *>(static_cast<uintptr_t>(offS + ((idx >> 2) << 1)))
-                                               : *reinterpret_cast<lds4_cu32 *>(static_cast<uintptr_t>(offS + ((idx >> 2) << 2)));
-                uint32_t under = __popc(own & below(d));
-                under += sub > 0 ? __popc(qx & 0x3fffffffu) : 0u;
-                under += sub > 1 ? __popc(qy & 0x3fffffffu) : 0u;
-                under += sub > 2 ? __popc(qz & 0x3fffffffu) : 0u;
-                rank = base + under;
-            }
-            if (TAIL) {
-                pend = g.dhit_t[rank];
-            } else {
-                const uint2 h = g.dhit_c[rank];
-                pend = uint4{h.x, h.y, 0u, 0u};
-            }
+            rank_and_ask(pend_lo);
         } else {
             pend_t0 = 0;   // (an idle lane: nothing of it may look like a branch that goes on)
             pend_t1 = 0;
@@ -361,8 +428,9 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
 
     uint64_t region = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg;
     while (region < a.nregions) {
-      slab_hi = static_cast<uint32_t>((region * a.region_bytes) >> 32);
-      for (; region < a.nregions && static_cast<uint32_t>((region * a.region_bytes) >> 32) == slab_hi; region += nwaves) {
+      slab_hi = static_cast<uint32_t>((region * a.region_bytes) >> 31);
+      epoch_base = static_cast<uint64_t>(slab_hi) << 31;
+      for (; region < a.nregions && static_cast<uint32_t>((region * a.region_bytes) >> 31) == slab_hi; region += nwaves) {
         const uint64_t rbase = region * a.region_bytes;
         const uint64_t rend = rbase + a.region_bytes < a.vlen ? rbase + a.region_bytes : a.vlen;
         // classes of the K bytes before the region, oldest in the low byte; the four raw bytes before it
@@ -413,7 +481,7 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
             }
             const uint32_t slot = tb;                             // wave-uniform
             const uint32_t my_text = slot + 16u + lane * P;       // LDS address of this lane's first byte
-            posbias = static_cast<uint32_t>(sb) - (slot + 16u);
+            posbias = static_cast<uint32_t>(sb - epoch_base) - (slot + 16u);
 #pragma unroll
             for (int q = 0; q < Q; ++q)
                 *reinterpret_cast<lds4_u32x4 *>(static_cast<uintptr_t>(my_text + 16u * q)) = g4_u32x4_t{cur[q].x, cur[q].y, cur[q].z, cur[q].w};
@@ -497,6 +565,7 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
         cnt32 = 0;
       }
       if (st_n + q_tail - q_head != 0) process_batch(st_n + q_tail - q_head);
+      if (FILT && sb_n != 0) { survivors_ask(sb_n); sb_n = 0; }
       consume_pending();
       finish_second();
       drain();
@@ -506,15 +575,16 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
     g4_reduce(tot_cnt, reinterpret_cast<unsigned long long *>(smem), a.result);
 }
 
-// One kernel, both variants: the workgroup stages the tables, decides TAIL (a.sel_want: 0 / 1, or 2 = by its own density probe)
-// and runs the body compiled for that choice (gram3_kernels.hip: two launches with a probe kernel in front cost 60-90 us per scan,
-// a run-time TAIL flag inside one body 10 % of the kernel).
-template <int K, int Q, bool ARITH, int DIR, int TPB>
+// One kernel, the variants inside: the workgroup stages M, decides TAIL (a.sel_want: 0 / 1, or 2 = by its own density probe), stages the
+// directory that goes with the choice and runs the body compiled for it (gram3_kernels.hip: two launches with a probe kernel in front
+// cost 60-90 us per scan, a run-time TAIL flag inside one body 10 % of the kernel).  FILT: a workgroup whose text is not made of
+// dictionary words takes [coarse directory | Bloom array] in the place of the per-word directory and runs the body with the filter.
+template <int K, int Q, bool ARITH, int DIR, int TPB, bool FILT>
 __global__ __launch_bounds__(TPB) void gram4_kernel(const Gram4Dev g, const GramArgs a, const Gram4Lds L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DIRC = DIR == 0 ? 1 : DIR;   // the coarse directory that goes with the filter (a per-word directory exists only beside u16 entries)
     if (!ARITH) g4_copy(smem + L.off_cls, g.cls, 256);
     g4_copy(smem + L.off_m, g.m, g.m_bytes);
-    g4_copy(smem + L.off_s, DIR == 0 ? static_cast<const void *>(g.rfull) : g.sdir, L.s_bytes);
     uint32_t *votes = reinterpret_cast<uint32_t *>(smem + L.off_wave);  // (the first wave's text slot: not in use yet)
     if (threadIdx.x == 0) *votes = 0;
     __syncthreads();
@@ -539,13 +609,10 @@ __global__ __launch_bounds__(TPB) void gram4_kernel(const Gram4Dev g, const Gram
             const uint32_t ctx = K == 3 ? (c0 * g.C + c1) * g.C + c2 : c1 * g.C + c2;
             const uint32_t w = m[ctx];
             if ((w >> d) & 1u & (d < OTH ? 1u : 0u)) {
+                // (the directory is not staged yet — which one depends on this probe —: its entry comes from device memory)
                 uint32_t rank = __popc(w & ((1u << d) - 1u));
-                if (DIR == 0) {
-                    rank += reinterpret_cast<const uint16_t *>(smem + L.off_s)[ctx];
-                } else {
-                    for (uint32_t j = ctx & ~3u; j < ctx; ++j) rank += __popc(m[j] & 0x3fffffffu);
-                    rank += DIR == 1 ? reinterpret_cast<const uint16_t *>(smem + L.off_s)[ctx >> 2] : reinterpret_cast<const uint32_t *>(smem + L.off_s)[ctx >> 2];
-                }
+                for (uint32_t j = ctx & ~3u; j < ctx; ++j) rank += __popc(m[j] & 0x3fffffffu);
+                rank += g.s16 ? reinterpret_cast<const uint16_t *>(g.sdir)[ctx >> 2] : reinterpret_cast<const uint32_t *>(g.sdir)[ctx >> 2];
                 const uint2 r = g.dhit_c[rank];
                 go = ((r.x >> k1) & 1u) != 0;
             }
@@ -556,35 +623,51 @@ __global__ __launch_bounds__(TPB) void gram4_kernel(const Gram4Dev g, const Gram
         tail = *votes * 100u > static_cast<uint32_t>(TPB) * kProbePercent4;
         __syncthreads();
     }
-    if (tail) gram4_body<K, Q, ARITH, DIR, true>(g, a, L, smem);
-    else gram4_body<K, Q, ARITH, DIR, false>(g, a, L, smem);
+    if (FILT && !tail) {
+        g4_copy(smem + L.off_s, g.sdir, L.s_bytes_f);
+        g4_copy(smem + L.off_b, g.bloom, g.bloom_words * 4u);
+    } else {
+        g4_copy(smem + L.off_s, DIR == 0 ? static_cast<const void *>(g.rfull) : g.sdir, L.s_bytes);
+    }
+    __syncthreads();
+    if (tail) gram4_body<K, Q, ARITH, DIR, true, false>(g, a, L, smem);
+    else if constexpr (FILT) gram4_body<K, Q, ARITH, DIRC, false, true>(g, a, L, smem);
+    else gram4_body<K, Q, ARITH, DIR, false, false>(g, a, L, smem);
 }
 
-template <int K, int Q, bool ARITH, int DIR, int TPB>
+template <int K, int Q, bool ARITH, int DIR, int TPB, bool FILT>
 static hipError_t launch4_inst(const Gram4Dev &dev, const GramArgs &a, const Gram4Lds &L, uint32_t blocks, hipStream_t stream) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram4_kernel<K, Q, ARITH, DIR, TPB>),
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gram4_kernel<K, Q, ARITH, DIR, TPB, FILT>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(L.lds_bytes));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((gram4_kernel<K, Q, ARITH, DIR, TPB>), dim3(blocks), dim3(TPB), L.lds_bytes, stream, dev, a, L);
+    hipLaunchKernelGGL((gram4_kernel<K, Q, ARITH, DIR, TPB, FILT>), dim3(blocks), dim3(TPB), L.lds_bytes, stream, dev, a, L);
     return hipGetLastError();
+}
+template <int K, int Q, int TPB, bool ARITH>
+static hipError_t launch4_d(const Gram4Dev &dev, const GramArgs &a, const Gram4Lds &L, uint32_t blocks, hipStream_t stream) {
+    if (L.filter) {
+        if (L.dir == 0) return launch4_inst<K, Q, ARITH, 0, TPB, true>(dev, a, L, blocks, stream);
+        if (L.dir == 1) return launch4_inst<K, Q, ARITH, 1, TPB, true>(dev, a, L, blocks, stream);
+        return launch4_inst<K, Q, ARITH, 2, TPB, true>(dev, a, L, blocks, stream);
+    }
+    if (L.dir == 0) return launch4_inst<K, Q, ARITH, 0, TPB, false>(dev, a, L, blocks, stream);
+    if (L.dir == 1) return launch4_inst<K, Q, ARITH, 1, TPB, false>(dev, a, L, blocks, stream);
+    return launch4_inst<K, Q, ARITH, 2, TPB, false>(dev, a, L, blocks, stream);
 }
 template <int K, int Q, int TPB>
 static hipError_t launch4_k(const Gram4Dev &dev, const GramArgs &a, const Gram4Lds &L, uint32_t blocks, hipStream_t stream) {
-    if (L.arith) {
-        if (L.dir == 0) return launch4_inst<K, Q, true, 0, TPB>(dev, a, L, blocks, stream);
-        if (L.dir == 1) return launch4_inst<K, Q, true, 1, TPB>(dev, a, L, blocks, stream);
-        return launch4_inst<K, Q, true, 2, TPB>(dev, a, L, blocks, stream);
-    }
-    if (L.dir == 0) return launch4_inst<K, Q, false, 0, TPB>(dev, a, L, blocks, stream);
-    if (L.dir == 1) return launch4_inst<K, Q, false, 1, TPB>(dev, a, L, blocks, stream);
-    return launch4_inst<K, Q, false, 2, TPB>(dev, a, L, blocks, stream);
+    return L.arith ? launch4_d<K, Q, TPB, true>(dev, a, L, blocks, stream) : launch4_d<K, Q, TPB, false>(dev, a, L, blocks, stream);
 }
 
 // LDS plan of a gram4 launch of `waves` waves per workgroup with `ppl` positions per lane and step:
 // [hit queues | one text slot per wave | class table (256 B, when the classes are not arithmetic) | rank directory | M].
-// Returns false when the tables and the per-wave areas do not fit.
-bool gram4_plan(const Gram4Dev &dev, uint32_t ppl, uint32_t waves, bool want_rfull, bool want_arith, uint32_t lds_limit, Gram4Lds &L) {
+// `rfull`: the per-word directory (false: one entry per four words).  `want_filter`: the directory's place is made large enough for
+// [coarse directory | Bloom array] as well, for the workgroups that run the body with the filter (gram4_filter.hpp) — not taken when the
+// array was not built or does not fit this shape.  Returns false when the directory asked for is not there or the tables and the
+// per-wave areas do not fit — it never hands back another shape than the one asked for.
+bool gram4_plan(const Gram4Dev &dev, uint32_t ppl, uint32_t waves, bool rfull, bool want_arith, bool want_filter, uint32_t lds_limit, Gram4Lds &L) {
     L = Gram4Lds{};
+    if (rfull && dev.rfull == nullptr) return false;
     const uint32_t slot = 64u * ppl + 32u;
     L.wave_stride = slot;
     L.off_wave = waves * kRing4 * 4u;      // the hit queues sit at 0
@@ -593,16 +676,25 @@ bool gram4_plan(const Gram4Dev &dev, uint32_t ppl, uint32_t waves, bool want_rfu
     const uint32_t per_wg = L.off_wave + waves * L.wave_stride;
     L.off_cls = per_wg;
     L.off_s = per_wg + (L.arith ? 0u : 256u);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        const bool rfull = attempt == 0 && want_rfull && dev.rfull != nullptr;
-        if (attempt == 0 && !rfull) continue;
-        L.dir = rfull ? 0u : (dev.s16 ? 1u : 2u);
-        L.s_bytes = rfull ? dev.rfull_bytes : dev.s_bytes;
-        L.off_m = L.off_s + L.s_bytes;
-        L.lds_bytes = L.off_m + dev.m_bytes;
-        if (L.lds_bytes <= lds_limit) return true;
+    L.dir = rfull ? 0u : (dev.s16 ? 1u : 2u);
+    L.s_bytes = rfull ? dev.rfull_bytes : dev.s_bytes;
+    uint32_t region = L.s_bytes;
+    if (want_filter && dev.bloom != nullptr) {
+        const uint32_t with = dev.s_bytes + dev.bloom_words * 4u;
+        if (L.off_s + std::max(region, with) + dev.m_bytes <= lds_limit) {
+            L.filter = 1u;
+            L.s_bytes_f = dev.s_bytes;
+            L.off_b = L.off_s + dev.s_bytes;
+            region = std::max(region, with);
+        }
     }
-    return false;
+    L.off_m = L.off_s + region;
+    L.lds_bytes = L.off_m + dev.m_bytes;
+    return L.lds_bytes <= lds_limit;
+}
+uint32_t gram4_filter_room(uint32_t m_bytes, uint32_t sdir_bytes, bool arith, uint32_t lds_limit) {
+    const uint32_t fixed = 16u * kRing4 * 4u + 16u * (64u * 32u + 32u) + (arith ? 0u : 256u) + sdir_bytes + m_bytes;
+    return fixed < lds_limit ? (lds_limit - fixed) & ~15u : 0u;
 }
 
 // a.sel_want: 0 = plain records, 1 = tail records from the hit record on, 2 = every workgroup decides by its density probe

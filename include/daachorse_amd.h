@@ -34,8 +34,12 @@ extern "C" {
  *   4 (round 4): daac_iter_next_batch; the lazy iterator runs its windows ahead of the consumer on a worker thread; DAAC_ENGINE_JUMP /
  *                DAAC_KERNEL_JUMP are gone (the experiment is in the history: commit c51e1c3 and before, tools/experiments/jump).
  *   5 (round 5): daac_scan_count_multi (one haystack sharded across the devices of a node); daac_pma_set_option (options per handle);
- *                daac_pma_trim; options gram4_arith, gram_tail. */
-#define DAAC_ABI_VERSION 5
+ *                daac_pma_trim; options gram4_arith, gram_tail.
+ *   6 (round 6): daac_stream_feed_compact; daac_scan_count_multi runs its shards on one persistent worker thread + stream per device;
+ *                daac_pma_set_option answers 6 for an option that is read at upload once the handle has tables on a device;
+ *                gram_version 3 is an alias of 4; the options emit_stagger, emit_v3_lds and the four names of engines that left the
+ *                library (restart_tier, emit_tiles, emit_rec_cap, emit_version) are gone. */
+#define DAAC_ABI_VERSION 6
 uint32_t daac_abi_version(void);
 
 /* src/errors.rs:10-22 (first four), plus the panics / extras of this boundary */
@@ -172,6 +176,10 @@ void daac_free(void *p);
 /* daac_engine that served this thread's most recent scan (AUTO resolves to GRAM / TIERED / DARRAY per request:
  * e.g. GRAM declines ranges of 32 GiB and more and automata whose tables do not fit LDS). */
 int daac_last_engine(void);
+/* The kernel family — and, for the `.count()` kernel, the launch shape the options in force gave it ("gram4 ppl=32 dir=0 waves=16 arith=1 filter=1
+ * tail=auto") — that served the calling thread's last daac_scan_count* call (daac_scan_count_multi: shard 0's, as run by its device's worker).
+ * ABI 6; a diagnostic: the text is not a contract. */
+const char *daac_last_kernel(void);
 
 /* ---- construction / (de)serialisation ------------------------------------------------------ */
 
@@ -339,6 +347,12 @@ void daac_iter_close(daac_iter *it);
 typedef struct daac_stream daac_stream;
 daac_status daac_stream_open(daac_pma *pma, int mode, int engine, void *stream, daac_stream **out);
 daac_status daac_stream_feed(daac_stream *s, const uint8_t *chunk, size_t len, int chunk_is_device, daac_matches **out);
+/* The same feed with the matches as 8-byte tuples (ABI 6; the form daac_iter_next_batch8 hands out): `*batch` points at `*n` tuples in a
+ * page-locked block of the stream object, valid until the next feed or close;  end = *end_base + (t.end_len & ((1 << *end_bits) - 1)),
+ * length = t.end_len >> *end_bits.  A third of daac_match's bytes over PCIe and nothing to allocate or free per feed.  A chunk (plus the
+ * bytes kept of earlier ones) must stay below 2^end_bits bytes (end_bits = 32 - the bits of the longest pattern's length): status 6 otherwise. */
+daac_status daac_stream_feed_compact(daac_stream *s, const uint8_t *chunk, size_t len, int chunk_is_device, const daac_match8 **batch,
+                                     size_t *n, uint64_t *end_base, uint32_t *end_bits);
 void daac_stream_close(daac_stream *s);
 
 /* ---- tuning knobs (optional) ----------------------------------------------------------------- */

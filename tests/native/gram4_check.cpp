@@ -1,8 +1,10 @@
 // Host-logic test for the renumbered `.count()` tables (gram4.hpp; no GPU needed): evaluates the count of the
 // find_overlapping stream from the tables, position by position with the rules of gram4_kernels.hip — both record
 // sets (plain / tail records from the hit record on), both rank directories, the arithmetic class map against the
-// class table — and compares with the literal automaton walk on the original double array.
-//   usage: gram4_check <blob> <lds_budget> <haystack-file>
+// class table — and compares with the literal automaton walk on the original double array.  Round 6: the filter in front of rank +
+// gather (gram4_filter.hpp) — every hit of the text that ends a pattern or goes on must pass (no false negatives), and the count with
+// the hits that do not pass dropped must be the same; prints how many hits pass and how many of those are false positives.
+//   usage: gram4_check <blob> <lds_budget> <haystack-file> [filter-bytes]
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -80,7 +82,12 @@ int main(int argc, char **argv) {
         }
         return c;
     };
-    uint64_t c_plain = 0, c_tail = 0, hits = 0;
+    // the filter, sized as the upload sizes it (or by the fourth argument)
+    const uint32_t fbytes = argc > 4 ? static_cast<uint32_t>(std::atoi(argv[4])) : 33000u;
+    const bool have_filter = build_gram4_filter(g, fbytes);
+    const uint32_t W = static_cast<uint32_t>(g.bloom.size());
+    auto raw = [&](long long pos) -> uint32_t { return (pos >= 0 && pos < n) ? hay[pos] : g.unused_byte; };
+    uint64_t c_plain = 0, c_tail = 0, hits = 0, c_filt = 0, passed = 0, useful = 0;
     for (long long pz = 0; pz < n; ++pz) {
         const uint32_t word = g.m[ctx_ending_at(pz)];
         c_plain += word >> 30;
@@ -99,7 +106,20 @@ int main(int argc, char **argv) {
             const U32x2 r = g.dhit_c[rank];
             if (r.x >> 31) { std::printf("MISMATCH dhit_c flag\n"); return 1; }
             c_plain += (r.x >> kGram4EndsBit) & 1u;
-            if ((r.x >> k1) & 1u) c_plain += walk(g.drec_c, r.y + __builtin_popcount(r.x & ((1u << k1) - 1u)), pz + 2);
+            uint64_t below = 0;
+            if ((r.x >> k1) & 1u) below = walk(g.drec_c, r.y + __builtin_popcount(r.x & ((1u << k1) - 1u)), pz + 2);
+            c_plain += below;
+            if (have_filter) {   // gram4_body<.., FILT = true>: the probes on the raw bytes pz-K .. pz and pz+1
+                uint32_t x = 0;
+                for (uint32_t i = 0; i <= K; ++i) x |= raw(pz - K + i) << (8 * i);
+                const uint32_t fb = g4f_base(x);
+                const G4Probe pg = g4f_go(fb, raw(pz + 1), W), pe = g4f_ends(fb, W);
+                const bool pass = (g.bloom[pg.word] & pg.mask) == pg.mask || (g.bloom[pe.word] & pe.mask) == pe.mask;
+                const bool is_useful = ((r.x >> kGram4EndsBit) & 1u) || ((r.x >> k1) & 1u);
+                if (is_useful && !pass) { std::printf("MISMATCH filter: a hit that ends a pattern or goes on does not pass (position %lld)\n", pz); return 1; }
+                if (pass) { ++passed; c_filt += ((r.x >> kGram4EndsBit) & 1u) + below; }
+                if (is_useful) ++useful;
+            }
         }
         {   // tail records from the hit record on
             const U32x4 r = g.dhit_t[rank];
@@ -115,6 +135,12 @@ int main(int argc, char **argv) {
         std::printf("MISMATCH count plain %llu tail %llu want %llu\n", (unsigned long long)c_plain, (unsigned long long)c_tail, (unsigned long long)rc);
         return 1;
     }
-    std::printf("OK K=%u C=%u arith=%d lo=%u count=%llu hits=%llu\n", K, C, g.arith ? 1 : 0, g.lo, (unsigned long long)rc, (unsigned long long)hits);
+    if (have_filter) {
+        uint64_t shorts = 0;
+        for (long long pz = 0; pz < n; ++pz) shorts += g.m[ctx_ending_at(pz)] >> 30;
+        if (shorts + c_filt != rc) { std::printf("MISMATCH count through the filter %llu want %llu\n", (unsigned long long)(shorts + c_filt), (unsigned long long)rc); return 1; }
+    }
+    std::printf("OK K=%u C=%u arith=%d lo=%u count=%llu hits=%llu filter=%d words=%u keys=%u passed=%llu useful=%llu\n", K, C, g.arith ? 1 : 0, g.lo, (unsigned long long)rc,
+                (unsigned long long)hits, have_filter ? 1 : 0, W, g.filter_keys, (unsigned long long)passed, (unsigned long long)useful);
     return 0;
 }

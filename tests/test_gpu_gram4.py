@@ -12,8 +12,10 @@ pytestmark = pytest.mark.gpu
 import daachorse_amd as da
 from daachorse_amd import Engine, ScanMode, synth
 
-# (positions per lane, tail records, per-word directory, threads per workgroup, arithmetic classes)
-VARIANTS = [(16, 0, 1, 1024, 1), (16, 1, 1, 1024, 1), (32, 0, 1, 1024, 1), (32, 1, 0, 512, 1), (16, 0, 0, 1024, 0), (32, 0, 1, 512, 0), (16, 1, 1, 512, 0), (32, 1, 0, 1024, 1)]
+# (positions per lane, tail records (-1: the workgroups' own probe), per-word directory, threads per workgroup, arithmetic classes, the filter in
+# front of rank + gather (round 6; it serves the plain records only: with tail = 1 the option is moot))
+VARIANTS = [(16, 0, 1, 1024, 1, 1), (16, 1, 1, 1024, 1, 1), (32, 0, 1, 1024, 1, 1), (32, 1, 0, 512, 1, 0), (16, 0, 0, 1024, 0, 1), (32, 0, 1, 512, 0, 1), (16, 1, 1, 512, 0, 0),
+            (32, 1, 0, 1024, 1, 1), (32, 0, 1, 1024, 1, 0), (16, 0, 0, 512, 1, 0), (32, -1, 1, 1024, 1, 1), (32, 0, 0, 1024, 0, 1)]
 
 
 def _pma(patterns):
@@ -23,12 +25,16 @@ def _pma(patterns):
     return o, p
 
 
-def _count3(p, hay, ppl, wtext, rfull, threads=1024, arith=1, **kw):
+def _count3(p, hay, ppl, wtext, rfull, threads=1024, arith=1, filt=1, **kw):
     """the launch shape is the HANDLE's (daac_pma_set_option): nothing process-wide is touched, nothing to reset"""
-    for k, v in (("gram_version", 4), ("gram4_arith", arith), ("gram_ppl", ppl), ("gram3_tail", wtext), ("gram2_rfull", rfull), ("threads", threads)):
+    for k, v in (("gram_version", 4), ("gram4_arith", arith), ("gram_ppl", ppl), ("gram3_tail", wtext), ("gram2_rfull", rfull), ("threads", threads), ("gram4_filter", filt)):
         p.set_option(k, v)
     got = p.count(ScanMode.FindOverlapping, hay, engine=Engine.Gram, **kw)
     assert da.last_engine() == int(Engine.Gram)
+    lk = da.last_kernel()
+    assert lk.startswith(f"gram4 ppl={ppl} ") and f"waves={threads // 64}" in lk, lk
+    if filt == 0:
+        assert "filter=0" in lk, lk
     return got
 
 
@@ -53,8 +59,8 @@ def test_gram4_against_the_oracle():
             q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
             q.set_option("gram_lds_budget", budget)   # (read at upload)
             assert q.upload().info().gram2_available
-            for ppl, wtext, rfull, nb, ar in VARIANTS:
-                assert _count3(q, dev, ppl, wtext, rfull, nb, ar) == want, (len(pats), budget, ppl, wtext, rfull, nb, ar)
+            for ppl, wtext, rfull, nb, ar, fl in VARIANTS:
+                assert _count3(q, dev, ppl, wtext, rfull, nb, ar, fl) == want, (len(pats), budget, ppl, wtext, rfull, nb, ar, fl)
             cut = int(rng.integers(1, len(hay)))
             assert _count3(q, dev[:cut], 16, 0, 1) + _count3(q, dev, 16, 0, 1, begin=cut) == want, cut
             assert _count3(q, dev[:cut], 32, 1, 1) + _count3(q, dev, 32, 1, 1, begin=cut) == want, cut
@@ -76,8 +82,8 @@ def test_gram4_short_and_ragged_haystacks():
         off = int(rng.integers(0, 32))
         h = base[off:off + n]
         want = o.overlapping_count(h, threads=1)[0] if n else 0
-        for ppl, wtext, rfull, nb, ar in VARIANTS[:5]:
-            assert _count3(p, buf[off:off + n], ppl, wtext, rfull, nb, ar) == want, (n, off, ppl, wtext, ar)
+        for ppl, wtext, rfull, nb, ar, fl in VARIANTS[:5] + VARIANTS[8:]:
+            assert _count3(p, buf[off:off + n], ppl, wtext, rfull, nb, ar, fl) == want, (n, off, ppl, wtext, ar, fl)
 
 
 def test_gram4_every_position_hits_and_continues():
@@ -92,14 +98,14 @@ def test_gram4_every_position_hits_and_continues():
         p.upload()
         dev = torch.from_numpy(hay).cuda()[13:]
         want = o.overlapping_count(dev.cpu().numpy(), threads=8)[0]
-        for ppl, wtext, rfull, nb, ar in VARIANTS:
-            assert _count3(p, dev, ppl, wtext, rfull, nb, ar) == want, (budget, ppl, wtext, rfull, nb, ar)
+        for ppl, wtext, rfull, nb, ar, fl in VARIANTS:
+            assert _count3(p, dev, ppl, wtext, rfull, nb, ar, fl) == want, (budget, ppl, wtext, rfull, nb, ar, fl)
     # "aaaa...": every prefix a pattern, every position a hit with a long walk behind it
     o, p = _pma([b"a" * k for k in range(1, 40)])
     hay = np.frombuffer(b"a" * 100_000 + b"b" + b"a" * 5000, dtype=np.uint8)
     want = o.overlapping_count(hay, threads=4)[0]
-    for ppl, wtext, rfull, nb, ar in VARIANTS:
-        assert _count3(p, torch.from_numpy(hay.copy()).cuda(), ppl, wtext, rfull, nb, ar) == want
+    for ppl, wtext, rfull, nb, ar, fl in VARIANTS:
+        assert _count3(p, torch.from_numpy(hay.copy()).cuda(), ppl, wtext, rfull, nb, ar, fl) == want
 
 
 def test_gram4_cfg3_agrees_with_gram2_and_oracle():
@@ -117,5 +123,40 @@ def test_gram4_cfg3_agrees_with_gram2_and_oracle():
         want = o.overlapping_count(dev.cpu().numpy(), threads=8)[0]
         p.set_option("gram_version", 2)
         assert p.count(ScanMode.FindOverlapping, dev, engine=Engine.Gram) == want
-        for ppl, wtext, rfull, nb, ar in VARIANTS:
-            assert _count3(p, dev, ppl, wtext, rfull, nb, ar) == want, (fill, ppl, wtext, rfull, nb, ar)
+        for ppl, wtext, rfull, nb, ar, fl in VARIANTS:
+            assert _count3(p, dev, ppl, wtext, rfull, nb, ar, fl) == want, (fill, ppl, wtext, rfull, nb, ar, fl)
+
+
+def test_gram4_walkers_across_2_and_4_gib():
+    """a walker that starts just below a multiple of 2 GiB / 4 GiB of the virtual position and walks across it (round-5 advisor: the slab kept
+    the low word of a walker's position, which wrapped at 4 GiB while the epoch's high word stayed): a haystack of 4 GiB + 32 MiB, blank
+    but for word soup — every position a hit, long walks — around both boundaries, with the dictionary's longest word laid across each
+    boundary at several offsets, two alignments of the first byte, both bodies of the kernel"""
+    import torch
+    pats = synth.patterns_cfg3()
+    longest = max(pats, key=len)
+    assert len(longest) >= 15
+    o, p = _pma(pats)
+    p.upload()
+    n = (4 << 30) + (32 << 20)
+    buf = torch.full((n + 16,), 0x20, dtype=torch.uint8, device="cuda")
+    w = 4 << 20
+    word = torch.from_numpy(np.frombuffer(longest, dtype=np.uint8).copy()).cuda()
+    checked_whole = False
+    for off in (0, 5):   # virtual position = index + (address & 15)
+        dev = buf[off:off + n]
+        for k in (2, 5, 9, 13):
+            want = 0
+            for b in (1 << 31, 1 << 32):
+                vb = b - off   # index of the byte whose virtual position is b
+                synth.device_wordsoup(dev[vb - w:vb + w], synth.SEEDS["cfg3_dense"] + k, pats, 20, noise_256=0)
+                dev[vb - k:vb - k + len(longest)] = word
+                dev[vb - k - 1] = 0x20
+                dev[vb - k + len(longest)] = 0x20
+                want += o.overlapping_count(dev[vb - w:vb + w].cpu().numpy(), threads=16)[0]
+            if not checked_whole:   # the blanks between the windows hold no match (' ' is no pattern byte): once against the whole haystack
+                assert o.overlapping_count(dev.cpu().numpy(), threads=16)[0] == want
+                checked_whole = True
+            assert want > 1_000_000
+            for ppl, tail, fl in ((32, 1, 1), (32, 0, 1), (32, 0, 0), (16, 1, 1), (32, -1, 1)):
+                assert _count3(p, dev, ppl, tail, 1, filt=fl) == want, (off, k, ppl, tail, fl)

@@ -857,6 +857,44 @@ def test_scan_count_multi_shards_on_one_device():
         with pytest.raises(da.DaachorseError) as ei:
             da.scan_count_multi(p, ScanMode.Find, [(0, dev, 0, 0)])
         assert ei.value.code == 6
+        with pytest.raises(da.DaachorseError) as ei:   # a halo that reaches in front of the haystack (halo > base): the re-basing would wrap
+            da.scan_count_multi(p, ScanMode.FindOverlapping, [(0, dev, 50, 10)])
+        assert ei.value.code == 1
+    # The HANDLE's options are in scope on every shard's worker thread (round-5 verdict: they were on the first shard only, the others ran with
+    # the process-wide values): a handle with its own launch shape for the `.count()` kernel, while the process-wide options say something
+    # else — daac_last_kernel() names the kernel and shape that served a shard, as its device's worker ran it.
+    o = orc.OraclePma.build(pats3)
+    q, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    q.upload()
+    hay = cases[0][1]
+    dev = torch.from_numpy(hay).cuda()
+    want = o.overlapping_count(hay, threads=8)[0]
+    cuts = [0, 700_001, 1_500_000, 2_222_222, len(hay)]
+    need = q.info().max_pattern_len - 1
+    shards = [(0, dev[b - min(b, need):e], min(b, need), b) for b, e in zip(cuts[:-1], cuts[1:])]
+    da.set_option("gram_ppl", 32)
+    da.set_option("gram_tail", 0)
+    try:
+        q.set_option("gram_version", 4).set_option("gram_ppl", 16).set_option("gram_tail", 1).set_option("threads", 512).set_option("gram2_rfull", 0).set_option("gram4_filter", 0)
+        assert da.scan_count_multi(q, ScanMode.FindOverlapping, shards, engine=Engine.Gram, checksum=False) == want
+        assert da.last_engine() == int(Engine.Gram)
+        for k in range(len(shards)):   # shard by shard: each goes through the device's worker
+            b, e = cuts[k], cuts[k + 1]
+            got = da.scan_count_multi(q, ScanMode.FindOverlapping, [shards[k]], engine=Engine.Gram, checksum=False)
+            assert got == q.count(ScanMode.FindOverlapping, dev[:e], engine=Engine.Gram, begin=b) and da.last_engine() == int(Engine.Gram), k
+            lk = da.last_kernel()
+            assert lk.startswith("gram4 ppl=16 dir=1 waves=8 ") and lk.endswith(" tail=1"), (k, lk)
+        for name in ("gram_ppl", "gram_tail", "threads", "gram2_rfull", "gram4_filter"):
+            q.set_option(name)
+        da.scan_count_multi(q, ScanMode.FindOverlapping, [shards[1]], engine=Engine.Gram, checksum=False)
+        lk = da.last_kernel()
+        assert lk.startswith("gram4 ppl=32 ") and "waves=16" in lk and lk.endswith(" tail=0"), lk   # (the process-wide values)
+    finally:
+        da.set_option("gram_ppl", 0)
+        da.set_option("gram_tail", -1)
+    with pytest.raises(da.DaachorseError) as ei:   # an option that is read at upload, set on a handle that has its tables already: said, not swallowed
+        q.set_option("gram_lds_budget", 64 * 1024)
+    assert ei.value.code == 6
 
 
 def test_trim_and_iterators_that_are_never_pulled():

@@ -17,11 +17,16 @@ def _sev(m):
     return [(int(x["start"]), int(x["end"]), int(x["value"])) for x in m]
 
 
-def _feed_all(stepper, raw, cuts):
+def _feed_all(stepper, raw, cuts, compact=False):
+    """compact: daac_stream_feed_compact (8-byte tuples in the stream's page-locked block, round 6) instead of daac_stream_feed"""
     got = []
     prev = 0
     for c in list(cuts) + [len(raw)]:
-        got += _sev(stepper.feed(raw[prev:c]))
+        if compact:
+            run, base, bits = stepper.feed_compact(raw[prev:c])
+            got += _sev(stepper.decode8(run, base, bits))
+        else:
+            got += _sev(stepper.feed(raw[prev:c]))
         prev = c
     return got
 
@@ -48,8 +53,9 @@ def test_golden_vectors_through_the_steppers(vectors):
         for flavour in ("bytewise", "charwise"):
             p = (da.DoubleArrayAhoCorasick if flavour == "bytewise" else da.CharwiseDoubleArrayAhoCorasick).new(case["patterns"])
             for cuts in ([], list(range(1, len(raw))), _cuts(rng, len(raw))):
-                got = _feed_all(getattr(p, runner["api"])(), raw, cuts)
-                assert got == want, (flavour, runner["api"], case["name"], cuts)
+                for compact in (False, True):
+                    got = _feed_all(getattr(p, runner["api"])(), raw, cuts, compact)
+                    assert got == want, (flavour, runner["api"], case["name"], cuts, compact)
         n += 1
     assert n == 61 + 57
 
@@ -77,7 +83,7 @@ def test_fuzz_chunkings(flavour):
             cuts = _cuts(rng, len(raw))
             if trial % 5 == 0:
                 cuts = sorted(cuts + cuts[:2])  # repeated cut positions = empty chunks
-            got = _feed_all(getattr(p, api)(), raw, cuts)
+            got = _feed_all(getattr(p, api)(), raw, cuts, compact=trial % 2 == 1)
             assert got == want, (flavour, api, pats, cuts, text[:100])
 
 
@@ -99,3 +105,15 @@ def test_long_stream_device_chunks_and_bounded_carry():
         got = np.concatenate([x for x in parts if len(x)])
         assert len(got) == len(want) and np.array_equal(got["start"], want["start"]) and np.array_equal(got["end"], want["end"]) and \
             np.array_equal(got["value"], want["value"]), api
+        # the compact form (8-byte tuples, the stream's own page-locked block) over chunks of changing sizes, host and device chunks mixed
+        st = getattr(p, api)()
+        parts, i, k = [], 0, 0
+        while i < len(hay):
+            n = [65536, 1 << 20, 3, 300_001, 4096][k % 5]
+            chunk = dev[i:i + n] if k % 3 else hay[i:i + n]
+            parts.append(st.decode8(*st.feed_compact(chunk)))   # (decoded at once: the view is the stream's until the next feed)
+            i += n
+            k += 1
+        got = np.concatenate([x for x in parts if len(x)])
+        assert len(got) == len(want) and np.array_equal(got["start"], want["start"]) and np.array_equal(got["end"], want["end"]) and \
+            np.array_equal(got["value"], want["value"]), (api, "compact")

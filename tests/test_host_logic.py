@@ -219,7 +219,8 @@ def test_gram2_tables_reproduce_the_match_stream(gram2_check, tmp_path):
 def test_gram4_tables_reproduce_the_count(tmp_path_factory, tmp_path):
     """the `.count()` tables of round 5 (gram4.hpp: "no pattern" as the last class, arithmetic class map where the dictionary's
     bytes are one range, per-word rank directory, "ends a pattern" in bit 30) walked with the rules of gram4_kernels.hip — plain
-    records and tail records from the hit record on — == literal automaton walk"""
+    records, tail records from the hit record on, and (round 6) the hits sent through the filter of gram4_filter.hpp first: every hit
+    that ends a pattern or goes on passes, the count is the same — == literal automaton walk"""
     exe = str(tmp_path_factory.mktemp("native") / "gram4_check")
     csrc = os.path.join(ROOT, "daachorse_amd", "csrc")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "gram4_check.cpp"),
@@ -240,13 +241,18 @@ def test_gram4_tables_reproduce_the_count(tmp_path_factory, tmp_path):
         blob.write_bytes(orc.OraclePma.build(pats).serialize())
         rng.choice(np.frombuffer(alpha, dtype=np.uint8), size=60000).tofile(h)
         for budget in (160000, 9000):
-            out = subprocess.check_output([exe, str(blob), str(budget), str(h)]).decode()
-            assert out.startswith("OK") and f"arith={arith}" in out, (out, pats[:3])
+            for fbytes in (33000, 600):   # (the filter of round 6: as the upload sizes it, and squeezed — no false negatives either way)
+                out = subprocess.check_output([exe, str(blob), str(budget), str(h), str(fbytes)]).decode()
+                assert out.startswith("OK") and f"arith={arith}" in out, (out, pats[:3])
     pats = synth.patterns_cfg3(20000)
     blob.write_bytes(orc.OraclePma.build(pats).serialize())
     synth.wordsoup_haystack(100000, synth.SEEDS["cfg3_dense"], pats, 20).tofile(h)
     out = subprocess.check_output([exe, str(blob), "160000", str(h)]).decode()
-    assert out.startswith("OK") and "K=3" in out and "arith=1 lo=97" in out, out
+    assert out.startswith("OK") and "K=3" in out and "arith=1 lo=97" in out and "filter=1" in out, out
+    rng.choice(np.frombuffer(synth.ALPHA_LOWER_SPACE, dtype=np.uint8), size=400000).tofile(h)   # uniform text: most hits neither end a pattern nor go on
+    out = subprocess.check_output([exe, str(blob), "160000", str(h)]).decode()
+    f = dict(kv.split("=") for kv in out.split()[1:])
+    assert out.startswith("OK") and int(f["useful"]) <= int(f["passed"]) < int(f["hits"]) // 2, out
     blob.write_bytes(orc.OraclePma.build(["ab", "ab", "b", "abab"]).serialize())
     np.frombuffer(b"abababbab" * 50, dtype=np.uint8).tofile(h)
     assert subprocess.check_output([exe, str(blob), "160000", str(h)]).decode().startswith("OK")

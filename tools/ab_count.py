@@ -13,7 +13,7 @@ import daachorse_amd as da
 from daachorse_amd import Engine, ScanMode, synth
 
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-DEFAULTS = {"gram3_tail": -1, "gram4_arith": 1, "gram_version": 0, "gram_ppl": 0, "gram2_rfull": 1, "gram_region": 0, "threads": 1024, "blocks_per_cu": 0, "gram_slab": 4096}
+DEFAULTS = {"gram3_tail": -1, "gram4_arith": 1, "gram4_filter": 1, "gram_version": 0, "gram_ppl": 0, "gram2_rfull": 1, "gram_region": 0, "threads": 1024, "blocks_per_cu": 0, "gram_slab": 4096}
 VARIANTS = [
     ("gram4 auto", {"gram_version": 4}),
     ("gram4 p16", {"gram_version": 4, "gram_ppl": 16}),
