@@ -465,8 +465,13 @@ struct daac_stream {
     void *pin8 = nullptr;    // page-locked: the last compact feed's tuples
     size_t pin8_bytes = 0;
     bool pin8_pinned = false;
+    hipStream_t s2 = nullptr;   // compact feeds: the second half of the tuples' copy back runs beside the first (one copy engine alone stays
+    hipEvent_t ev_ready = nullptr, ev_half = nullptr;   // at ~40 GB/s of the link's ~55: profiles/r04_iterator.txt)
     bool started = false;
     ~daac_stream() {
+        if (s2) (void)hipStreamDestroy(s2);
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_half) (void)hipEventDestroy(ev_half);
         for (void *b : buf) if (b) (void)hipFree(b);
         if (pin8) { if (pin8_pinned) (void)hipHostFree(pin8); else std::free(pin8); }
     }
@@ -618,10 +623,29 @@ static daac_status stream_feed_impl(daac_stream *s, const uint8_t *chunk, size_t
             }
             void *d8 = nullptr;
             HIP_TRY(dev_malloc(&d8, bytes, s->stream));
-            const hipError_t e1 = launch_repack8(dm.p, d8, dm.n, scan_from, s->end_bits, s->stream);
-            const hipError_t e2 = e1 == hipSuccess ? hipMemcpyAsync(s->pin8, d8, bytes, hipMemcpyDeviceToHost, s->stream) : e1;
+            hipError_t e = launch_repack8(dm.p, d8, dm.n, scan_from, s->end_bits, s->stream);
+            // two halves on two streams once the list is MBs long and the tuples are going to page-locked memory
+            const size_t half = (bytes >= (8u << 20) && s->pin8_pinned) ? (bytes / 2) & ~size_t(4095) : bytes;
+            if (e == hipSuccess && half != bytes && !s->s2) {
+                if (hipStreamCreateWithFlags(&s->s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&s->ev_half, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (s->s2) { (void)hipStreamDestroy(s->s2); s->s2 = nullptr; }
+                }
+            }
+            const bool split = half != bytes && s->s2 && s->ev_ready && s->ev_half;
+            if (e == hipSuccess && split) {
+                e = hipEventRecord(s->ev_ready, s->stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(s->s2, s->ev_ready, 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(static_cast<char *>(s->pin8) + half, static_cast<const char *>(d8) + half, bytes - half, hipMemcpyDeviceToHost, s->s2);
+                if (e == hipSuccess) e = hipEventRecord(s->ev_half, s->s2);
+                if (e == hipSuccess) e = hipMemcpyAsync(s->pin8, d8, half, hipMemcpyDeviceToHost, s->stream);
+                if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->ev_half, 0);
+            } else if (e == hipSuccess) {
+                e = hipMemcpyAsync(s->pin8, d8, bytes, hipMemcpyDeviceToHost, s->stream);
+            }
             dev_free(d8, s->stream);
-            HIP_TRY(e2);
+            HIP_TRY(e);
             HIP_TRY(hipStreamSynchronize(s->stream));
             const daac_match8 *p8 = static_cast<const daac_match8 *>(s->pin8);
             any = true;

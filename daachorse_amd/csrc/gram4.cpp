@@ -100,6 +100,7 @@ bool build_gram4_filter(Gram4Tables &t, uint32_t max_bytes) {
     if (keys == 0) return false;
     uint64_t words = std::min<uint64_t>(max_bytes / 4, (keys * 16 + 31) / 32);
     words &= ~3ull;   // (staged in 16-byte pieces)
+    if (words >= (1u << 14)) words = (1u << 14) - 4;   // (the word index is an 18 x 14-bit product)
     if (words < 64 || words * 32 < keys * 2) return false;
     t.bloom.assign(static_cast<size_t>(words), 0u);
     const uint32_t W = static_cast<uint32_t>(words);
@@ -119,12 +120,11 @@ bool build_gram4_filter(Gram4Tables &t, uint32_t max_bytes) {
         for (; w != 0; w &= w - 1, ++rank) {
             const uint32_t d = static_cast<uint32_t>(__builtin_ctz(w));
             const uint32_t x = xc | (byte_of[d] << (8 * K));
-            const uint32_t base = g4f_base(x);
             const uint32_t rx = t.dhit_c[rank].x;
-            if ((rx >> kGram4EndsBit) & 1u) { const G4Probe p = g4f_ends(base, W); t.bloom[p.word] |= p.mask; }
+            if ((rx >> kGram4EndsBit) & 1u) { const G4Probe p = g4f_probe(x, 0, W); t.bloom[p.word] |= p.ends; }
             for (uint32_t cm = rx & kGram4ChildBits; cm != 0; cm &= cm - 1) {
-                const G4Probe p = g4f_go(base, byte_of[__builtin_ctz(cm)], W);
-                t.bloom[p.word] |= p.mask;
+                const G4Probe p = g4f_probe(x, byte_of[__builtin_ctz(cm)], W);
+                t.bloom[p.word] |= p.go;
             }
         }
     }

@@ -385,11 +385,10 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
         if (FILT) {
             derive(st_n, n - st_n);
             st_n = 0;
-            // first stage: the two probes of gram4_filter.hpp on the raw bytes p-K .. p and p + 1
-            const uint32_t fb = g4f_base(K == 3 ? pend_lo : pend_lo >> 8);
-            const G4Probe pg = g4f_go(fb, pend_t0 & 0xffu, bloomW), pe = g4f_ends(fb, bloomW);
-            const uint32_t wg = lds_u32(offB + (pg.word << 2)), we = lds_u32(offB + (pe.word << 2));
-            const bool pass = lane < n && ((wg & pg.mask) == pg.mask || (we & pe.mask) == pe.mask);
+            // first stage: the probe of gram4_filter.hpp on the raw bytes p-K .. p and p + 1 — one word, the GO key's two bits or the ENDS key's four
+            const G4Probe pr = g4f_probe(K == 3 ? pend_lo : pend_lo >> 8, pend_t0 & 0xffu, bloomW);
+            const uint32_t fw = lds_u32(offB + (pr.word << 2));
+            const bool pass = lane < n && ((fw & pr.go) == pr.go || (fw & pr.ends) == pr.ends);
             const unsigned long long pm = __ballot(pass);
             if (pm != 0) {
                 // survivors move to lanes sb_n, sb_n + 1, .. (mod 64) — one forward permute per word, the others fill the lanes in between —

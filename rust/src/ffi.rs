@@ -2,7 +2,7 @@
 #![allow(non_camel_case_types)]
 use core::ffi::{c_char, c_void};
 
-pub const DAAC_ABI_VERSION: u32 = 5;
+pub const DAAC_ABI_VERSION: u32 = 6;
 
 /// daac_status
 pub const DAAC_OK: i32 = 0;
@@ -106,6 +106,8 @@ extern "C" {
     // the chunk-fed steppers (stepper_hip.rs): FindStepper / FindOverlappingStepper / the *_from_iter entry points
     pub fn daac_stream_open(pma: *mut daac_pma, mode: i32, engine: i32, stream: *mut c_void, out: *mut *mut daac_stream) -> i32;
     pub fn daac_stream_feed(s: *mut daac_stream, chunk: *const u8, len: usize, chunk_is_device: i32, out: *mut *mut daac_matches) -> i32;
+    pub fn daac_stream_feed_compact(s: *mut daac_stream, chunk: *const u8, len: usize, chunk_is_device: i32, batch: *mut *const daac_match8, n: *mut usize,
+                                    end_base: *mut u64, end_bits: *mut u32) -> i32; // ABI 6
     pub fn daac_stream_close(s: *mut daac_stream);
     pub fn daac_matches_count(m: *const daac_matches) -> usize;
     pub fn daac_matches_data(m: *const daac_matches) -> *const daac_match;

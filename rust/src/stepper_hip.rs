@@ -42,7 +42,22 @@ impl<'a> HipChunked<'a> {
         Self { s, _pma: pma, buf: Vec::new(), out: VecDeque::new(), done: false }
     }
     /// One feed: the matches the chunk decides (FindIterator: up to its last restart point), appended to `out` in the iterator's order.
+    /// The tuples come back as 8-byte `daac_match8` in the stream object's page-locked block (`daac_stream_feed_compact`, ABI 6: a third of
+    /// `daac_match`'s bytes over PCIe, no list to allocate and free per feed); a dictionary whose longest pattern leaves no room for a
+    /// 64 MiB chunk in the packed word (status 6) takes the 24-byte form.
     pub(crate) fn feed(&mut self, chunk: &[u8]) {
+        let (mut run, mut n, mut base, mut bits) = (core::ptr::null(), 0usize, 0u64, 0u32);
+        let st = unsafe { daac_stream_feed_compact(self.s, chunk.as_ptr(), chunk.len(), 0, &mut run, &mut n, &mut base, &mut bits) };
+        if st == DAAC_OK {
+            self.out.reserve(n);
+            let mask = (1u32 << bits) - 1;
+            for i in 0..n {
+                let t = unsafe { *run.add(i) }; // daac_match8 {value, end - base | length << bits}
+                self.out.push_back(Match { length: (t.end_len >> bits) as usize, end: (base + (t.end_len & mask) as u64) as usize, value: t.value });
+            }
+            return;
+        }
+        assert!(st == DAAC_ERR_UNSUPPORTED, "daachorse_amd: stream feed failed (status {st})");
         let mut m = core::ptr::null_mut();
         let st = unsafe { daac_stream_feed(self.s, chunk.as_ptr(), chunk.len(), 0, &mut m) };
         assert!(st == DAAC_OK, "daachorse_amd: stream feed failed (status {st})");

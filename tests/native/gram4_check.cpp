@@ -112,9 +112,9 @@ int main(int argc, char **argv) {
             if (have_filter) {   // gram4_body<.., FILT = true>: the probes on the raw bytes pz-K .. pz and pz+1
                 uint32_t x = 0;
                 for (uint32_t i = 0; i <= K; ++i) x |= raw(pz - K + i) << (8 * i);
-                const uint32_t fb = g4f_base(x);
-                const G4Probe pg = g4f_go(fb, raw(pz + 1), W), pe = g4f_ends(fb, W);
-                const bool pass = (g.bloom[pg.word] & pg.mask) == pg.mask || (g.bloom[pe.word] & pe.mask) == pe.mask;
+                const G4Probe pr = g4f_probe(x, raw(pz + 1), W);
+                const uint32_t fw = g.bloom[pr.word];
+                const bool pass = (fw & pr.go) == pr.go || (fw & pr.ends) == pr.ends;
                 const bool is_useful = ((r.x >> kGram4EndsBit) & 1u) || ((r.x >> k1) & 1u);
                 if (is_useful && !pass) { std::printf("MISMATCH filter: a hit that ends a pattern or goes on does not pass (position %lld)\n", pz); return 1; }
                 if (pass) { ++passed; c_filt += ((r.x >> kGram4EndsBit) & 1u) + below; }

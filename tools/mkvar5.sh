@@ -1,9 +1,9 @@
 #!/bin/bash
 # mkvar5.sh NAME SRC [-DFLAG=..]... -> abtmp/lib_NAME.so: the library with daachorse_amd/csrc/SRC.hip compiled with the given flags (timing
 # experiments; several may run side by side).  Needs an up-to-date daachorse_amd/build/ (python daachorse_amd/_build.py).
-# The timing-only stage switches of the count kernel (-DG4X=1..5: main path only / + hit queue / + consumer up to the rank / + record gather
+# The timing-only stage switches of the count kernel (-DG4X=1..5: main path only / + hit queue / + consumer up to the rank (filter body: the filter and the re-compaction; -DG4X=6: + the survivors ranked) / + record gather
 # and pending stage / + walker slab without the drain; -DG4X=9: fewer template instances; -DG4_GS=n: lookups in flight; WRONG counts on
-# purpose; -DG4F=1/2 -DG4F_Q=q -DG4F_N=n: upper bound of a filter in front of rank + gather, round 6) are not in the shipped source: tools/variants/<SRC minus _kernels>_decomposition.patch adds them to a copy compiled here.
+# purpose) are not in the shipped source: tools/variants/<SRC minus _kernels>_decomposition.patch adds them to a copy compiled here.
 set -e
 R=/root/repo; mkdir -p $R/abtmp /tmp/daac_var5/$1
 N=$1; S=$2; shift; shift
