@@ -76,9 +76,7 @@ const char *last_error_cstr();
     X(find3_window, 1ll << 30, 0)        /* find3: end positions per window (tests: small windows = many restarts) */                        \
     X(workspace_keep, 8ll << 30, 0)      /* bytes of scratch a handle may keep for its emitter / find3 calls (0: none) */                    \
     X(char_map_lds, 1, 1)                /* charwise chain scans: the populated stretch of the code mapper in LDS */                         \
-    X(char_row_lds, 1, 1)                /* ... and ROOT's row of children beside it */                                                      \
-    X(char_multi, 1, 0)                  /* charwise chain walkers: symbols settled by ROOT's row are taken without a memory round (0: one symbol per turn) */ \
-    X(stream_compact, 1, 0)
+    X(char_row_lds, 1, 1)                /* ... and ROOT's row of children beside it */
 
 enum OptionId : int {
 #define X(NAME, DEF, UP) OPT_##NAME,

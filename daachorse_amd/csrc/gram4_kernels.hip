@@ -30,11 +30,12 @@ namespace daac {
 namespace {
 
 typedef uint32_t g4_u32x4_t __attribute__((ext_vector_type(4)));
-constexpr uint32_t kRing4 = 128;        // entries of a wave's hit queue (FIFO; at most 63 left over + 64 new)
+constexpr uint32_t kRing4 = 128;        // entries of a wave's hit queue (FIFO; at most 63 left over + 64 new), u16 each: the hit byte's offset in the wave's text slot
 constexpr uint32_t kProbePercent4 = 3;  // density probe: TAIL when more than 3 % of the sampled positions start a walker
 typedef __attribute__((address_space(3))) const uint32_t lds4_cu32;
 typedef __attribute__((address_space(3))) uint32_t lds4_u32;
 typedef __attribute__((address_space(3))) const uint16_t lds4_cu16;
+typedef __attribute__((address_space(3))) uint16_t lds4_u16;
 typedef __attribute__((address_space(3))) const uint8_t lds4_cu8;
 typedef __attribute__((address_space(3))) g4_u32x4_t lds4_u32x4;
 
@@ -115,7 +116,7 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
     const uint64_t nwaves = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
     // per-wave LDS: the text slot; the hit queues of all waves come first (each starts at a multiple of its size)
     const uint32_t tb = L.off_wave + wave_in_wg * L.wave_stride;   // wave-uniform
-    const uint32_t ringb = wave_in_wg * (kRing4 * 4u);
+    const uint32_t ringb = wave_in_wg * (kRing4 * 2u);
     // this wave's slab of pending walkers, 16-byte entries.  plain: {position of the hit byte, hit record x, hit record y, the four text
     // bytes behind the hit}; TAIL: {position, state | class << 27, text bytes from position + 2 on, three more | how many << 24}
     const uint64_t slab_index = (static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg) * a.wq_slab;
@@ -224,7 +225,7 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
         wq_n = 0;
     };
 
-    // ---- the hit queue: entry = LDS address of the hit byte in one of the wave's two text slots
+    // ---- the hit queue: entry = offset of the hit byte from the start of the wave's text slot (u16)
     uint32_t q_head = 0, q_tail = 0;   // wave-uniform, free running; entries live at (index & (kRing4 - 1))
     uint32_t posbias = 0;              // (virtual position of a byte - epoch_base) - (its LDS address), of the text in the slot
     uint32_t st_n = 0;                 // wave-uniform: lanes [0, st_n) hold an entry of the NEXT batch already taken out of queue and slot
@@ -325,7 +326,7 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
     // four (TAIL: eight) behind it.  After this the entries no longer refer to the slot.
     auto derive = [&](uint32_t first, uint32_t cnt) {
         if (lane - first < cnt) {
-            const uint32_t e = lds_u32(ringb | (((q_head + lane - first) << 2) & (kRing4 * 4u - 4u)));
+            const uint32_t e = tb + *reinterpret_cast<lds4_cu16 *>(static_cast<uintptr_t>(ringb | (((q_head + lane - first) << 1) & (kRing4 * 2u - 2u))));
             pend_pos = e + posbias;
             const uint32_t t3 = e - 3u;
             const uint32_t a0 = t3 & ~3u, sh = t3 & 3u;
@@ -543,7 +544,7 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
             cnt32 += ccnt;
 
             // ---- queue the hits, one per lane and turn ----
-            const uint32_t text_adj = my_text - (32u - P);
+            const uint32_t text_adj = my_text - (32u - P) - tb;   // (queue entries are offsets in the wave's slot: 16 bits)
             for (;;) {
                 const bool has = H != 0;
                 const unsigned long long m = __ballot(has);
@@ -554,8 +555,8 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
                 const uint32_t entry = text_adj + b;
                 H &= H - 1u;
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), q_tail));
-                const uint32_t slot_addr = ((at << 2) & (kRing4 * 4u - 4u)) | ringb;   // (v_lshlrev_b32, v_and_or_b32)
-                if (has) *reinterpret_cast<lds4_u32 *>(static_cast<uintptr_t>(slot_addr)) = entry;
+                const uint32_t slot_addr = ((at << 1) & (kRing4 * 2u - 2u)) | ringb;   // (v_lshlrev_b32, v_and_or_b32)
+                if (has) *reinterpret_cast<lds4_u16 *>(static_cast<uintptr_t>(slot_addr)) = static_cast<uint16_t>(entry);
                 q_tail += static_cast<uint32_t>(__popcll(m));
                 if (st_n + q_tail - q_head >= 64u) process_batch(64u);
             }
@@ -669,7 +670,7 @@ bool gram4_plan(const Gram4Dev &dev, uint32_t ppl, uint32_t waves, bool rfull, b
     if (rfull && dev.rfull == nullptr) return false;
     const uint32_t slot = 64u * ppl + 32u;
     L.wave_stride = slot;
-    L.off_wave = waves * kRing4 * 4u;      // the hit queues sit at 0
+    L.off_wave = waves * kRing4 * 2u;      // the hit queues sit at 0
     L.threads = waves * 64u;
     L.arith = (want_arith && dev.arith) ? 1u : 0u;
     const uint32_t per_wg = L.off_wave + waves * L.wave_stride;
@@ -692,7 +693,7 @@ bool gram4_plan(const Gram4Dev &dev, uint32_t ppl, uint32_t waves, bool rfull, b
     return L.lds_bytes <= lds_limit;
 }
 uint32_t gram4_filter_room(uint32_t m_bytes, uint32_t sdir_bytes, bool arith, uint32_t lds_limit) {
-    const uint32_t fixed = 16u * kRing4 * 4u + 16u * (64u * 32u + 32u) + (arith ? 0u : 256u) + sdir_bytes + m_bytes;
+    const uint32_t fixed = 16u * kRing4 * 2u + 16u * (64u * 32u + 32u) + (arith ? 0u : 256u) + sdir_bytes + m_bytes;
     return fixed < lds_limit ? (lds_limit - fixed) & ~15u : 0u;
 }
 

@@ -197,7 +197,8 @@ def engines_soak(seconds, seed, max_cases=None):
         o = orc.OraclePma.build(pats)
         da.set_option("gram_lds_budget", int(rng.choice([158 * 1024, 40 * 1024])))
         opts = {"gram_region": int(rng.choice([0, 2048, 65536])), "gram_ppl": int(rng.choice([0, 16, 32])), "gram3_tail": int(rng.choice([-1, 0, 1])),
-                "gram_version": int(rng.choice([0, 4])), "gram4_arith": int(rng.choice([1, 1, 0])), "gram2_rfull": int(rng.choice([0, 1])), "threads": int(rng.choice([1024, 512]))}
+                "gram_version": int(rng.choice([0, 4])), "gram4_arith": int(rng.choice([1, 1, 0])), "gram2_rfull": int(rng.choice([0, 1])), "threads": int(rng.choice([1024, 512])),
+                "gram4_filter": int(rng.choice([1, 1, 0]))}
         for k, v in opts.items():
             da.set_option(k, v)
         p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
@@ -266,7 +267,7 @@ def engines_soak(seconds, seed, max_cases=None):
             da.set_option("iter_window", 64 << 20)
             assert np.array_equal(np.concatenate(e_), ref["end"]) and np.array_equal(np.concatenate(l_), (ref["end"] - ref["start"]).astype(np.uint32)) and \
                 np.array_equal(np.concatenate(v_), ref["value"]), ("compact iterator", ctx)
-    for k, v in (("gram_lds_budget", 158 * 1024), ("gram_region", 0), ("gram_ppl", 0), ("gram3_tail", -1), ("gram4_arith", 1), ("gram_version", 0), ("gram2_rfull", 1), ("threads", 1024),
+    for k, v in (("gram_lds_budget", 158 * 1024), ("gram_region", 0), ("gram_ppl", 0), ("gram3_tail", -1), ("gram4_arith", 1), ("gram4_filter", 1), ("gram_version", 0), ("gram2_rfull", 1), ("threads", 1024),
                  ("pfx", 1)):
         da.set_option(k, v)
     print(f"engines soak ok: {n_auto} automata ({n_g3} with GRAM tables, {n_pfx} with PFX tables, {n_emit} tuple lists from the GRAM emitter, {n_pfx_emit} from PFX's) in {time.time() - t0:.0f} s (seed {seed})")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Device-resident tuple emission (daac_scan_device) on cfg3: GB/s of haystack and of tuples written, GRAM emitter vs the
-segment scanners.  usage: python tools/time_emit.py [mib] [sparse|dense] [reps] [emit_version]"""
+segment scanners.  usage: python tools/time_emit.py [mib] [sparse|dense] [reps] [-] [only16]"""
 import os
 import sys
 import time
@@ -21,8 +21,7 @@ if hk == "sparse":
     synth.device_uniform(hay, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
 else:
     synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
-ver = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # (emit_version: an option of the round-3 emitter, ignored since)
-da.set_option("emit_version", ver)
+# (sys.argv[4] was the round-3 emitter's version: ignored, kept so that the positions of the arguments stay)
 for k, v in os.environ.items():  # DAAC_OPT_<name>=<value>: tuning options for A/B runs
     if k.startswith("DAAC_OPT_"):
         da.set_option(k[len("DAAC_OPT_"):], int(v))
