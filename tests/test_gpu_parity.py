@@ -897,6 +897,50 @@ def test_scan_count_multi_shards_on_one_device():
     assert ei.value.code == 6
 
 
+def test_scan_count_multi_from_several_threads_and_handles():
+    """the shard workers of daac_scan_count_multi (one per handle and device, round 6) under concurrent callers: four threads, two handles with
+    different launch shapes, every call with its own random cuts — each call's sum is the oracle's, whatever is queued on the workers beside it;
+    a handle is freed while the other's worker is busy"""
+    import threading
+    import torch
+    pats = synth.patterns_cfg3(20000)
+    o = orc.OraclePma.build(pats)
+    hay = synth.wordsoup_haystack(5 << 20, synth.SEEDS["cfg3_dense"] + 3, pats, 20)
+    dev = torch.from_numpy(hay).cuda()
+    want = o.overlapping_count(hay, threads=8)
+    a, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    b, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    a.set_option("gram_ppl", 16).set_option("gram4_filter", 0)
+    b.set_option("gram_tail", 0).set_option("threads", 512)
+    need = a.info().max_pattern_len - 1
+    errs = []
+
+    def work(p, seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for it in range(8):
+                k = int(rng.integers(1, 9))
+                cuts = [0] + sorted(int(x) for x in rng.integers(1, len(hay), size=k - 1)) + [len(hay)]
+                shards = [(0, dev[lo - min(lo, need):hi], min(lo, need), lo) for lo, hi in zip(cuts[:-1], cuts[1:])]
+                if it % 2:
+                    assert da.scan_count_multi(p, ScanMode.FindOverlapping, shards) == want, (seed, it, cuts)
+                else:
+                    assert da.scan_count_multi(p, ScanMode.FindOverlapping, shards, checksum=False) == want[0], (seed, it, cuts)
+        except Exception as e:  # noqa
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(p, s)) for p, s in ((a, 1), (b, 2), (a, 3), (b, 4))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    t = threading.Thread(target=work, args=(b, 5))
+    t.start()
+    del a          # joins a's worker while b's is scanning
+    t.join()
+    assert not errs, errs
+
+
 def test_trim_and_iterators_that_are_never_pulled():
     """daac_pma_trim gives the kept scratch back and the next scans allocate again; a lazy iterator that is opened and closed without a
     next() never starts its worker (the Rust cursor's `.count()` opens one and counts beside it), one that is pulled after a trim works"""

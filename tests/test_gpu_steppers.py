@@ -117,3 +117,33 @@ def test_long_stream_device_chunks_and_bounded_carry():
         got = np.concatenate([x for x in parts if len(x)])
         assert len(got) == len(want) and np.array_equal(got["start"], want["start"]) and np.array_equal(got["end"], want["end"]) and \
             np.array_equal(got["value"], want["value"]), (api, "compact")
+
+
+def test_compact_feed_refuses_what_it_cannot_say():
+    """daac_stream_feed_compact packs end and length into one word: a dictionary whose longest pattern leaves no room for a chunk (status 6: the
+    caller takes daac_stream_feed), and a chunk of 2^end_bits bytes or more; the stream goes on after a refusal"""
+    pats = [b"abc", b"bcd", b"x" * 5000]   # 13 length bits: 512 KiB of room for ends, less than a chunk is allowed to need
+    o = orc.OraclePma.build(pats)
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(o.serialize())
+    hay = np.frombuffer(b"xabcdx" * 1000, dtype=np.uint8)
+    st = p.find_overlapping_stepper()
+    with pytest.raises(da.DaachorseError) as ei:
+        st.feed_compact(hay)
+    assert ei.value.code == 6
+    got = st.feed(hay)
+    want = o.find_overlapping_iter(hay)
+    assert len(got) == len(want) and np.array_equal(got["end"], want["end"]) and np.array_equal(got["value"], want["value"])
+    pats = [b"abc", b"bcd", b"y" * 1500]   # 11 length bits: chunks below 2 MiB
+    o2 = orc.OraclePma.build(pats)
+    q, _ = da.DoubleArrayAhoCorasick.deserialize(o2.serialize())
+    long_hay = np.frombuffer(b"xabcdx" * 400_000, dtype=np.uint8)   # 2.4 MB
+    for api, oapi in (("find_overlapping_stepper", "find_overlapping_iter"), ("find_stepper", "find_iter")):
+        st = getattr(q, api)()
+        with pytest.raises(da.DaachorseError) as ei:
+            st.feed_compact(long_hay)
+        assert ei.value.code == 6
+        parts = [st.decode8(*st.feed_compact(long_hay[i:i + 700_001])) for i in range(0, len(long_hay), 700_001)]
+        got = np.concatenate([x for x in parts if len(x)])
+        want = getattr(o2, oapi)(long_hay)
+        assert len(got) == len(want) and np.array_equal(got["start"], want["start"]) and np.array_equal(got["end"], want["end"]) and \
+            np.array_equal(got["value"], want["value"]), api

@@ -21,7 +21,7 @@ if hk == "sparse":
     synth.device_uniform(hay, synth.SEEDS["cfg3_hay"], synth.ALPHA_LOWER_SPACE)
 else:
     synth.device_wordsoup(hay, synth.SEEDS["cfg3_dense"], pats, 20)
-# (sys.argv[4] was the round-3 emitter's version: ignored, kept so that the positions of the arguments stay)
+ver = 0  # (sys.argv[4] was the round-3 emitter's version: ignored, kept so that the positions of the arguments stay)
 for k, v in os.environ.items():  # DAAC_OPT_<name>=<value>: tuning options for A/B runs
     if k.startswith("DAAC_OPT_"):
         da.set_option(k[len("DAAC_OPT_"):], int(v))
