@@ -282,11 +282,13 @@ daac_status daac_scan_count_only_range(daac_pma *pma, int mode, int engine, cons
 /* One haystack sharded across the GPUs of a node (BASELINE configs[3]: 8 shards, one per MI355X).  Shard k is `len` bytes that begin at
  * haystack position `base`; `hay` points at the `halo` bytes in front of it followed by the shard itself, in the memory of `device`
  * (or in host memory when hay_is_device = 0).  Every shard but the one at position 0 needs halo >= max_pattern_len - 1 (charwise:
- * max_pattern_len, at least 3): a match is counted by the shard its END falls in, wherever it starts.  One host thread per shard
- * runs daac_scan_count[_only]_range on that device (tables are uploaded there on first use); the host adds the counts and — when
+ * max_pattern_len, at least 3): a match is counted by the shard its END falls in, wherever it starts; halo <= base.  One
+ * persistent worker thread per DEVICE the shards name (ABI 6: created at the handle's first such call, with a stream of its own — a
+ * blocking stream: it sees what the caller left on the device's default stream — and the handle's options in scope) queues
+ * daac_scan_count[_only]_range for its device's shards back to back (tables are uploaded there on first use) and waits once; the host adds the counts and — when
  * `checksum` is not NULL — the checksum sums with every shard's ends re-based to haystack positions, so the result equals
  * daac_scan_count of the whole haystack.  The find_overlapping modes only (status 6 otherwise: the other two iterators are chains).
- * Several shards may name the same device.  daac_last_engine() reports shard 0's engine. */
+ * Several shards may name the same device.  daac_last_engine() / daac_last_kernel() report shard 0's. */
 typedef struct {
     int device;           /* HIP device ordinal */
     const uint8_t *hay;   /* `halo` bytes of the haystack in front of the shard, then the shard */
@@ -365,10 +367,13 @@ void daac_stream_close(daac_stream *s);
  *   gram_lds_budget (161792), gram_region (0 = auto: 16384 for the first table set, 65536 for the second and PFX, 262144 from 2 GiB on; rounded down to a power of two >= 2048), gram_slab (4096), gram_dense (-1 = auto), gram_rank_in_lds (-1 = auto),
  *   gram_ppl (0 = auto: 32 positions per lane and step for automata without short patterns, else 16)
  *   gram_version (0 = auto: `.count()` on the gram4 kernel over the renumbered second table set, count + checksum on the first where it applies;
- *                 1 = first table set only, 2 = gram2 kernels only, 4 = gram4 for `.count()` or an error), gram2_dpp (1: DPP wave shifts),
+ *                 1 = first table set only, 2 = gram2 kernels only, 4 (3: its name in ABI 4) = gram4 for `.count()` or an error), gram2_dpp (1: DPP wave shifts),
  *   gram2_rfull (1)             rank directory with one entry per M word when LDS allows (0: one per four words)
  *   gram_tail (alias gram3_tail; -1 = every workgroup samples its text and picks; 0 / 1: the plain / the tail-record body of the gram4 kernel),
  *   gram4_arith (1: byte classes by arithmetic where the dictionary's bytes are one range; 0: the class table in LDS)
+ *   gram4_filter (1)            the gram4 kernel's LDS filter in front of rank + gather (gram4_filter.hpp, ABI 6): a hit asks the L2 for its record
+ *                               only if a Bloom word says the state may end a pattern or go on; workgroups whose text is made of dictionary
+ *                               words keep the per-word directory and the tail-record body.  0: round 5's bodies
  *   find3 (1)                   find_iter's count (+ checksum) by selection over the tuple emitter's per-position flags (find3_kernels.hip;
  *                               Standard bytewise dictionaries with K = 3 tables and no pattern beyond 19 bytes) instead of the chain walkers,
  *                               in windows of find3_window (2^30) end positions, each restarting at the last match of the one before; a handle
@@ -390,9 +395,7 @@ void daac_stream_close(daac_stream *s);
  *                               GRAM tables, or PFX's for any byte alphabet) where it applies (0: segment scanners);
  *   emit_rec_per_kib (32)       deep-match records per KiB of haystack the record list is first sized for (a handle remembers what its
  *                               last scan met; a list that proves too short is sized exactly and the detection is rerun once)
- *   emit_version, emit_tiles, emit_rec_cap   options of the round-3 COUNT + WRITE emitter (gone; in the history up to round 4): accepted, without effect
  *   restart_chain (1)           find_iter / leftmost_find_iter as speculate-reconcile-emit chains (0: sync-point scanners)
- *   restart_tier                (the TIERED chain walkers left the library in round 5: accepted, without effect)
  *   chain_rounds (24)           reconciliation rounds before falling back to the sync-point scanners
  *   restart_bpc (8)             256-lane workgroups per CU of the chain walkers (they are bound by VALU issue at full occupancy)
  *   char_map_lds (1)            charwise walkers: ASCII and the populated stretch of the code mapper staged in LDS when they fit 32 KB
@@ -404,9 +407,11 @@ void daac_stream_close(daac_stream *s);
  *   iter_window (64 MiB)        haystack bytes per window of the lazy iterator (the first windows are 16 and 32 MiB: matches arrive early)
  *   max_result_bytes (8 GiB)    largest match list daac_scan may materialise */
 daac_status daac_set_option(const char *name, int64_t value);
-/* The same option for ONE handle (ABI 5): overrides the process-wide value for every scan, iterator and stream of `pma` — and, for the
- * options read when the tables are laid out (gram_lds_budget, lds_budget, pfx, left3, char_map_lds, char_row_lds ...), for its next
- * daac_pma_upload.  Two threads scanning two handles with different settings do not share state.  unset != 0 removes the override.
+/* The same option for ONE handle (ABI 5): overrides the process-wide value for every scan, iterator and stream of `pma`, whichever thread runs
+ * them (the worker threads of the lazy iterator and of daac_scan_count_multi included).  Two threads scanning two handles with different
+ * settings do not share state.  unset != 0 removes the override.  The options read when the tables are laid out (lds_budget, dense_depth,
+ * rows_share_pct, gram_lds_budget, gram_rank_in_lds, pfx, char_map_lds, char_row_lds) are set BEFORE the handle's first upload: on a handle
+ * that already has tables on a device they could not take effect, and the call says so (status 6, ABI 6) instead of answering OK.
  * `pool` / `pool_keep` belong to the device's allocator, not to a handle (status 1). */
 daac_status daac_pma_set_option(daac_pma *pma, const char *name, int64_t value, int unset);
 
