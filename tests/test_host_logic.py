@@ -388,3 +388,32 @@ def test_scan_without_gpu_fails_loudly():
     with pytest.raises(da.DaachorseError) as ei:
         pma.scan_count(da.ScanMode.FindOverlapping, "aaa")
     assert ei.value.code == 7
+
+
+def test_options_need_no_device():
+    """daac_set_option / daac_pma_set_option (include/daachorse_amd.h, the list is DAAC_OPTIONS in api_internal.hpp): names, aliases, what a handle
+    may not override, and that a handle without tables takes every option — none of it touches a device.  (An upload-time option on a handle
+    that HAS tables answers 6: tests/test_gpu_parity.py.)"""
+    import ctypes as C
+    from daachorse_amd import _ffi
+    for name in ("gram_ppl", "gram_tail", "gram3_tail", "gram4_filter", "gram_version", "find3_window", "workspace_keep", "threads"):
+        da.set_option(name, {"gram_tail": -1, "gram3_tail": -1, "gram4_filter": 1, "find3_window": 1 << 30, "workspace_keep": 8 << 30, "threads": 1024}.get(name, 0))
+    da.set_option("gram_version", 3)   # ABI 4's name of the `.count()` kernel: an alias of 4
+    da.set_option("gram_version", 0)
+    for gone in ("emit_version", "emit_tiles", "emit_rec_cap", "restart_tier", "emit_stagger", "emit_v3_lds", "no_such_option"):
+        with pytest.raises(da.DaachorseError) as ei:
+            da.set_option(gone, 1)
+        assert ei.value.code == 1, gone
+    p, _ = da.DoubleArrayAhoCorasick.deserialize(orc.OraclePma.build(["ab", "b"]).serialize())
+    p.set_option("gram_lds_budget", 9216).set_option("pfx", 2).set_option("gram_ppl", 16).set_option("gram4_filter", 0)   # before any upload: all fine
+    p.set_option("gram_lds_budget").set_option("gram_ppl")                                                               # ... and taken away again
+    for name in ("pool", "pool_keep"):
+        with pytest.raises(da.DaachorseError) as ei:
+            p.set_option(name, 0)
+        assert ei.value.code == 1
+    with pytest.raises(da.DaachorseError) as ei:
+        p.set_option("no_such_option", 1)
+    assert ei.value.code == 1
+    assert _ffi.lib().daac_pma_set_option(None, b"gram_ppl", 16, 0) == 1
+    assert _ffi.lib().daac_abi_version() == _ffi.ABI_VERSION == 6
+    assert isinstance(da.last_kernel(), str)
