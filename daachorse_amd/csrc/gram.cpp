@@ -127,6 +127,40 @@ bool build_gram_tables(const HostPma &p, const TierTables &tier, uint32_t lds_bu
             out.cfirst.push_back(r.z);
         }
     }
+    // ---- tail records with the pattern's h inline (round 6) ------------------------------------------------
+    // Below the records the walkers start on (depth K + 2: most walkers of uniform text end there, and that record stays as it was), a
+    // state under which the trie is ONE path of at most eight edges with exactly ONE pattern end on it — a dictionary word's last
+    // letters — becomes {h of that pattern, 1 << 31 | edges | index of the ending node << 4, path bytes 0-3, path bytes 4-7}: the walker
+    // compares the path with the next eight text bytes in one step instead of fetching a record per letter (text made of dictionary
+    // words: every word walks its letters).  first_child is below 2^27, so bit 31 of the second word marks the form.  Children carry
+    // larger numbers than their parents: one pass from the back knows every subtree.
+    {
+        std::vector<uint8_t> plen(N, 0xff), nend(N, 0);   // edges of the single path below s (0xff: it branches, is too long, or a node ends two patterns)
+        for (uint32_t s = N; s-- > 0;) {
+            const U32x4 r = tier.grec[s];
+            const uint32_t kids = static_cast<uint32_t>(__builtin_popcount(r.x));
+            if (own_cnt[s] > 1) continue;
+            if (kids == 0) { plen[s] = 0; nend[s] = static_cast<uint8_t>(own_cnt[s]); continue; }
+            if (kids != 1) continue;
+            const uint32_t c = r.z;
+            if (plen[c] == 0xff || plen[c] >= 8) continue;
+            plen[s] = static_cast<uint8_t>(plen[c] + 1);
+            nend[s] = static_cast<uint8_t>(std::min<uint32_t>(3u, own_cnt[s] + nend[c]));
+        }
+        for (uint32_t s = 0; s < N; ++s) {
+            if (depth[s] < K + 3 || plen[s] == 0xff || plen[s] == 0 || nend[s] != 1) continue;
+            uint64_t bytes = 0;
+            uint32_t cur = s, at = own_cnt[s] ? 0u : 0xffu, h = own_cnt[s] ? own_hs[s] : 0u;
+            for (uint32_t i = 0; i < plen[s]; ++i) {
+                const U32x4 r = tier.grec[cur];
+                bytes |= static_cast<uint64_t>(rep[__builtin_ctz(r.x)]) << (8 * i);
+                cur = r.z;
+                if (own_cnt[cur]) { at = i + 1; h = own_hs[cur]; }
+            }
+            out.drec[s] = U32x4{h, 0x80000000u | plen[s] | (at << 4), static_cast<uint32_t>(bytes), static_cast<uint32_t>(bytes >> 32)};
+            ++out.n_tail;
+        }
+    }
     if (out.bbits.size() & 1) out.bbits.push_back(0);  // whole 64-bit pairs
     out.brank.resize(out.bbits.size() / 2);
     out.bsuper.assign((out.bbits.size() + 7) / 8, 0);

@@ -38,7 +38,9 @@ struct GramTables {
     std::vector<uint32_t> bbits;    // ceil(C^(K+1) / 32): (K+1)-gram is a trie prefix
     std::vector<uint8_t> brank;     // per PAIR of bbits words (64 bits): set bits before the pair within its 8-word superblock
     std::vector<uint32_t> bsuper;   // per 8 words (256 bits): set bits before the superblock
-    std::vector<U32x4> drec;        // N: {cmap, first_child, own_cnt, own_hsum}
+    std::vector<U32x4> drec;        // N: {cmap, first_child, own_cnt, own_hsum}; from depth K + 3 on a single path with one pattern end is a tail record
+                                    //    {h of the pattern, 1 << 31 | edges | index of the ending node << 4, path bytes 0-3, path bytes 4-7} (gram.cpp)
+    uint32_t n_tail = 0;            // tail records among them
     std::vector<U32x2> dhit;        // per depth-(K+1) state, in rank order: {cmap, own_hsum}; own_cnt == (own_hsum != 0)
     std::vector<uint32_t> cfirst;   // same order: id of the state's first child (read only when a branch goes on)
     uint32_t lds_bytes = 0;

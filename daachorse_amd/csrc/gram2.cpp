@@ -208,6 +208,22 @@ bool build_gram2_tables(const HostPma &p, uint32_t lds_budget, Gram2Tables &out)
             // record stays as cheap as it was)
             if (depth[s] >= out.K + 3) out.drec_c[s] = tail;
         }
+        // the count + checksum walkers' records (round 6, as gram.cpp): from depth K + 3 on, a single path with exactly ONE pattern end is
+        // {h of that pattern, 1 << 31 | edges | index of the ending node << 4, path bytes 0-3, path bytes 4-7} (first_child < 2^27: bit 31 of the
+        // second word marks the form).  After drec_c / drec_t were taken from the plain records.
+        for (uint32_t s = 0; s < N; ++s) {
+            if (depth[s] < out.K + 3 || path_len[s] == 0xff || path_len[s] == 0) continue;
+            uint64_t bytes = 0;
+            uint32_t cur = s, n_end = own_cnt[s] ? 1u : 0u, at = 0, h = own_cnt[s] ? own_hs[s] : 0u;
+            for (uint32_t i = 0; i < path_len[s]; ++i) {
+                const uint32_t d = static_cast<uint32_t>(__builtin_ctz(cmap[cur] & kGram2MaskBits));
+                bytes |= static_cast<uint64_t>(rep[d]) << (8 * i);
+                cur = first_child[cur];
+                if (own_cnt[cur]) { ++n_end; at = i + 1; h = own_hs[cur]; }
+            }
+            if (n_end != 1) continue;
+            out.drec[s] = U32x4{h, 0x80000000u | path_len[s] | (at << 4), static_cast<uint32_t>(bytes), static_cast<uint32_t>(bytes >> 32)};
+        }
     }
     out.available = true;
 

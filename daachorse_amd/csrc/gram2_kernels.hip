@@ -195,6 +195,21 @@ __global__ __launch_bounds__(TPB) void gram2_kernel(const Gram2Dev g, const Gram
                 unsigned long long ah = ahead[w];
                 uint32_t n_ahead = 8, k = 0;
                 for (;;) {
+                    if (rr.y >> 31) {
+                        // a tail record (gram2.cpp, round 6): one path of rr.y & 15 edges with one pattern end, at its node (rr.y >> 4) & 15;
+                        // {h of that pattern, -, path bytes} against the next eight text bytes in one step
+                        if (n_ahead < 8u) ah = read_ahead(vn);
+                        const unsigned long long diff = ((static_cast<unsigned long long>(rr.w) << 32) | rr.z) ^ ah;
+                        const uint32_t edges = rr.y & 15u, at = (rr.y >> 4) & 15u;
+                        uint32_t same = diff ? static_cast<uint32_t>(__builtin_ctzll(diff)) >> 3 : 8u;
+                        same = same < edges ? same : edges;
+                        if (at <= same) {
+                            cnt32 += 1u;
+                            tot_s1 += rr.x;
+                            tot_s2 += rr.x * static_cast<uint32_t>(vn + at - a.lead);
+                        }
+                        break;
+                    }
                     k = cls_of(static_cast<uint32_t>(ah) & 0xffu);
                     cnt32 += rr.z;
                     tot_s1 += rr.w;

@@ -175,6 +175,27 @@ __global__ __launch_bounds__(TPB) void gram_count_kernel(const GramDev g, const 
                 if (((r.x >> kn) & 1u) == 0) break;
                 r = g.drec[r.y + __popc(r.x & ((1u << kn) - 1u))];
                 ++vnext;
+                if (r.y >> 31) {
+                    // a tail record (gram.cpp, round 6): what is left below this state is one path of r.y & 15 edges with one pattern end, at its
+                    // node (r.y >> 4) & 15; {h of that pattern, -, path bytes} against the next eight text bytes in one step
+                    unsigned long long text;
+                    if (vnext >= a.lead && vnext + 8 <= a.vlen) {
+                        __builtin_memcpy(&text, hay + vnext, 8);
+                    } else {
+                        text = 0;
+                        for (int b = 7; b >= 0; --b) text = (text << 8) | ((vnext + b >= a.lead && vnext + b < a.vlen) ? hay[vnext + b] : g.unused_byte);
+                    }
+                    const unsigned long long diff = ((static_cast<unsigned long long>(r.w) << 32) | r.z) ^ text;
+                    const uint32_t edges = r.y & 15u, at = (r.y >> 4) & 15u;
+                    uint32_t same = diff ? static_cast<uint32_t>(__builtin_ctzll(diff)) >> 3 : 8u;
+                    same = same < edges ? same : edges;
+                    if (at <= same) {
+                        tot_cnt += 1;
+                        tot_s1 += r.x;
+                        tot_s2 += r.x * static_cast<uint32_t>(vnext + at - a.lead);
+                    }
+                    break;
+                }
                 if (n_ahead == 0) {
                     if (vnext >= a.lead && vnext + 4 <= a.vlen) {
                         __builtin_memcpy(&ahead, hay + vnext, 4);  // one (unaligned) dword

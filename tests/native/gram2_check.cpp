@@ -94,8 +94,19 @@ int main(int argc, char **argv) {
                         kc = cls(nc);
                     }
                 }
-                for (;;) {
+                for (bool first_rec = true;; first_rec = false) {
                     const U32x4 r = g.drec[id];
+                    if (r.y >> 31) {   // a tail record with the pattern's h inline (round 6): one path, one pattern end
+                        if (first_rec) { std::printf("MISMATCH a tail record where the walkers start\n"); return 1; }
+                        uint64_t text = 0;
+                        for (int b = 7; b >= 0; --b) text = (text << 8) | ((nx + b >= 0 && nx + b < n) ? hay[nx + b] : g.unused_byte);
+                        const uint64_t diff = ((static_cast<uint64_t>(r.w) << 32) | r.z) ^ text;
+                        const uint32_t edges = r.y & 15u, at = (r.y >> 4) & 15u;
+                        uint32_t same = diff ? static_cast<uint32_t>(__builtin_ctzll(diff)) >> 3 : 8u;
+                        same = same < edges ? same : edges;
+                        if (at <= same) { gc += 1; g1 += r.x; g2 += r.x * static_cast<uint32_t>(nx + at); gc_walk += 1; }
+                        break;
+                    }
                     gc += r.z; g1 += r.w; g2 += r.w * static_cast<uint32_t>(nx);
                     gc_walk += r.z;
                     if (((r.x >> kn) & 1u) == 0) break;

@@ -49,7 +49,7 @@ int main(int argc, char **argv) {
     auto cls = [&](long long pos) -> uint32_t { return (pos >= 0 && static_cast<size_t>(pos) < n) ? g.cls[hay[pos]] : 0u; };
     uint32_t pk1 = 1;
     for (uint32_t i = 0; i + 1 < K; ++i) pk1 *= C;
-    uint64_t gc = 0;
+    uint64_t gc = 0, tails_met = 0;
     uint32_t g1 = 0, g2 = 0;
     for (size_t pz = 0; pz < n; ++pz) {
         const long long p0 = static_cast<long long>(pz);
@@ -76,8 +76,22 @@ int main(int argc, char **argv) {
                 id = g.cfirst[rank] + __builtin_popcount(hrec.x & ((1u << k1) - 1u));
                 long long nx = p0 + 2;  // the state consumed the byte before nx
                 uint32_t kn = k2;
+                bool first_rec = true;
                 for (;;) {
                     const U32x4 r = g.drec[id];
+                    if (r.y >> 31) {   // a tail record (round 6): one path, one pattern end, compared with the next eight text bytes
+                        if (first_rec) { std::printf("MISMATCH a tail record where the walkers start\n"); return 1; }
+                        uint64_t text = 0;
+                        for (int b = 7; b >= 0; --b) text = (text << 8) | ((nx + b >= 0 && nx + b < static_cast<long long>(n)) ? hay[nx + b] : g.unused_byte);
+                        const uint64_t diff = ((static_cast<uint64_t>(r.w) << 32) | r.z) ^ text;
+                        const uint32_t edges = r.y & 15u, at = (r.y >> 4) & 15u;
+                        uint32_t same = diff ? static_cast<uint32_t>(__builtin_ctzll(diff)) >> 3 : 8u;
+                        same = same < edges ? same : edges;
+                        if (at <= same) { gc += 1; g1 += r.x; g2 += r.x * static_cast<uint32_t>(nx + at); }
+                        ++tails_met;
+                        break;
+                    }
+                    first_rec = false;
                     gc += r.z; g1 += r.w; g2 += r.w * static_cast<uint32_t>(nx);
                     if (((r.x >> kn) & 1u) == 0) break;
                     id = r.y + __builtin_popcount(r.x & ((1u << kn) - 1u));
@@ -91,6 +105,7 @@ int main(int argc, char **argv) {
         std::printf("MISMATCH count %llu vs %llu, s1 %08x vs %08x, s2 %08x vs %08x\n", (unsigned long long)gc, (unsigned long long)rc, g1, r1, g2, r2);
         return 1;
     }
-    std::printf("OK %zu K=%u C=%u count=%llu lds=%u short=%d combos=%zu\n", n, K, C, (unsigned long long)gc, g.lds_bytes, int(g.has_short), g.combo.size());
+    std::printf("OK %zu K=%u C=%u count=%llu lds=%u short=%d combos=%zu tail_records=%u tails_met=%llu\n", n, K, C, (unsigned long long)gc, g.lds_bytes, int(g.has_short), g.combo.size(),
+                g.n_tail, (unsigned long long)tails_met);
     return 0;
 }

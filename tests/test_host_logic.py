@@ -169,6 +169,18 @@ def test_gram_tables_reproduce_the_match_stream(gram_check, tmp_path):
         for budget in (160000, 9000):
             out = subprocess.check_output([gram_check, str(blob), str(budget), str(h)]).decode()
             assert out.startswith("OK"), out
+    # text made of the dictionary's words: the walkers meet the tail records of round 6 (one path, one pattern end, h inline) — also words cut
+    # short, a word's last letters replaced, and duplicates / nested words (paths with two ends keep their per-letter records)
+    pats = synth.patterns_cfg3(20000) + [b"abcdefghijk", b"abcdefghijklm", b"abcdefgh", b"zzzzzzzzzzzzzzzz", b"zzzzzzzzzzzzzzzz"]
+    blob.write_bytes(orc.OraclePma.build(pats).serialize())
+    soup = synth.wordsoup_haystack(120000, synth.SEEDS["cfg3_dense"], pats, 20).copy()
+    soup[rng.integers(0, len(soup), size=3000)] = ord("q")
+    soup[:40] = np.frombuffer(b"abcdefghijklm abcdefghijk abcdefghijklmn", dtype=np.uint8)
+    soup.tofile(h)
+    for budget in (160000, 9000):
+        out = subprocess.check_output([gram_check, str(blob), str(budget), str(h)]).decode()
+        f = dict(kv.split("=") for kv in out.split()[2:])
+        assert out.startswith("OK") and int(f["tail_records"]) > 5000 and int(f["tails_met"]) > 2000, out
     # "" as a pattern: declined
     blob.write_bytes(orc.OraclePma.build(["", "a"]).serialize())
     assert subprocess.check_output([gram_check, str(blob), "160000", str(h)]).decode().startswith("UNAVAILABLE")
