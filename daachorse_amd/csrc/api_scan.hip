@@ -760,6 +760,7 @@ daac_status daac_scan_count_multi(daac_pma *pma, int mode, int engine, const daa
             continue;
         }
         const std::vector<size_t> *mine = &kv.second;
+        try {
         w->post([&, mine](ShardWorker &me) {
             const size_t m = mine->size();
             bool ok = !me.failed && me.stream != nullptr && me.reserve(m);
@@ -793,6 +794,11 @@ daac_status daac_scan_count_multi(daac_pma *pma, int mode, int engine, const daa
             std::lock_guard<std::mutex> g(latch.mu);
             if (--latch.left == 0) latch.cv.notify_all();
         });
+        } catch (const std::exception &e) {   // (the job could not be queued: nothing of it runs)
+            for (size_t k : kv.second) { outs[k].st = DAAC_ERR_DEVICE; outs[k].err = std::string("the shard's job could not be queued: ") + e.what(); }
+            std::lock_guard<std::mutex> g(latch.mu);
+            --latch.left;
+        }
     }
     {
         std::unique_lock<std::mutex> g(latch.mu);
