@@ -1,4 +1,4 @@
-// GRAM engine, `.count()` kernel of round 5 (gfx950): find_overlapping_iter(haystack).count() of a Standard bytewise automaton
+// GRAM engine, `.count()` kernel of rounds 5-6 (gfx950): find_overlapping_iter(haystack).count() of a Standard bytewise automaton
 // (reference loop: src/bytewise/iter.rs:133-176 over src/bytewise.rs:1063-1088) with ONE LDS lookup per haystack byte in the main
 // path and six per hit.  Tables: gram4.hpp (M words, per-word rank directory, hit and walk records, "no pattern" as the last
 // class).  Method: gram_kernels.hip / gram3_kernels.hip — no state chain; an occurrence of at most K bytes is a function of the
@@ -16,6 +16,12 @@
 //     for a record that can go on) and leaves the first child of a branch that goes on to the drain, which runs 64 such
 //     branches wide where the batch that found them had three or four;
 //   * hit records carry "ends a pattern" in bit 30 and no class needs the `!= 0` test in front of its child bit.
+// Round 6: (a) a filter in front of rank + gather (gram4_filter.hpp; the FILT body below): 83 % of uniform text's hits neither end a
+// pattern nor go on — a batch of hits is probed in one Bloom word per (K+1)-gram, what passes is re-compacted by a forward permute and
+// ranked / gathered 64 at a time; the Bloom array lies where the per-word directory would, so workgroups whose text is made of
+// dictionary words (their own probe) keep that directory and the TAIL body.  1 400 -> 1 500 GB/s on cfg3 (profiles/r06_gram4_decomposition.txt).
+// (b) the hit queues hold 16-bit offsets into the wave's text slot (4 KB more for the Bloom array).  (c) walker positions are offsets
+// from a 2 GiB epoch base: they no longer wrap when a walker crosses a multiple of 4 GiB.
 // Roofline: HBM bytes of haystack (1 B read per byte); integer/bit work only, no MFMA.
 #include <hip/hip_runtime.h>
 
