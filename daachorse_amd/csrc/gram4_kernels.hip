@@ -123,6 +123,7 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
     // per-wave LDS: the text slot; the hit queues of all waves come first (each starts at a multiple of its size)
     const uint32_t tb = L.off_wave + wave_in_wg * L.wave_stride;   // wave-uniform
     const uint32_t ringb = wave_in_wg * (kRing4 * 2u);
+    const uint32_t ringb_v = pin4(ringb);   // (the same in a vector register, for the queue store's v_and_or_b32: one scalar / literal operand per VOP3)
     // this wave's slab of pending walkers, 16-byte entries.  plain: {position of the hit byte, hit record x, hit record y, the four text
     // bytes behind the hit}; TAIL: {position, state | class << 27, text bytes from position + 2 on, three more | how many << 24}
     const uint64_t slab_index = (static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave_in_wg) * a.wq_slab;
@@ -560,8 +561,14 @@ __device__ __forceinline__ void gram4_body(const Gram4Dev &g, const GramArgs &a,
                 asm("v_ffbl_b32 %0, %1" : "=v"(b) : "v"(H));   // (all lanes: -1 where there is no bit)
                 const uint32_t entry = text_adj + b;
                 H &= H - 1u;
-                const uint32_t at = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), q_tail));
-                const uint32_t slot_addr = ((at << 1) & (kRing4 * 2u - 2u)) | ringb;   // (v_lshlrev_b32, v_and_or_b32)
+                // slot = ((q_tail + lanes with a hit below this one) * 2 & ring mask) | ring base, in four instructions: the two mbcnt, one
+                // add-and-shift with q_tail as the scalar operand, one and-or (left to itself the compiler moves q_tail into a register for
+                // mbcnt's accumulator — both of mbcnt_lo's other operands are scalar already — and splits the and-or: six; this loop turns
+                // 9.5 times per step)
+                const uint32_t below_me = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+                uint32_t at2, slot_addr;
+                asm("v_add_lshl_u32 %0, %1, %2, 1" : "=v"(at2) : "v"(below_me), "s"(q_tail));
+                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(slot_addr) : "v"(at2), "s"(kRing4 * 2u - 2u), "v"(ringb_v));   // (VOP3 takes no literal on gfx950: the mask is a scalar register)
                 if (has) *reinterpret_cast<lds4_u16 *>(static_cast<uintptr_t>(slot_addr)) = static_cast<uint16_t>(entry);
                 q_tail += static_cast<uint32_t>(__popcll(m));
                 if (st_n + q_tail - q_head >= 64u) process_batch(64u);
